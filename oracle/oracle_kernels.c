@@ -1,0 +1,141 @@
+/*
+ * CPU oracle kernels -- TEST INFRASTRUCTURE ONLY (see oracle/iga_oracle.py).
+ *
+ * Plain-C restatement of the reference's entry-wise quadrature sums:
+ *   from_seq{2,3}            pyiga/assemble_tools_cy.pyx:36-49
+ *   intersect_intervals      pyiga/assemble_tools_cy.pyx:145-156
+ *   entry_impl               pyiga/assemblers.pyx:140-172,317-349,1281-1322,1499-1540
+ *   combine                  pyiga/assemblers.pyx:116-135,281-312,1255-1276,1455-1494
+ *   multi_entries_chunk      pyiga/genericasm.pxi:691-703 (+ thread chunks :742-757)
+ *
+ * One matrix entry = one scalar accumulator over the tensor Gauss grid restricted
+ * to the intersection of the two supports, loops nested axis 0 outermost, exactly
+ * as in the generated Cython.  Never linked into the product library.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <omp.h>
+
+typedef struct {
+    int dim, kind, nder, F;
+    size_t ndofs[3], ng[3];
+    const int64_t *ms[3];
+    const double *C[3];
+    const double *fields;
+} orc_ctx;
+
+static inline const double *Cptr(const orc_ctx *c, int ax, size_t dof, size_t g)
+{
+    return c->C[ax] + (dof * c->ng[ax] + g) * (size_t)c->nder;
+}
+
+static double entry2(const orc_ctx *c, const size_t i[2], const size_t j[2])
+{
+    size_t sta[2], end[2];
+    for (int k = 0; k < 2; ++k) {
+        int64_t a = c->ms[k][2 * j[k]], b = c->ms[k][2 * j[k] + 1];
+        int64_t a2 = c->ms[k][2 * i[k]], b2 = c->ms[k][2 * i[k] + 1];
+        int64_t lo = a > a2 ? a : a2, hi = b < b2 ? b : b2;
+        if (lo >= hi) return 0.0;
+        sta[k] = (size_t)lo; end[k] = (size_t)hi;
+    }
+    const double *u0 = Cptr(c, 0, j[0], sta[0]), *u1 = Cptr(c, 1, j[1], sta[1]);
+    const double *v0 = Cptr(c, 0, i[0], sta[0]), *v1 = Cptr(c, 1, i[1], sta[1]);
+    const size_t n0 = end[0] - sta[0], n1 = end[1] - sta[1];
+    const int F = c->F;
+    double r = 0.0;
+    if (c->kind == 0) {
+        for (size_t i0 = 0; i0 < n0; ++i0)
+            for (size_t i1 = 0; i1 < n1; ++i1) {
+                const double *f = c->fields + ((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * F;
+                r += (((u0[i0] * u1[i1]) * (v0[i0] * v1[i1])) * f[0]);
+            }
+    } else {
+        for (size_t i0 = 0; i0 < n0; ++i0)
+            for (size_t i1 = 0; i1 < n1; ++i1) {
+                const double *f = c->fields + ((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * F;
+                double du10 = u0[2 * i0 + 0] * u1[2 * i1 + 1];
+                double du01 = u0[2 * i0 + 1] * u1[2 * i1 + 0];
+                double dv10 = v0[2 * i0 + 0] * v1[2 * i1 + 1];
+                double dv01 = v0[2 * i0 + 1] * v1[2 * i1 + 0];
+                r += ((((f[0] * du10) + (f[1] * du01)) * dv10) + (((f[1] * du10) + (f[2] * du01)) * dv01));
+            }
+    }
+    return r;
+}
+
+static double entry3(const orc_ctx *c, const size_t i[3], const size_t j[3])
+{
+    size_t sta[3], end[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t a = c->ms[k][2 * j[k]], b = c->ms[k][2 * j[k] + 1];
+        int64_t a2 = c->ms[k][2 * i[k]], b2 = c->ms[k][2 * i[k] + 1];
+        int64_t lo = a > a2 ? a : a2, hi = b < b2 ? b : b2;
+        if (lo >= hi) return 0.0;
+        sta[k] = (size_t)lo; end[k] = (size_t)hi;
+    }
+    const double *u0 = Cptr(c, 0, j[0], sta[0]), *u1 = Cptr(c, 1, j[1], sta[1]), *u2 = Cptr(c, 2, j[2], sta[2]);
+    const double *v0 = Cptr(c, 0, i[0], sta[0]), *v1 = Cptr(c, 1, i[1], sta[1]), *v2 = Cptr(c, 2, i[2], sta[2]);
+    const size_t n0 = end[0] - sta[0], n1 = end[1] - sta[1], n2 = end[2] - sta[2];
+    const int F = c->F;
+    double r = 0.0;
+    if (c->kind == 0) {
+        for (size_t i0 = 0; i0 < n0; ++i0)
+            for (size_t i1 = 0; i1 < n1; ++i1) {
+                const double *f = c->fields + (((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * c->ng[2] + sta[2]) * F;
+                for (size_t i2 = 0; i2 < n2; ++i2)
+                    r += (((u0[i0] * u1[i1] * u2[i2]) * (v0[i0] * v1[i1] * v2[i2])) * f[i2 * F]);
+            }
+    } else {
+        for (size_t i0 = 0; i0 < n0; ++i0)
+            for (size_t i1 = 0; i1 < n1; ++i1) {
+                const double *fb = c->fields + (((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * c->ng[2] + sta[2]) * F;
+                for (size_t i2 = 0; i2 < n2; ++i2) {
+                    const double *f = fb + i2 * F;
+                    double du100 = (u0[2 * i0 + 0] * u1[2 * i1 + 0] * u2[2 * i2 + 1]);
+                    double du010 = (u0[2 * i0 + 0] * u1[2 * i1 + 1] * u2[2 * i2 + 0]);
+                    double du001 = (u0[2 * i0 + 1] * u1[2 * i1 + 0] * u2[2 * i2 + 0]);
+                    double dv100 = (v0[2 * i0 + 0] * v1[2 * i1 + 0] * v2[2 * i2 + 1]);
+                    double dv010 = (v0[2 * i0 + 0] * v1[2 * i1 + 1] * v2[2 * i2 + 0]);
+                    double dv001 = (v0[2 * i0 + 1] * v1[2 * i1 + 0] * v2[2 * i2 + 0]);
+                    r += ((((((f[0] * du100) + (f[1] * du010)) + (f[2] * du001)) * dv100)
+                           + ((((f[1] * du100) + (f[3] * du010)) + (f[4] * du001)) * dv010))
+                          + ((((f[2] * du100) + (f[4] * du010)) + (f[5] * du001)) * dv001));
+                }
+            }
+    }
+    return r;
+}
+
+int orc_entries(int dim, int kind, const size_t *ndofs, const size_t *ng,
+                const int64_t *ms0, const int64_t *ms1, const int64_t *ms2,
+                const double *C0, const double *C1, const double *C2, int nder,
+                const double *fields, int F,
+                const size_t *idx, size_t M, double *out, int nthreads)
+{
+    if (dim != 2 && dim != 3) return 1;
+    orc_ctx c;
+    c.dim = dim; c.kind = kind; c.nder = nder; c.F = F;
+    for (int k = 0; k < dim; ++k) { c.ndofs[k] = ndofs[k]; c.ng[k] = ng[k]; }
+    c.ms[0] = ms0; c.ms[1] = ms1; c.ms[2] = ms2;
+    c.C[0] = C0; c.C[1] = C1; c.C[2] = C2;
+    c.fields = fields;
+    if (nthreads < 1) nthreads = 1;
+    /* contiguous chunks, one per thread: chunk_tasks(), assemble_tools_cy.pyx:387-391 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (ptrdiff_t k = 0; k < (ptrdiff_t)M; ++k) {
+        size_t I = idx[2 * k], J = idx[2 * k + 1];
+        if (dim == 2) {
+            size_t i[2], j[2];
+            i[1] = I % c.ndofs[1]; i[0] = I / c.ndofs[1];
+            j[1] = J % c.ndofs[1]; j[0] = J / c.ndofs[1];
+            out[k] = (i[0] < c.ndofs[0] && j[0] < c.ndofs[0]) ? entry2(&c, i, j) : 0.0;
+        } else {
+            size_t i[3], j[3];
+            i[2] = I % c.ndofs[2]; I /= c.ndofs[2]; i[1] = I % c.ndofs[1]; i[0] = I / c.ndofs[1];
+            j[2] = J % c.ndofs[2]; J /= c.ndofs[2]; j[1] = J % c.ndofs[1]; j[0] = J / c.ndofs[1];
+            out[k] = (i[0] < c.ndofs[0] && j[0] < c.ndofs[0]) ? entry3(&c, i, j) : 0.0;
+        }
+    }
+    return 0;
+}

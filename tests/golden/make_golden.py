@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (c-f-h/pyiga).
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    # one-time scratch build of the unmodified reference, outside the repo
+    mkdir -p /tmp/pyiga_oracle && cp -r /root/reference/{pyiga,setup.py,test} /tmp/pyiga_oracle
+    (cd /tmp/pyiga_oracle && python3 setup.py build_ext -i)
+    # then
+    PYTHONPATH=/tmp/pyiga_oracle python3 tests/golden/make_golden.py
+
+Writes `tests/golden/golden_*.npz` -- inputs and expected outputs only (data, no
+reference source).  Every array is produced by calling the reference's public
+API; the recipe for each case is recorded in the `desc` string stored with it.
+
+Cases follow SURVEY.md section 8c.
+"""
+import os
+import sys
+import numpy as np
+import scipy.sparse
+
+import pyiga
+from pyiga import bspline, geometry, assemble, assemblers, quadrature, mlmatrix
+from pyiga import assemble_tools
+
+pyiga.set_max_threads(1)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, 'golden_%s.npz' % name)
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, {k: np.shape(v) for k, v in arrays.items()})
+
+
+def cylinder():
+    # quarter-annulus cylinder used by the 3D perf configs (test/test_assemble.py:325-327)
+    return geometry.tensor_product(geometry.line_segment(0.0, 1.0), geometry.quarter_annulus())
+
+
+# ---------------------------------------------------------------------------
+# (1) B-spline evaluation: active_deriv / findspan  (bspline_cy.pyx:13-145)
+def golden_bspline():
+    out = {}
+    kvs = {}
+    for p in (1, 2, 3, 4, 5):
+        kvs['p%d_n4' % p] = bspline.make_knots(p, 0.0, 1.0, 4)
+    kvs['p3_n5_mult2'] = bspline.make_knots(3, 0.0, 1.0, 5, mult=2)
+    kvs['p4_custom'] = bspline.KnotVector(np.array(
+        [0., 0., 0., 0., 0., 0.25, 0.35, 0.45, 0.55, 0.65, 0.9, 0.9, 0.9, 0.9, 0.9]), 4)
+    kvs['p2_nonuniform'] = bspline.KnotVector(np.array(
+        [0., 0., 0., 0.1, 0.15, 0.5, 0.5, 0.8, 1., 1., 1.]), 2)
+    for name, kv in kvs.items():
+        q = kv.p + 1
+        nodes, weights = quadrature.make_iterated_quadrature(kv.mesh, q)
+        der = np.asarray(bspline.active_deriv(kv, nodes, 1))   # (2, p+1, ng)
+        spans = np.array([kv.findspan(u) for u in nodes])
+        out[name + '_kv'] = kv.kv
+        out[name + '_p'] = np.array(kv.p)
+        out[name + '_nodes'] = nodes
+        out[name + '_weights'] = weights
+        out[name + '_deriv'] = der
+        out[name + '_spans'] = spans
+        out[name + '_meshsupp'] = kv.mesh_support_idx_all()
+        out[name + '_mesh'] = kv.mesh
+        # dense (ndofs, ngauss, 2) table the reference assemblers use
+        out[name + '_C'] = assemble_tools.compute_values_derivs(kv, nodes, derivs=1)
+        out[name + '_sparsity_ij'] = mlmatrix.compute_sparsity_ij(kv, kv)
+    save('bspline', **out)
+
+
+# ---------------------------------------------------------------------------
+# (2) sparsity structure (mlmatrix.py:59-130, mlmatrix_cy.pyx:189-289)
+def golden_sparsity():
+    out = {}
+    kv2 = bspline.make_knots(2, 0.0, 1.0, 3)
+    kv3 = bspline.make_knots(3, 0.0, 1.0, 4)
+    kvm = bspline.make_knots(2, 0.0, 1.0, 3, mult=2)
+    for name, kvs in (('d3_p2_n3', (kv2, kv2, kv2)), ('d2_p3_n4', (kv3, kv3)),
+                      ('d2_mixed', (kv2, kv3)), ('d3_mult', (kvm, kv2, kvm))):
+        S = mlmatrix.MLStructure.from_kvs(kvs, kvs)
+        for lt in (False, True):
+            I, J = S.nonzero(lower_tri=lt)
+            out['%s_lt%d_I' % (name, lt)] = np.asarray(I)
+            out['%s_lt%d_J' % (name, lt)] = np.asarray(J)
+        for k, kv in enumerate(kvs):
+            out['%s_kv%d' % (name, k)] = kv.kv
+            out['%s_p%d' % (name, k)] = np.array(kv.p)
+    save('sparsity', **out)
+
+
+# ---------------------------------------------------------------------------
+# (3) geometry Jacobians on the Gauss grid (bspline.py:897-921, geometry.py:116-123)
+def golden_geometry():
+    out = {}
+    geos = {
+        'quarter_annulus': (geometry.quarter_annulus(), 3),
+        'bspline_quarter_annulus': (geometry.bspline_quarter_annulus(), 3),
+        'twisted_box': (geometry.twisted_box(), 2),
+        'cylinder': (cylinder(), 4),
+        'unit_square': (geometry.unit_square(), 2),
+        'unit_cube': (geometry.unit_cube(), 2),
+    }
+    for name, (geo, p) in geos.items():
+        kv = bspline.make_knots(p, 0.0, 1.0, 2)
+        grid, w = quadrature.make_tensor_quadrature([kv.mesh] * geo.sdim, p + 1)
+        out[name + '_coeffs'] = np.asarray(geo.coeffs)
+        out[name + '_nurbs'] = np.array(isinstance(geo, geometry.NurbsFunc))
+        for k, gkv in enumerate(geo.kvs):
+            out[name + '_gkv%d' % k] = gkv.kv
+            out[name + '_gp%d' % k] = np.array(gkv.p)
+        for k in range(geo.sdim):
+            out[name + '_grid%d' % k] = grid[k]
+        out[name + '_jac'] = np.asarray(geo.grid_jacobian(grid))
+        out[name + '_eval'] = np.asarray(geo.grid_eval(grid))
+    save('geometry', **out)
+
+
+# ---------------------------------------------------------------------------
+# (4)+(5) assembler entries and full matrices
+def lower_csr(A):
+    L = scipy.sparse.tril(A.tocsr(), format='csr')
+    L.sort_indices()
+    return L
+
+
+def put_matrix(out, name, A):
+    A = A.tocsr()
+    A.sort_indices()
+    out[name + '_shape'] = np.array(A.shape)
+    out[name + '_indptr'] = A.indptr
+    out[name + '_indices'] = A.indices
+    out[name + '_data'] = A.data
+
+
+def golden_matrices():
+    out = {}
+    # -- 2D p=3 n=8 NURBS annulus, mass + stiffness (full)
+    kv = bspline.make_knots(3, 0.0, 1.0, 8)
+    geo = geometry.quarter_annulus()
+    put_matrix(out, 'd2_p3_n8_annulus_mass', assemble.mass((kv, kv), geo))
+    put_matrix(out, 'd2_p3_n8_annulus_stiff', assemble.stiffness((kv, kv), geo))
+    # -- 2D unequal degrees p=(4,3) n=(5,6) unit square
+    kvs = (bspline.make_knots(4, 0.0, 1.0, 5), bspline.make_knots(3, 0.0, 1.0, 6))
+    put_matrix(out, 'd2_p43_n56_square_mass', assemble.mass(kvs, geometry.unit_square()))
+    put_matrix(out, 'd2_p43_n56_square_stiff', assemble.stiffness(kvs, geometry.unit_square()))
+    # -- 2D with interior knot multiplicity 2 on the B-spline annulus
+    kvm = bspline.make_knots(3, 0.0, 1.0, 5, mult=2)
+    kvn = bspline.make_knots(2, 0.0, 1.0, 4)
+    geo_b = geometry.bspline_quarter_annulus()
+    put_matrix(out, 'd2_mult_annulus_mass', assemble.mass((kvm, kvn), geo_b))
+    put_matrix(out, 'd2_mult_annulus_stiff', assemble.stiffness((kvm, kvn), geo_b))
+    out['d2_mult_kv0'] = kvm.kv
+    out['d2_mult_kv1'] = kvn.kv
+    # -- 3D p=4 n=3 and p=5 n=3 annulus cylinder stiffness (lower triangle only)
+    cyl = cylinder()
+    for p in (4, 5):
+        kv = bspline.make_knots(p, 0.0, 1.0, 3)
+        A = assemble.stiffness((kv, kv, kv), cyl)
+        put_matrix(out, 'd3_p%d_n3_cyl_stiff_lower' % p, lower_csr(A))
+    # -- 3D p=3 mixed n, twisted box: mass + stiffness (lower)
+    kvs3 = (bspline.make_knots(3, 0.0, 1.0, 3), bspline.make_knots(2, 0.0, 1.0, 4),
+            bspline.make_knots(3, 0.0, 1.0, 2))
+    tb = geometry.twisted_box()
+    put_matrix(out, 'd3_p323_n342_tbox_mass_lower', lower_csr(assemble.mass(kvs3, tb)))
+    put_matrix(out, 'd3_p323_n342_tbox_stiff_lower', lower_csr(assemble.stiffness(kvs3, tb)))
+    # -- 3D with multiplicity on one axis, cylinder
+    kvs3m = (bspline.make_knots(2, 0.0, 1.0, 3, mult=2), bspline.make_knots(2, 0.0, 1.0, 3),
+             bspline.make_knots(3, 0.0, 1.0, 2))
+    put_matrix(out, 'd3_mult_cyl_stiff_lower', lower_csr(assemble.stiffness(kvs3m, cyl)))
+    put_matrix(out, 'd3_mult_cyl_mass_lower', lower_csr(assemble.mass(kvs3m, cyl)))
+    for k, kvx in enumerate(kvs3m):
+        out['d3_mult_kv%d' % k] = kvx.kv
+    save('matrices', **out)
+
+    # -- single entries via the assembler object (genericasm.pxi:677-758)
+    out = {}
+    kv = bspline.make_knots(2, 0.0, 1.0, 4)
+    for name, asm in (('stiff3d', assemblers.StiffnessAssembler3D((kv, kv, kv), cyl)),
+                      ('mass3d', assemblers.MassAssembler3D((kv, kv, kv), cyl))):
+        N = kv.numdofs
+        nd = N ** 3
+        rng = np.random.default_rng(7)
+        pairs = [(0, 0), (nd - 1, nd - 1), (nd // 2, nd // 2), (0, nd - 1), (nd - 1, 0),
+                 (N * N + N + 1, 1), (5, 5 + N * N), (5 + N * N, 5)]
+        pairs += [tuple(int(x) for x in rng.integers(0, nd, 2)) for _ in range(40)]
+        # add near-diagonal pairs (inside the pattern)
+        for _ in range(40):
+            i = int(rng.integers(0, nd))
+            off = int(rng.integers(-2, 3)) * N * N + int(rng.integers(-2, 3)) * N + int(rng.integers(-2, 3))
+            j = min(max(i + off, 0), nd - 1)
+            pairs.append((i, j))
+        idx = np.array(pairs, dtype=np.uintp)
+        out[name + '_idx'] = idx
+        out[name + '_multi'] = np.asarray(asm.multi_entries(idx))
+        out[name + '_single'] = np.array([asm.entry(int(i), int(j)) for i, j in idx])
+    kv2 = bspline.make_knots(3, 0.0, 1.0, 6)
+    ann = geometry.quarter_annulus()
+    for name, asm in (('stiff2d', assemblers.StiffnessAssembler2D((kv2, kv2), ann)),
+                      ('mass2d', assemblers.MassAssembler2D((kv2, kv2), ann))):
+        nd = kv2.numdofs ** 2
+        rng = np.random.default_rng(11)
+        idx = rng.integers(0, nd, (60, 2)).astype(np.uintp)
+        near = np.arange(0, nd, 7)
+        idx = np.concatenate([idx, np.stack([near, np.minimum(near + 3, nd - 1)], axis=1).astype(np.uintp)])
+        out[name + '_idx'] = idx
+        out[name + '_multi'] = np.asarray(asm.multi_entries(idx))
+    save('entries', **out)
+
+
+# ---------------------------------------------------------------------------
+# (6) Kronecker (geo=None) path and 1D matrices (assemble.py:125-190, 236-282)
+def golden_kron():
+    out = {}
+    kv = bspline.KnotVector(np.array(
+        [0., 0., 0., 0., 0., 0.25, 0.35, 0.45, 0.55, 0.65, 0.9, 0.9, 0.9, 0.9, 0.9]), 4)
+    out['kv1d'] = kv.kv
+    out['M1d'] = assemble.bsp_mass_1d(kv).toarray()
+    out['K1d'] = assemble.bsp_stiffness_1d(kv).toarray()
+    kvs = (bspline.make_knots(4, 0.0, 1.0, 10), bspline.make_knots(3, 0.0, 1.0, 12))
+    put_matrix(out, 'kron2d_stiff', assemble.stiffness(kvs))
+    put_matrix(out, 'kron2d_mass', assemble.mass(kvs))
+    kvs3 = (bspline.make_knots(3, 0.0, 1.0, 4), bspline.make_knots(3, 0.0, 1.0, 5),
+            bspline.make_knots(3, 0.0, 1.0, 6))
+    put_matrix(out, 'kron3d_stiff', assemble.stiffness(kvs3))
+    put_matrix(out, 'kron3d_mass', assemble.mass(kvs3))
+    save('kron', **out)
+
+
+# ---------------------------------------------------------------------------
+# make_knots bit patterns for the BASELINE sizes (bspline.py:192-213, SURVEY A.4 trap 1)
+def golden_knots():
+    out = {}
+    for p, n in ((3, 15), (3, 256), (2, 10), (2, 64), (4, 128), (5, 96), (3, 49), (4, 12), (2, 7)):
+        out['p%d_n%d' % (p, n)] = bspline.make_knots(p, 0.0, 1.0, n).kv
+    out['p3_n5_m2'] = bspline.make_knots(3, 0.0, 1.0, 5, mult=2).kv
+    out['p2_ab'] = bspline.make_knots(2, -1.5, 2.25, 9).kv
+    for q in range(1, 8):
+        x, w = np.polynomial.legendre.leggauss(q)
+        out['leggauss%d_x' % q] = x
+        out['leggauss%d_w' % q] = w
+    save('knots', **out)
+
+
+if __name__ == '__main__':
+    golden_knots()
+    golden_bspline()
+    golden_sparsity()
+    golden_geometry()
+    golden_matrices()
+    golden_kron()
+    print('reference version', pyiga.__version__)
