@@ -1,0 +1,159 @@
+/*
+ * igx.h -- C ABI of libigx: MI355X (gfx950) tensor-product IgA assembly.
+ *
+ * This is the drop-in boundary for the hot path of c-f-h/pyiga
+ *     pyiga.assemble.stiffness()/mass()  with a geometry map
+ * (SURVEY.md section 8b).  Plain pointers and sizes only; no C++ or torch types.
+ * Every entry point returns 0 on success and a non-zero code on failure
+ * (message via igx_last_error()); nothing throws across the ABI.  All
+ * `const double*` / `const size_t*` arguments are HOST pointers unless the name
+ * starts with `d_`.  Host output buffers are allocated by the caller.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   igx_active_deriv / igx_find_spans  <- pyiga/bspline_cy.pyx:13-27,126-145
+ *   igx_patch_create                   <- *Assembler{2,3}D.__init__
+ *                                         pyiga/assemblers.pyx:38-80,186-228,1170-1217,1336-1383
+ *                                         (quadrature.py:3-23, bspline.py:129-136,629-660,
+ *                                          geometry.py:17-25,116-123, tensor.py:97-128,
+ *                                          precompute_fields assemblers.pyx:86-110,234-275,1223-1249,1389-1449)
+ *   igx_grid_jacobian / igx_grid_eval  <- BSplineFunc/NurbsFunc.grid_jacobian/grid_eval
+ *                                         pyiga/bspline.py:874-921, pyiga/geometry.py:103-123
+ *   igx_pattern                        <- MLStructure.from_kvs + nonzero
+ *                                         pyiga/mlmatrix.py:59-65,113-130,420-440; mlmatrix_cy.pyx:189-289
+ *                                         (emits canonical CSR directly instead of COO pairs)
+ *   igx_entries                        <- BaseAssembler{2,3}D.multi_entries / entry
+ *                                         pyiga/genericasm.pxi:353-436,677-758
+ *                                         (entry_impl + combine, assemblers.pyx:116-172,281-349,1255-1322,1455-1540)
+ *   igx_assemble                       <- assemble_entries(asm, symmetric=True)
+ *                                         pyiga/assemble.py:703-754 (multi_entries + COO->CSR + mirror)
+ */
+#ifndef IGX_H
+#define IGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGX_VERSION 100            /* 0.1.0 */
+#define IGX_MAX_DIM 3
+#define IGX_MAX_DEGREE 15          /* basis evaluation / entry-wise kernels */
+#define IGX_MAX_SF_DEGREE 5        /* sum-factorised fast path */
+
+typedef struct igx_ctx igx_ctx;       /* one per GPU: device id + HIP stream */
+typedef struct igx_patch igx_patch;   /* device-resident state of one assembler */
+
+enum { IGX_MASS = 0, IGX_STIFFNESS = 1 };
+enum { IGX_GEO_BSPLINE = 0, IGX_GEO_NURBS = 1, IGX_GEO_JACOBIAN = 2 };
+/* algorithm selector for igx_assemble */
+enum { IGX_ALGO_AUTO = 0,      /* sum-factorised when the patch supports it, else entry-wise */
+       IGX_ALGO_ENTRYWISE = 1, /* one thread per matrix entry, the reference's own summation order */
+       IGX_ALGO_SUMFACT = 2 }; /* global sum factorisation (stage kernels) */
+
+enum { IGX_OK = 0, IGX_ERR_ARG = 1, IGX_ERR_HIP = 2, IGX_ERR_UNSUPPORTED = 3, IGX_ERR_NOMEM = 4 };
+
+/* Knot vectors are in the reference's (z, y, x) order: axis 0 is the slowest dof index. */
+typedef struct {
+    int32_t dim;                       /* 2 or 3 */
+    int32_t p[IGX_MAX_DIM];            /* spline degree per axis */
+    int32_t kv_len[IGX_MAX_DIM];       /* number of knots per axis */
+    const double *kv[IGX_MAX_DIM];     /* open knot vectors */
+
+    int32_t geo_kind;                  /* IGX_GEO_* */
+    int32_t geo_p[IGX_MAX_DIM];        /* geometry degrees (BSPLINE/NURBS) */
+    int32_t geo_kv_len[IGX_MAX_DIM];
+    const double *geo_kv[IGX_MAX_DIM];
+    const double *ctrl;                /* control net, C order, shape (Ng0,..,Ng{d-1}, dim [+1 weight, premultiplied]) */
+    const double *jac;                 /* IGX_GEO_JACOBIAN: (G0,..,G{d-1}, d, d), last axis = d/d(x,y,z) */
+
+    int32_t nqp;                       /* Gauss points per span; 0 -> max(p)+1 as in the reference */
+    const double *gauss_x;             /* optional nqp nodes on [-1,1] (NULL -> built-in Gauss-Legendre) */
+    const double *gauss_w;             /* optional nqp weights */
+
+    /* Row slab for multi-GPU: this patch owns the dof planes row0_lo <= i0 < row0_hi of axis 0
+       (row0_hi = 0 means "all").  Only those CSR rows are produced. */
+    int32_t row0_lo, row0_hi;
+} igx_patch_desc;
+
+typedef struct {
+    int32_t dim, nqp;
+    int32_t ndofs[IGX_MAX_DIM], nspans[IGX_MAX_DIM], ngauss[IGX_MAX_DIM];
+    int64_t nrows_total;               /* prod(ndofs) */
+    int64_t row_lo, row_hi;            /* owned global rows [row_lo, row_hi) */
+    int64_t nnz;                       /* nonzeros in the owned rows */
+    int64_t nnz_offset;                /* global indptr[row_lo] */
+    int64_t nelem_owned;               /* elements attributed to this slab (for throughput) */
+    int32_t sumfact_ok;                /* 1 if the fast path supports this patch */
+    int32_t reserved;
+} igx_patch_info;
+
+typedef struct {                       /* device time of the last igx_assemble, HIP events on the ctx stream */
+    float total_ms;
+    float fields_ms, stage0_ms, stage1_ms, final_ms, entry_ms;
+    int32_t algo_used;
+    int32_t n_launches;
+} igx_timing;
+
+int         igx_version(void);
+const char *igx_last_error(void);
+
+igx_ctx *igx_create(int device_id);                 /* NULL on failure */
+void     igx_destroy(igx_ctx *ctx);
+int      igx_sync(igx_ctx *ctx);
+void    *igx_stream(igx_ctx *ctx);                  /* hipStream_t of this context */
+
+/* --- B-spline evaluation (bspline_cy.pyx) ------------------------------------------------- */
+/* out has shape (numderiv+1, p+1, nu), C order, exactly like pyiga.bspline_cy.active_deriv */
+int igx_active_deriv(igx_ctx *ctx, const double *kv, int kv_len, int p,
+                     const double *u, size_t nu, int numderiv, double *out);
+/* spans[i] = pyx_findspan(kv, p, u[i]) */
+int igx_find_spans(igx_ctx *ctx, const double *kv, int kv_len, int p,
+                   const double *u, size_t nu, int64_t *spans);
+
+/* --- geometry on a tensor grid (bspline.py:874-921, geometry.py:103-123) ------------------- */
+/* desc uses only dim, geo_kind (BSPLINE/NURBS), geo_p, geo_kv_len, geo_kv, ctrl.
+   ncomp = number of output components (geo.dim).  jac_out: (n0,..,n{d-1}, ncomp, d); eval_out:
+   (n0,..,n{d-1}, ncomp).  Either output may be NULL. */
+int igx_grid_jacobian(igx_ctx *ctx, const igx_patch_desc *desc, int ncomp,
+                      const double *const grid[IGX_MAX_DIM], const int32_t ngrid[IGX_MAX_DIM],
+                      double *jac_out, double *eval_out);
+
+/* --- patch = assembler state on the device -------------------------------------------------- */
+igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *desc);   /* NULL on failure */
+void       igx_patch_destroy(igx_patch *patch);
+int        igx_patch_get_info(const igx_patch *patch, igx_patch_info *info);
+
+/* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
+int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);
+
+/* Canonical CSR pattern of the owned rows.  indptr has (row_hi-row_lo+1) entries, LOCAL
+   (indptr[0] = 0); indices has nnz entries (global column ids).  Either may be NULL.
+   The pattern is also kept on the device. */
+int igx_pattern(igx_patch *patch, int32_t *indptr, int32_t *indices);
+
+/* Assemble all CSR values of the owned rows into device memory (symmetric: lower triangle
+   computed, strict lower part mirrored -> exactly symmetric, as assemble_entries(symmetric=True)).
+   If data_out != NULL the nnz values are also copied to the host buffer. */
+int igx_assemble(igx_patch *patch, int kind, int algo, double *data_out);
+int igx_last_timing(const igx_patch *patch, igx_timing *t);
+
+/* Device pointers of the most recent results (valid until the patch is destroyed) */
+const double  *igx_d_csr_data(const igx_patch *patch);
+const int32_t *igx_d_csr_indices(const igx_patch *patch);
+const int32_t *igx_d_csr_indptr(const igx_patch *patch);
+
+/* multi_entries: ij is M x 2 (row, col) of ravelled dof indices; out[k] = 0.0 for pairs whose
+   supports do not intersect.  Works for any pair, inside or outside the owned slab provided the
+   fields of the pair's Gauss points are resident (always true for a full patch). */
+int igx_entries(igx_patch *patch, int kind, const size_t *ij, size_t M, double *out);
+
+/* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
+   (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */
+int igx_fields(igx_patch *patch, int kind, double *out, int64_t *shape4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGX_H */

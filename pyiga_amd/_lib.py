@@ -1,0 +1,161 @@
+"""ctypes binding of libigx (include/igx.h).  Thin: argument marshalling only.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible when a context is requested, this raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libigx.so')
+
+IGX_MASS, IGX_STIFFNESS = 0, 1
+IGX_GEO_BSPLINE, IGX_GEO_NURBS, IGX_GEO_JACOBIAN = 0, 1, 2
+IGX_ALGO_AUTO, IGX_ALGO_ENTRYWISE, IGX_ALGO_SUMFACT = 0, 1, 2
+ALGOS = {'auto': IGX_ALGO_AUTO, 'entrywise': IGX_ALGO_ENTRYWISE, 'sumfact': IGX_ALGO_SUMFACT}
+KINDS = {'mass': IGX_MASS, 'stiffness': IGX_STIFFNESS}
+
+_dp = C.POINTER(C.c_double)
+
+
+class PatchDesc(C.Structure):
+    _fields_ = [
+        ('dim', C.c_int32), ('p', C.c_int32 * 3), ('kv_len', C.c_int32 * 3), ('kv', _dp * 3),
+        ('geo_kind', C.c_int32), ('geo_p', C.c_int32 * 3), ('geo_kv_len', C.c_int32 * 3), ('geo_kv', _dp * 3),
+        ('ctrl', _dp), ('jac', _dp),
+        ('nqp', C.c_int32), ('gauss_x', _dp), ('gauss_w', _dp),
+        ('row0_lo', C.c_int32), ('row0_hi', C.c_int32),
+    ]
+
+
+class PatchInfo(C.Structure):
+    _fields_ = [
+        ('dim', C.c_int32), ('nqp', C.c_int32),
+        ('ndofs', C.c_int32 * 3), ('nspans', C.c_int32 * 3), ('ngauss', C.c_int32 * 3),
+        ('nrows_total', C.c_int64), ('row_lo', C.c_int64), ('row_hi', C.c_int64),
+        ('nnz', C.c_int64), ('nnz_offset', C.c_int64), ('nelem_owned', C.c_int64),
+        ('sumfact_ok', C.c_int32), ('reserved', C.c_int32),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ('total_ms', C.c_float), ('fields_ms', C.c_float), ('stage0_ms', C.c_float),
+        ('stage1_ms', C.c_float), ('final_ms', C.c_float), ('entry_ms', C.c_float),
+        ('algo_used', C.c_int32), ('n_launches', C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/igx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('igx_version', C.c_int, []),
+    ('igx_last_error', C.c_char_p, []),
+    ('igx_create', C.c_void_p, [C.c_int]),
+    ('igx_destroy', None, [C.c_void_p]),
+    ('igx_sync', C.c_int, [C.c_void_p]),
+    ('igx_stream', C.c_void_p, [C.c_void_p]),
+    ('igx_active_deriv', C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_size_t, C.c_int, _dp]),
+    ('igx_find_spans', C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_int64)]),
+    ('igx_grid_jacobian', C.c_int, [C.c_void_p, C.POINTER(PatchDesc), C.c_int, _dp * 3, C.c_int32 * 3, _dp, _dp]),
+    ('igx_patch_create', C.c_void_p, [C.c_void_p, C.POINTER(PatchDesc)]),
+    ('igx_patch_destroy', None, [C.c_void_p]),
+    ('igx_patch_get_info', C.c_int, [C.c_void_p, C.POINTER(PatchInfo)]),
+    ('igx_patch_gauss', C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    ('igx_pattern', C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ('igx_assemble', C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
+    ('igx_last_timing', C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    ('igx_d_csr_data', C.c_void_p, [C.c_void_p]),
+    ('igx_d_csr_indices', C.c_void_p, [C.c_void_p]),
+    ('igx_d_csr_indptr', C.c_void_p, [C.c_void_p]),
+    ('igx_entries', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, _dp]),
+    ('igx_fields', C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+class IgxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libigx.so and declare every prototype.  Raises if the library was not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise IgxError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(or `make -C pyiga_amd/csrc`). pyiga_amd has no CPU fallback.' % LIB_PATH)
+            lib = C.CDLL(LIB_PATH)
+            for name, res, args in SYMBOLS:
+                fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().igx_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise IgxError('%s failed (code %d): %s' % (what, rc, last_error()))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# -------------------------------------------------------------------------------------------
+_ctx = {}
+
+
+class Context:
+    """One per GPU: wraps igx_ctx (device id + HIP stream)."""
+
+    def __init__(self, device=0):
+        lib = load()
+        self.device = int(device)
+        self.handle = lib.igx_create(self.device)
+        if not self.handle:
+            raise IgxError('igx_create(%d) failed: %s' % (self.device, last_error()))
+
+    def sync(self):
+        check(load().igx_sync(self.handle), 'igx_sync')
+
+    def close(self):
+        if self.handle:
+            load().igx_destroy(self.handle)
+            self.handle = None
+
+
+def default_device():
+    """LOCAL_RANK under torch.distributed.run, else IGX_DEVICE, else 0."""
+    for key in ('IGX_DEVICE', 'LOCAL_RANK'):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0
+
+
+def context(device=None):
+    device = default_device() if device is None else int(device)
+    with _lock:
+        ctx = _ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _ctx[device] = ctx
+    return ctx

@@ -1,0 +1,205 @@
+"""Drop-in for the tensor-product mass/stiffness path of ``pyiga.assemble``.
+
+Same signatures, return types and assertions as the reference
+(pyiga/assemble.py:125-190, 236-282, 703-754, 1009-1049):
+
+    stiffness(kvs, geo=None, format='csr')      mass(kvs, geo=None, format='csr')
+
+With a geometry map the matrix is formed on the MI355X by libigx (assemblers.py); the result
+is a scipy sparse matrix with float64 data and int32 indices, canonical (sorted, no
+duplicates) and exactly symmetric, like the reference's.  With ``geo=None`` the reference
+defines the result as a Kronecker product of 1D matrices built with numpy; that definition
+is restated here verbatim in numpy/scipy (only the B-spline evaluation inside goes through
+the device).  There is no CPU fallback for the geometry path.
+"""
+import math
+
+import numpy as np
+import scipy.sparse
+
+from . import bspline
+from . import assemblers
+from .quadrature import make_iterated_quadrature
+
+################################################################################
+# 1D matrices (pyiga/assemble.py:125-190): per-span dense blocks f1 @ (f2*w)^T
+################################################################################
+
+
+def bsp_mixed_deriv_biform_1d(knotvec, du, dv, nqp=None):
+    """Matrix of ``a(u,v) = (u^(du), v^(dv))`` for the B-spline basis over `knotvec`.
+
+    Default rule: ``ceil((2p - du - dv + 1)/2)`` Gauss points per span, i.e. p+1 for mass but
+    only p for stiffness.
+    """
+    p, nspans = knotvec.p, knotvec.numspans
+    if nqp is None:
+        nqp = int(math.ceil((2 * p - du - dv + 1) / 2.0))
+    nodes, weights = make_iterated_quadrature(knotvec.mesh, nqp)
+    tab = bspline.active_deriv(knotvec, nodes, max(du, dv))        # (nder, p+1, nspans*nqp)
+    test = tab[dv].reshape(p + 1, nspans, nqp)                       # rows: test functions
+    trial = (tab[du] * weights).reshape(p + 1, nspans, nqp)          # cols: trial functions, weighted
+    blocks = np.empty((nspans, p + 1, p + 1))
+    for k in range(nspans):
+        blocks[k] = np.dot(test[:, k, :], trial[:, k, :].transpose())
+    first = knotvec.mesh_span_indices() - p                          # first active dof per span
+    loc = np.arange(p + 1)
+    rows = (first[:, None, None] + loc[None, :, None]) + 0 * loc[None, None, :]
+    cols = (first[:, None, None] + loc[None, None, :]) + 0 * loc[None, :, None]
+    n = knotvec.numdofs
+    return scipy.sparse.coo_matrix((blocks.ravel(), (rows.ravel(), cols.ravel())), shape=(n, n)).tocsr()
+
+
+def bsp_mass_1d(knotvec):
+    """1D mass matrix."""
+    return bsp_mixed_deriv_biform_1d(knotvec, 0, 0)
+
+
+def bsp_stiffness_1d(knotvec):
+    """1D Laplacian stiffness matrix."""
+    return bsp_mixed_deriv_biform_1d(knotvec, 1, 1)
+
+
+################################################################################
+# d-dimensional matrices (pyiga/assemble.py:236-282)
+################################################################################
+
+_ASSEMBLER = {('mass', 2): assemblers.MassAssembler2D, ('stiffness', 2): assemblers.StiffnessAssembler2D,
+              ('mass', 3): assemblers.MassAssembler3D, ('stiffness', 3): assemblers.StiffnessAssembler3D}
+
+
+def _kron_chain(mats, format):
+    out = mats[-1]
+    for A in reversed(mats[:-1]):
+        out = scipy.sparse.kron(A, out, format=format)
+    return out
+
+
+def _kronecker_form(kind, knotvecs, format):
+    """geo=None: the matrix is a (sum of) Kronecker product(s) of 1D matrices."""
+    M = [bsp_mass_1d(kv) for kv in knotvecs]
+    if kind == 'mass':
+        return _kron_chain(M, format)
+    K = [bsp_stiffness_1d(kv) for kv in knotvecs]
+    total = None
+    for a in range(len(knotvecs)):             # derivative on axis a, mass on the others
+        term = _kron_chain([K[k] if k == a else M[k] for k in range(len(knotvecs))], format)
+        total = term if total is None else total + term
+    return total
+
+
+def _tensor_form(kind, knotvecs, geo, format):
+    if geo is None:
+        return _kronecker_form(kind, knotvecs, format)
+    asm = _ASSEMBLER[(kind, len(knotvecs))](knotvecs, geo)
+    return assemble_entries(asm, symmetric=True, format=format)
+
+
+def bsp_mass_2d(knotvecs, geo=None, format='csr'):
+    return _tensor_form('mass', tuple(knotvecs), geo, format)
+
+
+def bsp_stiffness_2d(knotvecs, geo=None, format='csr'):
+    return _tensor_form('stiffness', tuple(knotvecs), geo, format)
+
+
+def bsp_mass_3d(knotvecs, geo=None, format='csr'):
+    return _tensor_form('mass', tuple(knotvecs), geo, format)
+
+
+def bsp_stiffness_3d(knotvecs, geo=None, format='csr'):
+    return _tensor_form('stiffness', tuple(knotvecs), geo, format)
+
+
+################################################################################
+# Driver (pyiga/assemble.py:703-754)
+################################################################################
+
+
+def _compute_sparsity_ij(kv_trial, kv_test):
+    """All 1D pairs (i, j) -- i test dof, j trial dof -- whose supports share a knot span, in
+    row-major order (same set and order as pyiga/mlmatrix.py:420-440).  Supports are the
+    mesh-index intervals [lo, hi) of ``mesh_support_idx_all``; because both bounds are
+    non-decreasing in the dof index, the partners of row i form one contiguous range."""
+    su = kv_trial.mesh_support_idx_all()
+    sv = kv_test.mesh_support_idx_all()
+    first = np.searchsorted(su[:, 1], sv[:, 0], side='right')      # first j with hi_j > lo_i
+    last = np.searchsorted(su[:, 0], sv[:, 1], side='left')        # first j with lo_j >= hi_i
+    counts = np.maximum(last - first, 0)
+    rows = np.repeat(np.arange(sv.shape[0]), counts)
+    cols = np.concatenate([np.arange(a, b) for a, b in zip(first, last)]) if counts.sum() else np.zeros(0, int)
+    return np.stack((rows, cols), axis=1).astype(np.uint32)
+
+
+def _ml_nonzero(kvs0, kvs1, lower_tri):
+    """Kronecker expansion of the per-axis pairs in the reference's emission order
+    (MLStructure.from_kvs + nonzero: pyiga/mlmatrix.py:59-65,113-130; mlmatrix_cy.pyx:189-289)."""
+    I = J = None
+    for kv0, kv1 in zip(kvs0, kvs1):
+        b = _compute_sparsity_ij(kv0, kv1).astype(np.int64)
+        if I is None:
+            I, J = b[:, 0], b[:, 1]
+        else:
+            I = (I[:, None] * kv1.numdofs + b[None, :, 0]).ravel()
+            J = (J[:, None] * kv0.numdofs + b[None, :, 1]).ravel()
+    if lower_tri:
+        keep = J <= I
+        I, J = I[keep], J[keep]
+    return I, J
+
+
+def assemble_entries(asm, symmetric=False, format='csr', algo='auto'):
+    """Assemble all entries of the assembler object `asm` into a sparse matrix.
+
+    Device assemblers (``pyiga_amd.assemblers``) form the whole matrix on the GPU; any other
+    object with the reference's assembler interface (``arity``, ``kvs``, ``multi_entries``) is
+    driven exactly like the reference does (pattern -> multi_entries -> COO -> CSR [+ mirror]).
+    """
+    if asm.arity == 1:
+        return asm.assemble_vector()
+    if isinstance(asm, assemblers._DeviceAssembler):
+        # mass and stiffness are symmetric forms; the kernels always compute the lower
+        # triangle and mirror it, which is what symmetric=True means in the reference
+        return asm.assemble_csr(algo=algo).asformat(format)
+    kvs0, kvs1 = asm.kvs
+    I, J = _ml_nonzero(kvs0, kvs1, lower_tri=symmetric)
+    entries = asm.multi_entries(np.column_stack((I, J)))
+    shape = (int(np.prod([kv.numdofs for kv in kvs1])), int(np.prod([kv.numdofs for kv in kvs0])))
+    A = scipy.sparse.coo_matrix((entries, (I, J)), shape=shape).tocsr()
+    if symmetric:
+        off = np.nonzero(I != J)[0]
+        A += scipy.sparse.coo_matrix((entries[off], (J[off], I[off])), shape=shape)
+    return A.asformat(format)
+
+
+################################################################################
+# Convenience functions (pyiga/assemble.py:1009-1049)
+################################################################################
+
+
+def _detect_dim(kvs):
+    if isinstance(kvs, bspline.KnotVector):
+        return 1, kvs
+    d = len(kvs)
+    return d, (kvs[0] if d == 1 else kvs)
+
+
+def _convenience(kind, kvs, geo, format):
+    dim, kvs = _detect_dim(kvs)
+    if geo:
+        assert geo.dim == dim, 'Geometry has wrong dimension'
+    if dim == 1:
+        assert geo is None, 'Geometry map not supported for 1D assembling'
+        return bsp_mass_1d(kvs) if kind == 'mass' else bsp_stiffness_1d(kvs)
+    assert dim in (2, 3), 'Dimensions higher than 3 are currently not implemented.'
+    return _tensor_form(kind, tuple(kvs), geo, format)
+
+
+def mass(kvs, geo=None, format='csr'):
+    """Mass matrix for a (tensor product) B-spline basis with an optional geometry map."""
+    return _convenience('mass', kvs, geo, format)
+
+
+def stiffness(kvs, geo=None, format='csr'):
+    """Stiffness matrix for a (tensor product) B-spline basis with an optional geometry map."""
+    return _convenience('stiffness', kvs, geo, format)

@@ -1,0 +1,241 @@
+"""Assembler objects -- the plugin boundary of the reference.
+
+``MassAssembler{2,3}D`` / ``StiffnessAssembler{2,3}D`` mirror the classes of
+``pyiga.assemblers`` (pyiga/assemblers.pyx:26-349,1158-1540; base class
+pyiga/genericasm.pxi:312-463,631-786): constructed from ``(kvs, geo)``, exposing ``arity``,
+``kvs``, ``entry(i, j)`` and ``multi_entries(indices)``.  All state lives on the MI355X in
+an ``igx_patch``; every number is produced by HIP kernels in libigx.
+
+In addition to the reference interface each assembler offers ``assemble_csr()`` which forms
+the whole matrix on the device (what ``assemble_entries`` uses) -- the reference has to go
+through ``multi_entries`` with one index pair per nonzero, which at 3D p=4 n=128 would be
+25 GB of index pairs.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse
+
+from . import _lib
+from . import bspline
+from .quadrature import make_tensor_quadrature
+
+
+def _is_spline_geo(geo):
+    return hasattr(geo, 'kvs') and hasattr(geo, 'coeffs') and hasattr(geo, 'sdim')
+
+
+def _is_nurbs(geo):
+    from .geometry import NurbsFunc
+    return isinstance(geo, NurbsFunc) or type(geo).__name__ == 'NurbsFunc'
+
+
+class DevicePatch:
+    """RAII wrapper of ``igx_patch``: discretisation + geometry resident on one GPU."""
+
+    def __init__(self, kvs, geo, device=None, row0=None, jacobian=None):
+        lib = _lib.load()
+        self.ctx = _lib.context(device)
+        self.kvs = tuple(kvs)
+        self.dim = len(self.kvs)
+        assert self.dim in (2, 3), 'libigx assembles 2D and 3D patches'
+        self.nqp = max(kv.p for kv in self.kvs) + 1
+        d = _lib.PatchDesc()
+        keep = []
+        d.dim = self.dim
+        for k, kv in enumerate(self.kvs):
+            a = _lib.f64(kv.kv)
+            keep.append(a)
+            d.kv[k] = _lib.dptr(a)
+            d.kv_len[k] = a.size
+            d.p[k] = int(kv.p)
+        d.nqp = self.nqp
+        gx, gw = np.polynomial.legendre.leggauss(self.nqp)      # pyiga/quadrature.py:8
+        gx, gw = _lib.f64(gx), _lib.f64(gw)
+        keep += [gx, gw]
+        d.gauss_x, d.gauss_w = _lib.dptr(gx), _lib.dptr(gw)
+        if jacobian is None and _is_spline_geo(geo) and len(geo.kvs) == self.dim:
+            d.geo_kind = _lib.IGX_GEO_NURBS if _is_nurbs(geo) else _lib.IGX_GEO_BSPLINE
+            for k, gkv in enumerate(geo.kvs):
+                a = _lib.f64(gkv.kv)
+                keep.append(a)
+                d.geo_kv[k] = _lib.dptr(a)
+                d.geo_kv_len[k] = a.size
+                d.geo_p[k] = int(gkv.p)
+            ncomp = self.dim + (1 if d.geo_kind == _lib.IGX_GEO_NURBS else 0)
+            ctrl = _lib.f64(geo.coeffs)
+            assert ctrl.shape[-1] == ncomp and ctrl.ndim == self.dim + 1, 'control net has wrong shape'
+            keep.append(ctrl)
+            d.ctrl = _lib.dptr(ctrl)
+        else:
+            # arbitrary geometry object: take its Jacobians on the Gauss grid as an array
+            # (the reference does this for every geometry, assemblers.pyx:1376)
+            if jacobian is None:
+                grid, _ = make_tensor_quadrature([kv.mesh for kv in self.kvs], self.nqp)
+                jacobian = geo.grid_jacobian(grid)
+            jac = _lib.f64(jacobian)
+            G = tuple(kv.numspans * self.nqp for kv in self.kvs)
+            assert jac.shape == G + (self.dim, self.dim), 'Jacobian array has wrong shape'
+            keep.append(jac)
+            d.geo_kind = _lib.IGX_GEO_JACOBIAN
+            d.jac = _lib.dptr(jac)
+        if row0 is not None:
+            d.row0_lo, d.row0_hi = int(row0[0]), int(row0[1])
+        self.handle = lib.igx_patch_create(self.ctx.handle, C.byref(d))
+        del keep
+        if not self.handle:
+            raise _lib.IgxError('igx_patch_create failed: ' + _lib.last_error())
+        self.info = _lib.PatchInfo()
+        _lib.check(lib.igx_patch_get_info(self.handle, C.byref(self.info)), 'igx_patch_get_info')
+        self._pattern = None
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            _lib.load().igx_patch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- sizes
+    @property
+    def ndofs(self):
+        return tuple(self.info.ndofs[k] for k in range(self.dim))
+
+    @property
+    def shape(self):
+        n = int(self.info.nrows_total)
+        return (n, n)
+
+    @property
+    def nnz(self):
+        return int(self.info.nnz)
+
+    @property
+    def row_range(self):
+        return int(self.info.row_lo), int(self.info.row_hi)
+
+    # -- operations
+    def pattern(self):
+        """(indptr, indices) of the owned rows, canonical CSR, int32 (local indptr)."""
+        if self._pattern is None:
+            nrows = self.row_range[1] - self.row_range[0]
+            indptr = np.empty(nrows + 1, dtype=np.int32)
+            indices = np.empty(self.nnz, dtype=np.int32)
+            _lib.check(_lib.load().igx_pattern(self.handle, indptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               indices.ctypes.data_as(C.POINTER(C.c_int32))), 'igx_pattern')
+            self._pattern = (indptr, indices)
+        return self._pattern
+
+    def assemble(self, kind, algo='auto', to_host=True):
+        """Form all CSR values on the device; returns them (host array) if `to_host`."""
+        out = np.empty(self.nnz) if to_host else None
+        _lib.check(_lib.load().igx_assemble(self.handle, _lib.KINDS[kind], _lib.ALGOS[algo],
+                                            _lib.dptr(out) if to_host else None), 'igx_assemble')
+        return out
+
+    def timing(self):
+        t = _lib.Timing()
+        _lib.check(_lib.load().igx_last_timing(self.handle, C.byref(t)), 'igx_last_timing')
+        return t.as_dict()
+
+    def entries(self, kind, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uintp)
+        assert idx.ndim == 2 and idx.shape[1] == 2
+        out = np.zeros(idx.shape[0])
+        _lib.check(_lib.load().igx_entries(self.handle, _lib.KINDS[kind], idx.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                           idx.shape[0], _lib.dptr(out)), 'igx_entries')
+        return out
+
+    def fields(self, kind):
+        """Quadrature fields, shape (F, G0_local, G1[, G2]) (W, or the upper triangle of B)."""
+        shp = (C.c_int64 * 4)()
+        _lib.check(_lib.load().igx_fields(self.handle, _lib.KINDS[kind], None, shp), 'igx_fields')
+        shape = tuple(int(x) for x in shp)[:1 + self.dim]
+        out = np.empty(shape)
+        _lib.check(_lib.load().igx_fields(self.handle, _lib.KINDS[kind], _lib.dptr(out), shp), 'igx_fields')
+        return out
+
+    def gauss(self, axis):
+        n = self.info.ngauss[axis]
+        nodes, weights = np.empty(n), np.empty(n)
+        _lib.check(_lib.load().igx_patch_gauss(self.handle, axis, _lib.dptr(nodes), _lib.dptr(weights)), 'igx_patch_gauss')
+        return nodes, weights
+
+    def csr(self, kind, algo='auto'):
+        """scipy CSR of the owned rows (all rows for a full patch): f64 data, int32 indices."""
+        data = self.assemble(kind, algo=algo, to_host=True)
+        indptr, indices = self.pattern()
+        nrows = self.row_range[1] - self.row_range[0]
+        return scipy.sparse.csr_matrix((data, indices, indptr), shape=(nrows, self.shape[1]))
+
+
+class _DeviceAssembler:
+    """Common part of the four assembler classes (genericasm.pxi BaseAssembler{2,3}D)."""
+    _kind = None
+    _dim = None
+    arity = 2
+
+    @classmethod
+    def inputs(cls):
+        return {'geo': (cls._dim,)}
+
+    @classmethod
+    def parameters(cls):
+        return {}
+
+    def __init__(self, kvs0, geo, device=None, row0=None):
+        assert len(kvs0) == self._dim, 'Assembler requires %d knot vectors' % self._dim
+        assert geo.sdim == self._dim, 'Geometry has wrong source dimension'
+        assert geo.dim == self._dim, 'Geometry has wrong dimension'
+        self._geo = geo
+        self.nqp = max(kv.p for kv in kvs0) + 1
+        kvs0 = tuple(kvs0)
+        self.kvs = (kvs0, kvs0)
+        self.patch = DevicePatch(kvs0, geo, device=device, row0=row0)
+
+    # --- the reference's per-entry interface (genericasm.pxi:677-758)
+    def entry(self, i, j):
+        """One matrix entry for the ravelled dof indices (i, j)."""
+        return float(self.patch.entries(self._kind, np.array([[i, j]], dtype=np.uintp))[0])
+
+    def multi_entries(self, indices):
+        """All entries for an ``N x 2`` array (or iterable) of (row, col) pairs; pairs whose
+        supports do not intersect give 0.0."""
+        if isinstance(indices, np.ndarray):
+            idx = np.asarray(indices, order='C', dtype=np.uintp)
+        else:
+            idx = np.array(list(indices), dtype=np.uintp)
+        return self.patch.entries(self._kind, idx.reshape(-1, 2))
+
+    def entry1(self, i):
+        return 0.0                       # arity 2: same answer as the reference
+
+    def multi_entries1(self, indices):
+        return None
+
+    def assemble_vector(self):
+        return None
+
+    # --- whole-matrix path
+    def assemble_csr(self, algo='auto'):
+        return self.patch.csr(self._kind, algo=algo)
+
+
+class MassAssembler2D(_DeviceAssembler):
+    _kind, _dim = 'mass', 2
+
+
+class StiffnessAssembler2D(_DeviceAssembler):
+    _kind, _dim = 'stiffness', 2
+
+
+class MassAssembler3D(_DeviceAssembler):
+    _kind, _dim = 'mass', 3
+
+
+class StiffnessAssembler3D(_DeviceAssembler):
+    _kind, _dim = 'stiffness', 3

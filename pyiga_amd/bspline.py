@@ -1,0 +1,285 @@
+"""Knot vectors, B-spline evaluation and spline functions -- host mirror of the parts
+of ``pyiga.bspline`` the assembly path needs (pyiga/bspline.py:36-222,591-660,820-921).
+
+Integer bookkeeping (meshes, supports) is numpy on the host, as in the reference.
+Everything that evaluates B-splines (``active_deriv``, ``grid_eval``, ``grid_jacobian``)
+runs on the MI355X through libigx; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class KnotVector:
+    """Open B-spline knot vector with a spline degree (pyiga/bspline.py:36-190).
+
+    Attributes:
+        kv (ndarray): the knots; first and last repeated ``p+1`` times
+        p (int): spline degree
+    """
+
+    def __init__(self, knots, p):
+        self.kv = np.asarray(knots)
+        assert np.all(self.kv[1:] - self.kv[:-1] >= 0), 'knots should be increasing'
+        self.p = p
+        self._mesh = None
+        self._knots_to_mesh = None
+
+    def __str__(self):
+        return '<KnotVector p=%d sz=%d>' % (self.p, self.kv.size)
+
+    def __repr__(self):
+        return 'KnotVector(%s, %s)' % (repr(self.kv), repr(self.p))
+
+    def __eq__(self, other):
+        return (self.p == other.p and len(self.kv) == len(other.kv)
+                and bool(np.allclose(self.kv, other.kv, atol=1e-8, rtol=1e-8)))
+
+    @property
+    def numknots(self):
+        return self.kv.size
+
+    @property
+    def numdofs(self):
+        """Number of B-splines over this knot vector."""
+        return self.kv.size - self.p - 1
+
+    @property
+    def numspans(self):
+        """Number of nonempty knot intervals."""
+        return self.mesh.size - 1
+
+    def copy(self):
+        return KnotVector(self.kv.copy(), self.p)
+
+    def support(self, j=None):
+        if j is None:
+            return (self.kv[0], self.kv[-1])
+        return (self.kv[j], self.kv[j + self.p + 1])
+
+    def support_idx(self, j):
+        return (j, j + self.p + 1)
+
+    def _ensure_mesh(self):
+        if self._knots_to_mesh is None:
+            self._mesh, self._knots_to_mesh = np.unique(self.kv, return_inverse=True)
+
+    @property
+    def mesh(self):
+        """Unique knots."""
+        self._ensure_mesh()
+        return self._mesh
+
+    def mesh_support_idx(self, j):
+        self._ensure_mesh()
+        a, b = self.support_idx(j)
+        return (self._knots_to_mesh[a], self._knots_to_mesh[b])
+
+    def mesh_support_idx_all(self):
+        """``N x 2`` array: first and one-past-last mesh index of every B-spline's support."""
+        self._ensure_mesh()
+        n = self.numdofs
+        startend = np.stack((np.arange(0, n), np.arange(self.p + 1, n + self.p + 1)), axis=1)
+        return self._knots_to_mesh[startend]
+
+    def mesh_span_indices(self):
+        """Knot indices ``i`` with ``kv[i] != kv[i+1]`` (one per nonempty span)."""
+        self._ensure_mesh()
+        k2m = self._knots_to_mesh
+        return np.where(k2m[1:] != k2m[:-1])[0]
+
+    def findspan(self, u):
+        """Index ``i`` with ``kv[i] <= u < kv[i+1]`` (last span closed on the right)."""
+        return int(findspans(self, np.array([u], dtype=float))[0])
+
+    def first_active(self, k):
+        return k - self.p
+
+    def first_active_at(self, u):
+        return self.first_active(self.findspan(u))
+
+    def meshsize_avg(self):
+        return abs(self.kv[-1] - self.kv[0]) / self.numspans
+
+
+def make_knots(p, a, b, n, mult=1):
+    """Open knot vector of degree `p` over `(a,b)` with `n` spans (pyiga/bspline.py:192-213).
+
+    Uses the same ``np.arange`` expression as the reference so the knots agree bit for bit
+    (including its quirk of producing ``n+1`` spans for a few ``n``).
+    """
+    kv = np.concatenate(
+        (np.repeat(a, p + 1),
+         np.repeat(np.arange(a, b, (b - a) / n)[1:], mult),
+         np.repeat(b, p + 1)))
+    return KnotVector(kv, p)
+
+
+def numdofs(kvs):
+    if isinstance(kvs, KnotVector):
+        return kvs.numdofs
+    return np.prod([kv.numdofs for kv in kvs])
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation on the device (pyiga/bspline_cy.pyx)
+def active_deriv(knotvec, u, numderiv):
+    """All active B-splines and their derivatives up to `numderiv` at the points `u`.
+
+    Shape ``(numderiv+1, p+1)`` for scalar `u`, else ``(numderiv+1, p+1, len(u))``
+    (pyiga/bspline_cy.pyx:126-145).
+    """
+    scalar = np.isscalar(u)
+    uu = _lib.f64(np.atleast_1d(u))
+    kv = _lib.f64(knotvec.kv)
+    out = np.empty((numderiv + 1, knotvec.p + 1, uu.shape[0]))
+    ctx = _lib.context()
+    _lib.check(_lib.load().igx_active_deriv(ctx.handle, _lib.dptr(kv), kv.size, int(knotvec.p),
+                                            _lib.dptr(uu), uu.shape[0], int(numderiv), _lib.dptr(out)),
+               'igx_active_deriv')
+    return out[:, :, 0] if scalar else out
+
+
+def active_ev(knotvec, u):
+    """Values of the active B-splines, shape ``(p+1, len(u))``."""
+    return active_deriv(knotvec, u, 0)[0]
+
+
+def findspans(knotvec, u):
+    """Vectorised ``pyx_findspan`` (pyiga/bspline_cy.pyx:13-38)."""
+    uu = _lib.f64(np.atleast_1d(u))
+    kv = _lib.f64(knotvec.kv)
+    out = np.empty(uu.shape[0], dtype=np.int64)
+    ctx = _lib.context()
+    _lib.check(_lib.load().igx_find_spans(ctx.handle, _lib.dptr(kv), kv.size, int(knotvec.p), _lib.dptr(uu),
+                                          uu.shape[0], out.ctypes.data_as(C.POINTER(C.c_int64))),
+               'igx_find_spans')
+    return out
+
+
+def collocation_derivs_info(kv, nodes, derivs=1):
+    """First active index per node and ``(derivs+1) x len(nodes) x (p+1)`` coefficients
+    (pyiga/bspline.py:648-660)."""
+    nodes = _lib.f64(nodes)
+    values = active_deriv(kv, nodes, derivs)
+    indices = findspans(kv, nodes) - kv.p
+    return indices, values.swapaxes(-2, -1)
+
+
+# ---------------------------------------------------------------------------------------------
+def _geo_desc(kvs, coeffs, nurbs):
+    """Fill the geometry part of an igx_patch_desc; returns (desc, keepalive)."""
+    d = _lib.PatchDesc()
+    sdim = len(kvs)
+    d.dim = sdim
+    d.geo_kind = _lib.IGX_GEO_NURBS if nurbs else _lib.IGX_GEO_BSPLINE
+    keep = []
+    for k, kv in enumerate(kvs):
+        a = _lib.f64(kv.kv)
+        keep.append(a)
+        d.geo_kv[k] = _lib.dptr(a)
+        d.geo_kv_len[k] = a.size
+        d.geo_p[k] = int(kv.p)
+    c = _lib.f64(coeffs)
+    keep.append(c)
+    d.ctrl = _lib.dptr(c)
+    return d, keep
+
+
+def _device_grid_eval(kvs, coeffs, nurbs, ncomp, gridaxes, want_jac):
+    sdim = len(kvs)
+    if sdim not in (2, 3):
+        raise NotImplementedError('device spline evaluation supports 2D and 3D parameter domains')
+    d, keep = _geo_desc(kvs, coeffs, nurbs)
+    axes = [_lib.f64(np.squeeze(ax) if np.ndim(ax) != 1 else ax) for ax in gridaxes]
+    assert all(ax.ndim == 1 for ax in axes), 'Grid axes should be one-dimensional'
+    grid = (_lib._dp * 3)()
+    ng = (C.c_int32 * 3)()
+    for k, ax in enumerate(axes):
+        grid[k] = _lib.dptr(ax)
+        ng[k] = ax.shape[0]
+    shape = tuple(ax.shape[0] for ax in axes)
+    jac = np.empty(shape + (ncomp, sdim)) if want_jac else None
+    ev = np.empty(shape + (ncomp,)) if not want_jac else None
+    ctx = _lib.context()
+    _lib.check(_lib.load().igx_grid_jacobian(ctx.handle, C.byref(d), int(ncomp), grid, ng,
+                                             _lib.dptr(jac) if want_jac else None,
+                                             _lib.dptr(ev) if not want_jac else None),
+               'igx_grid_jacobian')
+    return jac if want_jac else ev
+
+
+class _BaseSplineFunc:
+    def is_scalar(self):
+        return len(self.output_shape()) == 0
+
+    def is_vector(self):
+        return len(self.output_shape()) == 1
+
+    @property
+    def support(self):
+        return tuple(kv.support() for kv in self.kvs)
+
+
+class BSplineFunc(_BaseSplineFunc):
+    """Function given by tensor-product B-spline coefficients (pyiga/bspline.py:820-921).
+
+    `kvs` are in (z, y, x) order; trailing axes of `coeffs` give the output dimension.
+    """
+
+    def __init__(self, kvs, coeffs):
+        if isinstance(kvs, KnotVector):
+            kvs = (kvs,)
+        self.kvs = tuple(kvs)
+        self.sdim = len(kvs)
+        N = tuple(kv.numdofs for kv in kvs)
+        coeffs = np.asanyarray(coeffs)
+        if coeffs.ndim == 1:
+            assert coeffs.shape[0] == np.prod(N), 'Wrong length of coefficient vector'
+            coeffs = coeffs.reshape(N)
+        assert N == coeffs.shape[:self.sdim], 'Wrong shape of coefficients'
+        self.coeffs = coeffs
+        dim = coeffs.shape[self.sdim:]
+        if len(dim) == 0:
+            dim = 1
+        elif len(dim) == 1:
+            dim = dim[0]
+        self.dim = dim
+
+    def output_shape(self):
+        return self.coeffs.shape[self.sdim:]
+
+    def copy(self):
+        return BSplineFunc(tuple(kv.copy() for kv in self.kvs), self.coeffs.copy())
+
+    def _ncomp(self):
+        assert len(self.output_shape()) <= 1, 'tensor-valued functions are not supported on the device'
+        return int(np.prod(self.output_shape())) if self.output_shape() else 1
+
+    def grid_eval(self, gridaxes):
+        """Values on a tensor grid (x axis last)."""
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        nc = self._ncomp()
+        out = _device_grid_eval(self.kvs, self.coeffs.reshape(self.coeffs.shape[:self.sdim] + (nc,)),
+                                False, nc, gridaxes, want_jac=False)
+        return out[..., 0] if self.is_scalar() else out
+
+    def grid_jacobian(self, gridaxes):
+        """Jacobians ``shape(grid) x dim x sdim``; last axis is d/d(x,y,z)."""
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        nc = self._ncomp()
+        out = _device_grid_eval(self.kvs, self.coeffs.reshape(self.coeffs.shape[:self.sdim] + (nc,)),
+                                False, nc, gridaxes, want_jac=True)
+        return out[..., 0, :] if self.is_scalar() else out
+
+    def as_nurbs(self):
+        from .geometry import NurbsFunc
+        return NurbsFunc(self.kvs, self.coeffs.copy(), np.ones(self.coeffs.shape[:self.sdim]))
+
+    def as_vector(self):
+        if self.is_vector():
+            return self
+        assert self.is_scalar()
+        return BSplineFunc(self.kvs, self.coeffs[..., None])

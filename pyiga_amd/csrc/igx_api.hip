@@ -1,0 +1,569 @@
+// libigx C ABI: host logic (knot-vector bookkeeping, patch set-up, dispatch).  See include/igx.h.
+#include "igx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace igx {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// Gauss-Legendre rule on [-1,1] by Newton iteration on P_n (used when the caller gives no rule;
+// the Python host passes numpy.polynomial.legendre.leggauss like pyiga/quadrature.py:8)
+static void gauss_legendre(int n, std::vector<double> &x, std::vector<double> &w)
+{
+    x.assign(n, 0.0);
+    w.assign(n, 0.0);
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double z = std::cos(M_PI * (i + 0.75) / (n + 0.5));
+        double pp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            double z1 = z;
+            z = z1 - p1 / pp;
+            if (std::fabs(z - z1) < 1e-16) break;
+        }
+        x[i] = -z;
+        x[n - 1 - i] = z;
+        w[i] = w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+    if (n % 2 == 1) x[n / 2] = 0.0;
+}
+
+template <class T>
+static int dev_alloc_copy(T **dst, const T *src, size_t n, hipStream_t st)
+{
+    IGX_HIP(hipMalloc((void **)dst, std::max<size_t>(1, n) * sizeof(T)));
+    if (n) IGX_HIP(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+    return IGX_OK;
+}
+
+// Knot-vector bookkeeping: restates KnotVector.mesh / mesh_support_idx_all / mesh_span_indices
+// (pyiga/bspline.py:110-144), compute_sparsity_ij (pyiga/mlmatrix.py:420-440) and the iterated
+// Gauss rule (pyiga/quadrature.py:3-16).
+static int setup_axis(Axis &A, const double *kv, int len, int p, int q, const double *gx, const double *gw)
+{
+    if (p < 0 || p > IGX_MAX_DEGREE) { set_error("degree %d out of range [0,%d]", p, IGX_MAX_DEGREE); return IGX_ERR_ARG; }
+    if (len < 2 * (p + 1)) { set_error("knot vector too short (%d knots for degree %d)", len, p); return IGX_ERR_ARG; }
+    for (int i = 1; i < len; ++i)
+        if (kv[i] < kv[i - 1]) { set_error("knots should be increasing"); return IGX_ERR_ARG; }
+    A.p = p; A.P = p + 1; A.q = q;
+    A.kv.assign(kv, kv + len);
+    A.N = len - p - 1;
+    std::vector<int> k2m(len);
+    A.mesh.clear();
+    for (int i = 0; i < len; ++i) {
+        if (i == 0 || kv[i] != kv[i - 1]) A.mesh.push_back(kv[i]);
+        k2m[i] = (int)A.mesh.size() - 1;
+    }
+    A.n = (int)A.mesh.size() - 1;
+    if (A.n < 1) { set_error("knot vector has no nonempty span"); return IGX_ERR_ARG; }
+    A.G = A.n * q;
+    A.span_knot.assign(A.n, 0);
+    A.fa.assign(A.n, 0);
+    A.simple = true;
+    for (int i = 0; i + 1 < len; ++i)
+        if (k2m[i] != k2m[i + 1]) A.span_knot[k2m[i]] = i;          // last knot index equal to mesh[s]
+    for (int s = 0; s < A.n; ++s) {
+        A.fa[s] = A.span_knot[s] - p;
+        if (A.fa[s] < 0 || A.fa[s] + p >= A.N) { set_error("knot vector is not open (span %d)", s); return IGX_ERR_ARG; }
+        if (s > 0 && A.fa[s] - A.fa[s - 1] != 1) A.simple = false;
+    }
+    A.mslo.resize(A.N); A.mshi.resize(A.N); A.jlo.resize(A.N); A.jhi.resize(A.N); A.rp.resize(A.N + 1);
+    for (int i = 0; i < A.N; ++i) { A.mslo[i] = k2m[i]; A.mshi[i] = k2m[i + p + 1]; }
+    auto overlap = [&](int i, int j) { return std::min(A.mshi[i], A.mshi[j]) > std::max(A.mslo[i], A.mslo[j]); };
+    A.pair_i.clear(); A.pair_j.clear();
+    A.rp[0] = 0;
+    for (int i = 0; i < A.N; ++i) {
+        if (A.mshi[i] <= A.mslo[i]) { set_error("basis function %d has empty support", i); return IGX_ERR_ARG; }
+        int lo = i, hi = i + 1;
+        while (lo > 0 && overlap(i, lo - 1)) --lo;
+        while (hi < A.N && overlap(i, hi)) ++hi;
+        A.jlo[i] = lo; A.jhi[i] = hi;
+        A.rp[i + 1] = A.rp[i] + (hi - lo);
+        for (int j = lo; j < hi; ++j) { A.pair_i.push_back(i); A.pair_j.push_back(j); }
+    }
+    A.S = A.rp[A.N];
+    // iterated Gauss rule: nodes = outer(h, x) + m, weights = outer(h, w)
+    A.nodes.resize(A.G); A.weights.resize(A.G);
+    for (int s = 0; s < A.n; ++s) {
+        const double a = A.mesh[s], b = A.mesh[s + 1];
+        const double m = 0.5 * (a + b), h = 0.5 * (b - a);
+        for (int l = 0; l < q; ++l) {
+            const double hx = h * gx[l];
+            A.nodes[s * q + l] = hx + m;
+            A.weights[s * q + l] = h * gw[l];
+        }
+    }
+    return IGX_OK;
+}
+
+static int upload_axis(Axis &A, hipStream_t st)
+{
+    int rc;
+    if ((rc = dev_alloc_copy(&A.d_kv, A.kv.data(), A.kv.size(), st))) return rc;
+    if ((rc = dev_alloc_copy(&A.d_nodes, A.nodes.data(), A.nodes.size(), st))) return rc;
+    if ((rc = dev_alloc_copy(&A.d_w, A.weights.data(), A.weights.size(), st))) return rc;
+    std::vector<int> ints;
+    auto app = [&](const int *v, size_t n) { size_t o = ints.size(); ints.insert(ints.end(), v, v + n); return o; };
+    const size_t o_fa = app(A.fa.data(), A.n), o_lo = app(A.mslo.data(), A.N), o_hi = app(A.mshi.data(), A.N);
+    const size_t o_jl = app(A.jlo.data(), A.N), o_jh = app(A.jhi.data(), A.N), o_rp = app(A.rp.data(), A.N + 1);
+    const size_t o_pi = app(A.pair_i.data(), A.S), o_pj = app(A.pair_j.data(), A.S);
+    if ((rc = dev_alloc_copy(&A.d_ints, ints.data(), ints.size(), st))) return rc;
+    IGX_HIP(hipMalloc((void **)&A.d_V, (size_t)A.G * A.P * 2 * sizeof(double)));
+    IGX_HIP(hipMalloc((void **)&A.d_PI, (size_t)A.G * 4 * A.P * A.P * sizeof(double)));
+    if ((rc = launch_basis_tables(st, A.d_kv, (int)A.kv.size(), A.p, A.d_nodes, (size_t)A.G, 1, nullptr, A.d_V, nullptr, nullptr))) return rc;
+    if ((rc = launch_pi_tables(st, A.d_V, A.G, A.P, A.d_PI))) return rc;
+    AxisDev &D = A.dev;
+    D.p = A.p; D.P = A.P; D.N = A.N; D.n = A.n; D.q = A.q; D.G = A.G; D.S = A.S;
+    D.nodes = A.d_nodes; D.w = A.d_w; D.V = A.d_V; D.PI = A.d_PI;
+    D.fa = A.d_ints + o_fa; D.mslo = A.d_ints + o_lo; D.mshi = A.d_ints + o_hi;
+    D.jlo = A.d_ints + o_jl; D.jhi = A.d_ints + o_jh; D.rp = A.d_ints + o_rp;
+    D.pair_i = A.d_ints + o_pi; D.pair_j = A.d_ints + o_pj;
+    IGX_HIP(hipStreamSynchronize(st));            // `ints` is a local buffer
+    return IGX_OK;
+}
+
+static void free_axis(Axis &A)
+{
+    hipFree(A.d_kv); hipFree(A.d_nodes); hipFree(A.d_w); hipFree(A.d_V); hipFree(A.d_PI); hipFree(A.d_ints);
+}
+
+static int setup_geo_axis(GeoAxis &g, const double *kv, int len, int p, const double *d_nodes, int G, hipStream_t st)
+{
+    if (p < 0 || p > IGX_MAX_DEGREE || len < 2 * (p + 1)) { set_error("bad geometry knot vector (p=%d, %d knots)", p, len); return IGX_ERR_ARG; }
+    g.p = p; g.P = p + 1; g.N = len - p - 1;
+    g.kv.assign(kv, kv + len);
+    int rc;
+    if ((rc = dev_alloc_copy(&g.d_kv, kv, (size_t)len, st))) return rc;
+    IGX_HIP(hipMalloc((void **)&g.d_V, std::max<size_t>(1, (size_t)G * g.P * 2) * sizeof(double)));
+    IGX_HIP(hipMalloc((void **)&g.d_fa, std::max<size_t>(1, (size_t)G) * sizeof(int)));
+    return launch_basis_tables(st, g.d_kv, len, p, d_nodes, (size_t)G, 1, nullptr, g.d_V, g.d_fa, nullptr);
+}
+
+static void free_geo_axis(GeoAxis &g) { hipFree(g.d_kv); hipFree(g.d_V); hipFree(g.d_fa); }
+
+static int ensure_fields(igx_patch *pt, int kind)
+{
+    if (pt->fields_kind == kind) return IGX_OK;
+    const int nF = (kind == IGX_MASS) ? 1 : pt->dim * (pt->dim + 1) / 2;
+    const size_t need = (size_t)nF * pt->dev.npts_loc;
+    if (pt->fields_cap < need) {
+        if (pt->d_fields) hipFree(pt->d_fields);
+        pt->d_fields = nullptr; pt->fields_cap = 0;
+        hipError_t e = hipMalloc((void **)&pt->d_fields, std::max<size_t>(1, need) * sizeof(double));
+        if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for fields failed", need * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+        pt->fields_cap = need;
+    }
+    pt->fields_kind = -1;
+    int rc = launch_geo_fields(pt->ctx->stream, pt, kind, pt->d_fields);
+    if (rc) return rc;
+    pt->fields_kind = kind;
+    return IGX_OK;
+}
+
+} // namespace igx
+
+using namespace igx;
+
+// =============================================================================================
+extern "C" {
+
+int igx_version(void) { return IGX_VERSION; }
+const char *igx_last_error(void) { return g_err; }
+
+igx_ctx *igx_create(int device_id)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        set_error("no HIP device available (%s); libigx has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("device %d out of range (have %d)", device_id, ndev); return nullptr; }
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return nullptr; }
+    igx_ctx *ctx = new (std::nothrow) igx_ctx();
+    if (!ctx) return nullptr;
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
+    for (auto &ev : ctx->ev) hipEventCreate(&ev);
+    return ctx;
+}
+
+void igx_destroy(igx_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->ev) hipEventDestroy(ev);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int igx_sync(igx_ctx *ctx)
+{
+    if (!ctx) { set_error("null context"); return IGX_ERR_ARG; }
+    IGX_HIP(hipStreamSynchronize(ctx->stream));
+    return IGX_OK;
+}
+
+void *igx_stream(igx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+int igx_active_deriv(igx_ctx *ctx, const double *kv, int kv_len, int p, const double *u, size_t nu, int numderiv, double *out)
+{
+    if (!ctx || !kv || !u || !out) { set_error("igx_active_deriv: null argument"); return IGX_ERR_ARG; }
+    if (p < 0 || p > IGX_MAX_DEGREE || kv_len < 2 * (p + 1) || numderiv < 0) { set_error("igx_active_deriv: bad p/kv_len/numderiv"); return IGX_ERR_ARG; }
+    if (nu == 0) return IGX_OK;
+    IGX_HIP(hipSetDevice(ctx->device));
+    double *d_kv = nullptr, *d_u = nullptr, *d_out = nullptr;
+    const size_t nout = (size_t)(numderiv + 1) * (p + 1) * nu;
+    int rc;
+    if ((rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream))) return rc;
+    if ((rc = dev_alloc_copy(&d_u, u, nu, ctx->stream))) return rc;
+    IGX_HIP(hipMalloc((void **)&d_out, nout * sizeof(double)));
+    rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, numderiv, d_out, nullptr, nullptr, nullptr);
+    if (!rc) {
+        IGX_HIP(hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        IGX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    hipFree(d_kv); hipFree(d_u); hipFree(d_out);
+    return rc;
+}
+
+int igx_find_spans(igx_ctx *ctx, const double *kv, int kv_len, int p, const double *u, size_t nu, int64_t *spans)
+{
+    if (!ctx || !kv || !u || !spans) { set_error("igx_find_spans: null argument"); return IGX_ERR_ARG; }
+    if (p < 0 || p > IGX_MAX_DEGREE || kv_len < 2 * (p + 1)) { set_error("igx_find_spans: bad p/kv_len"); return IGX_ERR_ARG; }
+    if (nu == 0) return IGX_OK;
+    IGX_HIP(hipSetDevice(ctx->device));
+    double *d_kv = nullptr, *d_u = nullptr;
+    long long *d_sp = nullptr;
+    int rc;
+    if ((rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream))) return rc;
+    if ((rc = dev_alloc_copy(&d_u, u, nu, ctx->stream))) return rc;
+    IGX_HIP(hipMalloc((void **)&d_sp, nu * sizeof(long long)));
+    rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, 0, nullptr, nullptr, nullptr, d_sp);
+    if (!rc) {
+        IGX_HIP(hipMemcpyAsync(spans, d_sp, nu * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        IGX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    hipFree(d_kv); hipFree(d_u); hipFree(d_sp);
+    return rc;
+}
+
+int igx_grid_jacobian(igx_ctx *ctx, const igx_patch_desc *d, int ncomp, const double *const grid[IGX_MAX_DIM],
+                      const int32_t ngrid[IGX_MAX_DIM], double *jac_out, double *eval_out)
+{
+    if (!ctx || !d || !grid || !ngrid) { set_error("igx_grid_jacobian: null argument"); return IGX_ERR_ARG; }
+    const int dim = d->dim;
+    if (dim != 2 && dim != 3) { set_error("igx_grid_jacobian: dim must be 2 or 3"); return IGX_ERR_ARG; }
+    if (d->geo_kind != IGX_GEO_BSPLINE && d->geo_kind != IGX_GEO_NURBS) { set_error("igx_grid_jacobian: needs a spline geometry"); return IGX_ERR_ARG; }
+    const bool nurbs = d->geo_kind == IGX_GEO_NURBS;
+    const int nc = ncomp + (nurbs ? 1 : 0);
+    if (ncomp < 1 || nc > MAX_COMP) { set_error("igx_grid_jacobian: %d components unsupported", ncomp); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    GeoAxis gax[3];
+    double *d_grid[3] = {nullptr, nullptr, nullptr};
+    int G[3] = {1, 1, 1};
+    size_t nctrl = nc;
+    int rc = IGX_OK;
+    for (int k = 0; k < dim && !rc; ++k) {
+        G[k] = ngrid[k];
+        rc = dev_alloc_copy(&d_grid[k], grid[k], (size_t)G[k], st);
+        if (!rc) rc = setup_geo_axis(gax[k], d->geo_kv[k], d->geo_kv_len[k], d->geo_p[k], d_grid[k], G[k], st);
+        nctrl *= (size_t)gax[k].N;
+    }
+    double *d_ctrl = nullptr, *d_j = nullptr, *d_e = nullptr;
+    const size_t npts = (size_t)G[0] * G[1] * G[2];
+    if (!rc) rc = dev_alloc_copy(&d_ctrl, d->ctrl, nctrl, st);
+    if (!rc && jac_out && hipMalloc((void **)&d_j, std::max<size_t>(1, npts * ncomp * dim) * sizeof(double)) != hipSuccess) rc = IGX_ERR_NOMEM;
+    if (!rc && eval_out && hipMalloc((void **)&d_e, std::max<size_t>(1, npts * ncomp) * sizeof(double)) != hipSuccess) rc = IGX_ERR_NOMEM;
+    if (!rc) rc = launch_grid_geo(st, dim, nc, nurbs, gax, G, d_ctrl, d_j, d_e);
+    if (!rc && jac_out && hipMemcpyAsync(jac_out, d_j, npts * ncomp * dim * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = IGX_ERR_HIP;
+    if (!rc && eval_out && hipMemcpyAsync(eval_out, d_e, npts * ncomp * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = IGX_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { set_error("igx_grid_jacobian: stream sync failed"); rc = IGX_ERR_HIP; }
+    for (int k = 0; k < dim; ++k) { free_geo_axis(gax[k]); hipFree(d_grid[k]); }
+    hipFree(d_ctrl); hipFree(d_j); hipFree(d_e);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+void igx_patch_destroy(igx_patch *pt)
+{
+    if (!pt) return;
+    hipSetDevice(pt->ctx->device);
+    hipStreamSynchronize(pt->ctx->stream);
+    for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
+    hipFree(pt->d_ctrl); hipFree(pt->d_jac); hipFree(pt->d_fields); hipFree(pt->d_data);
+    hipFree(pt->d_indices); hipFree(pt->d_indptr); hipFree(pt->d_pl0); hipFree(pt->d_rl0_of);
+    hipFree(pt->d_K1); hipFree(pt->d_K2);
+    delete pt;
+}
+
+igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
+{
+    if (!ctx || !d) { set_error("igx_patch_create: null argument"); return nullptr; }
+    const int dim = d->dim;
+    if (dim != 2 && dim != 3) { set_error("igx_patch_create: dim must be 2 or 3 (got %d)", dim); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    igx_patch *pt = new (std::nothrow) igx_patch();
+    if (!pt) return nullptr;
+    pt->ctx = ctx;
+    pt->dim = dim;
+    hipStream_t st = ctx->stream;
+    int rc = IGX_OK;
+
+    // Gauss rule: nqp = max p + 1 shared by all axes (pyiga/assemblers.pyx:1338)
+    int q = d->nqp;
+    if (q <= 0) { q = 0; for (int k = 0; k < dim; ++k) q = std::max(q, d->p[k] + 1); }
+    pt->nqp = q;
+    std::vector<double> gx, gw;
+    if (d->gauss_x && d->gauss_w) { gx.assign(d->gauss_x, d->gauss_x + q); gw.assign(d->gauss_w, d->gauss_w + q); }
+    else gauss_legendre(q, gx, gw);
+
+    for (int k = 0; k < dim && !rc; ++k) {
+        if (!d->kv[k]) { set_error("igx_patch_create: kv[%d] is null", k); rc = IGX_ERR_ARG; break; }
+        rc = setup_axis(pt->ax[k], d->kv[k], d->kv_len[k], d->p[k], q, gx.data(), gw.data());
+        if (!rc) rc = upload_axis(pt->ax[k], st);
+    }
+    if (dim == 2) {            // neutral third axis for index arithmetic
+        pt->ax[2].N = 1; pt->ax[2].n = 1; pt->ax[2].G = 1; pt->ax[2].S = 1; pt->ax[2].q = q;
+        pt->ax[2].dev.N = 1; pt->ax[2].dev.n = 1; pt->ax[2].dev.G = 1; pt->ax[2].dev.S = 1; pt->ax[2].dev.q = q;
+    }
+    // slab
+    if (!rc) {
+        const Axis &A0 = pt->ax[0];
+        pt->r0_lo = d->row0_lo;
+        pt->r0_hi = d->row0_hi > 0 ? d->row0_hi : A0.N;
+        if (pt->r0_lo < 0 || pt->r0_hi > A0.N || pt->r0_lo >= pt->r0_hi) {
+            set_error("igx_patch_create: bad row slab [%d,%d) for %d dofs", pt->r0_lo, pt->r0_hi, A0.N);
+            rc = IGX_ERR_ARG;
+        }
+    }
+    if (!rc) {
+        const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
+        pt->s0_lo = A0.mslo[pt->r0_lo];
+        pt->s0_hi = A0.mshi[pt->r0_hi - 1];
+        const long long plane = (long long)A1.N * A2.N;
+        const long long Srest = (long long)A1.S * A2.S;
+        pt->nrows_total = (long long)A0.N * plane;
+        pt->row_lo = pt->r0_lo * plane;
+        pt->row_hi = pt->r0_hi * plane;
+        pt->nnz_off = (long long)A0.rp[pt->r0_lo] * Srest;
+        pt->nnz = (long long)(A0.rp[pt->r0_hi] - A0.rp[pt->r0_lo]) * Srest;
+        // elements attributed to this slab: spans of axis 0 split proportionally to the owned dofs
+        const long long sp_lo = (long long)A0.n * pt->r0_lo / A0.N, sp_hi = (long long)A0.n * pt->r0_hi / A0.N;
+        pt->nelem_owned = (sp_hi - sp_lo) * A1.n * A2.n;
+        if (pt->nnz > 0x7fffffffLL) {
+            set_error("slab has %lld nonzeros; int32 CSR indices need < 2^31 (use more slabs)", pt->nnz);
+            rc = IGX_ERR_UNSUPPORTED;
+        }
+        PatchDev &pd = pt->dev;
+        pd.dim = dim;
+        for (int k = 0; k < 3; ++k) pd.ax[k] = pt->ax[k].dev;
+        pd.r0_lo = pt->r0_lo; pd.r0_hi = pt->r0_hi; pd.s0_lo = pt->s0_lo; pd.s0_hi = pt->s0_hi;
+        pd.g0_lo = pt->s0_lo * q; pd.G0_loc = (pt->s0_hi - pt->s0_lo) * q;
+        pd.npts_loc = (long long)pd.G0_loc * A1.G * A2.G;
+        pd.nnz_off = pt->nnz_off;
+    }
+    // geometry
+    if (!rc) {
+        pt->geo_kind = d->geo_kind;
+        if (d->geo_kind == IGX_GEO_BSPLINE || d->geo_kind == IGX_GEO_NURBS) {
+            pt->ncomp = dim + (d->geo_kind == IGX_GEO_NURBS ? 1 : 0);
+            if (!d->ctrl) { set_error("igx_patch_create: ctrl is null"); rc = IGX_ERR_ARG; }
+            size_t nctrl = pt->ncomp;
+            for (int k = 0; k < dim && !rc; ++k) {
+                if (!d->geo_kv[k]) { set_error("igx_patch_create: geo_kv[%d] is null", k); rc = IGX_ERR_ARG; break; }
+                rc = setup_geo_axis(pt->gax[k], d->geo_kv[k], d->geo_kv_len[k], d->geo_p[k], pt->ax[k].d_nodes, pt->ax[k].G, st);
+                nctrl *= (size_t)pt->gax[k].N;
+                // the geometry must be defined on the parameter domain of the basis
+                if (!rc && (pt->gax[k].kv.front() > pt->ax[k].kv.front() || pt->gax[k].kv.back() < pt->ax[k].kv.back())) {
+                    set_error("geometry knot vector %d does not cover the parameter domain", k);
+                    rc = IGX_ERR_ARG;
+                }
+            }
+            if (!rc) rc = dev_alloc_copy(&pt->d_ctrl, d->ctrl, nctrl, st);
+        } else if (d->geo_kind == IGX_GEO_JACOBIAN) {
+            if (!d->jac) { set_error("igx_patch_create: jac is null"); rc = IGX_ERR_ARG; }
+            else {
+                const size_t per_plane = (size_t)pt->ax[1].G * pt->ax[2].G * dim * dim;
+                rc = dev_alloc_copy(&pt->d_jac, d->jac + (size_t)pt->dev.g0_lo * per_plane, (size_t)pt->dev.G0_loc * per_plane, st);
+            }
+        } else { set_error("igx_patch_create: unknown geo_kind %d", d->geo_kind); rc = IGX_ERR_ARG; }
+    }
+    if (!rc) {
+        pt->sumfact_ok = sumfact_supported(pt) != 0;
+        if (pt->sumfact_ok) rc = sumfact_prepare(pt);
+    }
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("igx_patch_create: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = IGX_ERR_HIP; }
+    if (rc) { igx_patch_destroy(pt); return nullptr; }
+    return pt;
+}
+
+int igx_patch_get_info(const igx_patch *pt, igx_patch_info *info)
+{
+    if (!pt || !info) { set_error("igx_patch_get_info: null argument"); return IGX_ERR_ARG; }
+    memset(info, 0, sizeof(*info));
+    info->dim = pt->dim; info->nqp = pt->nqp;
+    for (int k = 0; k < pt->dim; ++k) { info->ndofs[k] = pt->ax[k].N; info->nspans[k] = pt->ax[k].n; info->ngauss[k] = pt->ax[k].G; }
+    info->nrows_total = pt->nrows_total; info->row_lo = pt->row_lo; info->row_hi = pt->row_hi;
+    info->nnz = pt->nnz; info->nnz_offset = pt->nnz_off; info->nelem_owned = pt->nelem_owned;
+    info->sumfact_ok = pt->sumfact_ok ? 1 : 0;
+    return IGX_OK;
+}
+
+int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)
+{
+    if (!pt || axis < 0 || axis >= pt->dim) { set_error("igx_patch_gauss: bad argument"); return IGX_ERR_ARG; }
+    if (nodes) memcpy(nodes, pt->ax[axis].nodes.data(), pt->ax[axis].nodes.size() * sizeof(double));
+    if (weights) memcpy(weights, pt->ax[axis].weights.data(), pt->ax[axis].weights.size() * sizeof(double));
+    return IGX_OK;
+}
+
+int igx_pattern(igx_patch *pt, int32_t *indptr, int32_t *indices)
+{
+    if (!pt) { set_error("igx_pattern: null patch"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    const long long nrows = pt->row_hi - pt->row_lo;
+    if (!pt->have_pattern) {
+        if (!pt->d_indptr) IGX_HIP(hipMalloc((void **)&pt->d_indptr, (size_t)(nrows + 1) * sizeof(int32_t)));
+        if (!pt->d_indices) {
+            hipError_t e = hipMalloc((void **)&pt->d_indices, std::max<size_t>(1, (size_t)pt->nnz) * sizeof(int32_t));
+            if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR indices failed", pt->nnz * 4.0 / 1e9); return IGX_ERR_NOMEM; }
+        }
+        int rc = launch_pattern(st, pt, pt->d_indptr, pt->d_indices);
+        if (rc) return rc;
+        pt->have_pattern = true;
+    }
+    if (indptr) IGX_HIP(hipMemcpyAsync(indptr, pt->d_indptr, (size_t)(nrows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (indices) IGX_HIP(hipMemcpyAsync(indices, pt->d_indices, (size_t)pt->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    IGX_HIP(hipStreamSynchronize(st));
+    return IGX_OK;
+}
+
+int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
+{
+    if (!pt) { set_error("igx_assemble: null patch"); return IGX_ERR_ARG; }
+    if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    if (algo == IGX_ALGO_AUTO) algo = pt->sumfact_ok ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
+    if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
+    if (algo != IGX_ALGO_SUMFACT && algo != IGX_ALGO_ENTRYWISE) { set_error("igx_assemble: unknown algo %d", algo); return IGX_ERR_ARG; }
+    if (!pt->d_data) {
+        hipError_t e = hipMalloc((void **)&pt->d_data, std::max<size_t>(1, (size_t)pt->nnz) * sizeof(double));
+        if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR values failed", pt->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+    }
+    if (getenv("IGX_DEBUG_POISON"))               // every value must be written exactly once
+        IGX_HIP(hipMemsetAsync(pt->d_data, 0xFF, (size_t)pt->nnz * sizeof(double), st));
+    memset(&pt->timing, 0, sizeof(pt->timing));
+    pt->timing.algo_used = algo;
+    hipEvent_t *ev = pt->ctx->ev;
+    IGX_HIP(hipEventRecord(ev[0], st));
+    pt->fields_kind = -1;                           // the timed path always recomputes the fields
+    int rc = ensure_fields(pt, kind);
+    if (rc) return rc;
+    pt->timing.n_launches = 1;
+    IGX_HIP(hipEventRecord(ev[1], st));
+    if (algo == IGX_ALGO_SUMFACT) {
+        rc = sumfact_assemble(pt, kind, pt->d_data);
+        if (rc) return rc;
+    } else {
+        rc = launch_entries_csr(st, pt, kind, pt->d_data);
+        if (rc) return rc;
+        pt->timing.n_launches++;
+        IGX_HIP(hipEventRecord(ev[4], st));
+    }
+    IGX_HIP(hipEventRecord(ev[5], st));
+    IGX_HIP(hipStreamSynchronize(st));
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("igx_assemble: kernel failure: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+    }
+    hipEventElapsedTime(&pt->timing.total_ms, ev[0], ev[5]);
+    hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
+    if (algo == IGX_ALGO_SUMFACT) {
+        hipEventElapsedTime(&pt->timing.stage0_ms, ev[1], ev[2]);
+        hipEventElapsedTime(&pt->timing.stage1_ms, ev[2], ev[3]);
+        hipEventElapsedTime(&pt->timing.final_ms, ev[3], ev[4]);
+    } else {
+        hipEventElapsedTime(&pt->timing.entry_ms, ev[1], ev[4]);
+    }
+    if (data_out) {
+        IGX_HIP(hipMemcpyAsync(data_out, pt->d_data, (size_t)pt->nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+        IGX_HIP(hipStreamSynchronize(st));
+    }
+    return IGX_OK;
+}
+
+int igx_last_timing(const igx_patch *pt, igx_timing *t)
+{
+    if (!pt || !t) { set_error("igx_last_timing: null argument"); return IGX_ERR_ARG; }
+    *t = pt->timing;
+    return IGX_OK;
+}
+
+const double *igx_d_csr_data(const igx_patch *pt) { return pt ? pt->d_data : nullptr; }
+const int32_t *igx_d_csr_indices(const igx_patch *pt) { return pt ? pt->d_indices : nullptr; }
+const int32_t *igx_d_csr_indptr(const igx_patch *pt) { return pt ? pt->d_indptr : nullptr; }
+
+int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out)
+{
+    if (!pt || (M && (!ij || !out))) { set_error("igx_entries: null argument"); return IGX_ERR_ARG; }
+    if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_entries: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (M == 0) return IGX_OK;
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc = ensure_fields(pt, kind);
+    if (rc) return rc;
+    size_t *d_ij = nullptr;
+    double *d_out = nullptr;
+    if ((rc = dev_alloc_copy(&d_ij, ij, 2 * M, st))) return rc;
+    IGX_HIP(hipMalloc((void **)&d_out, M * sizeof(double)));
+    rc = launch_entries_list(st, pt, kind, d_ij, M, d_out);
+    if (!rc) {
+        IGX_HIP(hipMemcpyAsync(out, d_out, M * sizeof(double), hipMemcpyDeviceToHost, st));
+        IGX_HIP(hipStreamSynchronize(st));
+    }
+    hipFree(d_ij); hipFree(d_out);
+    return rc;
+}
+
+int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
+{
+    if (!pt) { set_error("igx_fields: null patch"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    int rc = ensure_fields(pt, kind);
+    if (rc) return rc;
+    const int nF = (kind == IGX_MASS) ? 1 : pt->dim * (pt->dim + 1) / 2;
+    if (shape4) { shape4[0] = nF; shape4[1] = pt->dev.G0_loc; shape4[2] = pt->ax[1].G; shape4[3] = pt->dim == 3 ? pt->ax[2].G : 1; }
+    if (out) {
+        IGX_HIP(hipMemcpyAsync(out, pt->d_fields, (size_t)nF * pt->dev.npts_loc * sizeof(double), hipMemcpyDeviceToHost, pt->ctx->stream));
+        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    }
+    return IGX_OK;
+}
+
+} // extern "C"

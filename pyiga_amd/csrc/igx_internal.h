@@ -1,0 +1,141 @@
+// Internal declarations shared by the libigx translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "igx.h"
+
+namespace igx {
+
+constexpr int MAXP = IGX_MAX_DEGREE + 1;      // max active functions per span
+constexpr int MAX_COMP = 4;                   // geometry components incl. NURBS weight
+
+void set_error(const char *fmt, ...);
+#define IGX_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            igx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return IGX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Device-side views (POD, passed to kernels by value)
+struct AxisDev {
+    int p, P, N, n, q, G;     // degree, p+1, ndofs, nspans, Gauss pts/span, G = n*q
+    int S;                    // number of 1D (i,j) pairs with overlapping support
+    const double *nodes;      // [G]
+    const double *w;          // [G]
+    const double *V;          // [G][P][2]   (value, derivative) of the P active functions
+    const double *PI;         // [G][4][P][P] products  PI[t][a][b] = V[b][tu]*V[a][tv], t = tu + 2*tv
+                              //              (a: test function i, b: trial function j)
+    const int *fa;            // [n]   first active dof of span s
+    const int *mslo, *mshi;   // [N]   mesh-span support [mslo, mshi) of dof i
+    const int *jlo, *jhi;     // [N]   1D column range of row i
+    const int *rp;            // [N+1] exclusive prefix sum of (jhi - jlo): 1D pair index base
+    const int *pair_i, *pair_j; // [S]  inverse of the pair index: r -> (i, j)
+};
+
+struct PatchDev {
+    int dim;
+    AxisDev ax[3];
+    int r0_lo, r0_hi;         // owned dof planes of axis 0
+    int s0_lo, s0_hi;         // resident span range of axis 0
+    int g0_lo;                // first resident Gauss index of axis 0 (= s0_lo * q)
+    int G0_loc;               // number of resident Gauss planes
+    long long npts_loc;       // resident Gauss points = G0_loc * G1 [* G2]
+    long long nnz_off;        // global indptr[row_lo]
+};
+
+// global CSR row pointer of row (i0,i1,i2); see DESIGN.md "CSR pattern without index arrays"
+__host__ __device__ inline long long igx_rowptr3(const int *rp0, const int *rp1, const int *rp2,
+                                                 long long S1, long long S2, int c0, int c1,
+                                                 int i0, int i1, int i2)
+{
+    return (long long)rp0[i0] * S1 * S2 + (long long)c0 * ((long long)rp1[i1] * S2 + (long long)c1 * rp2[i2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side state
+struct Axis {
+    int p = 0, P = 0, N = 0, n = 0, q = 0, G = 0, S = 0;
+    bool simple = true;                       // all interior knots have multiplicity 1
+    std::vector<double> kv, mesh, nodes, weights;
+    std::vector<int> span_knot, fa, mslo, mshi, jlo, jhi, rp, pair_i, pair_j;
+    // device
+    double *d_kv = nullptr, *d_nodes = nullptr, *d_w = nullptr, *d_V = nullptr, *d_PI = nullptr;
+    int *d_ints = nullptr;                    // one allocation: fa | mslo | mshi | jlo | jhi | rp | pair_i | pair_j
+    AxisDev dev{};
+};
+
+struct GeoAxis {                              // geometry basis restricted to the Gauss nodes
+    int p = 0, P = 0, N = 0;
+    std::vector<double> kv;
+    double *d_kv = nullptr;
+    double *d_V = nullptr;                    // [G][P][2]
+    int *d_fa = nullptr;                      // [G] first active control index at node g
+};
+
+struct Plan;                                   // sum-factorisation plan (sumfact.hip)
+
+} // namespace igx
+
+struct igx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+};
+
+struct igx_patch {
+    igx_ctx *ctx = nullptr;
+    int dim = 0, nqp = 0;
+    igx::Axis ax[3];
+    // geometry
+    int geo_kind = 0, ncomp = 0;              // ncomp = dim (+1 for NURBS)
+    igx::GeoAxis gax[3];
+    double *d_ctrl = nullptr;
+    double *d_jac = nullptr;                  // IGX_GEO_JACOBIAN: resident slab of the user array
+    // slab
+    int r0_lo = 0, r0_hi = 0, s0_lo = 0, s0_hi = 0;
+    long long row_lo = 0, row_hi = 0, nnz = 0, nnz_off = 0, nrows_total = 0, nelem_owned = 0;
+    igx::PatchDev dev{};
+    // fields cache
+    int fields_kind = -1;
+    double *d_fields = nullptr;               // [F][npts_loc]
+    size_t fields_cap = 0;
+    // CSR
+    double *d_data = nullptr;
+    int32_t *d_indices = nullptr, *d_indptr = nullptr;
+    bool have_pattern = false;
+    // sum factorisation workspaces
+    bool sumfact_ok = false;
+    int *d_pl0 = nullptr;                     // [npairs0][2] processed lower pairs (i0,j0) of axis 0
+    int *d_rl0_of = nullptr;                  // [S0] 1D pair index -> compact processed-pair index or -1
+    int npairs0 = 0;
+    double *d_K1 = nullptr, *d_K2 = nullptr;
+    size_t K1_cap = 0, K2_cap = 0;
+    igx_timing timing{};
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (defined in the kern_*.hip files)
+namespace igx {
+int launch_basis_tables(hipStream_t st, const double *d_kv, int nk, int p, const double *d_u, size_t nu,
+                        int numderiv, double *d_out_nd_p_n /* (nd+1,P,nu) or null */,
+                        double *d_V /* [nu][P][2] or null */, int *d_fa /* [nu] or null */,
+                        long long *d_spans /* or null */);
+int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_PI);
+int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields);
+int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3],
+                    const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);
+int launch_fields_dump(hipStream_t st, const igx_patch *pt);
+int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
+int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
+int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
+int sumfact_supported(const igx_patch *pt);
+int sumfact_prepare(igx_patch *pt);
+int sumfact_assemble(igx_patch *pt, int kind, double *d_data);
+} // namespace igx

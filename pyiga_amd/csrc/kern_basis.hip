@@ -1,0 +1,361 @@
+// B-spline basis evaluation, geometry Jacobians and quadrature fields on the device.
+//
+//   findspan / active_deriv   restate pyiga/bspline_cy.pyx:13-27, 42-121 (Piegl-Tiller A2.3)
+//   geometry evaluation       restates BSplineFunc.grid_eval/grid_jacobian (pyiga/bspline.py:874-921)
+//                             and the NURBS quotient rule (pyiga/geometry.py:17-25,116-123)
+//   fields                    restate precompute_fields (pyiga/assemblers.pyx:86-110,234-275,
+//                             1223-1249,1389-1449): W = gw*|det J|,  B = W * Jinv Jinv^T
+#include "igx_internal.h"
+
+namespace igx {
+
+// ---------------------------------------------------------------------------------------------
+__device__ inline int dev_findspan(const double *kv, int n, int p, double u)
+{
+    if (u >= kv[n - p - 1]) return n - p - 2;      // last interval
+    int a = 0, b = n - 1;
+    while (b - a > 1) {
+        int c = a + (b - a) / 2;
+        if (kv[c] > u) b = c; else a = c;
+    }
+    return a;
+}
+
+// All active basis functions and derivatives up to `nd` at u.  res(k, r) for k<=nd, r<=p.
+template <class Store>
+__device__ inline int dev_active_deriv(const double *kv, int nk, int p, double u, int nd, Store res)
+{
+    double NDU[MAXP][MAXP];
+    double left[MAXP], right[MAXP], abuf[2][MAXP + 1];
+    const int span = dev_findspan(kv, nk, p, u);
+    NDU[0][0] = 1.0;
+    for (int j = 1; j <= p; ++j) {
+        left[j - 1] = u - kv[span + 1 - j];
+        right[j - 1] = kv[span + j] - u;
+        double saved = 0.0;
+        for (int r = 0; r < j; ++r) {
+            NDU[j][r] = right[r] + left[j - r - 1];
+            double temp = NDU[r][j - 1] / NDU[j][r];
+            NDU[r][j] = saved + right[r] * temp;
+            saved = left[j - r - 1] * temp;
+        }
+        NDU[j][j] = saved;
+    }
+    for (int j = 0; j <= p; ++j) res(0, j, NDU[j][p]);
+    for (int r = 0; r <= p; ++r) {
+        int s1 = 0, s2 = 1;
+        abuf[0][0] = 1.0;
+        int fac = p;
+        for (int k = 1; k <= nd; ++k) {
+            double *a1 = abuf[s1], *a2 = abuf[s2];
+            const int rk = r - k, pk = p - k;
+            double d = 0.0;
+            if (pk < 0) { res(k, r, 0.0); continue; }
+            if (r >= k) {
+                a2[0] = a1[0] / NDU[pk + 1][rk];
+                d = a2[0] * NDU[rk][pk];
+            }
+            const int j1 = (rk >= -1) ? 1 : -rk;
+            const int j2 = (r - 1 <= pk) ? k - 1 : p - r;
+            for (int j = j1; j <= j2; ++j) {
+                a2[j] = (a1[j] - a1[j - 1]) / NDU[pk + 1][rk + j];
+                d += a2[j] * NDU[rk + j][pk];
+            }
+            if (r <= pk) {
+                a2[k] = -a1[k - 1] / NDU[pk + 1][r];
+                d += a2[k] * NDU[r][pk];
+            }
+            res(k, r, d * fac);
+            fac *= pk;
+            int t = s1; s1 = s2; s2 = t;
+        }
+    }
+    return span;
+}
+
+__global__ void k_basis_tables(const double *kv, int nk, int p, const double *u, size_t nu, int nd,
+                               double *out, double *V, int *fa, long long *spans)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nu) return;
+    const int P = p + 1;
+    double *o = out, *v = V;
+    int span = dev_active_deriv(kv, nk, p, u[i], nd, [=](int k, int r, double val) {
+        if (o) o[((size_t)k * P + r) * nu + i] = val;
+        if (v && k < 2) v[(i * P + r) * 2 + k] = val;
+    });
+    if (v && nd < 1)
+        for (int r = 0; r < P; ++r) v[(i * P + r) * 2 + 1] = 0.0;
+    if (fa) fa[i] = span - p;
+    if (spans) spans[i] = span;
+}
+
+int launch_basis_tables(hipStream_t st, const double *d_kv, int nk, int p, const double *d_u, size_t nu,
+                        int numderiv, double *d_out, double *d_V, int *d_fa, long long *d_spans)
+{
+    if (nu == 0) return IGX_OK;
+    const int bs = 64;
+    k_basis_tables<<<dim3((unsigned)((nu + bs - 1) / bs)), dim3(bs), 0, st>>>(d_kv, nk, p, d_u, nu, numderiv,
+                                                                              d_out, d_V, d_fa, d_spans);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+// PI[g][t][a][b] = V[g][b][tu] * V[g][a][tv],  t = tu + 2*tv
+__global__ void k_pi_tables(const double *V, int G, int P, double *PI)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)G * 4 * P * P;
+    if (idx >= total) return;
+    int b = idx % P;
+    int a = (idx / P) % P;
+    int t = (idx / ((size_t)P * P)) % 4;
+    size_t g = idx / ((size_t)4 * P * P);
+    int tu = t & 1, tv = t >> 1;
+    PI[idx] = V[(g * P + b) * 2 + tu] * V[(g * P + a) * 2 + tv];
+}
+
+int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_PI)
+{
+    size_t total = (size_t)G * 4 * P * P;
+    k_pi_tables<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(d_V, G, P, d_PI);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry: homogeneous spline value + parametric derivatives at one grid point.
+// jac[c][k]: component c, derivative along GRID AXIS k (not yet reordered to x,y,z).
+struct GeoView {
+    const double *V[3];   // [G][P][2]
+    const int *fa[3];     // [G]
+    int P[3], N[3];       // active count, number of control points per axis
+    const double *ctrl;   // (N0,N1[,N2], nc)
+    int nc;               // components incl. weight
+};
+
+template <int DIM>
+__device__ inline void eval_geo(const GeoView &gv, const int g[3], double val[MAX_COMP], double jac[MAX_COMP][3])
+{
+    const int nc = gv.nc;
+    for (int c = 0; c < MAX_COMP; ++c) {
+        val[c] = 0.0;
+        for (int k = 0; k < 3; ++k) jac[c][k] = 0.0;
+    }
+    const double *V0 = gv.V[0] + (size_t)g[0] * gv.P[0] * 2;
+    const double *V1 = gv.V[1] + (size_t)g[1] * gv.P[1] * 2;
+    const int f0 = gv.fa[0][g[0]], f1 = gv.fa[1][g[1]];
+    if (DIM == 2) {
+        for (int a0 = 0; a0 < gv.P[0]; ++a0) {
+            double sv[MAX_COMP], sd[MAX_COMP];
+            for (int c = 0; c < MAX_COMP; ++c) sv[c] = sd[c] = 0.0;
+            const double *row = gv.ctrl + ((size_t)(f0 + a0) * gv.N[1] + f1) * nc;
+            for (int a1 = 0; a1 < gv.P[1]; ++a1) {
+                const double n1 = V1[a1 * 2], d1 = V1[a1 * 2 + 1];
+                for (int c = 0; c < nc; ++c) {
+                    const double cf = row[(size_t)a1 * nc + c];
+                    sv[c] += n1 * cf;
+                    sd[c] += d1 * cf;
+                }
+            }
+            const double n0 = V0[a0 * 2], d0 = V0[a0 * 2 + 1];
+            for (int c = 0; c < nc; ++c) {
+                val[c] += n0 * sv[c];
+                jac[c][0] += d0 * sv[c];
+                jac[c][1] += n0 * sd[c];
+            }
+        }
+    } else {
+        const double *V2 = gv.V[2] + (size_t)g[2] * gv.P[2] * 2;
+        const int f2 = gv.fa[2][g[2]];
+        for (int a0 = 0; a0 < gv.P[0]; ++a0) {
+            double tv[MAX_COMP], t1[MAX_COMP], t2[MAX_COMP];
+            for (int c = 0; c < MAX_COMP; ++c) tv[c] = t1[c] = t2[c] = 0.0;
+            for (int a1 = 0; a1 < gv.P[1]; ++a1) {
+                double sv[MAX_COMP], sd[MAX_COMP];
+                for (int c = 0; c < MAX_COMP; ++c) sv[c] = sd[c] = 0.0;
+                const double *row = gv.ctrl + (((size_t)(f0 + a0) * gv.N[1] + (f1 + a1)) * gv.N[2] + f2) * nc;
+                for (int a2 = 0; a2 < gv.P[2]; ++a2) {
+                    const double n2 = V2[a2 * 2], d2 = V2[a2 * 2 + 1];
+                    for (int c = 0; c < nc; ++c) {
+                        const double cf = row[(size_t)a2 * nc + c];
+                        sv[c] += n2 * cf;
+                        sd[c] += d2 * cf;
+                    }
+                }
+                const double n1 = V1[a1 * 2], d1 = V1[a1 * 2 + 1];
+                for (int c = 0; c < nc; ++c) {
+                    tv[c] += n1 * sv[c];
+                    t1[c] += d1 * sv[c];
+                    t2[c] += n1 * sd[c];
+                }
+            }
+            const double n0 = V0[a0 * 2], d0 = V0[a0 * 2 + 1];
+            for (int c = 0; c < nc; ++c) {
+                val[c] += n0 * tv[c];
+                jac[c][0] += d0 * tv[c];
+                jac[c][1] += n0 * t1[c];
+                jac[c][2] += n0 * t2[c];
+            }
+        }
+    }
+}
+
+// Physical Jacobian Jm[r][c] = dG_r / d xi_c with c in (x,y,z) order, i.e. c = 0 differentiates
+// along the LAST grid axis (pyiga/bspline.py:917-921); NURBS by the quotient rule.
+template <int DIM>
+__device__ inline void physical_jacobian(const GeoView &gv, bool nurbs, const int g[3], int ncomp,
+                                         double Jm[MAX_COMP][3], double ev[MAX_COMP])
+{
+    double val[MAX_COMP], jac[MAX_COMP][3];
+    eval_geo<DIM>(gv, g, val, jac);
+    if (nurbs) {
+        const double W = val[gv.nc - 1];
+        for (int r = 0; r < ncomp; ++r) {
+            ev[r] = val[r] / W;
+            for (int c = 0; c < DIM; ++c) {
+                const int k = DIM - 1 - c;
+                Jm[r][c] = (jac[r][k] * W - val[r] * jac[gv.nc - 1][k]) / (W * W);
+            }
+        }
+    } else {
+        for (int r = 0; r < ncomp; ++r) {
+            ev[r] = val[r];
+            for (int c = 0; c < DIM; ++c) Jm[r][c] = jac[r][DIM - 1 - c];
+        }
+    }
+}
+
+template <int DIM>
+__global__ void k_grid_geo(GeoView gv, bool nurbs, int ncomp, int G0, int G1, int G2, double *jac_out, double *eval_out)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)G0 * G1 * (DIM == 3 ? G2 : 1);
+    if (idx >= total) return;
+    int g[3];
+    if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = idx / ((long long)G2 * G1); }
+    else { g[1] = idx % G1; g[0] = idx / G1; g[2] = 0; }
+    double Jm[MAX_COMP][3], ev[MAX_COMP];
+    physical_jacobian<DIM>(gv, nurbs, g, ncomp, Jm, ev);
+    if (jac_out)
+        for (int r = 0; r < ncomp; ++r)
+            for (int c = 0; c < DIM; ++c) jac_out[(idx * ncomp + r) * DIM + c] = Jm[r][c];
+    if (eval_out)
+        for (int r = 0; r < ncomp; ++r) eval_out[idx * ncomp + r] = ev[r];
+}
+
+static GeoView make_view(int dim, const GeoAxis gax[3], const double *d_ctrl, int nc)
+{
+    GeoView gv{};
+    for (int k = 0; k < 3; ++k) {
+        gv.V[k] = k < dim ? gax[k].d_V : nullptr;
+        gv.fa[k] = k < dim ? gax[k].d_fa : nullptr;
+        gv.P[k] = k < dim ? gax[k].P : 1;
+        gv.N[k] = k < dim ? gax[k].N : 1;
+    }
+    gv.ctrl = d_ctrl;
+    gv.nc = nc;
+    return gv;
+}
+
+int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3], const int G[3],
+                    const double *d_ctrl, double *d_jac, double *d_eval)
+{
+    GeoView gv = make_view(dim, gax, d_ctrl, ncomp_total);
+    const int ncomp = nurbs ? ncomp_total - 1 : ncomp_total;
+    long long total = (long long)G[0] * G[1] * (dim == 3 ? G[2] : 1);
+    if (total == 0) return IGX_OK;
+    dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    if (dim == 2) k_grid_geo<2><<<grid, block, 0, st>>>(gv, nurbs, ncomp, G[0], G[1], 1, d_jac, d_eval);
+    else k_grid_geo<3><<<grid, block, 0, st>>>(gv, nurbs, ncomp, G[0], G[1], G[2], d_jac, d_eval);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fields: one thread per resident Gauss point, structure-of-arrays output fields[f][pt]
+template <int DIM>
+__device__ inline void fields_from_jac(const double t[9], double GW, int kind, double *fields, long long stride, long long pt)
+{
+    if (DIM == 2) {
+        const double det = t[0] * t[3] - t[1] * t[2];
+        const double W = GW * fabs(det);
+        if (kind == IGX_MASS) { fields[pt] = W; return; }
+        const double inv = 1.0 / det;
+        const double J0 = inv * t[3], J1 = inv * -t[1], J2 = inv * -t[2], J3 = inv * t[0];
+        fields[pt] = W * (J0 * J0 + J1 * J1);
+        fields[stride + pt] = W * (J0 * J2 + J1 * J3);
+        fields[2 * stride + pt] = W * (J2 * J2 + J3 * J3);
+    } else {
+        const double t3 = t[4] * t[8] - t[5] * t[7];
+        const double t4 = t[3] * t[8] - t[5] * t[6];
+        const double t5 = t[3] * t[7] - t[4] * t[6];
+        const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
+        const double W = GW * fabs(det);
+        if (kind == IGX_MASS) { fields[pt] = W; return; }
+        const double inv = 1.0 / det;
+        double JI[9];
+        JI[0] = inv * t3;
+        JI[1] = inv * -(t[1] * t[8] - t[2] * t[7]);
+        JI[2] = inv * (t[1] * t[5] - t[2] * t[4]);
+        JI[3] = inv * -t4;
+        JI[4] = inv * (t[0] * t[8] - t[2] * t[6]);
+        JI[5] = inv * -(t[0] * t[5] - t[2] * t[3]);
+        JI[6] = inv * t5;
+        JI[7] = inv * -(t[0] * t[7] - t[1] * t[6]);
+        JI[8] = inv * (t[0] * t[4] - t[1] * t[3]);
+        fields[pt] = W * ((JI[0] * JI[0] + JI[1] * JI[1]) + JI[2] * JI[2]);
+        fields[stride + pt] = W * ((JI[0] * JI[3] + JI[1] * JI[4]) + JI[2] * JI[5]);
+        fields[2 * stride + pt] = W * ((JI[0] * JI[6] + JI[1] * JI[7]) + JI[2] * JI[8]);
+        fields[3 * stride + pt] = W * ((JI[3] * JI[3] + JI[4] * JI[4]) + JI[5] * JI[5]);
+        fields[4 * stride + pt] = W * ((JI[3] * JI[6] + JI[4] * JI[7]) + JI[5] * JI[8]);
+        fields[5 * stride + pt] = W * ((JI[6] * JI[6] + JI[7] * JI[7]) + JI[8] * JI[8]);
+    }
+}
+
+// geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
+template <int DIM>
+__global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int kind,
+                             const double *w0, const double *w1, const double *w2,
+                             int g0_lo, int G0loc, int G1, int G2, double *fields)
+{
+    const long long total = (long long)G0loc * G1 * (DIM == 3 ? G2 : 1);
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int g[3];
+    if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
+    else { g[1] = idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
+    double t[9];
+    if (geo_kind == IGX_GEO_JACOBIAN) {
+        const double *src = jac_in + idx * (DIM * DIM);
+        for (int k = 0; k < DIM * DIM; ++k) t[k] = src[k];
+    } else {
+        double Jm[MAX_COMP][3], ev[MAX_COMP];
+        physical_jacobian<DIM>(gv, geo_kind == IGX_GEO_NURBS, g, DIM, Jm, ev);
+        for (int r = 0; r < DIM; ++r)
+            for (int c = 0; c < DIM; ++c) t[r * DIM + c] = Jm[r][c];
+    }
+    double GW = w0[g[0]] * w1[g[1]];
+    if (DIM == 3) GW = GW * w2[g[2]];
+    fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
+}
+
+int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields)
+{
+    const int dim = pt->dim;
+    GeoView gv = make_view(dim, pt->gax, pt->d_ctrl, pt->ncomp);
+    const PatchDev &pd = pt->dev;
+    const long long total = pd.npts_loc;
+    if (total == 0) return IGX_OK;
+    dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    if (dim == 2)
+        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
+                                                pd.g0_lo, pd.G0_loc, pd.ax[1].G, 1, d_fields);
+    else
+        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
+                                                pd.g0_lo, pd.G0_loc, pd.ax[1].G, pd.ax[2].G, d_fields);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+} // namespace igx

@@ -1,0 +1,268 @@
+// CSR pattern and the entry-wise ("gather") quadrature kernels.
+//
+// One thread = one matrix entry, summed over the intersection of the two supports with the loops
+// nested axis 0 outermost and a single accumulator -- the reference's own order:
+//   entry_impl / combine      pyiga/assemblers.pyx:116-172 (M2D), 281-349 (S2D), 1255-1322 (M3D), 1455-1540 (S3D)
+//   from_seq{2,3}             pyiga/assemble_tools_cy.pyx:36-49
+//   multi_entries             pyiga/genericasm.pxi:353-436, 677-758
+// The pattern kernel replaces MLStructure.nonzero + COO->CSR (pyiga/mlmatrix.py:113-130,
+// pyiga/assemble.py:742-752) by writing canonical CSR directly.
+//
+// These kernels accept any degree <= IGX_MAX_DEGREE and any open knot vector (repeated interior
+// knots included); they are the general path and the parity anchor for the sum-factorised path.
+#include "igx_internal.h"
+
+namespace igx {
+
+struct Dof3 { int i[3]; };
+
+template <int DIM>
+__device__ inline bool unravel(const PatchDev &pd, size_t I, int out[3])
+{
+    if (DIM == 2) {
+        out[1] = (int)(I % pd.ax[1].N);
+        size_t r = I / pd.ax[1].N;
+        out[0] = (int)r; out[2] = 0;
+        return r < (size_t)pd.ax[0].N;
+    }
+    out[2] = (int)(I % pd.ax[2].N); I /= pd.ax[2].N;
+    out[1] = (int)(I % pd.ax[1].N);
+    size_t r = I / pd.ax[1].N;
+    out[0] = (int)r;
+    return r < (size_t)pd.ax[0].N;
+}
+
+// value of entry (i, j); fields are structure-of-arrays over the resident Gauss slab
+template <int DIM, int KIND>
+__device__ inline double entry_value(const PatchDev &pd, const double *fields, const int i[3], const int j[3])
+{
+    int glo[3], ghi[3];
+    for (int k = 0; k < DIM; ++k) {
+        const AxisDev &A = pd.ax[k];
+        const int lo = max(A.mslo[i[k]], A.mslo[j[k]]);
+        const int hi = min(A.mshi[i[k]], A.mshi[j[k]]);
+        if (lo >= hi) return 0.0;                     // no intersection of supports
+        glo[k] = lo * A.q; ghi[k] = hi * A.q;
+    }
+    // Gauss points outside the resident slab cannot be evaluated here
+    if (glo[0] < pd.g0_lo || ghi[0] > pd.g0_lo + pd.G0_loc) return __builtin_nan("");
+    const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1], &A2 = pd.ax[2];
+    const long long stride = pd.npts_loc;
+    double r = 0.0;
+    for (int g0 = glo[0]; g0 < ghi[0]; ++g0) {
+        const int f0 = A0.fa[g0 / A0.q];
+        const double *u0 = A0.V + ((size_t)g0 * A0.P + (j[0] - f0)) * 2;
+        const double *v0 = A0.V + ((size_t)g0 * A0.P + (i[0] - f0)) * 2;
+        for (int g1 = glo[1]; g1 < ghi[1]; ++g1) {
+            const int f1 = A1.fa[g1 / A1.q];
+            const double *u1 = A1.V + ((size_t)g1 * A1.P + (j[1] - f1)) * 2;
+            const double *v1 = A1.V + ((size_t)g1 * A1.P + (i[1] - f1)) * 2;
+            if (DIM == 2) {
+                const long long pt = (long long)(g0 - pd.g0_lo) * A1.G + g1;
+                if (KIND == IGX_MASS) {
+                    r += (((u0[0] * u1[0]) * (v0[0] * v1[0])) * fields[pt]);
+                } else {
+                    const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
+                    const double du10 = u0[0] * u1[1], du01 = u0[1] * u1[0];
+                    const double dv10 = v0[0] * v1[1], dv01 = v0[1] * v1[0];
+                    r += ((((f_0 * du10) + (f_1 * du01)) * dv10) + (((f_1 * du10) + (f_2 * du01)) * dv01));
+                }
+            } else {
+                for (int g2 = glo[2]; g2 < ghi[2]; ++g2) {
+                    const int f2 = A2.fa[g2 / A2.q];
+                    const double *u2 = A2.V + ((size_t)g2 * A2.P + (j[2] - f2)) * 2;
+                    const double *v2 = A2.V + ((size_t)g2 * A2.P + (i[2] - f2)) * 2;
+                    const long long pt = ((long long)(g0 - pd.g0_lo) * A1.G + g1) * A2.G + g2;
+                    if (KIND == IGX_MASS) {
+                        r += (((u0[0] * u1[0] * u2[0]) * (v0[0] * v1[0] * v2[0])) * fields[pt]);
+                    } else {
+                        const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
+                        const double f_3 = fields[3 * stride + pt], f_4 = fields[4 * stride + pt], f_5 = fields[5 * stride + pt];
+                        const double du100 = u0[0] * u1[0] * u2[1];
+                        const double du010 = u0[0] * u1[1] * u2[0];
+                        const double du001 = u0[1] * u1[0] * u2[0];
+                        const double dv100 = v0[0] * v1[0] * v2[1];
+                        const double dv010 = v0[0] * v1[1] * v2[0];
+                        const double dv001 = v0[1] * v1[0] * v2[0];
+                        r += ((((((f_0 * du100) + (f_1 * du010)) + (f_2 * du001)) * dv100)
+                               + ((((f_1 * du100) + (f_3 * du010)) + (f_4 * du001)) * dv010))
+                              + ((((f_2 * du100) + (f_4 * du010)) + (f_5 * du001)) * dv001));
+                    }
+                }
+            }
+        }
+    }
+    return r;
+}
+
+template <int DIM, int KIND>
+__global__ void k_entries_list(PatchDev pd, const double *fields, const size_t *ij, size_t M, double *out)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    int i[3], j[3];
+    const bool ok = unravel<DIM>(pd, ij[2 * k], i) & unravel<DIM>(pd, ij[2 * k + 1], j);
+    out[k] = ok ? entry_value<DIM, KIND>(pd, fields, i, j) : 0.0;
+}
+
+int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out)
+{
+    if (M == 0) return IGX_OK;
+    dim3 grid((unsigned)((M + 127) / 128)), block(128);
+    const PatchDev &pd = pt->dev;
+    if (pt->dim == 2) {
+        if (kind == IGX_MASS) k_entries_list<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        else k_entries_list<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+    } else {
+        if (kind == IGX_MASS) k_entries_list<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        else k_entries_list<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+    }
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row geometry helpers.  Row I = (i0,i1[,i2]); its columns are the product of the per-axis ranges
+// [jlo_k, jhi_k) in lexicographic order (canonical CSR), so
+//   indptr(I) = rp0[i0]*S1*S2 + c0*(rp1[i1]*S2 + c1*rp2[i2])        (c_k = jhi_k - jlo_k)
+template <int DIM>
+__device__ inline long long row_start(const PatchDev &pd, const int i[3], int c[3])
+{
+    for (int k = 0; k < DIM; ++k) c[k] = pd.ax[k].jhi[i[k]] - pd.ax[k].jlo[i[k]];
+    if (DIM == 2)
+        return (long long)pd.ax[0].rp[i[0]] * pd.ax[1].S + (long long)c[0] * pd.ax[1].rp[i[1]];
+    return igx_rowptr3(pd.ax[0].rp, pd.ax[1].rp, pd.ax[2].rp, pd.ax[1].S, pd.ax[2].S, c[0], c[1], i[0], i[1], i[2]);
+}
+
+// position of column j in row i (j must be inside the row's pattern)
+template <int DIM>
+__device__ inline long long entry_pos(const PatchDev &pd, const int i[3], const int j[3])
+{
+    int c[3];
+    long long base = row_start<DIM>(pd, i, c);
+    long long off = j[0] - pd.ax[0].jlo[i[0]];
+    off = off * c[1] + (j[1] - pd.ax[1].jlo[i[1]]);
+    if (DIM == 3) off = off * c[2] + (j[2] - pd.ax[2].jlo[i[2]]);
+    return base + off - pd.nnz_off;
+}
+
+template <int DIM>
+__global__ void k_pattern(PatchDev pd, long long row_lo, long long nrows, int maxrow, int32_t *indptr, int32_t *indices)
+{
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long lr = tid / maxrow;
+    int o = (int)(tid % maxrow);
+    if (lr > nrows) return;
+    if (lr == nrows) {                               // closing indptr entry
+        if (o == 0 && indptr) {
+            // total nnz of the owned rows = start of the (virtual) next row
+            int i[3], c[3];
+            long long I = row_lo + nrows - 1;
+            unravel<DIM>(pd, (size_t)I, i);
+            long long st = row_start<DIM>(pd, i, c);
+            long long len = (long long)c[0] * c[1] * (DIM == 3 ? c[2] : 1);
+            indptr[nrows] = (int32_t)(st + len - pd.nnz_off);
+        }
+        return;
+    }
+    int i[3], c[3];
+    unravel<DIM>(pd, (size_t)(row_lo + lr), i);
+    long long st = row_start<DIM>(pd, i, c) - pd.nnz_off;
+    const int len = c[0] * c[1] * (DIM == 3 ? c[2] : 1);
+    if (o == 0 && indptr) indptr[lr] = (int32_t)st;
+    if (o >= len || !indices) return;
+    int j[3];
+    int rem = o;
+    if (DIM == 3) { j[2] = pd.ax[2].jlo[i[2]] + rem % c[2]; rem /= c[2]; }
+    j[1] = pd.ax[1].jlo[i[1]] + rem % c[1]; rem /= c[1];
+    j[0] = pd.ax[0].jlo[i[0]] + rem;
+    long long J = (long long)j[0] * pd.ax[1].N + j[1];
+    if (DIM == 3) J = J * pd.ax[2].N + j[2];
+    indices[st + o] = (int32_t)J;
+}
+
+static int max_row_len(const igx_patch *pt)
+{
+    int m = 1;
+    for (int k = 0; k < pt->dim; ++k) {
+        int mk = 0;
+        for (int i = 0; i < pt->ax[k].N; ++i) mk = std::max(mk, pt->ax[k].jhi[i] - pt->ax[k].jlo[i]);
+        m *= mk;
+    }
+    return m;
+}
+
+int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices)
+{
+    const long long nrows = pt->row_hi - pt->row_lo;
+    const int maxrow = max_row_len(pt);
+    const long long total = (nrows + 1) * maxrow;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (pt->dim == 2) k_pattern<2><<<grid, block, 0, st>>>(pt->dev, pt->row_lo, nrows, maxrow, d_indptr, d_indices);
+    else k_pattern<3><<<grid, block, 0, st>>>(pt->dev, pt->row_lo, nrows, maxrow, d_indptr, d_indices);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-matrix entry-wise assembly: thread (row, offset) computes the lower-triangle entry and
+// writes it and its mirror (assemble_entries(symmetric=True), pyiga/assemble.py:742-752).
+// Rows r0_lo..r0_hi are owned; additionally the lower entries of the rows in the p planes above
+// the slab whose COLUMN is owned are computed so that their mirror lands in an owned row
+// (zero-communication multi-GPU scheme, DESIGN.md section "multi-GPU").
+template <int DIM, int KIND>
+__global__ void k_entries_csr(PatchDev pd, const double *fields, long long row_first, long long nrows_scan,
+                              int maxrow, double *data)
+{
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long lr = tid / maxrow;
+    int o = (int)(tid % maxrow);
+    if (lr >= nrows_scan) return;
+    int i[3], c[3], j[3];
+    unravel<DIM>(pd, (size_t)(row_first + lr), i);
+    for (int k = 0; k < DIM; ++k) c[k] = pd.ax[k].jhi[i[k]] - pd.ax[k].jlo[i[k]];
+    const int len = c[0] * c[1] * (DIM == 3 ? c[2] : 1);
+    if (o >= len) return;
+    int rem = o;
+    if (DIM == 3) { j[2] = pd.ax[2].jlo[i[2]] + rem % c[2]; rem /= c[2]; } else j[2] = 0;
+    j[1] = pd.ax[1].jlo[i[1]] + rem % c[1]; rem /= c[1];
+    j[0] = pd.ax[0].jlo[i[0]] + rem;
+    // lower triangle only: J <= I  <=>  (j0,j1,j2) <=lex (i0,i1,i2)
+    bool lower = true, diag = true;
+    for (int k = 0; k < DIM; ++k) {
+        if (j[k] != i[k]) { lower = j[k] < i[k]; diag = false; break; }
+    }
+    if (!lower) return;
+    const bool own_row = i[0] >= pd.r0_lo && i[0] < pd.r0_hi;
+    const bool own_col = j[0] >= pd.r0_lo && j[0] < pd.r0_hi;
+    if (!own_row && !own_col) return;
+    const double v = entry_value<DIM, KIND>(pd, fields, i, j);
+    if (own_row) data[entry_pos<DIM>(pd, i, j)] = v;
+    if (own_col && !diag) data[entry_pos<DIM>(pd, j, i)] = v;
+}
+
+int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data)
+{
+    const PatchDev &pd = pt->dev;
+    long long plane = (long long)pt->ax[1].N * (pt->dim == 3 ? pt->ax[2].N : 1);
+    // scan rows of the owned planes plus the planes above that can still couple to owned columns
+    int scan_hi = pt->r0_hi;
+    while (scan_hi < pt->ax[0].N && pt->ax[0].jlo[scan_hi] < pt->r0_hi) ++scan_hi;
+    const long long row_first = (long long)pt->r0_lo * plane;
+    const long long nrows_scan = (long long)(scan_hi - pt->r0_lo) * plane;
+    const int maxrow = max_row_len(pt);
+    const long long total = nrows_scan * maxrow;
+    if (total == 0) return IGX_OK;
+    dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    if (pt->dim == 2) {
+        if (kind == IGX_MASS) k_entries_csr<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+        else k_entries_csr<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+    } else {
+        if (kind == IGX_MASS) k_entries_csr<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+        else k_entries_csr<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+    }
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+} // namespace igx

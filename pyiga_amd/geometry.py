@@ -1,0 +1,192 @@
+"""Tensor-product B-spline / NURBS geometry maps -- host mirror of the parts of
+``pyiga.geometry`` the assembly path uses (pyiga/geometry.py:17-123,425-491,533-615,755-809).
+
+Control nets live on the host (they are tiny); evaluation on tensor grids runs on the
+device through libigx.  When a geometry is handed to ``assemble.mass/stiffness`` it is never
+evaluated on the host at all: the kernels take the control net directly.
+"""
+import functools
+
+import numpy as np
+
+from . import bspline
+from .bspline import BSplineFunc, _BaseSplineFunc, _device_grid_eval
+
+
+class NurbsFunc(_BaseSplineFunc):
+    """Function in a tensor-product NURBS basis (pyiga/geometry.py:27-123).
+
+    ``coeffs`` holds the premultiplied coefficients with the weight as last component.
+    """
+
+    def __init__(self, kvs, coeffs, weights, premultiplied=False):
+        if isinstance(kvs, bspline.KnotVector):
+            kvs = (kvs,)
+        self.kvs = tuple(kvs)
+        self.sdim = len(self.kvs)
+        N = tuple(kv.numdofs for kv in self.kvs)
+        coeffs = np.asanyarray(coeffs)
+        if coeffs.ndim == 1:
+            assert coeffs.shape[0] == np.prod(N), 'Wrong length of coefficient vector'
+            coeffs = coeffs.reshape(N)
+        assert N == coeffs.shape[:self.sdim], 'Wrong shape of coefficients'
+        self.coeffs = coeffs
+        dim = coeffs.shape[self.sdim:]
+        if len(dim) == 0:
+            dim = 1
+            self._isscalar = True
+        elif len(dim) == 1:
+            dim = dim[0]
+            self._isscalar = False
+        else:
+            assert False, 'Tensor-valued NURBS functions not implemented'
+        self.dim = dim
+        if weights is None:
+            assert self.dim > 1, 'Weights must be specified in the coeffs array'
+            self.dim -= 1
+        else:
+            weights = np.asanyarray(weights)
+            assert weights.shape == N, 'Wrong shape of weights array'
+            if self.coeffs.shape == N:
+                self.coeffs = np.stack((self.coeffs, weights), axis=-1)
+            else:
+                self.coeffs = np.concatenate((self.coeffs, weights[..., None]), axis=-1)
+        if not premultiplied:
+            self.coeffs[..., :-1] *= self.coeffs[..., -1:]
+
+    def output_shape(self):
+        if self._isscalar:
+            return ()
+        shp = list(self.coeffs.shape[self.sdim:])
+        shp[-1] -= 1
+        return tuple(shp)
+
+    def copy(self):
+        return NurbsFunc(tuple(kv.copy() for kv in self.kvs), self.coeffs.copy(), None, premultiplied=True)
+
+    def coeffs_weights(self):
+        """Non-premultiplied coefficients and weights."""
+        W = self.coeffs[..., -1]
+        return self.coeffs[..., :-1] / W[..., None], W.copy()
+
+    def grid_eval(self, gridaxes):
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        f = _device_grid_eval(self.kvs, self.coeffs, True, self.dim, gridaxes, want_jac=False)
+        return np.squeeze(f, -1) if self._isscalar else f
+
+    def grid_jacobian(self, gridaxes):
+        """Quotient rule on the homogeneous spline (pyiga/geometry.py:17-25,116-123)."""
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        J = _device_grid_eval(self.kvs, self.coeffs, True, self.dim, gridaxes, want_jac=True)
+        return np.squeeze(J, -2) if self._isscalar else J
+
+    def as_nurbs(self):
+        return self
+
+    def as_vector(self):
+        if self.is_vector():
+            return self
+        assert self.is_scalar()
+        C, W = self.coeffs_weights()
+        return NurbsFunc(self.kvs, C, W)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2D geometries
+def unit_square(num_intervals=1):
+    """Unit square (pyiga/geometry.py:425-431)."""
+    return unit_cube(dim=2, num_intervals=num_intervals)
+
+
+def bspline_quarter_annulus(r1=1.0, r2=2.0):
+    """B-spline approximation of a quarter annulus (pyiga/geometry.py:445-466)."""
+    kvx = bspline.make_knots(1, 0.0, 1.0, 1)
+    kvy = bspline.make_knots(2, 0.0, 1.0, 1)
+    coeffs = np.array([
+        [[r1, 0.0], [r2, 0.0]],
+        [[r1, r1], [r2, r2]],
+        [[0.0, r1], [0.0, r2]],
+    ])
+    return BSplineFunc((kvy, kvx), coeffs)
+
+
+def quarter_annulus(r1=1.0, r2=2.0):
+    """Exact NURBS quarter annulus in the first quadrant (pyiga/geometry.py:468-491)."""
+    kvx = bspline.make_knots(1, 0.0, 1.0, 1)
+    kvy = bspline.make_knots(2, 0.0, 1.0, 1)
+    w = 1.0 / np.sqrt(2.0)
+    coeffs = np.array([
+        [[r1, 0.0, 1.0], [r2, 0.0, 1.0]],
+        [[r1, r1, w], [r2, r2, w]],
+        [[0.0, r1, 1.0], [0.0, r2, 1.0]],
+    ])
+    return NurbsFunc((kvy, kvx), coeffs, weights=None)
+
+
+# ---------------------------------------------------------------------------------------------
+# 3D geometries
+def unit_cube(dim=3, num_intervals=1):
+    """`dim`-dimensional unit cube (pyiga/geometry.py:533-540)."""
+    return functools.reduce(tensor_product, dim * (line_segment(0.0, 1.0, intervals=num_intervals),))
+
+
+def twisted_box():
+    """Box with a twisted, bent right face (pyiga/geometry.py:557-589; G+Smo's
+    twistedFlatQuarterAnnulus)."""
+    kv1 = bspline.make_knots(1, 0.0, 1.0, 1)
+    kv2 = bspline.make_knots(3, 0.0, 1.0, 1)
+    coeffs = np.array([
+        1, 0, 0, 2, 0, 0, 1, 0.5, 0, 2, 1.5, 0,
+        0.5, 1, 0.5, 1.5, 2, 0.5, 0, 1, 2, 0, 2, 2,
+        1, 0, 1, 2, 0, 1, 1, 0.5, 1, 2, 1.5, 1,
+        1, 1, 1.5, 1.5, 2, 1.5, 1, 1, 2, 1, 2, 2,
+    ], dtype=float).reshape((2, 4, 2, 3))
+    return BSplineFunc((kv1, kv2, kv1), coeffs)
+
+
+# ---------------------------------------------------------------------------------------------
+# curves and products
+def line_segment(x0, x1, support=(0.0, 1.0), intervals=1):
+    """Straight line from `x0` to `x1` as a linear spline (pyiga/geometry.py:595-615)."""
+    if np.isscalar(x0):
+        x0 = [x0]
+    if np.isscalar(x1):
+        x1 = [x1]
+    assert len(x0) == len(x1), 'Vectors must have same dimension'
+    x0 = np.array(x0, dtype=float).ravel()
+    x1 = np.array(x1, dtype=float).ravel()
+    S = np.linspace(0.0, 1.0, intervals + 1).reshape((intervals + 1, 1))
+    coeffs = (1 - S) * x0 + S * x1
+    return BSplineFunc(bspline.make_knots(1, support[0], support[1], intervals), coeffs)
+
+
+def _split_control_net(G):
+    """(plain coefficients, weights or None) with a trailing component axis."""
+    if isinstance(G, NurbsFunc):
+        return G.coeffs_weights()
+    C = G.coeffs if G.is_vector() else G.coeffs[..., None]
+    return C, None
+
+
+def tensor_product(G1, G2, *Gs):
+    """``G(x,y) = G2(x) x G1(y)``: components are joined (x first), parameter axes are
+    concatenated (y first) -- pyiga/geometry.py:755-809.  NURBS if any factor is NURBS."""
+    if Gs:
+        return tensor_product(G1, tensor_product(G2, *Gs))
+    for G in (G1, G2):
+        assert G.is_scalar() or G.is_vector(), 'only implemented for scalar- or vector-valued functions'
+    C1, W1 = _split_control_net(G1)
+    C2, W2 = _split_control_net(G2)
+    n1, n2 = C1.shape[:G1.sdim], C2.shape[:G2.sdim]
+    ones1, ones2 = (1,) * G1.sdim, (1,) * G2.sdim
+    # broadcast both nets over the joint index space (axes of G1 first)
+    B1 = np.broadcast_to(C1.reshape(n1 + ones2 + C1.shape[G1.sdim:]), n1 + n2 + C1.shape[G1.sdim:])
+    B2 = np.broadcast_to(C2.reshape(ones1 + n2 + C2.shape[G2.sdim:]), n1 + n2 + C2.shape[G2.sdim:])
+    C = np.concatenate((B2, B1), axis=-1)         # coefficients in (x, y) order
+    kvs = tuple(G1.kvs) + tuple(G2.kvs)
+    if W1 is None and W2 is None:
+        return BSplineFunc(kvs, C)
+    W1 = np.ones(n1) if W1 is None else W1
+    W2 = np.ones(n2) if W2 is None else W2
+    W = W1.reshape(n1 + ones2) * W2.reshape(ones1 + n2)
+    return NurbsFunc(kvs, C, W)

@@ -1,0 +1,113 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/igx.h declares, the product path fails loudly without a GPU, and the host-side integer
+logic (knot vectors, pair enumeration) matches the golden vectors.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, 'pyiga_amd', 'libigx.so')):
+        ge.build()
+    import pyiga_amd
+    return pyiga_amd._lib
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'igx.h')).read()
+    declared = set(re.findall(r'\b(igx_[a-z_0-9]+)\s*\(', hdr))
+    declared -= {'igx_ctx', 'igx_patch'}
+    bound = {name for name, _, _ in lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    cdll = lib.load()
+    for name in declared:
+        assert hasattr(cdll, name)
+    assert cdll.igx_version() == 100
+    nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r'\bT %s\b' % name, nm), name
+
+
+def test_struct_layout_matches_header(lib, tmp_path):
+    """sizeof/offsetof of the ctypes structures equal the C compiler's."""
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "igx.h"\nint main(){'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(igx_patch_desc), offsetof(igx_patch_desc, kv),'
+                   'offsetof(igx_patch_desc, geo_kind), offsetof(igx_patch_desc, ctrl), offsetof(igx_patch_desc, gauss_x),'
+                   'offsetof(igx_patch_desc, row0_lo), sizeof(igx_patch_info)); printf("%zu\\n", sizeof(igx_timing)); return 0;}')
+    exe = tmp_path / 'sz'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    D = lib.PatchDesc
+    mine = [ctypes.sizeof(D), D.kv.offset, D.geo_kind.offset, D.ctrl.offset, D.gauss_x.offset, D.row0_lo.offset,
+            ctypes.sizeof(lib.PatchInfo), ctypes.sizeof(lib.Timing)]
+    assert [int(x) for x in out] == mine
+
+
+def test_fails_loudly_without_gpu(lib):
+    """No CPU fallback: without a HIP device the product API raises instead of computing."""
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'import pyiga_amd\n'
+            'from pyiga_amd import bspline, geometry, assemble\n'
+            'kv = bspline.make_knots(2, 0.0, 1.0, 4)\n'
+            'try:\n'
+            '    assemble.stiffness((kv, kv), geometry.unit_square())\n'
+            'except pyiga_amd._lib.IgxError as e:\n'
+            '    print("RAISED", e)\n' % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='-1', ROCR_VISIBLE_DEVICES='-1')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env)
+    assert 'RAISED' in out.stdout and 'no CPU fallback' in out.stdout, out.stdout + out.stderr
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure; nothing under pyiga_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'pyiga_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'iga_oracle' not in txt and 'from oracle' not in txt and 'import oracle' not in txt, f
+
+
+def test_host_knot_logic(golden):
+    from pyiga_amd import bspline, assemble
+    g = golden('bspline')
+    for name in sorted({k[:-3] for k in g.files if k.endswith('_kv')}):
+        kv = bspline.KnotVector(g[name + '_kv'], int(g[name + '_p']))
+        assert np.array_equal(kv.mesh, g[name + '_mesh'])
+        assert np.array_equal(kv.mesh_support_idx_all(), g[name + '_meshsupp'])
+        assert np.array_equal(assemble._compute_sparsity_ij(kv, kv), g[name + '_sparsity_ij'])
+        assert kv.numdofs == g[name + '_C'].shape[0] and kv.numspans == len(g[name + '_mesh']) - 1
+    k = golden('knots')
+    assert np.array_equal(bspline.make_knots(4, 0.0, 1.0, 128).kv, k['p4_n128'])
+    assert np.array_equal(bspline.make_knots(3, 0.0, 1.0, 49).kv, k['p3_n49'])      # the n+1-span quirk, replicated
+    assert np.array_equal(bspline.make_knots(2, -1.5, 2.25, 9).kv, k['p2_ab'])
+    s = golden('sparsity')
+    for name, d in (('d3_p2_n3', 3), ('d2_mixed', 2), ('d3_mult', 3)):
+        kvs = tuple(bspline.KnotVector(s['%s_kv%d' % (name, i)], int(s['%s_p%d' % (name, i)])) for i in range(d))
+        for lt in (0, 1):
+            I, J = assemble._ml_nonzero(kvs, kvs, lower_tri=bool(lt))
+            assert np.array_equal(I, s['%s_lt%d_I' % (name, lt)]) and np.array_equal(J, s['%s_lt%d_J' % (name, lt)])
+
+
+def test_geometry_constructors(golden):
+    from pyiga_amd import geometry
+    g = golden('geometry')
+    cyl = geometry.tensor_product(geometry.line_segment(0.0, 1.0), geometry.quarter_annulus())
+    for name, geo in (('quarter_annulus', geometry.quarter_annulus()), ('bspline_quarter_annulus', geometry.bspline_quarter_annulus()),
+                      ('twisted_box', geometry.twisted_box()), ('cylinder', cyl),
+                      ('unit_square', geometry.unit_square()), ('unit_cube', geometry.unit_cube())):
+        assert geo.coeffs.shape == g[name + '_coeffs'].shape, name
+        assert np.allclose(geo.coeffs, g[name + '_coeffs'], rtol=0, atol=1e-15), name
+        assert isinstance(geo, geometry.NurbsFunc) == bool(g[name + '_nurbs'])
+        for k, kv in enumerate(geo.kvs):
+            assert kv.p == int(g['%s_gp%d' % (name, k)]) and np.array_equal(kv.kv, g['%s_gkv%d' % (name, k)])
+        assert geo.dim == geo.sdim == len(geo.kvs)

@@ -1,0 +1,334 @@
+"""Parity of the HIP path (through the C ABI) with the oracle, the reference's fixtures and the
+golden vectors.  Needs a real MI355X:  pytest -m gpu.
+
+Tolerances:
+  * the four bundled fixtures: max|A - A_ref| < 1e-14 absolute (the reference's own tolerance,
+    test/test_assemble.py:138-168)
+  * everything else: max|A - A_ref| <= 1e-12 * max|A_ref|
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from conftest import GOLDEN, golden_csr, rel_maxdiff
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def iga():
+    import pyiga_amd
+    pyiga_amd._lib.context()          # raises if no GPU / library: there is no fallback
+    return pyiga_amd
+
+
+def _kv(iga, okv):
+    return iga.bspline.KnotVector(okv.kv.copy(), okv.p)
+
+
+def _geo(iga, name):
+    g = iga.geometry
+    return {'quarter_annulus': g.quarter_annulus, 'bspline_quarter_annulus': g.bspline_quarter_annulus,
+            'twisted_box': g.twisted_box, 'unit_square': g.unit_square, 'unit_cube': g.unit_cube,
+            'cylinder': lambda: g.tensor_product(g.line_segment(0.0, 1.0), g.quarter_annulus())}[name]()
+
+
+# ------------------------------------------------------------------------------------------
+def test_knots_bits(iga, golden):
+    g = golden('knots')
+    for key in g.files:
+        if key.startswith('leggauss') or key in ('p3_n5_m2', 'p2_ab'):
+            continue
+        p, n = (int(x[1:]) for x in key.split('_'))
+        assert np.array_equal(iga.bspline.make_knots(p, 0.0, 1.0, n).kv, g[key])
+    assert np.array_equal(iga.bspline.make_knots(3, 0.0, 1.0, 5, mult=2).kv, g['p3_n5_m2'])
+
+
+def test_active_deriv(iga, golden):
+    """bspline_cy.active_deriv / pyx_findspan on the device vs the reference's values."""
+    g = golden('bspline')
+    for name in sorted({k[:-3] for k in g.files if k.endswith('_kv')}):
+        kv = iga.bspline.KnotVector(g[name + '_kv'], int(g[name + '_p']))
+        nodes = g[name + '_nodes']
+        ref = g[name + '_deriv']
+        out = iga.bspline.active_deriv(kv, nodes, 1)
+        assert out.shape == ref.shape
+        assert np.abs(out - ref).max() <= 1e-14 * np.abs(ref).max(), name
+        assert np.array_equal(iga.bspline.findspans(kv, nodes), g[name + '_spans'])
+        assert np.array_equal(kv.mesh_support_idx_all(), g[name + '_meshsupp'])
+        # scalar argument form
+        one = iga.bspline.active_deriv(kv, float(nodes[3]), 1)
+        assert one.shape == (2, kv.p + 1) and np.allclose(one, ref[:, :, 3], rtol=0, atol=1e-13)
+        # second derivatives agree with the oracle's restatement
+        from oracle import iga_oracle as orc
+        okv = orc.KnotVector(g[name + '_kv'], kv.p)
+        d2 = iga.bspline.active_deriv(kv, nodes, 2)
+        r2 = orc.active_deriv(okv, nodes, 2)
+        assert np.abs(d2 - r2).max() <= 1e-13 * max(1.0, np.abs(r2).max())
+    # boundary points: u = last knot belongs to the last span
+    kv = iga.bspline.make_knots(3, 0.0, 1.0, 4)
+    assert iga.bspline.findspans(kv, np.array([0.0, 1.0]))[1] == kv.kv.size - kv.p - 2
+
+
+@pytest.mark.parametrize('name', ['quarter_annulus', 'bspline_quarter_annulus', 'twisted_box', 'cylinder',
+                                  'unit_square', 'unit_cube'])
+def test_grid_jacobian(iga, golden, name):
+    g = golden('geometry')
+    geo = _geo(iga, name)
+    assert np.allclose(geo.coeffs, g[name + '_coeffs'], rtol=0, atol=1e-15)
+    d = geo.sdim
+    grid = [g['%s_grid%d' % (name, k)] for k in range(d)]
+    jac = geo.grid_jacobian(grid)
+    assert jac.shape == g[name + '_jac'].shape
+    assert np.abs(jac - g[name + '_jac']).max() < 1e-13
+    ev = geo.grid_eval(grid)
+    assert np.abs(ev - g[name + '_eval']).max() < 1e-13
+
+
+def test_fields(iga, oracle):
+    """precompute_fields on the device vs the oracle (assemblers.pyx:1389-1449 etc.)."""
+    for d, gname, ogeo, p, n in ((2, 'quarter_annulus', oracle.geo_quarter_annulus(), 3, 5),
+                                 (3, 'cylinder', oracle.geo_cylinder(), 2, 3),
+                                 (3, 'twisted_box', oracle.geo_twisted_box(), 3, 2)):
+        okv = oracle.make_knots(p, 0., 1., n)
+        kvs = (_kv(iga, okv),) * d
+        patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
+        for kind in ('mass', 'stiffness'):
+            oasm = oracle.Assembler(kind, (okv,) * d, ogeo)
+            F = patch.fields(kind)                       # (F, G0, G1[, G2])
+            ref = np.moveaxis(oasm.fields, -1, 0)
+            assert F.shape == ref.shape
+            assert np.abs(F - ref).max() <= 1e-13 * np.abs(ref).max()
+        for k in range(d):
+            nodes, w = patch.gauss(k)
+            assert np.array_equal(nodes, oasm.grid[k]) and np.array_equal(w, oasm.gw[k])
+        patch.close()
+
+
+def test_pattern(iga, oracle, golden):
+    g = golden('sparsity')
+    for name, d in (('d3_p2_n3', 3), ('d2_p3_n4', 2), ('d2_mixed', 2), ('d3_mult', 3)):
+        kvs = tuple(iga.bspline.KnotVector(g['%s_kv%d' % (name, k)], int(g['%s_p%d' % (name, k)])) for k in range(d))
+        geo = iga.geometry.unit_cube(dim=d)
+        patch = iga.assemblers.DevicePatch(kvs, geo)
+        indptr, indices = patch.pattern()
+        n = patch.shape[0]
+        I, J = g[name + '_lt0_I'], g[name + '_lt0_J']
+        R = scipy.sparse.coo_matrix((np.ones(len(I)), (I, J)), shape=(n, n)).tocsr()
+        R.sort_indices()
+        assert indptr.dtype == np.int32 and indices.dtype == np.int32
+        assert np.array_equal(indptr, R.indptr) and np.array_equal(indices, R.indices)
+        # host-side emission order of the generic driver matches the reference
+        for lt in (0, 1):
+            I2, J2 = iga.assemble._ml_nonzero(kvs, kvs, lower_tri=bool(lt))
+            assert np.array_equal(I2, g['%s_lt%d_I' % (name, lt)]) and np.array_equal(J2, g['%s_lt%d_J' % (name, lt)])
+        patch.close()
+
+
+def test_multi_entries(iga, golden):
+    g = golden('entries')
+    kv = iga.bspline.make_knots(2, 0., 1., 4)
+    cyl = _geo(iga, 'cylinder')
+    for name, cls in (('stiff3d', iga.assemblers.StiffnessAssembler3D), ('mass3d', iga.assemblers.MassAssembler3D)):
+        asm = cls((kv, kv, kv), cyl)
+        assert asm.arity == 2 and asm.kvs[0][0] is kv
+        idx, ref = g[name + '_idx'], g[name + '_multi']
+        out = asm.multi_entries(idx)
+        assert np.abs(out - ref).max() <= RTOL * np.abs(ref).max()
+        assert np.array_equal(out == 0.0, ref == 0.0)        # out-of-pattern pairs -> exact 0.0
+        assert asm.entry(int(idx[2, 0]), int(idx[2, 1])) == out[2]
+        assert np.array_equal(asm.multi_entries([tuple(r) for r in idx[:5]]), out[:5])   # iterable of pairs
+    kv2 = iga.bspline.make_knots(3, 0., 1., 6)
+    for name, cls in (('stiff2d', iga.assemblers.StiffnessAssembler2D), ('mass2d', iga.assemblers.MassAssembler2D)):
+        asm = cls((kv2, kv2), _geo(iga, 'quarter_annulus'))
+        out = asm.multi_entries(g[name + '_idx'])
+        ref = g[name + '_multi']
+        assert np.abs(out - ref).max() <= RTOL * np.abs(ref).max()
+
+
+FIXTURES = [('d2_p3_n15', 'mass', 2), ('d2_p3_n15', 'stiff', 2), ('d3_p2_n10', 'mass', 3), ('d3_p2_n10', 'stiff', 3)]
+
+
+@pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
+@pytest.mark.parametrize('tag,kind,d', FIXTURES)
+def test_reference_fixtures(iga, tag, kind, d, algo):
+    """test/test_assemble.py:138-168 with the reference's own files and tolerance."""
+    if d == 2:
+        kvs = (iga.bspline.make_knots(3, 0.0, 1.0, 15),) * 2
+        geo = iga.geometry.bspline_quarter_annulus()
+        cls = iga.assemblers.MassAssembler2D if kind == 'mass' else iga.assemblers.StiffnessAssembler2D
+    else:
+        kvs = (iga.bspline.make_knots(2, 0.0, 1.0, 10),) * 3
+        geo = iga.geometry.twisted_box()
+        cls = iga.assemblers.MassAssembler3D if kind == 'mass' else iga.assemblers.StiffnessAssembler3D
+    A = iga.assemble.assemble_entries(cls(kvs, geo), symmetric=True, algo=algo)
+    A_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_%s_%s.mtx.gz' % (tag, kind)))
+    assert abs(A - A_ref).max() < 1e-14
+    assert abs(A - A.T).max() == 0.0                      # exactly symmetric, like the reference
+    assert A.data.dtype == np.float64 and A.indices.dtype == np.int32 and A.has_canonical_format
+    # public API (auto algorithm)
+    fn = iga.assemble.mass if kind == 'mass' else iga.assemble.stiffness
+    assert abs(fn(kvs, geo) - A_ref).max() < 1e-14
+
+
+def _matrix_cases(iga):
+    mk = iga.bspline.make_knots
+    return [
+        ('d2_p3_n8_annulus_mass', 'mass', (mk(3, 0., 1., 8),) * 2, 'quarter_annulus', False),
+        ('d2_p3_n8_annulus_stiff', 'stiffness', (mk(3, 0., 1., 8),) * 2, 'quarter_annulus', False),
+        ('d2_p43_n56_square_mass', 'mass', (mk(4, 0., 1., 5), mk(3, 0., 1., 6)), 'unit_square', False),
+        ('d2_p43_n56_square_stiff', 'stiffness', (mk(4, 0., 1., 5), mk(3, 0., 1., 6)), 'unit_square', False),
+        ('d2_mult_annulus_mass', 'mass', (mk(3, 0., 1., 5, mult=2), mk(2, 0., 1., 4)), 'bspline_quarter_annulus', False),
+        ('d2_mult_annulus_stiff', 'stiffness', (mk(3, 0., 1., 5, mult=2), mk(2, 0., 1., 4)), 'bspline_quarter_annulus', False),
+        ('d3_p4_n3_cyl_stiff_lower', 'stiffness', (mk(4, 0., 1., 3),) * 3, 'cylinder', True),
+        ('d3_p5_n3_cyl_stiff_lower', 'stiffness', (mk(5, 0., 1., 3),) * 3, 'cylinder', True),
+        ('d3_p323_n342_tbox_mass_lower', 'mass', (mk(3, 0., 1., 3), mk(2, 0., 1., 4), mk(3, 0., 1., 2)), 'twisted_box', True),
+        ('d3_p323_n342_tbox_stiff_lower', 'stiffness', (mk(3, 0., 1., 3), mk(2, 0., 1., 4), mk(3, 0., 1., 2)), 'twisted_box', True),
+        ('d3_mult_cyl_stiff_lower', 'stiffness', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), 'cylinder', True),
+        ('d3_mult_cyl_mass_lower', 'mass', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), 'cylinder', True),
+    ]
+
+
+@pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
+def test_golden_matrices(iga, golden, algo, monkeypatch):
+    """Full matrices produced by the real reference: NURBS, unequal degrees per axis (shared
+    nqp = max p + 1), repeated interior knots, p = 4 and 5 in 3D."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')           # NaN-fill: every value must be written
+    g = golden('matrices')
+    for name, kind, kvs, gname, lower in _matrix_cases(iga):
+        fn = iga.assemble.bsp_mass_2d if kind == 'mass' else iga.assemble.bsp_stiffness_2d   # any d
+        cls = iga.assemble._ASSEMBLER[(kind, len(kvs))]
+        A = iga.assemble.assemble_entries(cls(kvs, _geo(iga, gname)), symmetric=True, algo=algo)
+        assert not np.isnan(A.data).any(), name
+        assert abs(A - A.T).max() == 0.0
+        if lower:
+            A = scipy.sparse.tril(A, format='csr')
+        R = golden_csr(g, name)
+        assert A.shape == R.shape and A.nnz >= R.nnz
+        assert rel_maxdiff(A, R) <= RTOL, (name, rel_maxdiff(A, R))
+        del fn
+
+
+def test_kronecker_path(iga, golden):
+    """geo=None -> Kronecker product of 1D matrices; identity geometry gives the same matrix
+    (test/test_assemble.py:10-40,83-100)."""
+    g = golden('kron')
+    kv = iga.bspline.KnotVector(g['kv1d'], 4)
+    assert np.abs(iga.assemble.bsp_mass_1d(kv).toarray() - g['M1d']).max() < 1e-14
+    assert np.abs(iga.assemble.bsp_stiffness_1d(kv).toarray() - g['K1d']).max() < 1e-12
+    assert np.abs(iga.assemble.mass(kv).toarray() - g['M1d']).max() < 1e-14
+    mk = iga.bspline.make_knots
+    kvs2 = (mk(4, 0., 1., 10), mk(3, 0., 1., 12))
+    kvs3 = (mk(3, 0., 1., 4), mk(3, 0., 1., 5), mk(3, 0., 1., 6))
+    for name, fn, kvs in (('kron2d_stiff', iga.assemble.stiffness, kvs2), ('kron2d_mass', iga.assemble.mass, kvs2),
+                          ('kron3d_stiff', iga.assemble.stiffness, kvs3), ('kron3d_mass', iga.assemble.mass, kvs3)):
+        assert rel_maxdiff(fn(kvs), golden_csr(g, name)) < 1e-13
+    assert np.allclose(iga.assemble.bsp_stiffness_2d(kvs2, geo=None).toarray(),
+                       iga.assemble.bsp_stiffness_2d(kvs2, geo=iga.geometry.unit_square()).toarray(), rtol=0, atol=1e-14)
+    assert np.allclose(iga.assemble.bsp_stiffness_3d(kvs3, geo=None).toarray(),
+                       iga.assemble.bsp_stiffness_3d(kvs3, geo=iga.geometry.unit_cube()).toarray(), rtol=0, atol=1e-14)
+
+
+def test_api_errors(iga):
+    kv = iga.bspline.make_knots(2, 0., 1., 4)
+    with pytest.raises(AssertionError):
+        iga.assemble.mass(kv, geo=iga.geometry.unit_square())            # 1D rejects geo
+    with pytest.raises(AssertionError):
+        iga.assemble.stiffness((kv, kv, kv), geo=iga.geometry.unit_square())   # dimension mismatch
+    with pytest.raises(AssertionError):
+        iga.assemble.stiffness((kv,) * 4, geo=None)
+    A = iga.assemble.stiffness((kv, kv), iga.geometry.unit_square(), format='csc')
+    assert A.format == 'csc'
+
+
+class _OpaqueGeo:
+    """A geometry object that only offers grid_jacobian (like pyiga's UserFunction)."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.dim, self.sdim = inner.dim, inner.sdim
+
+    def grid_jacobian(self, grid):
+        return self._inner.grid_jacobian(grid)
+
+
+def test_jacobian_array_geometry(iga):
+    kv = iga.bspline.make_knots(3, 0., 1., 5)
+    for geo, kvs in ((iga.geometry.quarter_annulus(), (kv, kv)), (_geo(iga, 'cylinder'), (kv, kv, kv))):
+        for fn in (iga.assemble.mass, iga.assemble.stiffness):
+            A = fn(kvs, geo)
+            B = fn(kvs, _OpaqueGeo(geo))
+            assert rel_maxdiff(B, A) < 1e-14
+
+
+def test_foreign_assembler_driver(iga, oracle):
+    """assemble_entries drives any object with the reference's assembler interface."""
+    okv = oracle.make_knots(2, 0., 1., 4)
+    oasm = oracle.Assembler('stiffness', (okv, okv), oracle.geo_quarter_annulus())
+
+    class Foreign:
+        arity = 2
+        kvs = ((_kv(iga, okv),) * 2,) * 2
+
+        def multi_entries(self, idx):
+            return oasm.multi_entries(idx)
+    A = iga.assemble.assemble_entries(Foreign(), symmetric=True)
+    kv = _kv(iga, okv)
+    B = iga.assemble.stiffness((kv, kv), iga.geometry.quarter_annulus())
+    assert rel_maxdiff(A, B) < RTOL
+
+
+# ------------------------------------------------------------------------------------------
+# size-independent properties at larger sizes (no oracle needed)
+@pytest.mark.parametrize('d,p,n', [(2, 3, 256), (3, 2, 24), (3, 4, 10), (2, 5, 40), (3, 1, 12)])
+def test_properties_larger(iga, d, p, n, monkeypatch):
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    geo = iga.geometry.quarter_annulus() if d == 2 else _geo(iga, 'cylinder')
+    kvs = (kv,) * d
+    K = iga.assemble.stiffness(kvs, geo)
+    M = iga.assemble.mass(kvs, geo)
+    for A in (K, M):
+        assert not np.isnan(A.data).any()
+        assert abs(A - A.T).max() == 0.0
+    # constants are in the kernel of the stiffness form (partition of unity)
+    assert np.abs(K @ np.ones(K.shape[0])).max() <= 1e-11 * abs(K).max()
+    # sum of the mass matrix = measure of the domain: quarter annulus r in [1,2] (x height 1)
+    assert abs(M.sum() - 0.75 * np.pi) < 1e-11
+    # sum-factorised == entry-wise at this size
+    if K.nnz < 3e7:
+        cls = iga.assemble._ASSEMBLER[('stiffness', d)]
+        E = cls(kvs, geo).assemble_csr(algo='entrywise')
+        assert rel_maxdiff(K, E) <= RTOL
+
+
+@pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
+@pytest.mark.parametrize('d,p,n,G', [(3, 2, 9, 2), (3, 3, 7, 3), (2, 3, 20, 4), (3, 4, 6, 2)])
+def test_row_slabs_equal_full(iga, d, p, n, G, algo, monkeypatch):
+    """Multi-GPU decomposition: each slab of axis-0 dof planes reproduces its rows of the full
+    matrix bit for bit, with no exchange between slabs."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * d
+    geo = iga.geometry.quarter_annulus() if d == 2 else _geo(iga, 'cylinder')
+    for kind in ('mass', 'stiffness'):
+        full = iga.assemblers.DevicePatch(kvs, geo).csr(kind, algo=algo)
+        N0 = kv.numdofs
+        bounds = [N0 * g // G for g in range(G + 1)]
+        blocks = []
+        for g in range(G):
+            patch = iga.assemblers.DevicePatch(kvs, geo, row0=(bounds[g], bounds[g + 1]))
+            blk = patch.csr(kind, algo=algo)
+            assert not np.isnan(blk.data).any()
+            lo, hi = patch.row_range
+            assert blk.shape[0] == hi - lo
+            blocks.append(blk)
+            patch.close()
+        stacked = scipy.sparse.vstack(blocks).tocsr()
+        assert stacked.shape == full.shape and stacked.nnz == full.nnz
+        assert np.array_equal(stacked.indices, full.indices) and np.array_equal(stacked.indptr, full.indptr)
+        assert np.array_equal(stacked.data, full.data)
