@@ -298,7 +298,8 @@ def test_properties_larger(iga, d, p, n, monkeypatch):
     # constants are in the kernel of the stiffness form (partition of unity)
     assert np.abs(K @ np.ones(K.shape[0])).max() <= 1e-11 * abs(K).max()
     # sum of the mass matrix = measure of the domain: quarter annulus r in [1,2] (x height 1)
-    assert abs(M.sum() - 0.75 * np.pi) < 1e-11
+    # (the integrand |det J| is rational for NURBS: Gauss quadrature converges, it is not exact)
+    assert abs(M.sum() - 0.75 * np.pi) < (1e-5 if p < 2 else 1e-9)
     # sum-factorised == entry-wise at this size
     if K.nnz < 3e7:
         cls = iga.assemble._ASSEMBLER[('stiffness', d)]
