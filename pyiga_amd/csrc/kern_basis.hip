@@ -6,6 +6,7 @@
 //   fields                    restate precompute_fields (pyiga/assemblers.pyx:86-110,234-275,
 //                             1223-1249,1389-1449): W = gw*|det J|,  B = W * Jinv Jinv^T
 #include "igx_internal.h"
+#include <algorithm>
 
 namespace igx {
 
@@ -203,19 +204,20 @@ __device__ inline void eval_geo(const GeoView &gv, const int g[3], double val[MA
 
 // Physical Jacobian Jm[r][c] = dG_r / d xi_c with c in (x,y,z) order, i.e. c = 0 differentiates
 // along the LAST grid axis (pyiga/bspline.py:917-921); NURBS by the quotient rule.
+// homogeneous value/derivatives -> physical Jacobian Jm[r][c] = dG_r / d xi_c with c in (x,y,z)
+// order, i.e. c = 0 differentiates along the LAST grid axis (pyiga/bspline.py:917-921); NURBS by
+// the quotient rule (pyiga/geometry.py:17-25).
 template <int DIM>
-__device__ inline void physical_jacobian(const GeoView &gv, bool nurbs, const int g[3], int ncomp,
-                                         double Jm[MAX_COMP][3], double ev[MAX_COMP])
+__device__ inline void finish_jacobian(const double val[MAX_COMP], const double jac[MAX_COMP][3], bool nurbs,
+                                       int ncomp, int nc, double Jm[MAX_COMP][3], double ev[MAX_COMP])
 {
-    double val[MAX_COMP], jac[MAX_COMP][3];
-    eval_geo<DIM>(gv, g, val, jac);
     if (nurbs) {
-        const double W = val[gv.nc - 1];
+        const double W = val[nc - 1];
         for (int r = 0; r < ncomp; ++r) {
             ev[r] = val[r] / W;
             for (int c = 0; c < DIM; ++c) {
                 const int k = DIM - 1 - c;
-                Jm[r][c] = (jac[r][k] * W - val[r] * jac[gv.nc - 1][k]) / (W * W);
+                Jm[r][c] = (jac[r][k] * W - val[r] * jac[nc - 1][k]) / (W * W);
             }
         }
     } else {
@@ -224,6 +226,15 @@ __device__ inline void physical_jacobian(const GeoView &gv, bool nurbs, const in
             for (int c = 0; c < DIM; ++c) Jm[r][c] = jac[r][DIM - 1 - c];
         }
     }
+}
+
+template <int DIM>
+__device__ inline void physical_jacobian(const GeoView &gv, bool nurbs, const int g[3], int ncomp,
+                                         double Jm[MAX_COMP][3], double ev[MAX_COMP])
+{
+    double val[MAX_COMP], jac[MAX_COMP][3];
+    eval_geo<DIM>(gv, g, val, jac);
+    finish_jacobian<DIM>(val, jac, nurbs, ncomp, gv.nc, Jm, ev);
 }
 
 template <int DIM>
@@ -340,6 +351,101 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int
     fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
 
+// Line-wise variant for spline geometries: the tensor-product structure of the geometry map is
+// exploited per grid line.  A block first contracts the control net with the basis functions of
+// the leading axes for its line(s) -> "line coefficients" Lc[cL][comp][{value, d/d axis0, d/d axis1}]
+// in LDS, then each thread evaluates its point with only (pL+1) * ncomp * (DIM+1) FMAs.
+// (The per-point kernel above costs prod(p_k+1) * ncomp * (DIM+1) FMAs and is memory-latency bound
+// on the control-net gathers.)
+template <int DIM>
+__global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind,
+                                                          const double *w0, const double *w1, const double *w2,
+                                                          int g0_lo, int G0loc, int G1, int G2, int LPB, double *fields)
+{
+    extern __shared__ double Lc[];                        // [LPB][NgL][nc][DIM]
+    const int LN = (DIM == 3) ? G2 : G1;                  // line length (last axis)
+    const long long nlines = (DIM == 3) ? (long long)G0loc * G1 : G0loc;
+    const long long total = nlines * LN;
+    const int nc = gv.nc;
+    const int NgL = gv.N[DIM - 1];
+    const long long line0 = (long long)blockIdx.x * LPB;
+    const int per_line = NgL * nc;
+
+    // ---- phase 1: line coefficients
+    for (int w = threadIdx.x; w < LPB * per_line; w += blockDim.x) {
+        const int ll = w / per_line, rem = w - ll * per_line;
+        const int cL = rem / nc, c = rem - cL * nc;
+        const long long line = line0 + ll;
+        if (line >= nlines) continue;
+        double sv = 0.0, s0 = 0.0, s1 = 0.0;
+        if (DIM == 2) {
+            const int g0 = g0_lo + (int)line;
+            const double *V0 = gv.V[0] + (size_t)g0 * gv.P[0] * 2;
+            const int f0 = gv.fa[0][g0];
+            for (int a0 = 0; a0 < gv.P[0]; ++a0) {
+                const double cf = gv.ctrl[((size_t)(f0 + a0) * gv.N[1] + cL) * nc + c];
+                sv += V0[a0 * 2] * cf;
+                s0 += V0[a0 * 2 + 1] * cf;
+            }
+        } else {
+            const int g0 = g0_lo + (int)(line / G1), g1 = (int)(line % G1);
+            const double *V0 = gv.V[0] + (size_t)g0 * gv.P[0] * 2;
+            const double *V1 = gv.V[1] + (size_t)g1 * gv.P[1] * 2;
+            const int f0 = gv.fa[0][g0], f1 = gv.fa[1][g1];
+            for (int a0 = 0; a0 < gv.P[0]; ++a0) {
+                double tv = 0.0, t1 = 0.0;
+                for (int a1 = 0; a1 < gv.P[1]; ++a1) {
+                    const double cf = gv.ctrl[(((size_t)(f0 + a0) * gv.N[1] + (f1 + a1)) * gv.N[2] + cL) * nc + c];
+                    tv += V1[a1 * 2] * cf;
+                    t1 += V1[a1 * 2 + 1] * cf;
+                }
+                sv += V0[a0 * 2] * tv;
+                s0 += V0[a0 * 2 + 1] * tv;
+                s1 += V0[a0 * 2] * t1;
+            }
+        }
+        double *dst = Lc + (size_t)w * DIM;
+        dst[0] = sv; dst[1] = s0;
+        if (DIM == 3) dst[2] = s1;
+    }
+    __syncthreads();
+
+    // ---- phase 2: points of the line(s)
+    const int PL = gv.P[DIM - 1];
+    const int npts_blk = LPB * LN;
+    for (int t = threadIdx.x; t < npts_blk; t += blockDim.x) {
+        const int ll = t / LN, gL = t - ll * LN;
+        const long long line = line0 + ll;
+        if (line >= nlines) break;
+        const double *VL = gv.V[DIM - 1] + (size_t)gL * PL * 2;
+        const int fL = gv.fa[DIM - 1][gL];
+        double val[MAX_COMP], jac[MAX_COMP][3];
+        for (int c = 0; c < MAX_COMP; ++c) { val[c] = 0.0; jac[c][0] = jac[c][1] = jac[c][2] = 0.0; }
+        const double *lc = Lc + ((size_t)ll * NgL + fL) * nc * DIM;
+        for (int aL = 0; aL < PL; ++aL) {
+            const double n = VL[aL * 2], d = VL[aL * 2 + 1];
+            for (int c = 0; c < nc; ++c) {
+                const double *e = lc + ((size_t)aL * nc + c) * DIM;
+                val[c] += n * e[0];
+                jac[c][0] += n * e[1];
+                if (DIM == 3) jac[c][1] += n * e[2];
+                jac[c][DIM - 1] += d * e[0];
+            }
+        }
+        double Jm[MAX_COMP][3], ev[MAX_COMP];
+        finish_jacobian<DIM>(val, jac, nurbs, DIM, nc, Jm, ev);
+        double tt[9];
+        for (int r = 0; r < DIM; ++r)
+            for (int c = 0; c < DIM; ++c) tt[r * DIM + c] = Jm[r][c];
+        int g0, g1;
+        if (DIM == 3) { g0 = g0_lo + (int)(line / G1); g1 = (int)(line % G1); }
+        else { g0 = g0_lo + (int)line; g1 = gL; }
+        double GW = w0[g0] * w1[g1];
+        if (DIM == 3) GW = GW * w2[gL];
+        fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
+    }
+}
+
 int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields)
 {
     const int dim = pt->dim;
@@ -347,13 +453,32 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     const PatchDev &pd = pt->dev;
     const long long total = pd.npts_loc;
     if (total == 0) return IGX_OK;
+    const int G1 = pd.ax[1].G, G2 = (dim == 3) ? pd.ax[2].G : 1;
+    if (pt->geo_kind != IGX_GEO_JACOBIAN) {
+        const int LN = (dim == 3) ? G2 : G1;
+        const int LPB = std::max(1, 256 / LN);
+        const size_t lds = (size_t)LPB * pt->gax[dim - 1].N * pt->ncomp * dim * sizeof(double);
+        if (lds <= 64 * 1024) {
+            const long long nlines = total / LN;
+            dim3 grid((unsigned)((nlines + LPB - 1) / LPB)), block(256);
+            const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
+            if (dim == 2)
+                k_geo_fields_lines<2><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
+                                                                pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+            else
+                k_geo_fields_lines<3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
+                                                                pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+            IGX_HIP(hipGetLastError());
+            return IGX_OK;
+        }
+    }
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     if (dim == 2)
         k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
-                                                pd.g0_lo, pd.G0_loc, pd.ax[1].G, 1, d_fields);
+                                                pd.g0_lo, pd.G0_loc, G1, 1, d_fields);
     else
         k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
-                                                pd.g0_lo, pd.G0_loc, pd.ax[1].G, pd.ax[2].G, d_fields);
+                                                pd.g0_lo, pd.G0_loc, G1, G2, d_fields);
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }

@@ -60,23 +60,57 @@ static std::vector<Term> form_terms(int dim, int kind)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stage A: sweep axis 0.  One thread per point of the remaining grid (g1[,g2]), NT types of one field.
-struct StageAArgs {
+// Tables that every lane reads at the same index are accessed through the constant address space:
+// hipcc then emits scalar loads (s_load_dwordx16 ...) and the coefficients feed v_fma_f64 straight
+// from SGPRs.  (Through a plain pointer it falls back to per-lane global_load + vmcnt(0) waits.)
+typedef const double __attribute__((address_space(4))) *cdp;
+typedef const int __attribute__((address_space(4))) *cip;
+
+// ---------------------------------------------------------------------------------------------
+// The two sweep kernels share one structure.  A thread owns one point of the axes that are NOT
+// contracted and walks along the contracted axis span by span, holding the (p+1)x(p+1) dof pairs
+// that are active on the current span in registers.  The coefficients PI[g][t][a][b] are the same
+// for every lane; the slice of the current span (q x 4 x P x P doubles, a few KB) is staged in LDS,
+// double-buffered (one barrier per span), and read back with broadcast ds_reads.
+// (Scalar loads were tried first: 25 coefficients x terms x q per span exceed the ~100 SGPRs of a
+// wave and hipcc spilled them through v_writelane/v_readlane -- 4x more VALU than FMAs.)
+//
+// Parallelism along the sweep: blockIdx.z selects a chunk of spans.  A chunk starts P-1 spans
+// early with zero accumulators (warm-up, nothing is written) so that every pair it completes inside
+// its own range has seen all of its spans.
+
+constexpr int SWEEP_MAX_STAGE = 8;     // PI slice values staged per thread (q*4*P*P / blockDim)
+
+struct SweepChunks { int nchunks, len; };
+
+// ---------------------------------------------------------------------------------------------
+// Stage A: sweep axis 0.  One thread per point of the remaining grid (g1[,g2]); blockIdx.y selects
+// the field; the (at most two) types of that field share the field load.
+struct StageAGroup {
     const double *field;        // [G0_loc][NPL]
-    double *out[2];             // K1 arrays [npairs0][NPL]
-    int t[2];
+    double *out0, *out1;        // K1 arrays [npairs0][NPL]
+    int t0, t1, nt;
+};
+struct StageAArgs {
+    StageAGroup grp[6];
     const double *PI0;          // [G0][4][P][P]
     const int *fa0, *rp0, *jlo0, *rl0_of;
     int s_lo, s_hi, n0, N0, q, g0_lo;
+    int chunk_len;
     long long NPL;
 };
 
-template <int P, int NT>
-__global__ void __launch_bounds__(256) k_stageA(StageAArgs A)
+template <int P, int NT, int Q>
+__device__ __forceinline__ void stageA_body(const double *__restrict__ field, double *__restrict__ out0,
+                                            double *__restrict__ out1, const int t0, const int t1,
+                                            const StageAArgs &A, const long long pt, const bool live, double *pis)
 {
-    long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = pt < A.NPL;
-    if (!live) pt = A.NPL - 1;
+    cip fa0 = (cip)A.fa0, rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, rl0_of = (cip)A.rl0_of;
+    const int q = Q ? Q : A.q;
+    const int SL = q * 4 * P * P;                         // coefficient slice of one span
+    const int own_lo = A.s_lo + blockIdx.z * A.chunk_len; // spans whose completed pairs this chunk writes
+    const int own_hi = min(own_lo + A.chunk_len, A.s_hi);
+    const int s_begin = max(A.s_lo, own_lo - (P - 1));
     double acc[NT][P][P];
 #pragma unroll
     for (int ty = 0; ty < NT; ++ty)
@@ -85,33 +119,75 @@ __global__ void __launch_bounds__(256) k_stageA(StageAArgs A)
 #pragma unroll
             for (int b = 0; b < P; ++b) acc[ty][a][b] = 0.0;
 
-    for (int s = A.s_lo; s < A.s_hi; ++s) {
-        for (int l = 0; l < A.q; ++l) {
-            const int g = s * A.q + l;
-            const double bv = A.field[(long long)(g - A.g0_lo) * A.NPL + pt];
-            const double *pi = A.PI0 + (size_t)g * 4 * P * P;
+    double stg[SWEEP_MAX_STAGE];
+    auto stage_load = [&](const int s) {
+        const double *src = A.PI0 + (size_t)s * SL;
+#pragma unroll
+        for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
+            const int idx = threadIdx.x + c * blockDim.x;
+            if (idx < SL) stg[c] = src[idx];
+        }
+    };
+    auto stage_store = [&](const int buf) {
+#pragma unroll
+        for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
+            const int idx = threadIdx.x + c * blockDim.x;
+            if (idx < SL) pis[buf * SL + idx] = stg[c];
+        }
+    };
+    stage_load(s_begin);
+    stage_store(0);
+
+    const double *fp = field + (long long)(s_begin * q - A.g0_lo) * A.NPL + pt;
+    for (int s = s_begin; s < own_hi; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < own_hi) stage_load(s + 1);            // in flight during this span
+        const double *pi_s = pis + buf * SL;
+        auto accumulate = [&](const int l, const double bv) {
 #pragma unroll
             for (int ty = 0; ty < NT; ++ty) {
-                const double *pt_ = pi + A.t[ty] * P * P;
+                const double *pt_ = pi_s + (l * 4 + (ty == 0 ? t0 : t1)) * P * P;
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
                     for (int b = 0; b <= a; ++b) acc[ty][a][b] = fma(pt_[a * P + b], bv, acc[ty][a][b]);
+                // keep hipcc from hoisting the LDS reads of every batch to the top (register blow-up):
+                // the next batch's reads may not cross this point, and the FMAs above must precede it
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[ty][a][b]));
+                asm volatile("" ::: "memory");
             }
+        };
+        if (Q) {
+            double bv[Q ? Q : 1];
+#pragma unroll
+            for (int l = 0; l < Q; ++l) bv[l] = fp[(long long)l * A.NPL];      // Q loads in flight
+            __syncthreads();                              // slice `buf` is complete
+#pragma unroll
+            for (int l = 0; l < Q; ++l) accumulate(l, bv[l]);
+        } else {
+            __syncthreads();
+            for (int l = 0; l < q; ++l) accumulate(l, fp[(long long)l * A.NPL]);
         }
-        const int base = A.fa0[s];
-        const int m = (s + 1 < A.s_hi && s + 1 < A.n0) ? (A.fa0[s + 1] - base) : P;
+        fp += (long long)q * A.NPL;
+        if (s + 1 < own_hi) stage_store(buf ^ 1);
+
+        const int base = fa0[s];
+        const int m = (s + 1 < A.s_hi && s + 1 < A.n0) ? (fa0[s + 1] - base) : P;
+        const bool write = live && s >= own_lo;
         for (int k = 0; k < m; ++k) {
             const int j0 = base + k;
             // dof j0 leaves the active set: its pairs (i0 = j0 + a, j0) are complete
 #pragma unroll
             for (int a = 0; a < P; ++a) {
                 const int i0 = j0 + a;
-                if (a <= P - 1 - k && i0 < A.N0) {
-                    const int r = A.rl0_of[A.rp0[i0] + (j0 - A.jlo0[i0])];
-                    if (r >= 0 && live) {
-#pragma unroll
-                        for (int ty = 0; ty < NT; ++ty) A.out[ty][(long long)r * A.NPL + pt] = acc[ty][a][0];
+                if (a <= P - 1 - k && i0 < A.N0 && write) {
+                    const int r = rl0_of[rp0[i0] + (j0 - jlo0[i0])];
+                    if (r >= 0) {
+                        out0[(long long)r * A.NPL + pt] = acc[0][a][0];
+                        if (NT == 2) out1[(long long)r * A.NPL + pt] = acc[NT - 1][a][0];
                     }
                 }
             }
@@ -128,39 +204,56 @@ __global__ void __launch_bounds__(256) k_stageA(StageAArgs A)
     }
 }
 
+template <int P, int Q>
+__global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
+{
+    extern __shared__ double pis[];                       // [2][q*4*P*P]
+    long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pt < A.NPL;
+    if (!live) pt = A.NPL - 1;
+    const StageAGroup &G = A.grp[blockIdx.y];
+    if (G.nt == 2) stageA_body<P, 2, Q>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
+    else stageA_body<P, 1, Q>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Stage B (3D): sweep axis 1.  Block = (chunk of g2, processed pair r0, output group y).
+// Stage B (3D): sweep axis 1.  Block = (chunk of g2, processed pair r0, output group y [x span chunk]).
 struct StageBGroup {
     int nterm;
     int x[4];                   // K1 array index of each term
     int t1[4];                  // axis-1 type of each term
 };
 struct StageBArgs {
-    const double *K1;           // [nX][npairs0][G1][G2]
-    double *K2;                 // [nY][npairs0][S1][G2]
     StageBGroup grp[4];
     const double *PI1;          // [G1][4][P][P]
     const int *fa1, *rp1, *jlo1;
     const int *pl0;             // [npairs0][2]
     int n1, N1, q, G1, G2, S1, npairs0;
+    int ngroups, chunk_len;
 };
 
-template <int P>
-__global__ void __launch_bounds__(256) k_stageB(StageBArgs B)
+template <int P, int NTERM, int Q>
+__device__ __forceinline__ void stageB_body(const double *__restrict__ K1, double *__restrict__ K2,
+                                            const StageBArgs &B, const StageBGroup &G, const int y, const int chunk,
+                                            const int g2, const bool live, double *pis)
 {
-    int g2 = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = g2 < B.G2;
-    if (!live) g2 = B.G2 - 1;
+    cip fa1 = (cip)B.fa1, rp1 = (cip)B.rp1, jlo1 = (cip)B.jlo1, pl0 = (cip)B.pl0;
     const int r0 = blockIdx.y;
-    const int y = blockIdx.z;
-    const StageBGroup &G = B.grp[y];
-    const bool diag0 = B.pl0[2 * r0] == B.pl0[2 * r0 + 1];
+    const bool diag0 = pl0[2 * r0] == pl0[2 * r0 + 1];
     const long long plane = (long long)B.G1 * B.G2;
-    const double *k1base[4];
+    const int q = Q ? Q : B.q;
+    const int SL = q * 4 * P * P;
+    const int own_lo = chunk * B.chunk_len;
+    const int own_hi = min(own_lo + B.chunk_len, B.n1);
+    const int s_begin = max(0, own_lo - (P - 1));
+    const double *kp[NTERM];
+    int t1[NTERM];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-        k1base[t] = B.K1 + ((long long)(t < G.nterm ? G.x[t] : 0) * B.npairs0 + r0) * plane + g2;
-    double *out = B.K2 + ((long long)y * B.npairs0 + r0) * B.S1 * B.G2 + g2;
+    for (int t = 0; t < NTERM; ++t) {
+        kp[t] = K1 + ((long long)G.x[t] * B.npairs0 + r0) * plane + (long long)s_begin * q * B.G2 + g2;
+        t1[t] = G.t1[t];
+    }
+    double *out = K2 + ((long long)y * B.npairs0 + r0) * B.S1 * B.G2 + g2;
 
     double acc[P][P];
 #pragma unroll
@@ -168,31 +261,79 @@ __global__ void __launch_bounds__(256) k_stageB(StageBArgs B)
 #pragma unroll
         for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
 
-    for (int s = 0; s < B.n1; ++s) {
-        for (int l = 0; l < B.q; ++l) {
-            const int g1 = s * B.q + l;
-            const double *pi = B.PI1 + (size_t)g1 * 4 * P * P;
-            for (int t = 0; t < G.nterm; ++t) {
-                const double kv = k1base[t][(long long)g1 * B.G2];
-                const double *pt_ = pi + G.t1[t] * P * P;
+    double stg[SWEEP_MAX_STAGE];
+    auto stage_load = [&](const int s) {
+        const double *src = B.PI1 + (size_t)s * SL;
+#pragma unroll
+        for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
+            const int idx = threadIdx.x + c * blockDim.x;
+            if (idx < SL) stg[c] = src[idx];
+        }
+    };
+    auto stage_store = [&](const int buf) {
+#pragma unroll
+        for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
+            const int idx = threadIdx.x + c * blockDim.x;
+            if (idx < SL) pis[buf * SL + idx] = stg[c];
+        }
+    };
+    stage_load(s_begin);
+    stage_store(0);
+
+    for (int s = s_begin; s < own_hi; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < own_hi) stage_load(s + 1);
+        const double *pi_s = pis + buf * SL;
+        auto accumulate = [&](const int l, const double (&kv)[NTERM]) {
+#pragma unroll
+            for (int t = 0; t < NTERM; ++t) {
+                const double *pt_ = pi_s + (l * 4 + t1[t]) * P * P;
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
-                    for (int b = 0; b < P; ++b) acc[a][b] = fma(pt_[a * P + b], kv, acc[a][b]);
+                    for (int b = 0; b < P; ++b) acc[a][b] = fma(pt_[a * P + b], kv[t], acc[a][b]);
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+                asm volatile("" ::: "memory");
+            }
+        };
+        if (Q) {
+            double kv[Q ? Q : 1][NTERM];
+#pragma unroll
+            for (int l = 0; l < Q; ++l)
+#pragma unroll
+                for (int t = 0; t < NTERM; ++t) kv[l][t] = kp[t][(long long)l * B.G2];
+            __syncthreads();
+#pragma unroll
+            for (int l = 0; l < Q; ++l) accumulate(l, kv[l]);
+        } else {
+            __syncthreads();
+            for (int l = 0; l < q; ++l) {
+                double kv[NTERM];
+#pragma unroll
+                for (int t = 0; t < NTERM; ++t) kv[t] = kp[t][(long long)l * B.G2];
+                accumulate(l, kv);
             }
         }
-        const int base = B.fa1[s];
-        const int m = (s + 1 < B.n1) ? (B.fa1[s + 1] - base) : P;
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) kp[t] += (long long)q * B.G2;
+        if (s + 1 < own_hi) stage_store(buf ^ 1);
+
+        const int base = fa1[s];
+        const int m = (s + 1 < B.n1) ? (fa1[s + 1] - base) : P;
+        const bool write = live && s >= own_lo;
         for (int k = 0; k < m; ++k) {
             const int d = base + k;              // dof leaving the active set
 #pragma unroll
             for (int a = 0; a < P; ++a) {
                 const int o = d + a;             // partner dof
-                if (a <= P - 1 - k && o < B.N1 && live) {
+                if (a <= P - 1 - k && o < B.N1 && write) {
                     // pair (i1 = o, j1 = d): lower or diagonal
-                    out[(long long)(B.rp1[o] + (d - B.jlo1[o])) * B.G2] = acc[a][0];
+                    out[(long long)(rp1[o] + (d - jlo1[o])) * B.G2] = acc[a][0];
                     // pair (i1 = d, j1 = o): strictly upper; not needed when (i0,j0) is diagonal
-                    if (a > 0 && !diag0) out[(long long)(B.rp1[d] + (o - B.jlo1[d])) * B.G2] = acc[0][a];
+                    if (a > 0 && !diag0) out[(long long)(rp1[d] + (o - jlo1[d])) * B.G2] = acc[0][a];
                 }
             }
 #pragma unroll
@@ -205,32 +346,54 @@ __global__ void __launch_bounds__(256) k_stageB(StageBArgs B)
     }
 }
 
+template <int P, int Q>
+__global__ void __launch_bounds__(256) k_stageB(const double *__restrict__ K1, double *__restrict__ K2, const StageBArgs B)
+{
+    extern __shared__ double pis[];                       // [2][q*4*P*P]
+    int g2 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = g2 < B.G2;
+    if (!live) g2 = B.G2 - 1;
+    const int y = blockIdx.z % B.ngroups, chunk = blockIdx.z / B.ngroups;
+    const StageBGroup &G = B.grp[y];
+    switch (G.nterm) {
+    case 1: stageB_body<P, 1, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 2: stageB_body<P, 2, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 3: stageB_body<P, 3, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    default: stageB_body<P, 4, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Final stage: contract the last (contiguous) grid axis and write CSR values + mirror.
-// Block = (row tile of the last axis, line).  A "line" is one K vector of length G_last:
-//   3D: line = (r0, r1) -> K2[y][r0][r1][:],   2D: line = r0 -> K1[x][r0][:].
+//
+// Block = (row tile of the last axis, row group).  A row group is all K lines that end up in the same
+// CSR rows:  3D: (r0, i1) with its lines j1 = jlo1[i1] .. (K2[y][r0][r1][:]),   2D: r0 (one line,
+// K1[x][r0][:]).  The basis table segment is staged in LDS once per block; the K lines are streamed
+// through registers into LDS one after the other (the next line's loads are in flight while the
+// current one is contracted); results leave through an LDS transpose so that every store
+// instruction writes runs of up to 2p+1 consecutive doubles.
 struct FinalArgs {
-    const double *K;            // [NY][nlines][G]
-    double *data;               // CSR values of the owned rows
     const double *V;            // last axis [G][P][2]
     const int *fa, *mslo, *mshi, *jlo, *jhi, *rp;   // last axis tables
     int N, q, G, TR;            // last axis dofs, q, Gauss count, rows per tile
     long long nlines;
-    // leading axes
     int dim;
     const int *pl0;             // [npairs0][2]
     const int *rp0, *jlo0, *jhi0;
-    const int *pair1_i, *pair1_j, *rp1, *jlo1, *jhi1;   // axis 1 (3D)
-    int S1;                     // pairs of axis 1 (3D), 1 in 2D
+    const int *rp1, *jlo1, *jhi1;   // axis 1 (3D)
+    int N1, S1;                 // dofs / pairs of axis 1 (3D); 1 in 2D
     long long Smid, Slast;      // 3D: S1, S2 ; 2D: unused, S1
     int r0_lo, r0_hi;
     long long nnz_off;
-    int seg_max;                // LDS segment capacity (Gauss points)
+    int nsp_max;                // LDS segment capacity in spans
+    int SSTR, KSTR;             // padded per-span strides (doubles) of the V / K images in LDS (odd => conflict-free)
     int ntiles;                 // row tiles per line
 };
 
+constexpr int KPY = 6;          // K values per thread and K array held in registers while prefetching
+
 template <int P, int D>
-__device__ inline void acc_add(double (&acc)[2 * P - 1], const double *vs, double cu0, double cu1)
+__device__ __forceinline__ void acc_add(double (&acc)[2 * P - 1], const double *vs, double cu0, double cu1)
 {
 #pragma unroll
     for (int b = 0; b < P; ++b)
@@ -239,7 +402,7 @@ __device__ inline void acc_add(double (&acc)[2 * P - 1], const double *vs, doubl
 
 template <int P, int D>
 struct AccSwitch {
-    __device__ static inline void run(int d, double (&acc)[2 * P - 1], const double *vs, double cu0, double cu1)
+    __device__ static __forceinline__ void run(int d, double (&acc)[2 * P - 1], const double *vs, double cu0, double cu1)
     {
         if (d == D) acc_add<P, D>(acc, vs, cu0, cu1);
         else AccSwitch<P, D + 1>::run(d, acc, vs, cu0, cu1);
@@ -247,29 +410,26 @@ struct AccSwitch {
 };
 template <int P>
 struct AccSwitch<P, 2 * P - 1> {
-    __device__ static inline void run(int, double (&)[2 * P - 1], const double *, double, double) {}
+    __device__ static __forceinline__ void run(int, double (&)[2 * P - 1], const double *, double, double) {}
 };
 
 // contribution of the K-th span of the support of row i (compile-time K so that the accumulator
 // index d + b is static in the common case d == K)
 template <int P, int NY, int K>
-__device__ inline void final_span(const FinalArgs &F, const double *Ks, const double *Vs, int seg_lo,
-                                  int i, int slo, int jl, double (&acc)[2 * P - 1])
+__device__ __forceinline__ void final_span(const int q, const int kcap, const int fa_s, const double *Ksp,
+                                           const double *Vsp, int i, int jl, double (&acc)[2 * P - 1])
 {
-    const int s = slo + K;
-    const int fa_s = F.fa[s];
     const int a = i - fa_s;                       // local index of the test function
     const int d = fa_s - jl;                      // output offset of local trial function 0
-    for (int l = 0; l < F.q; ++l) {
-        const int gl = s * F.q + l - seg_lo;
-        const double *vs = Vs + (size_t)gl * P * 2;
+    for (int l = 0; l < q; ++l) {
+        const double *vs = Vsp + l * P * 2;
         const double v0 = vs[2 * a], v1 = vs[2 * a + 1];
         double cu0, cu1;
-        if (NY == 1) { cu0 = v0 * Ks[gl]; cu1 = 0.0; }
+        if (NY == 1) { cu0 = v0 * Ksp[l]; cu1 = 0.0; }
         else {
             // K arrays are ordered by type t = tu + 2*tv of the last axis
-            cu0 = fma(v1, Ks[2 * F.seg_max + gl], v0 * Ks[gl]);
-            cu1 = fma(v1, Ks[3 * F.seg_max + gl], v0 * Ks[F.seg_max + gl]);
+            cu0 = fma(v1, Ksp[2 * kcap + l], v0 * Ksp[l]);
+            cu1 = fma(v1, Ksp[3 * kcap + l], v0 * Ksp[kcap + l]);
         }
         if (d == K) acc_add<P, K>(acc, vs, cu0, cu1);
         else AccSwitch<P, 0>::run(d, acc, vs, cu0, cu1);
@@ -278,96 +438,170 @@ __device__ inline void final_span(const FinalArgs &F, const double *Ks, const do
 
 template <int P, int NY, int K>
 struct SpanLoop {
-    __device__ static inline void run(const FinalArgs &F, const double *Ks, const double *Vs, int seg_lo,
-                                      int i, int slo, int nsp, int jl, double (&acc)[2 * P - 1])
+    __device__ static __forceinline__ void run(const int q, const int kcap, const int sstr, const int kstr, const int *fa_sp,
+                                               const double *Ksp, const double *Vsp, int i, int nsp, int jl,
+                                               double (&acc)[2 * P - 1])
     {
-        if (K < nsp) final_span<P, NY, K>(F, Ks, Vs, seg_lo, i, slo, jl, acc);
-        SpanLoop<P, NY, K + 1>::run(F, Ks, Vs, seg_lo, i, slo, nsp, jl, acc);
+        if (K < nsp) final_span<P, NY, K>(q, kcap, fa_sp[K], Ksp + K * kstr, Vsp + K * sstr, i, jl, acc);
+        SpanLoop<P, NY, K + 1>::run(q, kcap, sstr, kstr, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
     }
 };
 template <int P, int NY>
 struct SpanLoop<P, NY, P> {
-    __device__ static inline void run(const FinalArgs &, const double *, const double *, int, int, int, int, int,
-                                      double (&)[2 * P - 1]) {}
+    __device__ static __forceinline__ void run(const int, const int, const int, const int, const int *, const double *,
+                                               const double *, int, int, int, double (&)[2 * P - 1]) {}
 };
 
 template <int P, int NY>
-__global__ void __launch_bounds__(256) k_final(FinalArgs F)
+__global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, double *__restrict__ data, const FinalArgs F)
 {
+    constexpr int W = 2 * P - 1;
     extern __shared__ double lds[];
-    double *Ks = lds;                                   // [NY][seg_max]
-    double *Vs = lds + (size_t)NY * F.seg_max;          // [seg_max][P][2]
+    const int kcap = F.nsp_max * F.KSTR;                // doubles per K array image
+    double *Vs = lds;                                   // [nsp_max] spans x SSTR (q x P x (value, derivative), padded)
+    double *Ks = lds + (size_t)F.nsp_max * F.SSTR;      // [NY][nsp_max x KSTR]; reused as out_s[TR][W]
+    int *row_jl = (int *)(Ks + max(NY * kcap, F.TR * W));   // [TR + 2P] per-row tables of the rows this tile touches
+    int *row_c = row_jl + (F.TR + 2 * P);
+    int *row_rp = row_c + (F.TR + 2 * P);
 
-    const long long line = blockIdx.x / F.ntiles;
-    const int tile_lo = (int)(blockIdx.x % F.ntiles) * F.TR;
+    cip pl0 = (cip)F.pl0, rp0 = (cip)F.rp0, jlo0 = (cip)F.jlo0, jhi0 = (cip)F.jhi0;
+    cip rp1 = (cip)F.rp1, jlo1 = (cip)F.jlo1, jhi1 = (cip)F.jhi1;
+    cip mslo = (cip)F.mslo, mshi = (cip)F.mshi, jlo = (cip)F.jlo, jhi = (cip)F.jhi;
+
+    const int tile = blockIdx.x % F.ntiles;
+    const long long grp = blockIdx.x / F.ntiles;
+    const int tile_lo = tile * F.TR;
     const int tile_hi = min(tile_lo + F.TR, F.N);
+    const int ntr = tile_hi - tile_lo;
 
-    // ---- which (i0,j0[,i1,j1]) is this line?
-    int r0, i1 = 0, j1 = 0;
-    if (F.dim == 3) { r0 = (int)(line / F.S1); const int r1 = (int)(line % F.S1); i1 = F.pair1_i[r1]; j1 = F.pair1_j[r1]; }
-    else r0 = (int)line;
-    const int i0 = F.pl0[2 * r0], j0 = F.pl0[2 * r0 + 1];
-    bool diag_lead = (i0 == j0);
+    // ---- row group -> (i0, j0[, i1]) and its K lines
+    int r0, i1 = 0, nl = 1, jl1 = 0;
+    long long line0;
+    if (F.dim == 3) { r0 = (int)(grp / F.N1); i1 = (int)(grp % F.N1); }
+    else r0 = (int)grp;
+    const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
+    const bool diag0 = (i0 == j0);
     if (F.dim == 3) {
-        if (diag_lead && j1 > i1) return;               // upper part of a diagonal block: mirrored, not computed
-        diag_lead = diag_lead && (i1 == j1);
-    }
+        jl1 = jlo1[i1];
+        nl = diag0 ? (i1 - jl1 + 1) : (jhi1[i1] - jl1);    // upper part of a diagonal block is mirrored, not computed
+        line0 = (long long)r0 * F.S1 + rp1[i1];
+    } else line0 = r0;
     const bool own_row = i0 >= F.r0_lo && i0 < F.r0_hi;
     const bool own_col = j0 >= F.r0_lo && j0 < F.r0_hi;
+    const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
 
-    // position coefficients: pos = A + B*rp[i] + C*c[i] + o   
-    long long A_d, B_d, C_d, A_m, B_m, C_m;
-    {
-        const int c0i = F.jhi0[i0] - F.jlo0[i0], c0j = F.jhi0[j0] - F.jlo0[j0];
-        if (F.dim == 3) {
-            const int c1i = F.jhi1[i1] - F.jlo1[i1], c1j = F.jhi1[j1] - F.jlo1[j1];
-            A_d = (long long)F.rp0[i0] * F.Smid * F.Slast + (long long)c0i * F.rp1[i1] * F.Slast - F.nnz_off;
-            B_d = (long long)c0i * c1i;
-            C_d = (long long)(j0 - F.jlo0[i0]) * c1i + (j1 - F.jlo1[i1]);
-            A_m = (long long)F.rp0[j0] * F.Smid * F.Slast + (long long)c0j * F.rp1[j1] * F.Slast - F.nnz_off;
-            B_m = (long long)c0j * c1j;
-            C_m = (long long)(i0 - F.jlo0[j0]) * c1j + (i1 - F.jlo1[j1]);
-        } else {
-            A_d = (long long)F.rp0[i0] * F.Slast - F.nnz_off;  B_d = c0i;  C_d = j0 - F.jlo0[i0];
-            A_m = (long long)F.rp0[j0] * F.Slast - F.nnz_off;  B_m = c0j;  C_m = i0 - F.jlo0[j0];
-        }
-    }
-
-    // ---- stage the needed segment of the K line(s) and of the basis table in LDS
-    const int seg_lo = F.mslo[tile_lo] * F.q;
-    const int seg_hi = F.mshi[tile_hi - 1] * F.q;
-    const int seglen = seg_hi - seg_lo;
-    for (int idx = threadIdx.x; idx < seglen; idx += blockDim.x) {
-#pragma unroll
-        for (int y = 0; y < NY; ++y) Ks[y * F.seg_max + idx] = F.K[((long long)y * F.nlines + line) * F.G + seg_lo + idx];
-    }
+    // ---- stage the basis-table segment and the per-row tables (once per block)
+    const int sp_lo = mslo[tile_lo];
+    const int seg_lo = sp_lo * F.q;
+    const int seglen = mshi[tile_hi - 1] * F.q - seg_lo;
     {
         const double *vsrc = F.V + (size_t)seg_lo * P * 2;
-        for (int idx = threadIdx.x; idx < seglen * P * 2; idx += blockDim.x) Vs[idx] = vsrc[idx];
+        const int per_span = F.q * P * 2;
+        for (int idx = threadIdx.x; idx < seglen * P * 2; idx += blockDim.x) {
+            const int sp = idx / per_span;
+            Vs[sp * F.SSTR + (idx - sp * per_span)] = vsrc[idx];
+        }
     }
-    __syncthreads();
+    const int jmin = jlo[tile_lo], jmax = jhi[tile_hi - 1];     // rows touched by the mirror pass
+    for (int r = threadIdx.x; r < jmax - jmin; r += blockDim.x) {
+        const int j = jmin + r;
+        row_jl[r] = F.jlo[j];
+        row_c[r] = F.jhi[j] - F.jlo[j];
+        row_rp[r] = F.rp[j];
+    }
 
+    // ---- this thread's row
     const int i = tile_lo + threadIdx.x;
-    if (i >= tile_hi) return;
-    double acc[2 * P - 1];
+    const bool active = i < tile_hi;
+    int slo = 0, nsp = 0, jl = 0, fa_sp[P];
+    if (active) { slo = F.mslo[i]; nsp = F.mshi[i] - slo; jl = F.jlo[i]; }
 #pragma unroll
-    for (int o = 0; o < 2 * P - 1; ++o) acc[o] = 0.0;
-    const int slo = F.mslo[i], nsp = F.mshi[i] - slo, jl = F.jlo[i];
-    SpanLoop<P, NY, 0>::run(F, Ks, Vs, seg_lo, i, slo, nsp, jl, acc);
+    for (int k = 0; k < P; ++k) fa_sp[k] = (k < nsp) ? F.fa[slo + k] : 0;
+    const double *Vsp = Vs + (slo - sp_lo) * F.SSTR;
+    const double *Ksp = Ks + (slo - sp_lo) * F.KSTR;
 
-    // ---- write: direct entries (row I, cols j) and mirrored entries (row J, col I)
-    const int ci = F.jhi[i] - jl;
-    const long long pd = A_d + B_d * F.rp[i] + C_d * ci;
+    // ---- K prefetch: line -> registers
+    double kreg[NY][KPY];
+    int koff[KPY];                                      // LDS offset of the c-th value this thread stages
 #pragma unroll
-    for (int o = 0; o < 2 * P - 1; ++o) {
-        if (o < ci) {
-            const int j = jl + o;
-            if (diag_lead && j > i) continue;             // computed as the mirror of (j, i)
-            const double v = acc[o];
-            if (own_row) F.data[pd + o] = v;
-            if (own_col && !(diag_lead && j == i)) {
-                const int cj = F.jhi[j] - F.jlo[j];
-                F.data[A_m + B_m * F.rp[j] + C_m * cj + (i - F.jlo[j])] = v;
+    for (int c = 0; c < KPY; ++c) {
+        const int idx = threadIdx.x + c * blockDim.x;
+        const int sp = idx / F.q;
+        koff[c] = sp * F.KSTR + (idx - sp * F.q);
+    }
+    auto prefetch = [&](const long long line) {
+#pragma unroll
+        for (int y = 0; y < NY; ++y) {
+            const double *src = K + ((long long)y * F.nlines + line) * F.G + seg_lo;
+#pragma unroll
+            for (int c = 0; c < KPY; ++c) {
+                const int idx = threadIdx.x + c * blockDim.x;
+                if (idx < seglen) kreg[y][c] = src[idx];
+            }
+        }
+    };
+    prefetch(line0);
+
+    for (int ln = 0; ln < nl; ++ln) {
+        const int j1 = jl1 + ln;
+        __syncthreads();                                // previous line's out_s reads are done
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int c = 0; c < KPY; ++c) {
+                const int idx = threadIdx.x + c * blockDim.x;
+                if (idx < seglen) Ks[y * kcap + koff[c]] = kreg[y][c];
+            }
+        __syncthreads();
+        if (ln + 1 < nl) prefetch(line0 + ln + 1);      // in flight during the contraction below
+
+        double acc[W];
+#pragma unroll
+        for (int o = 0; o < W; ++o) acc[o] = 0.0;
+        if (active) SpanLoop<P, NY, 0>::run(F.q, kcap, F.SSTR, F.KSTR, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
+        __syncthreads();                                // everyone is done reading Ks
+        double *out_s = Ks;                             // [ntr][W]
+        if (active) {
+#pragma unroll
+            for (int o = 0; o < W; ++o) out_s[threadIdx.x * W + o] = acc[o];
+        }
+        __syncthreads();
+
+        // position coefficients: pos = A + B*rp[row] + C*c[row] + o   
+        const bool diag_lead = diag0 && (F.dim == 2 || j1 == i1);
+        long long A_d, B_d, C_d, A_m, B_m, C_m;
+        if (F.dim == 3) {
+            const int c1i = jhi1[i1] - jlo1[i1], c1j = jhi1[j1] - jlo1[j1];
+            A_d = (long long)rp0[i0] * F.Smid * F.Slast + (long long)c0i * rp1[i1] * F.Slast - F.nnz_off;
+            B_d = (long long)c0i * c1i;
+            C_d = (long long)(j0 - jlo0[i0]) * c1i + (j1 - jlo1[i1]);
+            A_m = (long long)rp0[j0] * F.Smid * F.Slast + (long long)c0j * rp1[j1] * F.Slast - F.nnz_off;
+            B_m = (long long)c0j * c1j;
+            C_m = (long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1]);
+        } else {
+            A_d = (long long)rp0[i0] * F.Slast - F.nnz_off;  B_d = c0i;  C_d = j0 - jlo0[i0];
+            A_m = (long long)rp0[j0] * F.Slast - F.nnz_off;  B_m = c0j;  C_m = i0 - jlo0[j0];
+        }
+        // direct entries: row (.., i), columns jl + o
+        if (own_row) {
+            for (int f = threadIdx.x; f < ntr * W; f += blockDim.x) {
+                const int r = f / W, o = f - r * W;
+                const int ii = tile_lo + r, rr = ii - jmin;
+                const int jli = row_jl[rr], ci = row_c[rr];
+                if (o < ci && !(diag_lead && jli + o > ii))
+                    data[A_d + B_d * row_rp[rr] + C_d * ci + o] = out_s[f];
+            }
+        }
+        // mirrored entries: row (.., j), column (.., i) for every computed (i, j) of this tile
+        if (own_col) {
+            const int nj = jmax - jmin;
+            for (int f = threadIdx.x; f < nj * W; f += blockDim.x) {
+                const int rr = f / W, o = f - rr * W;
+                const int j = jmin + rr;
+                const int cj = row_c[rr];
+                const int ii = row_jl[rr] + o;
+                if (o < cj && ii >= tile_lo && ii < tile_hi && !(diag_lead && j >= ii))
+                    data[A_m + B_m * row_rp[rr] + C_m * cj + o] = out_s[(ii - tile_lo) * W + (j - row_jl[ii - jmin])];
             }
         }
     }
@@ -419,29 +653,44 @@ static int ensure(double **buf, size_t *cap, size_t need)
 }
 
 template <int P>
-static void launch_stageA(hipStream_t st, const StageAArgs &A, int nt, dim3 grid, dim3 block)
+static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, dim3 grid, dim3 block, size_t lds)
 {
-    if (nt == 1) k_stageA<P, 1><<<grid, block, 0, st>>>(A);
-    else k_stageA<P, 2><<<grid, block, 0, st>>>(A);
+    if (qeq) k_stageA<P, P><<<grid, block, lds, st>>>(A);
+    else k_stageA<P, 0><<<grid, block, lds, st>>>(A);
 }
 
 template <int P>
-static int launch_final(hipStream_t st, const FinalArgs &F, int ny, dim3 grid, dim3 block, size_t lds)
+static void launch_stageB(hipStream_t st, const double *K1, double *K2, const StageBArgs &B, bool qeq, dim3 grid, dim3 block, size_t lds)
+{
+    if (qeq) k_stageB<P, P><<<grid, block, lds, st>>>(K1, K2, B);
+    else k_stageB<P, 0><<<grid, block, lds, st>>>(K1, K2, B);
+}
+
+// split a sweep of `nspans` into chunks so that the launch has enough blocks to fill the chip;
+// each chunk re-walks P-1 warm-up spans, so chunks are kept at least 4*P spans long
+static SweepChunks sweep_chunks(long long blocks_without, int nspans, int P)
+{
+    SweepChunks c{1, nspans};
+    const long long want = 2048;
+    if (blocks_without >= want || nspans < 8 * P) return c;
+    int n = (int)std::min<long long>((want + blocks_without - 1) / blocks_without, nspans / (4 * P));
+    n = std::max(n, 1);
+    c.len = (nspans + n - 1) / n;
+    c.nchunks = (nspans + c.len - 1) / c.len;
+    return c;
+}
+
+template <int P>
+static int launch_final(hipStream_t st, const double *K, double *data, const FinalArgs &F, int ny, dim3 grid, dim3 block, size_t lds)
 {
     if (ny == 1) {
         IGX_HIP(hipFuncSetAttribute((const void *)k_final<P, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_final<P, 1><<<grid, block, lds, st>>>(F);
+        k_final<P, 1><<<grid, block, lds, st>>>(K, data, F);
     } else {
         IGX_HIP(hipFuncSetAttribute((const void *)k_final<P, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_final<P, 4><<<grid, block, lds, st>>>(F);
+        k_final<P, 4><<<grid, block, lds, st>>>(K, data, F);
     }
     return IGX_OK;
-}
-
-template <int P>
-static void launch_stageB(hipStream_t st, const StageBArgs &B, dim3 grid, dim3 block)
-{
-    k_stageB<P><<<grid, block, 0, st>>>(B);
 }
 
 #define DISPATCH_P(Pv, CALL)                                   \
@@ -485,24 +734,34 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 
     const int nF = (kind == IGX_MASS) ? 1 : dim * (dim + 1) / 2;
     hipEventRecord(pt->ctx->ev[1], st);
-    // one launch per field: the types of that field share the field load
-    for (int f = 0; f < nF; ++f) {
+    // one launch for all fields (blockIdx.y); the types of a field share the field load
+    {
         StageAArgs A{};
-        int nt = 0;
-        for (int x = 0; x < nX; ++x)
-            if (X[x].f == f) {
-                if (nt == 2) { set_error("internal: more than two stage-A types per field"); return IGX_ERR_UNSUPPORTED; }
-                A.t[nt] = X[x].t0;
-                A.out[nt] = pt->d_K1 + (size_t)X[x].slot * np0 * NPL;
-                ++nt;
-            }
-        if (nt == 0) continue;
-        A.field = pt->d_fields + (size_t)f * pd.npts_loc;
+        int ng = 0;
+        for (int f = 0; f < nF; ++f) {
+            StageAGroup g{};
+            for (int x = 0; x < nX; ++x)
+                if (X[x].f == f) {
+                    if (g.nt == 2) { set_error("internal: more than two stage-A types per field"); return IGX_ERR_UNSUPPORTED; }
+                    double *o = pt->d_K1 + (size_t)X[x].slot * np0 * NPL;
+                    if (g.nt == 0) { g.t0 = X[x].t0; g.out0 = o; } else { g.t1 = X[x].t0; g.out1 = o; }
+                    g.nt++;
+                }
+            if (g.nt == 0) continue;
+            g.field = pt->d_fields + (size_t)f * pd.npts_loc;
+            A.grp[ng++] = g;
+        }
         A.PI0 = A0.d_PI; A.fa0 = A0.dev.fa; A.rp0 = A0.dev.rp; A.jlo0 = A0.dev.jlo; A.rl0_of = pt->d_rl0_of;
         A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.n0 = A0.n; A.N0 = A0.N; A.q = A0.q; A.g0_lo = pd.g0_lo;
         A.NPL = NPL;
-        dim3 block(256), grid((unsigned)((NPL + 255) / 256));
-        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, nt, grid, block));
+        const int bsA = 256;
+        const long long bx = (NPL + bsA - 1) / bsA;
+        const SweepChunks ch = sweep_chunks(bx * ng, pt->s0_hi - pt->s0_lo, A0.P);
+        A.chunk_len = ch.len;
+        const size_t ldsA = (size_t)2 * A0.q * 4 * A0.P * A0.P * sizeof(double);
+        if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
+        dim3 block(bsA), grid((unsigned)bx, ng, ch.nchunks);
+        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, grid, block, ldsA));
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
@@ -512,6 +771,8 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     FinalArgs F{};
     const Axis &AL = (dim == 3) ? A2 : A1;
     int NY;
+    const double *Kfinal = nullptr;
+    long long ngroups = 0;
     if (dim == 3) {
         // stage B groups by the last-axis type y = t2
         StageBArgs B{};
@@ -527,54 +788,68 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         }
         NY = ymax + 1;
         if (ensure(&pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
-        B.K1 = pt->d_K1; B.K2 = pt->d_K2; B.PI1 = A1.d_PI;
+        B.PI1 = A1.d_PI;
         B.fa1 = A1.dev.fa; B.rp1 = A1.dev.rp; B.jlo1 = A1.dev.jlo; B.pl0 = pt->d_pl0;
         B.n1 = A1.n; B.N1 = A1.N; B.q = A1.q; B.G1 = A1.G; B.G2 = A2.G; B.S1 = A1.S; B.npairs0 = np0;
-        const int bs = A2.G >= 256 ? 128 : 64;
-        dim3 block(bs), grid((A2.G + bs - 1) / bs, np0, NY);
-        if (np0 > 65535) { set_error("stage B: more than 65535 axis-0 pairs"); return IGX_ERR_UNSUPPORTED; }
-        DISPATCH_P(A1.P, launch_stageB<PP>(st, B, grid, block));
+        const int bs = 128;
+        const long long bxB = (A2.G + bs - 1) / bs;
+        const SweepChunks ch = sweep_chunks(bxB * np0 * NY, A1.n, A1.P);
+        B.ngroups = NY; B.chunk_len = ch.len;
+        const size_t ldsB = (size_t)2 * A1.q * 4 * A1.P * A1.P * sizeof(double);
+        if ((size_t)A1.q * 4 * A1.P * A1.P > (size_t)SWEEP_MAX_STAGE * bs) { set_error("stage B: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
+        dim3 block(bs), grid((unsigned)bxB, np0, NY * ch.nchunks);
+        if (np0 > 65535 || NY * ch.nchunks > 65535) { set_error("stage B: grid too large"); return IGX_ERR_UNSUPPORTED; }
+        DISPATCH_P(A1.P, launch_stageB<PP>(st, pt->d_K1, pt->d_K2, B, A1.q == A1.P, grid, block, ldsB));
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
-        F.K = pt->d_K2;
+        Kfinal = pt->d_K2;
         F.nlines = (long long)np0 * A1.S;
-        F.S1 = A1.S; F.Smid = A1.S; F.Slast = A2.S;
+        F.N1 = A1.N; F.S1 = A1.S; F.Smid = A1.S; F.Slast = A2.S;
+        ngroups = (long long)np0 * A1.N;
     } else {
         NY = (kind == IGX_MASS) ? 1 : 4;
-        F.K = pt->d_K1;
+        Kfinal = pt->d_K1;
         F.nlines = np0;
-        F.S1 = 1; F.Smid = 1; F.Slast = A1.S;
+        F.N1 = 1; F.S1 = 1; F.Smid = 1; F.Slast = A1.S;
+        ngroups = np0;
     }
     hipEventRecord(pt->ctx->ev[3], st);
 
-    F.data = d_data;
     F.V = AL.d_V; F.fa = AL.dev.fa; F.mslo = AL.dev.mslo; F.mshi = AL.dev.mshi;
     F.jlo = AL.dev.jlo; F.jhi = AL.dev.jhi; F.rp = AL.dev.rp;
     F.N = AL.N; F.q = AL.q; F.G = AL.G;
     F.dim = dim; F.pl0 = pt->d_pl0;
     F.rp0 = A0.dev.rp; F.jlo0 = A0.dev.jlo; F.jhi0 = A0.dev.jhi;
     F.rp1 = A1.dev.rp; F.jlo1 = A1.dev.jlo; F.jhi1 = A1.dev.jhi;
-    F.pair1_i = A1.dev.pair_i; F.pair1_j = A1.dev.pair_j;
     F.r0_lo = pt->r0_lo; F.r0_hi = pt->r0_hi; F.nnz_off = pt->nnz_off;
-    // row tiles of the last axis
-    int TR = std::min(256, ((AL.N + 63) / 64) * 64);
-    if (TR > 128 && AL.N > 256) TR = 128;
-    F.TR = TR;
-    int seg_max = 0;
-    for (int lo = 0; lo < AL.N; lo += TR) {
-        const int hi = std::min(lo + TR, AL.N);
-        seg_max = std::max(seg_max, (AL.mshi[hi - 1] - AL.mslo[lo]) * AL.q);
-    }
-    F.seg_max = seg_max;
-    const size_t lds = ((size_t)NY * seg_max + (size_t)seg_max * AL.P * 2) * sizeof(double);
-    if (lds > 160 * 1024) { set_error("final stage needs %zu B of LDS", lds); return IGX_ERR_UNSUPPORTED; }
     {
-        F.ntiles = (AL.N + TR - 1) / TR;
-        const long long nblocks = F.nlines * F.ntiles;
+        // row tiles of the last axis: as few tiles as possible with at most 256 rows each; the block
+        // has one thread per row (rounded up to whole waves, at least 128 threads)
+        int ntiles = (AL.N + 255) / 256;
+        int TR = (AL.N + ntiles - 1) / ntiles;
+        int bs = std::max(128, ((TR + 63) / 64) * 64);
+        auto span_cap = [&](int tr) {
+            int m = 0;
+            for (int lo = 0; lo < AL.N; lo += tr) m = std::max(m, AL.mshi[std::min(lo + tr, AL.N) - 1] - AL.mslo[lo]);
+            return m;
+        };
+        int nsp_max = span_cap(TR);
+        while (nsp_max * AL.q > KPY * bs && TR > 32) {       // K prefetch registers: KPY values per thread
+            TR -= 16; ntiles = (AL.N + TR - 1) / TR; nsp_max = span_cap(TR);
+        }
+        if (nsp_max * AL.q > KPY * bs) { set_error("final stage: K segment does not fit the prefetch registers"); return IGX_ERR_UNSUPPORTED; }
+        F.TR = TR; F.ntiles = ntiles; F.nsp_max = nsp_max;
+        F.SSTR = (AL.q * AL.P * 2) | 1;
+        F.KSTR = AL.q | 1;
+        const int W = 2 * AL.P - 1;
+        const size_t lds = ((size_t)nsp_max * F.SSTR + std::max((size_t)NY * nsp_max * F.KSTR, (size_t)TR * W)) * sizeof(double)
+                           + (size_t)3 * (TR + 2 * AL.P) * sizeof(int);
+        if (lds > 160 * 1024) { set_error("final stage needs %zu B of LDS", lds); return IGX_ERR_UNSUPPORTED; }
+        const long long nblocks = ngroups * ntiles;
         if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
-        dim3 block(TR), grid((unsigned)nblocks);
+        dim3 block(bs), grid((unsigned)nblocks);
         int rc = IGX_OK;
-        DISPATCH_P(AL.P, rc = launch_final<PP>(st, F, NY, grid, block, lds));
+        DISPATCH_P(AL.P, rc = launch_final<PP>(st, Kfinal, d_data, F, NY, grid, block, lds));
         if (rc) return rc;
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
