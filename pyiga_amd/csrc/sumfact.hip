@@ -28,6 +28,7 @@
 #include "igx_internal.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace igx {
 
@@ -388,9 +389,8 @@ struct FinalArgs {
     int nsp_max;                // LDS segment capacity in spans
     int SSTR, KSTR;             // padded per-span strides (doubles) of the V / K images in LDS (odd => conflict-free)
     int ntiles;                 // row tiles per line
+    int NS, slot_threads;       // line slots per block, threads per slot
 };
-
-constexpr int KPY = 6;          // K values per thread and K array held in registers while prefetching
 
 template <int P, int D>
 __device__ __forceinline__ void acc_add(double (&acc)[2 * P - 1], const double *vs, double cu0, double cu1)
@@ -413,60 +413,73 @@ struct AccSwitch<P, 2 * P - 1> {
     __device__ static __forceinline__ void run(int, double (&)[2 * P - 1], const double *, double, double) {}
 };
 
-// contribution of the K-th span of the support of row i (compile-time K so that the accumulator
-// index d + b is static in the common case d == K)
-template <int P, int NY, int K>
-__device__ __forceinline__ void final_span(const int q, const int kcap, const int fa_s, const double *Ksp,
+// contribution of the K-th span of the support of row i.  `d` is the output offset of the span's
+// local trial function 0; for single interior knots d == K for every row, which makes the
+// accumulator index static (the generic path is a compile-time switch over d).
+template <int P, int NY, int Q, bool SIMPLE, int K>
+__device__ __forceinline__ void final_span(const int q_rt, const int kcap, const int fa_s, const double *Ksp,
                                            const double *Vsp, int i, int jl, double (&acc)[2 * P - 1])
 {
     const int a = i - fa_s;                       // local index of the test function
-    const int d = fa_s - jl;                      // output offset of local trial function 0
-    for (int l = 0; l < q; ++l) {
+    const int d = fa_s - jl;
+    const int q = Q ? Q : q_rt;
+    auto point = [&](const int l, double &cu0, double &cu1) -> const double * {
         const double *vs = Vsp + l * P * 2;
         const double v0 = vs[2 * a], v1 = vs[2 * a + 1];
-        double cu0, cu1;
         if (NY == 1) { cu0 = v0 * Ksp[l]; cu1 = 0.0; }
         else {
             // K arrays are ordered by type t = tu + 2*tv of the last axis
             cu0 = fma(v1, Ksp[2 * kcap + l], v0 * Ksp[l]);
             cu1 = fma(v1, Ksp[3 * kcap + l], v0 * Ksp[kcap + l]);
         }
-        if (d == K) acc_add<P, K>(acc, vs, cu0, cu1);
-        else AccSwitch<P, 0>::run(d, acc, vs, cu0, cu1);
+        return vs;
+    };
+    if (SIMPLE || d == K) {
+#pragma unroll
+        for (int l = 0; l < q; ++l) { double c0, c1; const double *vs = point(l, c0, c1); acc_add<P, K>(acc, vs, c0, c1); }
+    } else {
+        for (int l = 0; l < q; ++l) { double c0, c1; const double *vs = point(l, c0, c1); AccSwitch<P, 0>::run(d, acc, vs, c0, c1); }
     }
 }
 
-template <int P, int NY, int K>
+template <int P, int NY, int Q, bool SIMPLE, int K>
 struct SpanLoop {
     __device__ static __forceinline__ void run(const int q, const int kcap, const int sstr, const int kstr, const int *fa_sp,
                                                const double *Ksp, const double *Vsp, int i, int nsp, int jl,
                                                double (&acc)[2 * P - 1])
     {
-        if (K < nsp) final_span<P, NY, K>(q, kcap, fa_sp[K], Ksp + K * kstr, Vsp + K * sstr, i, jl, acc);
-        SpanLoop<P, NY, K + 1>::run(q, kcap, sstr, kstr, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
+        if (K < nsp) final_span<P, NY, Q, SIMPLE, K>(q, kcap, fa_sp[K], Ksp + K * kstr, Vsp + K * sstr, i, jl, acc);
+        SpanLoop<P, NY, Q, SIMPLE, K + 1>::run(q, kcap, sstr, kstr, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
     }
 };
-template <int P, int NY>
-struct SpanLoop<P, NY, P> {
+template <int P, int NY, int Q, bool SIMPLE>
+struct SpanLoop<P, NY, Q, SIMPLE, P> {
     __device__ static __forceinline__ void run(const int, const int, const int, const int, const int *, const double *,
                                                const double *, int, int, int, double (&)[2 * P - 1]) {}
 };
 
-template <int P, int NY>
-__global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, double *__restrict__ data, const FinalArgs F)
+// Block = NS "line slots" x one row tile.  Every slot (slot_threads threads, one per row) works on
+// its own K line of the row group; the basis-table segment Vs is shared by all slots.
+template <int P, int NY, int Q, int KPY, bool SIMPLE>
+__global__ void __launch_bounds__(SIMPLE ? 1024 : 384) k_final(const double *__restrict__ K, double *__restrict__ data, const FinalArgs F)
 {
     constexpr int W = 2 * P - 1;
     extern __shared__ double lds[];
     const int kcap = F.nsp_max * F.KSTR;                // doubles per K array image
+    const int kslot = max(NY * kcap, F.TR * W);         // doubles per slot (K images, reused as out_s[TR][W])
     double *Vs = lds;                                   // [nsp_max] spans x SSTR (q x P x (value, derivative), padded)
-    double *Ks = lds + (size_t)F.nsp_max * F.SSTR;      // [NY][nsp_max x KSTR]; reused as out_s[TR][W]
-    int *row_jl = (int *)(Ks + max(NY * kcap, F.TR * W));   // [TR + 2P] per-row tables of the rows this tile touches
+    double *Kbase = lds + (size_t)F.nsp_max * F.SSTR;
+    int *row_jl = (int *)(Kbase + (size_t)F.NS * kslot);  // [TR + 2P] per-row tables of the rows this tile touches
     int *row_c = row_jl + (F.TR + 2 * P);
     int *row_rp = row_c + (F.TR + 2 * P);
 
     cip pl0 = (cip)F.pl0, rp0 = (cip)F.rp0, jlo0 = (cip)F.jlo0, jhi0 = (cip)F.jhi0;
     cip rp1 = (cip)F.rp1, jlo1 = (cip)F.jlo1, jhi1 = (cip)F.jhi1;
     cip mslo = (cip)F.mslo, mshi = (cip)F.mshi, jlo = (cip)F.jlo, jhi = (cip)F.jhi;
+
+    const int slot = threadIdx.x / F.slot_threads;
+    const int tid = threadIdx.x - slot * F.slot_threads;
+    double *Ks = Kbase + (size_t)slot * kslot;
 
     const int tile = blockIdx.x % F.ntiles;
     const long long grp = blockIdx.x / F.ntiles;
@@ -511,7 +524,7 @@ __global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, dou
     }
 
     // ---- this thread's row
-    const int i = tile_lo + threadIdx.x;
+    const int i = tile_lo + tid;
     const bool active = i < tile_hi;
     int slo = 0, nsp = 0, jl = 0, fa_sp[P];
     if (active) { slo = F.mslo[i]; nsp = F.mshi[i] - slo; jl = F.jlo[i]; }
@@ -525,7 +538,7 @@ __global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, dou
     int koff[KPY];                                      // LDS offset of the c-th value this thread stages
 #pragma unroll
     for (int c = 0; c < KPY; ++c) {
-        const int idx = threadIdx.x + c * blockDim.x;
+        const int idx = tid + c * F.slot_threads;
         const int sp = idx / F.q;
         koff[c] = sp * F.KSTR + (idx - sp * F.q);
     }
@@ -535,37 +548,42 @@ __global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, dou
             const double *src = K + ((long long)y * F.nlines + line) * F.G + seg_lo;
 #pragma unroll
             for (int c = 0; c < KPY; ++c) {
-                const int idx = threadIdx.x + c * blockDim.x;
+                const int idx = tid + c * F.slot_threads;
                 if (idx < seglen) kreg[y][c] = src[idx];
             }
         }
     };
-    prefetch(line0);
+    if (slot < nl) prefetch(line0 + slot);
 
-    for (int ln = 0; ln < nl; ++ln) {
+    for (int ln0 = 0; ln0 < nl; ln0 += F.NS) {
+        const int ln = ln0 + slot;
+        const bool has = ln < nl;
         const int j1 = jl1 + ln;
-        __syncthreads();                                // previous line's out_s reads are done
+        __syncthreads();                                // previous round's out_s reads are done
+        if (has) {
 #pragma unroll
-        for (int y = 0; y < NY; ++y)
+            for (int y = 0; y < NY; ++y)
 #pragma unroll
-            for (int c = 0; c < KPY; ++c) {
-                const int idx = threadIdx.x + c * blockDim.x;
-                if (idx < seglen) Ks[y * kcap + koff[c]] = kreg[y][c];
-            }
+                for (int c = 0; c < KPY; ++c) {
+                    const int idx = tid + c * F.slot_threads;
+                    if (idx < seglen) Ks[y * kcap + koff[c]] = kreg[y][c];
+                }
+        }
         __syncthreads();
-        if (ln + 1 < nl) prefetch(line0 + ln + 1);      // in flight during the contraction below
+        if (ln + F.NS < nl) prefetch(line0 + ln + F.NS);   // in flight during the contraction below
 
         double acc[W];
 #pragma unroll
         for (int o = 0; o < W; ++o) acc[o] = 0.0;
-        if (active) SpanLoop<P, NY, 0>::run(F.q, kcap, F.SSTR, F.KSTR, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
+        if (has && active) SpanLoop<P, NY, Q, SIMPLE, 0>::run(F.q, kcap, F.SSTR, F.KSTR, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
         __syncthreads();                                // everyone is done reading Ks
         double *out_s = Ks;                             // [ntr][W]
-        if (active) {
+        if (has && active) {
 #pragma unroll
-            for (int o = 0; o < W; ++o) out_s[threadIdx.x * W + o] = acc[o];
+            for (int o = 0; o < W; ++o) out_s[tid * W + o] = acc[o];
         }
         __syncthreads();
+        if (!has) continue;
 
         // position coefficients: pos = A + B*rp[row] + C*c[row] + o   
         const bool diag_lead = diag0 && (F.dim == 2 || j1 == i1);
@@ -584,7 +602,7 @@ __global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, dou
         }
         // direct entries: row (.., i), columns jl + o
         if (own_row) {
-            for (int f = threadIdx.x; f < ntr * W; f += blockDim.x) {
+            for (int f = tid; f < ntr * W; f += F.slot_threads) {
                 const int r = f / W, o = f - r * W;
                 const int ii = tile_lo + r, rr = ii - jmin;
                 const int jli = row_jl[rr], ci = row_c[rr];
@@ -595,7 +613,7 @@ __global__ void __launch_bounds__(256) k_final(const double *__restrict__ K, dou
         // mirrored entries: row (.., j), column (.., i) for every computed (i, j) of this tile
         if (own_col) {
             const int nj = jmax - jmin;
-            for (int f = threadIdx.x; f < nj * W; f += blockDim.x) {
+            for (int f = tid; f < nj * W; f += F.slot_threads) {
                 const int rr = f / W, o = f - rr * W;
                 const int j = jmin + rr;
                 const int cj = row_c[rr];
@@ -680,17 +698,27 @@ static SweepChunks sweep_chunks(long long blocks_without, int nspans, int P)
     return c;
 }
 
+template <int P, int NY, int Q, int KPY, bool SIMPLE>
+static int launch_final_k(hipStream_t st, const double *K, double *data, const FinalArgs &F, dim3 grid, dim3 block, size_t lds)
+{
+    IGX_HIP(hipFuncSetAttribute((const void *)k_final<P, NY, Q, KPY, SIMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_final<P, NY, Q, KPY, SIMPLE><<<grid, block, lds, st>>>(K, data, F);
+    return IGX_OK;
+}
+
+// Two instantiations per (P, NY): the fast one fixes q == P at compile time and assumes single
+// interior knots on the last axis (output offset of span k is k); the generic one handles any q and
+// any knot multiplicities.
 template <int P>
-static int launch_final(hipStream_t st, const double *K, double *data, const FinalArgs &F, int ny, dim3 grid, dim3 block, size_t lds)
+static int launch_final(hipStream_t st, const double *K, double *data, const FinalArgs &F, int ny, bool fast, int kpy,
+                        dim3 grid, dim3 block, size_t lds)
 {
     if (ny == 1) {
-        IGX_HIP(hipFuncSetAttribute((const void *)k_final<P, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_final<P, 1><<<grid, block, lds, st>>>(K, data, F);
-    } else {
-        IGX_HIP(hipFuncSetAttribute((const void *)k_final<P, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_final<P, 4><<<grid, block, lds, st>>>(K, data, F);
+        if (fast) return kpy <= 4 ? launch_final_k<P, 1, P, 4, true>(st, K, data, F, grid, block, lds) : launch_final_k<P, 1, P, 8, true>(st, K, data, F, grid, block, lds);
+        return kpy <= 4 ? launch_final_k<P, 1, 0, 4, false>(st, K, data, F, grid, block, lds) : launch_final_k<P, 1, 0, 8, false>(st, K, data, F, grid, block, lds);
     }
-    return IGX_OK;
+    if (fast) return kpy <= 4 ? launch_final_k<P, 4, P, 4, true>(st, K, data, F, grid, block, lds) : launch_final_k<P, 4, P, 8, true>(st, K, data, F, grid, block, lds);
+    return kpy <= 4 ? launch_final_k<P, 4, 0, 4, false>(st, K, data, F, grid, block, lds) : launch_final_k<P, 4, 0, 8, false>(st, K, data, F, grid, block, lds);
 }
 
 #define DISPATCH_P(Pv, CALL)                                   \
@@ -823,33 +851,42 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     F.rp1 = A1.dev.rp; F.jlo1 = A1.dev.jlo; F.jhi1 = A1.dev.jhi;
     F.r0_lo = pt->r0_lo; F.r0_hi = pt->r0_hi; F.nnz_off = pt->nnz_off;
     {
-        // row tiles of the last axis: as few tiles as possible with at most 256 rows each; the block
-        // has one thread per row (rounded up to whole waves, at least 128 threads)
+        // row tiles of the last axis: as few tiles as possible with at most 256 rows each; a slot has
+        // one thread per row (rounded up to whole waves); NS slots share the staged basis table
         int ntiles = (AL.N + 255) / 256;
         int TR = (AL.N + ntiles - 1) / ntiles;
-        int bs = std::max(128, ((TR + 63) / 64) * 64);
         auto span_cap = [&](int tr) {
             int m = 0;
             for (int lo = 0; lo < AL.N; lo += tr) m = std::max(m, AL.mshi[std::min(lo + tr, AL.N) - 1] - AL.mslo[lo]);
             return m;
         };
-        int nsp_max = span_cap(TR);
-        while (nsp_max * AL.q > KPY * bs && TR > 32) {       // K prefetch registers: KPY values per thread
-            TR -= 16; ntiles = (AL.N + TR - 1) / TR; nsp_max = span_cap(TR);
-        }
-        if (nsp_max * AL.q > KPY * bs) { set_error("final stage: K segment does not fit the prefetch registers"); return IGX_ERR_UNSUPPORTED; }
-        F.TR = TR; F.ntiles = ntiles; F.nsp_max = nsp_max;
+        const int slot_threads = ((TR + 63) / 64) * 64;
+        const int nsp_max = span_cap(TR);
+        const int kpy = (nsp_max * AL.q + slot_threads - 1) / slot_threads;
+        if (kpy > 8) { set_error("final stage: K segment does not fit the prefetch registers"); return IGX_ERR_UNSUPPORTED; }
+        F.TR = TR; F.ntiles = ntiles; F.nsp_max = nsp_max; F.slot_threads = slot_threads;
         F.SSTR = (AL.q * AL.P * 2) | 1;
         F.KSTR = AL.q | 1;
         const int W = 2 * AL.P - 1;
-        const size_t lds = ((size_t)nsp_max * F.SSTR + std::max((size_t)NY * nsp_max * F.KSTR, (size_t)TR * W)) * sizeof(double)
-                           + (size_t)3 * (TR + 2 * AL.P) * sizeof(int);
+        const size_t vbytes = (size_t)nsp_max * F.SSTR * sizeof(double);
+        const size_t kslot = std::max((size_t)NY * nsp_max * F.KSTR, (size_t)TR * W) * sizeof(double);
+        const size_t tbytes = (size_t)3 * (TR + 2 * AL.P) * sizeof(int);
+        int max_lines = 1;
+        if (dim == 3)
+            for (int i = 0; i < A1.N; ++i) max_lines = std::max(max_lines, A1.jhi[i] - A1.jlo[i]);
+        const bool fast = AL.q == AL.P && AL.simple;
+        const int max_threads = fast ? 1024 : 384;
+        int NS = 1;
+        while (NS < max_lines && NS < 5 && (NS + 1) * slot_threads <= max_threads && vbytes + (NS + 1) * kslot + tbytes <= 160 * 1024) ++NS;
+        if (const char *e = getenv("IGX_FINAL_NS")) NS = std::max(1, std::min(NS, atoi(e)));
+        F.NS = NS;
+        const size_t lds = vbytes + NS * kslot + tbytes;
         if (lds > 160 * 1024) { set_error("final stage needs %zu B of LDS", lds); return IGX_ERR_UNSUPPORTED; }
         const long long nblocks = ngroups * ntiles;
         if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
-        dim3 block(bs), grid((unsigned)nblocks);
+        dim3 block(NS * slot_threads), grid((unsigned)nblocks);
         int rc = IGX_OK;
-        DISPATCH_P(AL.P, rc = launch_final<PP>(st, Kfinal, d_data, F, NY, grid, block, lds));
+        DISPATCH_P(AL.P, rc = launch_final<PP>(st, Kfinal, d_data, F, NY, fast, kpy, grid, block, lds));
         if (rc) return rc;
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
