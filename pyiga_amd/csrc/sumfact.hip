@@ -95,7 +95,8 @@ struct StageAGroup {
 struct StageAArgs {
     StageAGroup grp[6];
     const double *PI0;          // [G0][4][P][P]
-    const int *fa0, *rp0, *jlo0, *rl0_of;
+    const int *step_ptr;        // [n0+1] first flush step of each span
+    const int *steps;           // [nsteps][8] K1 slot of pair (leaving dof + a, leaving dof), or -1
     int s_lo, s_hi, n0, N0, q, g0_lo;
     int chunk_len;
     long long NPL;
@@ -106,9 +107,11 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
                                             double *__restrict__ out1, const int t0, const int t1,
                                             const StageAArgs &A, const long long pt, const bool live, double *pis)
 {
-    cip fa0 = (cip)A.fa0, rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, rl0_of = (cip)A.rl0_of;
+    cip step_ptr = (cip)A.step_ptr, steps = (cip)A.steps;
     const int q = Q ? Q : A.q;
-    const int SL = q * 4 * P * P;                         // coefficient slice of one span
+    constexpr int PP = (P * P + 1) & ~1;                  // padded row: 16-byte aligned => ds_read_b128
+    const int SL = q * 4 * P * P;                         // coefficient slice of one span (global)
+    const int SLP = q * 4 * PP;                           // ... and its padded LDS image
     const int own_lo = A.s_lo + blockIdx.z * A.chunk_len; // spans whose completed pairs this chunk writes
     const int own_hi = min(own_lo + A.chunk_len, A.s_hi);
     const int s_begin = max(A.s_lo, own_lo - (P - 1));
@@ -133,7 +136,7 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
 #pragma unroll
         for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
             const int idx = threadIdx.x + c * blockDim.x;
-            if (idx < SL) pis[buf * SL + idx] = stg[c];
+            if (idx < SL) pis[buf * SLP + (idx / (P * P)) * PP + idx % (P * P)] = stg[c];
         }
     };
     stage_load(s_begin);
@@ -143,11 +146,11 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
     for (int s = s_begin; s < own_hi; ++s) {
         const int buf = (s - s_begin) & 1;
         if (s + 1 < own_hi) stage_load(s + 1);            // in flight during this span
-        const double *pi_s = pis + buf * SL;
+        const double *pi_s = pis + buf * SLP;
         auto accumulate = [&](const int l, const double bv) {
 #pragma unroll
             for (int ty = 0; ty < NT; ++ty) {
-                const double *pt_ = pi_s + (l * 4 + (ty == 0 ? t0 : t1)) * P * P;
+                const double *pt_ = (const double *)__builtin_assume_aligned(pi_s + (l * 4 + (ty == 0 ? t0 : t1)) * PP, 16);
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -175,21 +178,17 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
         fp += (long long)q * A.NPL;
         if (s + 1 < own_hi) stage_store(buf ^ 1);
 
-        const int base = fa0[s];
-        const int m = (s + 1 < A.s_hi && s + 1 < A.n0) ? (fa0[s + 1] - base) : P;
+        // dofs that leave the active set after this span: their pairs are complete (one flush step
+        // per leaving dof; the K1 slots come from a host-built table, one scalar load per step)
         const bool write = live && s >= own_lo;
-        for (int k = 0; k < m; ++k) {
-            const int j0 = base + k;
-            // dof j0 leaves the active set: its pairs (i0 = j0 + a, j0) are complete
+        for (int st = step_ptr[s]; st < step_ptr[s + 1]; ++st) {
+            cip rec = steps + (size_t)st * 8;
 #pragma unroll
             for (int a = 0; a < P; ++a) {
-                const int i0 = j0 + a;
-                if (a <= P - 1 - k && i0 < A.N0 && write) {
-                    const int r = rl0_of[rp0[i0] + (j0 - jlo0[i0])];
-                    if (r >= 0) {
-                        out0[(long long)r * A.NPL + pt] = acc[0][a][0];
-                        if (NT == 2) out1[(long long)r * A.NPL + pt] = acc[NT - 1][a][0];
-                    }
+                const int r = rec[a];
+                if (r >= 0 && write) {
+                    out0[(long long)r * A.NPL + pt] = acc[0][a][0];
+                    if (NT == 2) out1[(long long)r * A.NPL + pt] = acc[NT - 1][a][0];
                 }
             }
 #pragma unroll
@@ -208,7 +207,7 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
 template <int P, int Q>
 __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
 {
-    extern __shared__ double pis[];                       // [2][q*4*P*P]
+    extern __shared__ __attribute__((aligned(16))) double pis[];   // [2][q*4*PP]
     long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = pt < A.NPL;
     if (!live) pt = A.NPL - 1;
@@ -227,7 +226,8 @@ struct StageBGroup {
 struct StageBArgs {
     StageBGroup grp[4];
     const double *PI1;          // [G1][4][P][P]
-    const int *fa1, *rp1, *jlo1;
+    const int *step_ptr;        // [n1+1]
+    const int *steps;           // [nsteps][16]: [a] = pair index of (d+a, d), [8+a] = pair index of (d, d+a); -1 if none
     const int *pl0;             // [npairs0][2]
     int n1, N1, q, G1, G2, S1, npairs0;
     int ngroups, chunk_len;
@@ -238,12 +238,14 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
                                             const StageBArgs &B, const StageBGroup &G, const int y, const int chunk,
                                             const int g2, const bool live, double *pis)
 {
-    cip fa1 = (cip)B.fa1, rp1 = (cip)B.rp1, jlo1 = (cip)B.jlo1, pl0 = (cip)B.pl0;
+    cip step_ptr = (cip)B.step_ptr, steps = (cip)B.steps, pl0 = (cip)B.pl0;
     const int r0 = blockIdx.y;
     const bool diag0 = pl0[2 * r0] == pl0[2 * r0 + 1];
     const long long plane = (long long)B.G1 * B.G2;
     const int q = Q ? Q : B.q;
+    constexpr int PP = (P * P + 1) & ~1;
     const int SL = q * 4 * P * P;
+    const int SLP = q * 4 * PP;
     const int own_lo = chunk * B.chunk_len;
     const int own_hi = min(own_lo + B.chunk_len, B.n1);
     const int s_begin = max(0, own_lo - (P - 1));
@@ -275,7 +277,7 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
 #pragma unroll
         for (int c = 0; c < SWEEP_MAX_STAGE; ++c) {
             const int idx = threadIdx.x + c * blockDim.x;
-            if (idx < SL) pis[buf * SL + idx] = stg[c];
+            if (idx < SL) pis[buf * SLP + (idx / (P * P)) * PP + idx % (P * P)] = stg[c];
         }
     };
     stage_load(s_begin);
@@ -284,11 +286,11 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
     for (int s = s_begin; s < own_hi; ++s) {
         const int buf = (s - s_begin) & 1;
         if (s + 1 < own_hi) stage_load(s + 1);
-        const double *pi_s = pis + buf * SL;
+        const double *pi_s = pis + buf * SLP;
         auto accumulate = [&](const int l, const double (&kv)[NTERM]) {
 #pragma unroll
             for (int t = 0; t < NTERM; ++t) {
-                const double *pt_ = pi_s + (l * 4 + t1[t]) * P * P;
+                const double *pt_ = (const double *)__builtin_assume_aligned(pi_s + (l * 4 + t1[t]) * PP, 16);
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -322,19 +324,16 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
         for (int t = 0; t < NTERM; ++t) kp[t] += (long long)q * B.G2;
         if (s + 1 < own_hi) stage_store(buf ^ 1);
 
-        const int base = fa1[s];
-        const int m = (s + 1 < B.n1) ? (fa1[s + 1] - base) : P;
         const bool write = live && s >= own_lo;
-        for (int k = 0; k < m; ++k) {
-            const int d = base + k;              // dof leaving the active set
+        for (int st = step_ptr[s]; st < step_ptr[s + 1]; ++st) {
+            cip rec = steps + (size_t)st * 16;
 #pragma unroll
             for (int a = 0; a < P; ++a) {
-                const int o = d + a;             // partner dof
-                if (a <= P - 1 - k && o < B.N1 && write) {
-                    // pair (i1 = o, j1 = d): lower or diagonal
-                    out[(long long)(rp1[o] + (d - jlo1[o])) * B.G2] = acc[a][0];
-                    // pair (i1 = d, j1 = o): strictly upper; not needed when (i0,j0) is diagonal
-                    if (a > 0 && !diag0) out[(long long)(rp1[d] + (o - jlo1[d])) * B.G2] = acc[0][a];
+                const int rl = rec[a];               // pair (i1 = d + a, j1 = d): lower or diagonal
+                if (rl >= 0 && write) out[(long long)rl * B.G2] = acc[a][0];
+                if (a > 0) {
+                    const int ru = rec[8 + a];       // pair (i1 = d, j1 = d + a): strictly upper,
+                    if (ru >= 0 && write && !diag0) out[(long long)ru * B.G2] = acc[0][a];   // not needed on a diagonal (i0,j0)
                 }
             }
 #pragma unroll
@@ -350,7 +349,7 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
 template <int P, int Q>
 __global__ void __launch_bounds__(256) k_stageB(const double *__restrict__ K1, double *__restrict__ K2, const StageBArgs B)
 {
-    extern __shared__ double pis[];                       // [2][q*4*P*P]
+    extern __shared__ __attribute__((aligned(16))) double pis[];   // [2][q*4*PP]
     int g2 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g2 < B.G2;
     if (!live) g2 = B.G2 - 1;
@@ -649,6 +648,44 @@ int sumfact_prepare(igx_patch *pt)
             pl.push_back(j0);
         }
     pt->npairs0 = (int)(pl.size() / 2);
+    // flush-step tables of the two sweeps: after span s the dofs fa[s] .. fa[s+1]-1 (all remaining
+    // ones after the last span) leave the active set, one step each, in increasing order
+    auto build_steps = [&](const Axis &A, int width, std::vector<int> &ptr, std::vector<int> &rec, bool stageA) {
+        ptr.assign(A.n + 1, 0);
+        rec.clear();
+        for (int s = 0; s < A.n; ++s) {
+            const int base = A.fa[s];
+            const int m = (s + 1 < A.n) ? (A.fa[s + 1] - base) : A.P;
+            for (int k = 0; k < m; ++k) {
+                const int d = base + k;
+                std::vector<int> r(width, -1);
+                for (int a = 0; a < A.P; ++a) {
+                    const int o = d + a;
+                    if (a > A.P - 1 - k || o >= A.N) continue;       // slot holds no accumulated pair
+                    if (stageA) r[a] = rl[A.rp[o] + (d - A.jlo[o])];
+                    else {
+                        r[a] = A.rp[o] + (d - A.jlo[o]);
+                        if (a > 0) r[8 + a] = A.rp[d] + (o - A.jlo[d]);
+                    }
+                }
+                rec.insert(rec.end(), r.begin(), r.end());
+            }
+            ptr[s + 1] = (int)(rec.size() / width);
+        }
+    };
+    std::vector<int> ptrA, recA, ptrB, recB;
+    build_steps(A0, 8, ptrA, recA, true);
+    if (pt->dim == 3) build_steps(pt->ax[1], 16, ptrB, recB, false);
+    std::vector<int> tab;
+    const size_t oA0 = 0, oA1 = ptrA.size(), oB0 = oA1 + recA.size(), oB1 = oB0 + ptrB.size();
+    tab.insert(tab.end(), ptrA.begin(), ptrA.end());
+    tab.insert(tab.end(), recA.begin(), recA.end());
+    tab.insert(tab.end(), ptrB.begin(), ptrB.end());
+    tab.insert(tab.end(), recB.begin(), recB.end());
+    IGX_HIP(hipMalloc(&pt->d_steps, std::max<size_t>(1, tab.size()) * sizeof(int)));
+    IGX_HIP(hipMemcpyAsync(pt->d_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+    pt->stepA_ptr = pt->d_steps + oA0; pt->stepA_rec = pt->d_steps + oA1;
+    pt->stepB_ptr = pt->d_steps + oB0; pt->stepB_rec = pt->d_steps + oB1;
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
     IGX_HIP(hipMalloc(&pt->d_rl0_of, std::max<size_t>(1, rl.size()) * sizeof(int)));
     IGX_HIP(hipMemcpyAsync(pt->d_pl0, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
@@ -779,14 +816,14 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             g.field = pt->d_fields + (size_t)f * pd.npts_loc;
             A.grp[ng++] = g;
         }
-        A.PI0 = A0.d_PI; A.fa0 = A0.dev.fa; A.rp0 = A0.dev.rp; A.jlo0 = A0.dev.jlo; A.rl0_of = pt->d_rl0_of;
+        A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
         A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.n0 = A0.n; A.N0 = A0.N; A.q = A0.q; A.g0_lo = pd.g0_lo;
         A.NPL = NPL;
         const int bsA = 256;
         const long long bx = (NPL + bsA - 1) / bsA;
         const SweepChunks ch = sweep_chunks(bx * ng, pt->s0_hi - pt->s0_lo, A0.P);
         A.chunk_len = ch.len;
-        const size_t ldsA = (size_t)2 * A0.q * 4 * A0.P * A0.P * sizeof(double);
+        const size_t ldsA = (size_t)2 * A0.q * 4 * ((A0.P * A0.P + 1) & ~1) * sizeof(double);
         if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
         dim3 block(bsA), grid((unsigned)bx, ng, ch.nchunks);
         DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, grid, block, ldsA));
@@ -817,13 +854,13 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         NY = ymax + 1;
         if (ensure(&pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
         B.PI1 = A1.d_PI;
-        B.fa1 = A1.dev.fa; B.rp1 = A1.dev.rp; B.jlo1 = A1.dev.jlo; B.pl0 = pt->d_pl0;
+        B.step_ptr = pt->stepB_ptr; B.steps = pt->stepB_rec; B.pl0 = pt->d_pl0;
         B.n1 = A1.n; B.N1 = A1.N; B.q = A1.q; B.G1 = A1.G; B.G2 = A2.G; B.S1 = A1.S; B.npairs0 = np0;
         const int bs = 128;
         const long long bxB = (A2.G + bs - 1) / bs;
         const SweepChunks ch = sweep_chunks(bxB * np0 * NY, A1.n, A1.P);
         B.ngroups = NY; B.chunk_len = ch.len;
-        const size_t ldsB = (size_t)2 * A1.q * 4 * A1.P * A1.P * sizeof(double);
+        const size_t ldsB = (size_t)2 * A1.q * 4 * ((A1.P * A1.P + 1) & ~1) * sizeof(double);
         if ((size_t)A1.q * 4 * A1.P * A1.P > (size_t)SWEEP_MAX_STAGE * bs) { set_error("stage B: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
         dim3 block(bs), grid((unsigned)bxB, np0, NY * ch.nchunks);
         if (np0 > 65535 || NY * ch.nchunks > 65535) { set_error("stage B: grid too large"); return IGX_ERR_UNSUPPORTED; }
