@@ -98,7 +98,7 @@ def main():
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     import pyiga_amd
-    from pyiga_amd import bspline, geometry, assemblers
+    from pyiga_amd import bspline, geometry, assemblers, distributed
     os.environ['IGX_DEVICE'] = str(local_rank)
 
     dim, p, n, kind, gname = CONFIGS[args.config]
@@ -110,8 +110,7 @@ def main():
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
-    N0 = kv0.numdofs
-    row0 = (N0 * rank // world, N0 * (rank + 1) // world)
+    row0 = distributed.slab_range(kv0.numdofs, rank, world)
     patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if world > 1 else None)
     nel_total = n0 * n ** (dim - 1)
     nnz_local = patch.nnz

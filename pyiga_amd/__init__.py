@@ -17,3 +17,4 @@ from . import quadrature      # noqa: F401
 from . import assemblers      # noqa: F401
 from . import assemble        # noqa: F401
 from . import utils           # noqa: F401
+from . import distributed     # noqa: F401
