@@ -315,7 +315,7 @@ void igx_patch_destroy(igx_patch *pt)
     hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
     hipFree(pt->d_ctrl); hipFree(pt->d_jac); hipFree(pt->d_fields); hipFree(pt->d_data);
-    hipFree(pt->d_indices); hipFree(pt->d_indptr); hipFree(pt->d_pl0); hipFree(pt->d_rl0_of); hipFree(pt->d_steps);
+    hipFree(pt->d_indices); hipFree(pt->d_indptr); hipFree(pt->d_pl0); hipFree(pt->d_rl0_of); hipFree(pt->d_steps); hipFree(pt->d_ldesc);
     hipFree(pt->d_K1); hipFree(pt->d_K2);
     delete pt;
 }

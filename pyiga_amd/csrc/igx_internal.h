@@ -115,6 +115,9 @@ struct igx_patch {
     int *d_pl0 = nullptr;                     // [npairs0][2] processed lower pairs (i0,j0) of axis 0
     int *d_rl0_of = nullptr;                  // [S0] 1D pair index -> compact processed-pair index or -1
     int npairs0 = 0;
+    int *d_ldesc = nullptr;                   // [n_ldesc][4] line descriptors of the final stage
+    int n_ldesc = 0;
+    bool ldesc_ok = false;
     int *d_steps = nullptr;                   // flush-step tables of the sweeps (one allocation)
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
     double *d_K1 = nullptr, *d_K2 = nullptr;

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace igx {
 
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(256) k_stageB(const double *__restrict__ K1, d
 struct FinalArgs {
     const double *V;            // last axis [G][P][2]
     const int *fa, *mslo, *mshi, *jlo, *jhi, *rp;   // last axis tables
-    int N, q, G, TR;            // last axis dofs, q, Gauss count, rows per tile
+    int N, q, G;                // last axis dofs, q, Gauss count
     long long nlines;
     int dim;
     const int *pl0;             // [npairs0][2]
@@ -387,8 +388,11 @@ struct FinalArgs {
     long long nnz_off;
     int nsp_max;                // LDS segment capacity in spans
     int SSTR, KSTR;             // padded per-span strides (doubles) of the V / K images in LDS (odd => conflict-free)
-    int ntiles;                 // row tiles per line
-    int NS, slot_threads;       // line slots per block, threads per slot
+    int tile_rows, ntiles;      // rows per block tile (multiple of CR), tiles per line
+    int tsp_max, trow_max;      // LDS capacities: spans / table rows of a tile
+    int CR;                     // rows per wave task
+    int NW, GPB;                // waves per block, row groups per block
+    long long ngroups;
 };
 
 template <int P, int D>
@@ -457,169 +461,334 @@ struct SpanLoop<P, NY, Q, SIMPLE, P> {
                                                const double *, int, int, int, double (&)[2 * P - 1]) {}
 };
 
-// Block = NS "line slots" x one row tile.  Every slot (slot_threads threads, one per row) works on
-// its own K line of the row group; the basis-table segment Vs is shared by all slots.
+// Block = NW independent waves sharing the basis table of the last axis (staged once in LDS).
+// A wave task = (K line, chunk of CR <= 64 consecutive rows): the wave stages the K window of its
+// chunk in a private LDS region (through registers; the next task's window is in flight while the
+// current one is contracted), lane = matrix row, and the results leave through the same private
+// region as an LDS transpose so that store instructions write runs of 2p+1 consecutive doubles.
+// After the initial staging there is no block-wide barrier: LDS operations of one wave execute in
+// order, so a wave's private region needs no synchronisation.
 template <int P, int NY, int Q, int KPY, bool SIMPLE>
-__global__ void __launch_bounds__(SIMPLE ? 1024 : 384) k_final(const double *__restrict__ K, double *__restrict__ data, const FinalArgs F)
+__global__ void __launch_bounds__(SIMPLE ? 768 : 384) k_final(const double *__restrict__ K, double *__restrict__ data, const FinalArgs F)
 {
     constexpr int W = 2 * P - 1;
     extern __shared__ double lds[];
-    const int kcap = F.nsp_max * F.KSTR;                // doubles per K array image
-    const int kslot = max(NY * kcap, F.TR * W);         // doubles per slot (K images, reused as out_s[TR][W])
-    double *Vs = lds;                                   // [nsp_max] spans x SSTR (q x P x (value, derivative), padded)
-    double *Kbase = lds + (size_t)F.nsp_max * F.SSTR;
-    int *row_jl = (int *)(Kbase + (size_t)F.NS * kslot);  // [TR + 2P] per-row tables of the rows this tile touches
-    int *row_c = row_jl + (F.TR + 2 * P);
-    int *row_rp = row_c + (F.TR + 2 * P);
+    const int kcap = F.nsp_max * F.KSTR;                // doubles per K array window
+    const int kslot = max(NY * kcap, F.CR * W);         // doubles per wave (K windows, reused as out_s[CR][W])
+    double *Vs = lds;                                   // [tile spans] x SSTR (q x P x (value, derivative), padded)
+    double *Kbase = Vs + (size_t)F.tsp_max * F.SSTR;
+    int *row_jl = (int *)(Kbase + (size_t)F.NW * kslot);  // per-row tables of the rows this tile touches
+    int *row_c = row_jl + F.trow_max;
+    int *row_rp = row_c + F.trow_max;
+    int *row_slo = row_rp + F.trow_max;
+    int *row_nsp = row_slo + F.trow_max;
+    int *fa_s = row_nsp + F.trow_max;                   // [tile spans]
 
     cip pl0 = (cip)F.pl0, rp0 = (cip)F.rp0, jlo0 = (cip)F.jlo0, jhi0 = (cip)F.jhi0;
     cip rp1 = (cip)F.rp1, jlo1 = (cip)F.jlo1, jhi1 = (cip)F.jhi1;
     cip mslo = (cip)F.mslo, mshi = (cip)F.mshi, jlo = (cip)F.jlo, jhi = (cip)F.jhi;
 
-    const int slot = threadIdx.x / F.slot_threads;
-    const int tid = threadIdx.x - slot * F.slot_threads;
-    double *Ks = Kbase + (size_t)slot * kslot;
-
+    // ---- row tile of this block; stage its basis-table segment and row tables (once per block)
     const int tile = blockIdx.x % F.ntiles;
-    const long long grp = blockIdx.x / F.ntiles;
-    const int tile_lo = tile * F.TR;
-    const int tile_hi = min(tile_lo + F.TR, F.N);
-    const int ntr = tile_hi - tile_lo;
-
-    // ---- row group -> (i0, j0[, i1]) and its K lines
-    int r0, i1 = 0, nl = 1, jl1 = 0;
-    long long line0;
-    if (F.dim == 3) { r0 = (int)(grp / F.N1); i1 = (int)(grp % F.N1); }
-    else r0 = (int)grp;
-    const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
-    const bool diag0 = (i0 == j0);
-    if (F.dim == 3) {
-        jl1 = jlo1[i1];
-        nl = diag0 ? (i1 - jl1 + 1) : (jhi1[i1] - jl1);    // upper part of a diagonal block is mirrored, not computed
-        line0 = (long long)r0 * F.S1 + rp1[i1];
-    } else line0 = r0;
-    const bool own_row = i0 >= F.r0_lo && i0 < F.r0_hi;
-    const bool own_col = j0 >= F.r0_lo && j0 < F.r0_hi;
-    const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
-
-    // ---- stage the basis-table segment and the per-row tables (once per block)
-    const int sp_lo = mslo[tile_lo];
-    const int seg_lo = sp_lo * F.q;
-    const int seglen = mshi[tile_hi - 1] * F.q - seg_lo;
+    const int tile_lo = tile * F.tile_rows, tile_hi = min(tile_lo + F.tile_rows, F.N);
+    const int spb = mslo[tile_lo];                      // first span of the segment
+    const int rb = jlo[tile_lo];                        // first row of the tables
     {
-        const double *vsrc = F.V + (size_t)seg_lo * P * 2;
         const int per_span = F.q * P * 2;
-        for (int idx = threadIdx.x; idx < seglen * P * 2; idx += blockDim.x) {
+        const int total = (mshi[tile_hi - 1] - spb) * per_span;
+        const double *vsrc = F.V + (size_t)spb * per_span;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
             const int sp = idx / per_span;
             Vs[sp * F.SSTR + (idx - sp * per_span)] = vsrc[idx];
         }
-    }
-    const int jmin = jlo[tile_lo], jmax = jhi[tile_hi - 1];     // rows touched by the mirror pass
-    for (int r = threadIdx.x; r < jmax - jmin; r += blockDim.x) {
-        const int j = jmin + r;
-        row_jl[r] = F.jlo[j];
-        row_c[r] = F.jhi[j] - F.jlo[j];
-        row_rp[r] = F.rp[j];
-    }
-
-    // ---- this thread's row
-    const int i = tile_lo + tid;
-    const bool active = i < tile_hi;
-    int slo = 0, nsp = 0, jl = 0, fa_sp[P];
-    if (active) { slo = F.mslo[i]; nsp = F.mshi[i] - slo; jl = F.jlo[i]; }
-#pragma unroll
-    for (int k = 0; k < P; ++k) fa_sp[k] = (k < nsp) ? F.fa[slo + k] : 0;
-    const double *Vsp = Vs + (slo - sp_lo) * F.SSTR;
-    const double *Ksp = Ks + (slo - sp_lo) * F.KSTR;
-
-    // ---- K prefetch: line -> registers
-    double kreg[NY][KPY];
-    int koff[KPY];                                      // LDS offset of the c-th value this thread stages
-#pragma unroll
-    for (int c = 0; c < KPY; ++c) {
-        const int idx = tid + c * F.slot_threads;
-        const int sp = idx / F.q;
-        koff[c] = sp * F.KSTR + (idx - sp * F.q);
-    }
-    auto prefetch = [&](const long long line) {
-#pragma unroll
-        for (int y = 0; y < NY; ++y) {
-            const double *src = K + ((long long)y * F.nlines + line) * F.G + seg_lo;
-#pragma unroll
-            for (int c = 0; c < KPY; ++c) {
-                const int idx = tid + c * F.slot_threads;
-                if (idx < seglen) kreg[y][c] = src[idx];
-            }
+        const int nrows = jhi[tile_hi - 1] - rb;
+        for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+            const int lo = F.jlo[rb + r], sl = F.mslo[rb + r];
+            row_jl[r] = lo; row_c[r] = F.jhi[rb + r] - lo; row_rp[r] = F.rp[rb + r];
+            row_slo[r] = sl; row_nsp[r] = F.mshi[rb + r] - sl;
         }
-    };
-    if (slot < nl) prefetch(line0 + slot);
+        for (int sp = threadIdx.x; sp < mshi[tile_hi - 1] - spb; sp += blockDim.x) fa_s[sp] = F.fa[spb + sp];
+    }
+    __syncthreads();
+    const int nchunks = (tile_hi - tile_lo + F.CR - 1) / F.CR;   // chunks of this tile
 
-    for (int ln0 = 0; ln0 < nl; ln0 += F.NS) {
-        const int ln = ln0 + slot;
-        const bool has = ln < nl;
-        const int j1 = jl1 + ln;
-        __syncthreads();                                // previous round's out_s reads are done
-        if (has) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *Ks = Kbase + (size_t)wave * kslot;          // private to this wave
+
+    const long long grp_lo = (long long)(blockIdx.x / F.ntiles) * F.GPB;
+    const long long grp_hi = min(grp_lo + F.GPB, F.ngroups);
+    int task_base = 0;                                  // tasks of the groups before `grp` in this block
+    for (long long grp = grp_lo; grp < grp_hi; ++grp) {
+        // ---- row group -> (i0, j0[, i1]) and its K lines
+        int r0, i1 = 0, nl = 1, jl1 = 0;
+        long long line0;
+        if (F.dim == 3) { r0 = (int)(grp / F.N1); i1 = (int)(grp % F.N1); }
+        else r0 = (int)grp;
+        const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
+        const bool diag0 = (i0 == j0);
+        if (F.dim == 3) {
+            jl1 = jlo1[i1];
+            nl = diag0 ? (i1 - jl1 + 1) : (jhi1[i1] - jl1);    // upper part of a diagonal block is mirrored, not computed
+            line0 = (long long)r0 * F.S1 + rp1[i1];
+        } else line0 = r0;
+        const bool own_row = i0 >= F.r0_lo && i0 < F.r0_hi;
+        const bool own_col = j0 >= F.r0_lo && j0 < F.r0_hi;
+        const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
+        const int ntask = nl * nchunks;
+        const int first = (wave - task_base % F.NW + F.NW) % F.NW;
+        task_base += ntask;
+
+        double kreg[NY][KPY];
+        auto window = [&](const int chunk, int &row_lo, int &row_hi, int &sp_lo, int &seglen) {
+            row_lo = tile_lo + chunk * F.CR;
+            row_hi = min(row_lo + F.CR, tile_hi);
+            sp_lo = mslo[row_lo];
+            seglen = (mshi[row_hi - 1] - sp_lo) * F.q;
+        };
+        auto prefetch = [&](const int task) {
+            const int ln = task / nchunks, chunk = task - ln * nchunks;
+            int row_lo, row_hi, sp_lo, seglen;
+            window(chunk, row_lo, row_hi, sp_lo, seglen);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) {
+                const double *src = K + ((long long)y * F.nlines + (line0 + ln)) * F.G + sp_lo * F.q;
+#pragma unroll
+                for (int c = 0; c < KPY; ++c) {
+                    const int idx = lane + c * 64;
+                    if (idx < seglen) kreg[y][c] = src[idx];
+                }
+            }
+        };
+        if (first < ntask) prefetch(first);
+
+        for (int task = first; task < ntask; task += F.NW) {
+            const int ln = task / nchunks, chunk = task - ln * nchunks;
+            const int j1 = jl1 + ln;
+            int row_lo, row_hi, sp_lo, seglen;
+            window(chunk, row_lo, row_hi, sp_lo, seglen);
+            const int ntr = row_hi - row_lo;
+            // K window: registers -> private LDS (per-span padded stride KSTR)
 #pragma unroll
             for (int y = 0; y < NY; ++y)
 #pragma unroll
                 for (int c = 0; c < KPY; ++c) {
-                    const int idx = tid + c * F.slot_threads;
-                    if (idx < seglen) Ks[y * kcap + koff[c]] = kreg[y][c];
+                    const int idx = lane + c * 64;
+                    if (idx < seglen) {
+                        const int sp = idx / F.q;
+                        Ks[y * kcap + sp * F.KSTR + (idx - sp * F.q)] = kreg[y][c];
+                    }
                 }
-        }
-        __syncthreads();
-        if (ln + F.NS < nl) prefetch(line0 + ln + F.NS);   // in flight during the contraction below
+            if (task + F.NW < ntask) prefetch(task + F.NW);    // in flight during the contraction below
 
-        double acc[W];
+            // ---- this lane's row
+            const int i = row_lo + lane;
+            const bool active = lane < ntr;
+            double acc[W];
 #pragma unroll
-        for (int o = 0; o < W; ++o) acc[o] = 0.0;
-        if (has && active) SpanLoop<P, NY, Q, SIMPLE, 0>::run(F.q, kcap, F.SSTR, F.KSTR, fa_sp, Ksp, Vsp, i, nsp, jl, acc);
-        __syncthreads();                                // everyone is done reading Ks
-        double *out_s = Ks;                             // [ntr][W]
-        if (has && active) {
+            for (int o = 0; o < W; ++o) acc[o] = 0.0;
+            if (active) {
+                const int slo = row_slo[i - rb], nsp = row_nsp[i - rb], jl = row_jl[i - rb];
+                int fa_sp[P];
 #pragma unroll
-            for (int o = 0; o < W; ++o) out_s[tid * W + o] = acc[o];
-        }
-        __syncthreads();
-        if (!has) continue;
+                for (int k = 0; k < P; ++k) fa_sp[k] = (k < nsp) ? fa_s[slo - spb + k] : 0;
+                SpanLoop<P, NY, Q, SIMPLE, 0>::run(F.q, kcap, F.SSTR, F.KSTR, fa_sp, Ks + (slo - sp_lo) * F.KSTR,
+                                                   Vs + (slo - spb) * F.SSTR, i, nsp, jl, acc);
+            }
+            __builtin_amdgcn_wave_barrier();
+            double *out_s = Ks;                             // [ntr][W]; LDS ops of a wave execute in order
+            if (active) {
+#pragma unroll
+                for (int o = 0; o < W; ++o) out_s[lane * W + o] = acc[o];
+            }
+            __builtin_amdgcn_wave_barrier();
 
-        // position coefficients: pos = A + B*rp[row] + C*c[row] + o   
-        const bool diag_lead = diag0 && (F.dim == 2 || j1 == i1);
-        long long A_d, B_d, C_d, A_m, B_m, C_m;
-        if (F.dim == 3) {
-            const int c1i = jhi1[i1] - jlo1[i1], c1j = jhi1[j1] - jlo1[j1];
-            A_d = (long long)rp0[i0] * F.Smid * F.Slast + (long long)c0i * rp1[i1] * F.Slast - F.nnz_off;
-            B_d = (long long)c0i * c1i;
-            C_d = (long long)(j0 - jlo0[i0]) * c1i + (j1 - jlo1[i1]);
-            A_m = (long long)rp0[j0] * F.Smid * F.Slast + (long long)c0j * rp1[j1] * F.Slast - F.nnz_off;
-            B_m = (long long)c0j * c1j;
-            C_m = (long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1]);
-        } else {
-            A_d = (long long)rp0[i0] * F.Slast - F.nnz_off;  B_d = c0i;  C_d = j0 - jlo0[i0];
-            A_m = (long long)rp0[j0] * F.Slast - F.nnz_off;  B_m = c0j;  C_m = i0 - jlo0[j0];
-        }
-        // direct entries: row (.., i), columns jl + o
-        if (own_row) {
-            for (int f = tid; f < ntr * W; f += F.slot_threads) {
-                const int r = f / W, o = f - r * W;
-                const int ii = tile_lo + r, rr = ii - jmin;
-                const int jli = row_jl[rr], ci = row_c[rr];
-                if (o < ci && !(diag_lead && jli + o > ii))
-                    data[A_d + B_d * row_rp[rr] + C_d * ci + o] = out_s[f];
+            // position coefficients: pos = A + B*rp[row] + C*c[row] + o   
+            const bool diag_lead = diag0 && (F.dim == 2 || j1 == i1);
+            long long A_d, B_d, C_d, A_m, B_m, C_m;
+            if (F.dim == 3) {
+                const int c1i = jhi1[i1] - jlo1[i1], c1j = jhi1[j1] - jlo1[j1];
+                A_d = (long long)rp0[i0] * F.Smid * F.Slast + (long long)c0i * rp1[i1] * F.Slast - F.nnz_off;
+                B_d = (long long)c0i * c1i;
+                C_d = (long long)(j0 - jlo0[i0]) * c1i + (j1 - jlo1[i1]);
+                A_m = (long long)rp0[j0] * F.Smid * F.Slast + (long long)c0j * rp1[j1] * F.Slast - F.nnz_off;
+                B_m = (long long)c0j * c1j;
+                C_m = (long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1]);
+            } else {
+                A_d = (long long)rp0[i0] * F.Slast - F.nnz_off;  B_d = c0i;  C_d = j0 - jlo0[i0];
+                A_m = (long long)rp0[j0] * F.Slast - F.nnz_off;  B_m = c0j;  C_m = i0 - jlo0[j0];
             }
-        }
-        // mirrored entries: row (.., j), column (.., i) for every computed (i, j) of this tile
-        if (own_col) {
-            const int nj = jmax - jmin;
-            for (int f = tid; f < nj * W; f += F.slot_threads) {
-                const int rr = f / W, o = f - rr * W;
-                const int j = jmin + rr;
-                const int cj = row_c[rr];
-                const int ii = row_jl[rr] + o;
-                if (o < cj && ii >= tile_lo && ii < tile_hi && !(diag_lead && j >= ii))
-                    data[A_m + B_m * row_rp[rr] + C_m * cj + o] = out_s[(ii - tile_lo) * W + (j - row_jl[ii - jmin])];
+            // direct entries: row (.., i), columns jl + o
+            if (own_row) {
+                for (int f = lane; f < ntr * W; f += 64) {
+                    const int r = f / W, o = f - r * W;
+                    const int ii = row_lo + r;
+                    const int jli = row_jl[ii - rb], ci = row_c[ii - rb];
+                    if (o < ci && !(diag_lead && jli + o > ii))
+                        data[A_d + B_d * row_rp[ii - rb] + C_d * ci + o] = out_s[f];
+                }
             }
+            // mirrored entries: row (.., j), column (.., i) for every computed (i, j) of this chunk
+            if (own_col) {
+                const int jmin = jlo[row_lo], jmax = jhi[row_hi - 1];
+                const int nj = jmax - jmin;
+                for (int f = lane; f < nj * W; f += 64) {
+                    const int rr = f / W, o = f - rr * W;
+                    const int j = jmin + rr;
+                    const int cj = row_c[j - rb];
+                    const int ii = row_jl[j - rb] + o;
+                    if (o < cj && ii >= row_lo && ii < row_hi && !(diag_lead && j >= ii))
+                        data[A_m + B_m * row_rp[j - rb] + C_m * cj + o] = out_s[(ii - row_lo) * W + (j - row_jl[ii - rb])];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // out_s reads precede the next task's K writes
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final stage as a banded FP64 GEMM on the matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   D[line][(i,o)] = sum_t sum_g  K[t][line][g] * PI_last[t][(i,o)][g]
+//
+// M = 16 K lines, N = 16 consecutive output slots (i,o) of the last axis (slot = i*W + o, W = 2p+1),
+// K dimension = the Gauss window of those slots (<= NCH*8 points) x NY types.  The PI products are
+// the stationary B operand: a wave builds them once from the basis table and keeps them in
+// registers while it streams line tiles; the A operand comes straight from global memory in
+// fragment layout (lane (m,kk) reads two consecutive doubles of line m), reloaded right after the
+// MFMA that consumed it, so the loads of the next tile are in flight under the current tile's
+// MFMAs.  No LDS, no barriers.  MI355X measured: 65 cycles/MFMA/SIMD = 2048 flop -> 77 TFLOP/s, twice
+// what v_fma_f64 reaches at the 1-2 waves/SIMD this kernel runs at (profiles/r01_ubench_fp64_rates.txt).
+// Epilogue: lane (n, rows r) holds D[line r][slot n]; CSR positions from a 16-byte line descriptor
+// and per-lane slot constants; direct and mirrored stores in runs of up to W doubles per line.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+
+struct FinalMArgs {
+    const int4 *desc;           // [nl] {A_d, A_m, B_d | C_d<<8 | B_m<<16 | C_m<<24, line | flags<<28}
+    int nl;                     // valid lines
+    long long nlines;           // lines per K array (stride between types)
+    const double *V;            // last axis [G][P][2]
+    const int *fa, *mslo, *mshi, *jlo, *jhi, *rp;
+    int N, P, q, G, W, ntile;   // last axis: dofs, p+1, q, Gauss points, 2p+1, N-tiles
+    int LC;                     // lines per wave (multiple of 16)
+    int nchunk_blocks;          // line chunks
+    int debug;
+};
+
+template <int NY, int NCH>
+__global__ void __launch_bounds__(256) k_final_mfma(const double *__restrict__ K, double *__restrict__ data, const FinalMArgs F)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware order: consecutive logical blocks (the N-tiles of one line chunk, which re-read the
+    // same K lines) run on one XCD and share its L2
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, per = nb / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    const int tgroups = (F.ntile + 3) / 4;
+    const int tile = (bid % tgroups) * 4 + wave;
+    const int lchunk = bid / tgroups;
+    if (tile >= F.ntile) return;
+    const int n = lane & 15, kk = lane >> 4;
+
+    // ---- per-lane output slot constants
+    const int slot = tile * 16 + n;
+    const int i = slot / F.W, o = slot - i * F.W;
+    bool valid = i < F.N;
+    int j = 0, RP = 0, CI = 0, RPm = 0, CJ = 0, om = 0;
+    if (valid) {
+        const int jl = F.jlo[i];
+        CI = F.jhi[i] - jl;
+        valid = o < CI;
+        if (valid) { j = jl + o; RP = F.rp[i]; RPm = F.rp[j]; CJ = F.jhi[j] - F.jlo[j]; om = i - F.jlo[j]; }
+    }
+    const bool upper = j > i, ondiag = (j == i);
+
+    // ---- Gauss window of the tile (wave-uniform)
+    const int i_first = min(F.N - 1, (tile * 16) / F.W), i_last = min(F.N - 1, (tile * 16 + 15) / F.W);
+    const int glo = F.mslo[i_first] * F.q;
+    const bool overrun = glo + NCH * 8 > F.G;       // window padding reaches past the end of the line
+
+    // ---- stationary operand: PI products of this lane's slot at its k positions
+    double bf[NY][NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+            const int g = glo + 8 * c + 2 * kk + j2;
+            double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
+            if (valid && g < F.G) {
+                const int s = g / F.q;
+                if (s >= F.mslo[i] && s < F.mshi[i] && s >= F.mslo[j] && s < F.mshi[j]) {
+                    const int f = F.fa[s];
+                    const double *vu = F.V + ((size_t)g * F.P + (j - f)) * 2;
+                    const double *vv = F.V + ((size_t)g * F.P + (i - f)) * 2;
+                    u0 = vu[0]; u1 = vu[1]; v0 = vv[0]; v1 = vv[1];
+                }
+            }
+            bf[0][c][j2] = u0 * v0;
+            if (NY == 4) { bf[1][c][j2] = u1 * v0; bf[2][c][j2] = u0 * v1; bf[3][c][j2] = u1 * v1; }
+        }
+
+    // ---- stream line tiles
+    const int l_lo = lchunk * F.LC, l_hi = min(l_lo + F.LC, F.nl);
+    if (l_lo >= l_hi) return;
+    const long long tstride = F.nlines * (long long)F.G;
+    int goff[NCH];                                  // offset of this lane's pair inside the line
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) goff[c] = min(glo + 8 * c + 2 * kk, F.G - 2);
+    double2_u a[NY][NCH];
+    auto load_tile = [&](const int mt) {
+        const int mi = min(mt + (lane & 15), l_hi - 1);
+        const int line = F.desc[mi].w & 0x0fffffff;
+        const double *base = K + (long long)line * F.G;
+#pragma unroll
+        for (int t = 0; t < NY; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) a[t][c] = *(const double2_u *)(base + t * tstride + goff[c]);
+    };
+    load_tile(l_lo);
+    // line index of the tile after next is requested two tiles ahead, so the address of a reload never
+    // waits on a descriptor load
+    int line_n1 = F.desc[min(l_lo + 16 + (lane & 15), l_hi - 1)].w & 0x0fffffff;
+    int4 dsc_n[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsc_n[r] = F.desc[min(l_lo + kk + 4 * r, l_hi - 1)];
+    for (int mt = l_lo; mt < l_hi; mt += 16) {
+        // descriptors of the 4 lines whose results this lane holds (loaded one tile ahead)
+        int4 dsc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dsc[r] = dsc_n[r]; dsc_n[r] = F.desc[min(mt + 16 + kk + 4 * r, l_hi - 1)]; }
+        const bool more = mt + 16 < l_hi;
+        const double *nbase = K + (long long)line_n1 * F.G;
+        line_n1 = F.desc[min(mt + 32 + (lane & 15), l_hi - 1)].w & 0x0fffffff;
+
+        double4_t d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NY; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                double ax = a[t][c].x, ay = a[t][c].y;
+                if (overrun) {                       // never let data of the next line in (0 * inf = nan)
+                    const int g = glo + 8 * c + 2 * kk;
+                    if (g >= F.G - 1) { ax = (g == F.G - 1) ? ay : 0.0; ay = 0.0; }   // pair was clamped to [G-2, G-1]
+                }
+                d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bf[t][c][0], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bf[t][c][1], d1, 0, 0, 0);
+                if (more) a[t][c] = *(const double2_u *)(nbase + t * tstride + goff[c]);
+            }
+        // ---- epilogue: D[row = kk + 4r][col = n]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (mt + kk + 4 * r >= l_hi || !valid) continue;
+            const double v = d0[r] + d1[r];
+            const int4 ds = dsc[r];
+            const int flags = (unsigned)ds.w >> 28;     // bit0 own_row, bit1 own_col, bit2 diag_lead
+            const bool dl = flags & 4;
+            const int Bd = ds.z & 255, Cd = (ds.z >> 8) & 255, Bm = (ds.z >> 16) & 255, Cm = (ds.z >> 24) & 255;
+            if ((flags & 1) && !(dl && upper) && !(F.debug & 1)) data[(long long)ds.x + Bd * RP + Cd * CI + o] = v;
+            if ((flags & 2) && !(dl && (upper || ondiag)) && !(F.debug & 2)) data[(long long)ds.y + Bm * RPm + Cm * CJ + om] = v;
         }
     }
 }
@@ -686,6 +855,46 @@ int sumfact_prepare(igx_patch *pt)
     IGX_HIP(hipMemcpyAsync(pt->d_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
     pt->stepA_ptr = pt->d_steps + oA0; pt->stepA_rec = pt->d_steps + oA1;
     pt->stepB_ptr = pt->d_steps + oB0; pt->stepB_rec = pt->d_steps + oB1;
+    // line descriptors of the final stage (MFMA kernel): one per K line that is actually contracted
+    {
+        const Axis &A1 = pt->ax[1], &A2 = pt->ax[2];
+        const int dim = pt->dim;
+        std::vector<int> ld;
+        const long long S1 = A1.S, S2 = A2.S;
+        for (int r0 = 0; r0 < pt->npairs0; ++r0) {
+            const int i0 = pl[2 * r0], j0 = pl[2 * r0 + 1];
+            const int c0i = A0.jhi[i0] - A0.jlo[i0], c0j = A0.jhi[j0] - A0.jlo[j0];
+            int flags = 0;
+            if (i0 >= pt->r0_lo && i0 < pt->r0_hi) flags |= 1;
+            if (j0 >= pt->r0_lo && j0 < pt->r0_hi) flags |= 2;
+            if (dim == 2) {
+                const long long Ad = (long long)A0.rp[i0] * S1 - pt->nnz_off, Am = (long long)A0.rp[j0] * S1 - pt->nnz_off;
+                const int fl = flags | ((i0 == j0) ? 4 : 0);
+                ld.push_back((int)Ad); ld.push_back((int)Am);
+                ld.push_back(c0i | ((j0 - A0.jlo[i0]) << 8) | (c0j << 16) | ((i0 - A0.jlo[j0]) << 24));
+                ld.push_back(r0 | (fl << 28));
+            } else {
+                for (int r1 = 0; r1 < A1.S; ++r1) {
+                    const int i1 = A1.pair_i[r1], j1 = A1.pair_j[r1];
+                    if (i0 == j0 && j1 > i1) continue;          // mirrored, not computed
+                    const int c1i = A1.jhi[i1] - A1.jlo[i1], c1j = A1.jhi[j1] - A1.jlo[j1];
+                    const long long Ad = (long long)A0.rp[i0] * S1 * S2 + (long long)c0i * A1.rp[i1] * S2 - pt->nnz_off;
+                    const long long Am = (long long)A0.rp[j0] * S1 * S2 + (long long)c0j * A1.rp[j1] * S2 - pt->nnz_off;
+                    const int Bd = c0i * c1i, Cd = (j0 - A0.jlo[i0]) * c1i + (j1 - A1.jlo[i1]);
+                    const int Bm = c0j * c1j, Cm = (i0 - A0.jlo[j0]) * c1j + (i1 - A1.jlo[j1]);
+                    const int fl = flags | ((i0 == j0 && i1 == j1) ? 4 : 0);
+                    ld.push_back((int)Ad); ld.push_back((int)Am);
+                    ld.push_back(Bd | (Cd << 8) | (Bm << 16) | (Cm << 24));
+                    ld.push_back((int)((long long)r0 * A1.S + r1) | (fl << 28));
+                }
+            }
+        }
+        pt->n_ldesc = (int)(ld.size() / 4);
+        pt->ldesc_ok = (long long)pt->npairs0 * (dim == 3 ? A1.S : 1) < (1LL << 28);
+        IGX_HIP(hipMalloc(&pt->d_ldesc, std::max<size_t>(1, ld.size()) * sizeof(int)));
+        IGX_HIP(hipMemcpyAsync(pt->d_ldesc, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    }
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
     IGX_HIP(hipMalloc(&pt->d_rl0_of, std::max<size_t>(1, rl.size()) * sizeof(int)));
     IGX_HIP(hipMemcpyAsync(pt->d_pl0, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
@@ -694,15 +903,18 @@ int sumfact_prepare(igx_patch *pt)
     return IGX_OK;
 }
 
-static int ensure(double **buf, size_t *cap, size_t need)
+static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 {
     if (*cap >= need) return IGX_OK;
     if (*buf) { hipFree(*buf); *buf = nullptr; *cap = 0; }
-    hipError_t e = hipMalloc(buf, need * sizeof(double));
+    hipError_t e = hipMalloc(buf, (need + 16) * sizeof(double));
     if (e != hipSuccess) {
         set_error("hipMalloc of %.2f GB sum-factorisation workspace failed: %s", need * 8.0 / 1e9, hipGetErrorString(e));
         return IGX_ERR_NOMEM;
     }
+    // lines that are never produced (upper part of diagonal blocks) must stay finite: the final
+    // stage multiplies window padding by exact zeros
+    if (hipMemsetAsync(*buf, 0, (need + 16) * sizeof(double), st) != hipSuccess) return IGX_ERR_HIP;   // same stream as the kernels
     *cap = need;
     return IGX_OK;
 }
@@ -795,7 +1007,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         term_x[i] = found;
     }
     const int nX = (int)X.size();
-    if (ensure(&pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
+    if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
 
     const int nF = (kind == IGX_MASS) ? 1 : dim * (dim + 1) / 2;
     hipEventRecord(pt->ctx->ev[1], st);
@@ -852,7 +1064,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             ymax = std::max(ymax, y);
         }
         NY = ymax + 1;
-        if (ensure(&pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
+        if (ensure(st, &pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
         B.PI1 = A1.d_PI;
         B.step_ptr = pt->stepB_ptr; B.steps = pt->stepB_rec; B.pl0 = pt->d_pl0;
         B.n1 = A1.n; B.N1 = A1.N; B.q = A1.q; B.G1 = A1.G; B.G2 = A2.G; B.S1 = A1.S; B.npairs0 = np0;
@@ -888,40 +1100,93 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     F.rp1 = A1.dev.rp; F.jlo1 = A1.dev.jlo; F.jhi1 = A1.dev.jhi;
     F.r0_lo = pt->r0_lo; F.r0_hi = pt->r0_hi; F.nnz_off = pt->nnz_off;
     {
-        // row tiles of the last axis: as few tiles as possible with at most 256 rows each; a slot has
-        // one thread per row (rounded up to whole waves); NS slots share the staged basis table
-        int ntiles = (AL.N + 255) / 256;
-        int TR = (AL.N + ntiles - 1) / ntiles;
-        auto span_cap = [&](int tr) {
-            int m = 0;
-            for (int lo = 0; lo < AL.N; lo += tr) m = std::max(m, AL.mshi[std::min(lo + tr, AL.N) - 1] - AL.mslo[lo]);
-            return m;
-        };
-        const int slot_threads = ((TR + 63) / 64) * 64;
-        const int nsp_max = span_cap(TR);
-        const int kpy = (nsp_max * AL.q + slot_threads - 1) / slot_threads;
-        if (kpy > 8) { set_error("final stage: K segment does not fit the prefetch registers"); return IGX_ERR_UNSUPPORTED; }
-        F.TR = TR; F.ntiles = ntiles; F.nsp_max = nsp_max; F.slot_threads = slot_threads;
+        // ---- matrix-core path (opt-in, IGX_FINAL=mfma): banded FP64 GEMM, see k_final_mfma.  Correct and
+        // tested, but at 2 waves/SIMD its load->MFMA loop is latency-bound (MFMA pipe 25 % busy,
+        // 13.7 ms vs 11.0 ms for the VALU kernel at C4); it needs an LDS-DMA staged A operand to pay off.
+        {
+            const int W = 2 * AL.P - 1;
+            const int ntile = (AL.N * W + 15) / 16;
+            int wmax = 0;
+            for (int t = 0; t < ntile; ++t) {
+                const int i_first = std::min(AL.N - 1, (t * 16) / W), i_last = std::min(AL.N - 1, (t * 16 + 15) / W);
+                wmax = std::max(wmax, (AL.mshi[i_last] - AL.mslo[i_first]) * AL.q);
+            }
+            const int nch = (wmax + 7) / 8;
+            const char *sel = getenv("IGX_FINAL");
+            const bool want_mfma = sel && !strcmp(sel, "mfma");
+            if (want_mfma && nch >= 1 && nch <= 6 && pt->ldesc_ok && AL.G >= 2) {
+                FinalMArgs M{};
+                M.desc = (const int4 *)pt->d_ldesc; M.nl = pt->n_ldesc; M.nlines = F.nlines;
+                M.V = AL.d_V; M.fa = AL.dev.fa; M.mslo = AL.dev.mslo; M.mshi = AL.dev.mshi;
+                M.jlo = AL.dev.jlo; M.jhi = AL.dev.jhi; M.rp = AL.dev.rp;
+                M.N = AL.N; M.P = AL.P; M.q = AL.q; M.G = AL.G; M.W = W; M.ntile = ntile;
+                int LC = 256;
+                if (const char *e = getenv("IGX_FINAL_LC")) LC = std::max(16, (atoi(e) / 16) * 16);
+                M.LC = LC; M.debug = getenv("IGX_DEBUG_M") ? atoi(getenv("IGX_DEBUG_M")) : 0;
+                M.nchunk_blocks = (M.nl + LC - 1) / LC;
+                const long long nblocks = (long long)((ntile + 3) / 4) * M.nchunk_blocks;
+                if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
+                dim3 block(256), grid((unsigned)nblocks);
+#define LAUNCH_M(NYV, NCHV) k_final_mfma<NYV, NCHV><<<grid, block, 0, st>>>(Kfinal, d_data, M)
+                if (NY == 1) {
+                    switch (nch) { case 1: LAUNCH_M(1, 1); break; case 2: LAUNCH_M(1, 2); break; case 3: LAUNCH_M(1, 3); break;
+                                   case 4: LAUNCH_M(1, 4); break; case 5: LAUNCH_M(1, 5); break; default: LAUNCH_M(1, 6); break; }
+                } else {
+                    switch (nch) { case 1: LAUNCH_M(4, 1); break; case 2: LAUNCH_M(4, 2); break; case 3: LAUNCH_M(4, 3); break;
+                                   case 4: LAUNCH_M(4, 4); break; case 5: LAUNCH_M(4, 5); break; default: LAUNCH_M(4, 6); break; }
+                }
+#undef LAUNCH_M
+                IGX_HIP(hipGetLastError());
+                pt->timing.n_launches++;
+                hipEventRecord(pt->ctx->ev[4], st);
+                return IGX_OK;
+            }
+        }
+        // wave tasks: chunks of CR <= 64 consecutive rows; NW waves share the staged basis-table
+        // segment of a row tile (the whole axis when it fits in ~64 KB of LDS)
+        const int W = 2 * AL.P - 1;
         F.SSTR = (AL.q * AL.P * 2) | 1;
         F.KSTR = AL.q | 1;
-        const int W = 2 * AL.P - 1;
-        const size_t vbytes = (size_t)nsp_max * F.SSTR * sizeof(double);
-        const size_t kslot = std::max((size_t)NY * nsp_max * F.KSTR, (size_t)TR * W) * sizeof(double);
-        const size_t tbytes = (size_t)3 * (TR + 2 * AL.P) * sizeof(int);
+        int ntiles = 1, tile_rows, CR, tsp_max, trow_max, nsp_max;
+        for (;; ++ntiles) {
+            const int rows_per_tile = (AL.N + ntiles - 1) / ntiles;
+            const int nch = (rows_per_tile + 63) / 64;
+            CR = (rows_per_tile + nch - 1) / nch;
+            tile_rows = CR * nch;
+            tsp_max = trow_max = nsp_max = 0;
+            for (int lo = 0; lo < AL.N; lo += tile_rows) {
+                const int hi = std::min(lo + tile_rows, AL.N);
+                tsp_max = std::max(tsp_max, AL.mshi[hi - 1] - AL.mslo[lo]);
+                trow_max = std::max(trow_max, AL.jhi[hi - 1] - AL.jlo[lo]);
+                for (int cl = lo; cl < hi; cl += CR)
+                    nsp_max = std::max(nsp_max, AL.mshi[std::min(cl + CR, hi) - 1] - AL.mslo[cl]);
+            }
+            if ((size_t)tsp_max * F.SSTR * sizeof(double) <= 64 * 1024 || tile_rows <= 64) break;
+        }
+        ntiles = (AL.N + tile_rows - 1) / tile_rows;
+        const int kpy = (nsp_max * AL.q + 63) / 64;
+        if (kpy > 8) { set_error("final stage: K window does not fit the prefetch registers"); return IGX_ERR_UNSUPPORTED; }
+        F.CR = CR; F.tile_rows = tile_rows; F.ntiles = ntiles; F.tsp_max = tsp_max; F.trow_max = trow_max;
+        F.nsp_max = nsp_max; F.ngroups = ngroups;
+        const size_t vbytes = (size_t)tsp_max * F.SSTR * sizeof(double);
+        const size_t kslot = std::max((size_t)NY * nsp_max * F.KSTR, (size_t)CR * W) * sizeof(double);
+        const size_t tbytes = ((size_t)5 * trow_max + tsp_max) * sizeof(int);
+        if (vbytes + kslot + tbytes > 160 * 1024) { set_error("final stage: basis table segment (%zu B) does not fit LDS", vbytes); return IGX_ERR_UNSUPPORTED; }
+        const bool fast = AL.q == AL.P && AL.simple;
+        const int max_waves = fast ? 12 : 6;
+        int NW = (int)std::min<size_t>(max_waves, (160 * 1024 - vbytes - tbytes) / kslot);
+        if (const char *e = getenv("IGX_FINAL_NW")) NW = std::max(1, std::min(NW, atoi(e)));
         int max_lines = 1;
         if (dim == 3)
             for (int i = 0; i < A1.N; ++i) max_lines = std::max(max_lines, A1.jhi[i] - A1.jlo[i]);
-        const bool fast = AL.q == AL.P && AL.simple;
-        const int max_threads = fast ? 1024 : 384;
-        int NS = 1;
-        while (NS < max_lines && NS < 5 && (NS + 1) * slot_threads <= max_threads && vbytes + (NS + 1) * kslot + tbytes <= 160 * 1024) ++NS;
-        if (const char *e = getenv("IGX_FINAL_NS")) NS = std::max(1, std::min(NS, atoi(e)));
-        F.NS = NS;
-        const size_t lds = vbytes + NS * kslot + tbytes;
-        if (lds > 160 * 1024) { set_error("final stage needs %zu B of LDS", lds); return IGX_ERR_UNSUPPORTED; }
-        const long long nblocks = ngroups * ntiles;
+        // row groups per block: enough tasks for ~8 rounds per wave
+        int GPB = std::max(1, (8 * NW) / std::max(1, max_lines * (tile_rows / CR)));
+        if (const char *e = getenv("IGX_FINAL_GPB")) GPB = std::max(1, atoi(e));
+        F.NW = NW; F.GPB = GPB;
+        const size_t lds = vbytes + (size_t)NW * kslot + tbytes;
+        const long long nblocks = ((ngroups + GPB - 1) / GPB) * ntiles;
         if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
-        dim3 block(NS * slot_threads), grid((unsigned)nblocks);
+        dim3 block(64 * NW), grid((unsigned)nblocks);
         int rc = IGX_OK;
         DISPATCH_P(AL.P, rc = launch_final<PP>(st, Kfinal, d_data, F, NY, fast, kpy, grid, block, lds));
         if (rc) return rc;

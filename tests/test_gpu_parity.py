@@ -333,3 +333,25 @@ def test_row_slabs_equal_full(iga, d, p, n, G, algo, monkeypatch):
         assert stacked.shape == full.shape and stacked.nnz == full.nnz
         assert np.array_equal(stacked.indices, full.indices) and np.array_equal(stacked.indptr, full.indptr)
         assert np.array_equal(stacked.data, full.data)
+
+
+def test_final_stage_variants_agree(iga, monkeypatch):
+    """The matrix-core (MFMA) final stage and the VALU final stage give the same matrix; the MFMA
+    one mirrors too, so both are exactly symmetric."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    mk = iga.bspline.make_knots
+    cases = [((mk(2, 0., 1., 10),) * 3, 'twisted_box'), ((mk(4, 0., 1., 5),) * 3, 'cylinder'),
+             ((mk(3, 0., 1., 40), mk(3, 0., 1., 33)), 'quarter_annulus'),
+             ((mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 4)), 'cylinder')]
+    for kvs, gname in cases:
+        for kind in ('mass', 'stiffness'):
+            out = {}
+            for sel in ('valu', 'mfma'):
+                monkeypatch.setenv('IGX_FINAL', sel)
+                patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
+                out[sel] = patch.csr(kind, algo='sumfact')
+                patch.close()
+                assert not np.isnan(out[sel].data).any()
+                assert abs(out[sel] - out[sel].T).max() == 0.0
+            assert rel_maxdiff(out['mfma'], out['valu']) <= 1e-14
+    monkeypatch.delenv('IGX_FINAL')
