@@ -212,12 +212,15 @@ __device__ inline void finish_jacobian(const double val[MAX_COMP], const double 
                                        int ncomp, int nc, double Jm[MAX_COMP][3], double ev[MAX_COMP])
 {
     if (nurbs) {
+        // quotient rule (V'W - V W') / W^2 with ONE reciprocal: an f64 division costs ~30 VALU
+        // instructions on gfx950 and the reference formula has d*d + d of them per point
         const double W = val[nc - 1];
+        const double iW = 1.0 / W, iW2 = iW * iW;
         for (int r = 0; r < ncomp; ++r) {
-            ev[r] = val[r] / W;
+            ev[r] = val[r] * iW;
             for (int c = 0; c < DIM; ++c) {
                 const int k = DIM - 1 - c;
-                Jm[r][c] = (jac[r][k] * W - val[r] * jac[nc - 1][k]) / (W * W);
+                Jm[r][c] = (jac[r][k] * W - val[r] * jac[nc - 1][k]) * iW2;
             }
         }
     } else {
@@ -357,7 +360,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int
 // in LDS, then each thread evaluates its point with only (pL+1) * ncomp * (DIM+1) FMAs.
 // (The per-point kernel above costs prod(p_k+1) * ncomp * (DIM+1) FMAs and is memory-latency bound
 // on the control-net gathers.)
-template <int DIM>
+template <int DIM, int NC>
 __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind,
                                                           const double *w0, const double *w1, const double *w2,
                                                           int g0_lo, int G0loc, int G1, int G2, int LPB, double *fields)
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
     const int LN = (DIM == 3) ? G2 : G1;                  // line length (last axis)
     const long long nlines = (DIM == 3) ? (long long)G0loc * G1 : G0loc;
     const long long total = nlines * LN;
-    const int nc = gv.nc;
+    constexpr int nc = NC;                               // components incl. the NURBS weight (compile time: clean unrolling)
     const int NgL = gv.N[DIM - 1];
     const long long line0 = (long long)blockIdx.x * LPB;
     const int per_line = NgL * nc;
@@ -420,10 +423,12 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         const double *VL = gv.V[DIM - 1] + (size_t)gL * PL * 2;
         const int fL = gv.fa[DIM - 1][gL];
         double val[MAX_COMP], jac[MAX_COMP][3];
+#pragma unroll
         for (int c = 0; c < MAX_COMP; ++c) { val[c] = 0.0; jac[c][0] = jac[c][1] = jac[c][2] = 0.0; }
         const double *lc = Lc + ((size_t)ll * NgL + fL) * nc * DIM;
         for (int aL = 0; aL < PL; ++aL) {
             const double n = VL[aL * 2], d = VL[aL * 2 + 1];
+#pragma unroll
             for (int c = 0; c < nc; ++c) {
                 const double *e = lc + ((size_t)aL * nc + c) * DIM;
                 val[c] += n * e[0];
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
             }
         }
         double Jm[MAX_COMP][3], ev[MAX_COMP];
-        finish_jacobian<DIM>(val, jac, nurbs, DIM, nc, Jm, ev);
+        finish_jacobian<DIM>(val, jac, NC == DIM + 1, DIM, NC, Jm, ev);
         double tt[9];
         for (int r = 0; r < DIM; ++r)
             for (int c = 0; c < DIM; ++c) tt[r * DIM + c] = Jm[r][c];
@@ -462,12 +467,13 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
             const long long nlines = total / LN;
             dim3 grid((unsigned)((nlines + LPB - 1) / LPB)), block(256);
             const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
-            if (dim == 2)
-                k_geo_fields_lines<2><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
-                                                                pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
-            else
-                k_geo_fields_lines<3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
-                                                                pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+            if (dim == 2) {
+                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+            } else {
+                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+            }
             IGX_HIP(hipGetLastError());
             return IGX_OK;
         }
