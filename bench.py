@@ -44,6 +44,15 @@ def algorithmic_bytes_per_element(dim, p, nnz, nelem):
     return 8.0 * dim * dim * q ** dim + 8.0 * nnz / nelem
 
 
+def measured_traffic(config, world):
+    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))[config]
+        return t['chain_bytes'] if world == 1 else None
+    except Exception:
+        return None
+
+
 def make_geo(geometry, name):
     if name == 'cylinder':
         return geometry.tensor_product(geometry.line_segment(0.0, 1.0), geometry.quarter_annulus())
@@ -55,7 +64,7 @@ def cpu_baseline(dim, p, kind):
     host cores on a bounded sample of the same workload."""
     from oracle import iga_oracle as orc
     orc.build()
-    n = {(3, 4): 14, (3, 2): 28, (2, 3): 192}.get((dim, p), 12)
+    n = {(3, 4): 24, (3, 2): 48, (2, 3): 256}.get((dim, p), 12)
     cores = os.cpu_count() or 1
     kv = orc.make_knots(p, 0.0, 1.0, n)
     geo = orc.geo_cylinder() if dim == 3 else orc.geo_quarter_annulus()
@@ -177,7 +186,7 @@ def main():
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
+            'traffic': measured_traffic(args.config, world),
             'kernel': 'assembly chain (k_geo_fields + k_stageA x fields + k_stageB + k_final), HIP events on the igx stream',
             'algorithmic_bytes_per_element': b_el, 'chain_ms': chain_ms, 'kernel_ms': parts, 'dominant_kernel': dominant,
         },
