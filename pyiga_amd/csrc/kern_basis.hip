@@ -6,6 +6,7 @@
 //   fields                    restate precompute_fields (pyiga/assemblers.pyx:86-110,234-275,
 //                             1223-1249,1389-1449): W = gw*|det J|,  B = W * Jinv Jinv^T
 #include "igx_internal.h"
+#include "geo_device.h"
 #include <algorithm>
 
 namespace igx {
@@ -127,13 +128,6 @@ int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_
 // ---------------------------------------------------------------------------------------------
 // geometry: homogeneous spline value + parametric derivatives at one grid point.
 // jac[c][k]: component c, derivative along GRID AXIS k (not yet reordered to x,y,z).
-struct GeoView {
-    const double *V[3];   // [G][P][2]
-    const int *fa[3];     // [G]
-    int P[3], N[3];       // active count, number of control points per axis
-    const double *ctrl;   // (N0,N1[,N2], nc)
-    int nc;               // components incl. weight
-};
 
 template <int DIM>
 __device__ inline void eval_geo(const GeoView &gv, const int g[3], double val[MAX_COMP], double jac[MAX_COMP][3])
@@ -204,33 +198,6 @@ __device__ inline void eval_geo(const GeoView &gv, const int g[3], double val[MA
 
 // Physical Jacobian Jm[r][c] = dG_r / d xi_c with c in (x,y,z) order, i.e. c = 0 differentiates
 // along the LAST grid axis (pyiga/bspline.py:917-921); NURBS by the quotient rule.
-// homogeneous value/derivatives -> physical Jacobian Jm[r][c] = dG_r / d xi_c with c in (x,y,z)
-// order, i.e. c = 0 differentiates along the LAST grid axis (pyiga/bspline.py:917-921); NURBS by
-// the quotient rule (pyiga/geometry.py:17-25).
-template <int DIM>
-__device__ inline void finish_jacobian(const double val[MAX_COMP], const double jac[MAX_COMP][3], bool nurbs,
-                                       int ncomp, int nc, double Jm[MAX_COMP][3], double ev[MAX_COMP])
-{
-    if (nurbs) {
-        // quotient rule (V'W - V W') / W^2 with ONE reciprocal: an f64 division costs ~30 VALU
-        // instructions on gfx950 and the reference formula has d*d + d of them per point
-        const double W = val[nc - 1];
-        const double iW = 1.0 / W, iW2 = iW * iW;
-        for (int r = 0; r < ncomp; ++r) {
-            ev[r] = val[r] * iW;
-            for (int c = 0; c < DIM; ++c) {
-                const int k = DIM - 1 - c;
-                Jm[r][c] = (jac[r][k] * W - val[r] * jac[nc - 1][k]) * iW2;
-            }
-        }
-    } else {
-        for (int r = 0; r < ncomp; ++r) {
-            ev[r] = val[r];
-            for (int c = 0; c < DIM; ++c) Jm[r][c] = jac[r][DIM - 1 - c];
-        }
-    }
-}
-
 template <int DIM>
 __device__ inline void physical_jacobian(const GeoView &gv, bool nurbs, const int g[3], int ncomp,
                                          double Jm[MAX_COMP][3], double ev[MAX_COMP])
@@ -258,19 +225,6 @@ __global__ void k_grid_geo(GeoView gv, bool nurbs, int ncomp, int G0, int G1, in
         for (int r = 0; r < ncomp; ++r) eval_out[idx * ncomp + r] = ev[r];
 }
 
-static GeoView make_view(int dim, const GeoAxis gax[3], const double *d_ctrl, int nc)
-{
-    GeoView gv{};
-    for (int k = 0; k < 3; ++k) {
-        gv.V[k] = k < dim ? gax[k].d_V : nullptr;
-        gv.fa[k] = k < dim ? gax[k].d_fa : nullptr;
-        gv.P[k] = k < dim ? gax[k].P : 1;
-        gv.N[k] = k < dim ? gax[k].N : 1;
-    }
-    gv.ctrl = d_ctrl;
-    gv.nc = nc;
-    return gv;
-}
 
 int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3], const int G[3],
                     const double *d_ctrl, double *d_jac, double *d_eval)
@@ -287,46 +241,6 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// fields: one thread per resident Gauss point, structure-of-arrays output fields[f][pt]
-template <int DIM>
-__device__ inline void fields_from_jac(const double t[9], double GW, int kind, double *fields, long long stride, long long pt)
-{
-    if (DIM == 2) {
-        const double det = t[0] * t[3] - t[1] * t[2];
-        const double W = GW * fabs(det);
-        if (kind == IGX_MASS) { fields[pt] = W; return; }
-        const double inv = 1.0 / det;
-        const double J0 = inv * t[3], J1 = inv * -t[1], J2 = inv * -t[2], J3 = inv * t[0];
-        fields[pt] = W * (J0 * J0 + J1 * J1);
-        fields[stride + pt] = W * (J0 * J2 + J1 * J3);
-        fields[2 * stride + pt] = W * (J2 * J2 + J3 * J3);
-    } else {
-        const double t3 = t[4] * t[8] - t[5] * t[7];
-        const double t4 = t[3] * t[8] - t[5] * t[6];
-        const double t5 = t[3] * t[7] - t[4] * t[6];
-        const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
-        const double W = GW * fabs(det);
-        if (kind == IGX_MASS) { fields[pt] = W; return; }
-        const double inv = 1.0 / det;
-        double JI[9];
-        JI[0] = inv * t3;
-        JI[1] = inv * -(t[1] * t[8] - t[2] * t[7]);
-        JI[2] = inv * (t[1] * t[5] - t[2] * t[4]);
-        JI[3] = inv * -t4;
-        JI[4] = inv * (t[0] * t[8] - t[2] * t[6]);
-        JI[5] = inv * -(t[0] * t[5] - t[2] * t[3]);
-        JI[6] = inv * t5;
-        JI[7] = inv * -(t[0] * t[7] - t[1] * t[6]);
-        JI[8] = inv * (t[0] * t[4] - t[1] * t[3]);
-        fields[pt] = W * ((JI[0] * JI[0] + JI[1] * JI[1]) + JI[2] * JI[2]);
-        fields[stride + pt] = W * ((JI[0] * JI[3] + JI[1] * JI[4]) + JI[2] * JI[5]);
-        fields[2 * stride + pt] = W * ((JI[0] * JI[6] + JI[1] * JI[7]) + JI[2] * JI[8]);
-        fields[3 * stride + pt] = W * ((JI[3] * JI[3] + JI[4] * JI[4]) + JI[5] * JI[5]);
-        fields[4 * stride + pt] = W * ((JI[3] * JI[6] + JI[4] * JI[7]) + JI[5] * JI[8]);
-        fields[5 * stride + pt] = W * ((JI[6] * JI[6] + JI[7] * JI[7]) + JI[8] * JI[8]);
-    }
-}
-
 // geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
 template <int DIM>
 __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int kind,
