@@ -92,15 +92,19 @@ def main():
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--strong', action='store_true', help='strong scaling: keep the patch fixed, split its rows')
+    ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank weak-scaling run on this one GPU (no collectives)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    emu = None
+    if args.emulate:
+        emu = tuple(int(x) for x in args.emulate.split('/'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('BENCH_FORCE_DIST'):      # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -115,13 +119,18 @@ def main():
         n = args.n
     geo = make_geo(geometry, gname)
     # weak scaling: axis 0 grows with the number of ranks; each rank owns one slab of dof planes
-    n0 = n if (args.strong or world == 1) else n * world
+    part_rank, part_world = (rank, world) if emu is None else emu
+    n0 = n if (args.strong or part_world == 1) else n * part_world
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
-    row0 = distributed.slab_range(kv0.numdofs, rank, world)
-    patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if world > 1 else None)
+    row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world)
+    patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
+    if rank == 0 and os.environ.get('BENCH_VERBOSE'):
+        print('rank 0 slab', row0, 'nnz', patch.nnz, 'rows', patch.row_range, file=sys.stderr)
     nel_total = n0 * n ** (dim - 1)
+    if emu is not None:
+        nel_total //= part_world        # one slab's share
     nnz_local = patch.nnz
 
     def barrier():
