@@ -144,7 +144,7 @@ static int upload_axis(Axis &A, hipStream_t st)
 
 static void free_axis(Axis &A)
 {
-    hipFree(A.d_kv); hipFree(A.d_nodes); hipFree(A.d_w); hipFree(A.d_V); hipFree(A.d_PI); hipFree(A.d_ints);
+    (void)hipFree(A.d_kv); (void)hipFree(A.d_nodes); (void)hipFree(A.d_w); (void)hipFree(A.d_V); (void)hipFree(A.d_PI); (void)hipFree(A.d_ints);
 }
 
 static int setup_geo_axis(GeoAxis &g, const double *kv, int len, int p, const double *d_nodes, int G, hipStream_t st)
@@ -159,7 +159,7 @@ static int setup_geo_axis(GeoAxis &g, const double *kv, int len, int p, const do
     return launch_basis_tables(st, g.d_kv, len, p, d_nodes, (size_t)G, 1, nullptr, g.d_V, g.d_fa, nullptr);
 }
 
-static void free_geo_axis(GeoAxis &g) { hipFree(g.d_kv); hipFree(g.d_V); hipFree(g.d_fa); }
+static void free_geo_axis(GeoAxis &g) { (void)hipFree(g.d_kv); (void)hipFree(g.d_V); (void)hipFree(g.d_fa); }
 
 static int ensure_fields(igx_patch *pt, int kind)
 {
@@ -167,7 +167,7 @@ static int ensure_fields(igx_patch *pt, int kind)
     const int nF = (kind == IGX_MASS) ? 1 : pt->dim * (pt->dim + 1) / 2;
     const size_t need = (size_t)nF * pt->dev.npts_loc;
     if (pt->fields_cap < need) {
-        if (pt->d_fields) hipFree(pt->d_fields);
+        if (pt->d_fields) (void)hipFree(pt->d_fields);
         pt->d_fields = nullptr; pt->fields_cap = 0;
         hipError_t e = hipMalloc((void **)&pt->d_fields, std::max<size_t>(1, need) * sizeof(double));
         if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for fields failed", need * 8.0 / 1e9); return IGX_ERR_NOMEM; }
@@ -204,17 +204,17 @@ igx_ctx *igx_create(int device_id)
     if (!ctx) return nullptr;
     ctx->device = device_id;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
-    for (auto &ev : ctx->ev) hipEventCreate(&ev);
+    for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
     return ctx;
 }
 
 void igx_destroy(igx_ctx *ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    for (auto &ev : ctx->ev) hipEventDestroy(ev);
-    hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -245,7 +245,7 @@ int igx_active_deriv(igx_ctx *ctx, const double *kv, int kv_len, int p, const do
         IGX_HIP(hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         IGX_HIP(hipStreamSynchronize(ctx->stream));
     }
-    hipFree(d_kv); hipFree(d_u); hipFree(d_out);
+    (void)hipFree(d_kv); (void)hipFree(d_u); (void)hipFree(d_out);
     return rc;
 }
 
@@ -266,7 +266,7 @@ int igx_find_spans(igx_ctx *ctx, const double *kv, int kv_len, int p, const doub
         IGX_HIP(hipMemcpyAsync(spans, d_sp, nu * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         IGX_HIP(hipStreamSynchronize(ctx->stream));
     }
-    hipFree(d_kv); hipFree(d_u); hipFree(d_sp);
+    (void)hipFree(d_kv); (void)hipFree(d_u); (void)hipFree(d_sp);
     return rc;
 }
 
@@ -302,8 +302,8 @@ int igx_grid_jacobian(igx_ctx *ctx, const igx_patch_desc *d, int ncomp, const do
     if (!rc && jac_out && hipMemcpyAsync(jac_out, d_j, npts * ncomp * dim * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = IGX_ERR_HIP;
     if (!rc && eval_out && hipMemcpyAsync(eval_out, d_e, npts * ncomp * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = IGX_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { set_error("igx_grid_jacobian: stream sync failed"); rc = IGX_ERR_HIP; }
-    for (int k = 0; k < dim; ++k) { free_geo_axis(gax[k]); hipFree(d_grid[k]); }
-    hipFree(d_ctrl); hipFree(d_j); hipFree(d_e);
+    for (int k = 0; k < dim; ++k) { free_geo_axis(gax[k]); (void)hipFree(d_grid[k]); }
+    (void)hipFree(d_ctrl); (void)hipFree(d_j); (void)hipFree(d_e);
     return rc;
 }
 
@@ -311,12 +311,12 @@ int igx_grid_jacobian(igx_ctx *ctx, const igx_patch_desc *d, int ncomp, const do
 void igx_patch_destroy(igx_patch *pt)
 {
     if (!pt) return;
-    hipSetDevice(pt->ctx->device);
-    hipStreamSynchronize(pt->ctx->stream);
+    (void)hipSetDevice(pt->ctx->device);
+    (void)hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
-    hipFree(pt->d_ctrl); hipFree(pt->d_jac); hipFree(pt->d_fields); hipFree(pt->d_data);
-    hipFree(pt->d_indices); hipFree(pt->d_indptr); hipFree(pt->d_pl0); hipFree(pt->d_rl0_of); hipFree(pt->d_steps); hipFree(pt->d_ldesc);
-    hipFree(pt->d_K1); hipFree(pt->d_K2);
+    (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
+    (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
+    (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
     delete pt;
 }
 
@@ -502,14 +502,14 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("igx_assemble: kernel failure: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
     }
-    hipEventElapsedTime(&pt->timing.total_ms, ev[0], ev[5]);
-    hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&pt->timing.total_ms, ev[0], ev[5]);
+    (void)hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
     if (algo == IGX_ALGO_SUMFACT) {
-        hipEventElapsedTime(&pt->timing.stage0_ms, ev[1], ev[2]);
-        hipEventElapsedTime(&pt->timing.stage1_ms, ev[2], ev[3]);
-        hipEventElapsedTime(&pt->timing.final_ms, ev[3], ev[4]);
+        (void)hipEventElapsedTime(&pt->timing.stage0_ms, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&pt->timing.stage1_ms, ev[2], ev[3]);
+        (void)hipEventElapsedTime(&pt->timing.final_ms, ev[3], ev[4]);
     } else {
-        hipEventElapsedTime(&pt->timing.entry_ms, ev[1], ev[4]);
+        (void)hipEventElapsedTime(&pt->timing.entry_ms, ev[1], ev[4]);
     }
     if (data_out) {
         IGX_HIP(hipMemcpyAsync(data_out, pt->d_data, (size_t)pt->nnz * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -547,7 +547,7 @@ int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out
         IGX_HIP(hipMemcpyAsync(out, d_out, M * sizeof(double), hipMemcpyDeviceToHost, st));
         IGX_HIP(hipStreamSynchronize(st));
     }
-    hipFree(d_ij); hipFree(d_out);
+    (void)hipFree(d_ij); (void)hipFree(d_out);
     return rc;
 }
 

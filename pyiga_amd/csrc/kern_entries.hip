@@ -101,7 +101,8 @@ __global__ void k_entries_list(PatchDev pd, const double *fields, const size_t *
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
     int i[3], j[3];
-    const bool ok = unravel<DIM>(pd, ij[2 * k], i) & unravel<DIM>(pd, ij[2 * k + 1], j);
+    const bool ok_i = unravel<DIM>(pd, ij[2 * k], i), ok_j = unravel<DIM>(pd, ij[2 * k + 1], j);
+    const bool ok = ok_i && ok_j;
     out[k] = ok ? entry_value<DIM, KIND>(pd, fields, i, j) : 0.0;
 }
 

@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(256) k_final_mfma(const double *__restrict__ K
     const bool upper = j > i, ondiag = (j == i);
 
     // ---- Gauss window of the tile (wave-uniform)
-    const int i_first = min(F.N - 1, (tile * 16) / F.W), i_last = min(F.N - 1, (tile * 16 + 15) / F.W);
+    const int i_first = min(F.N - 1, (tile * 16) / F.W);
     const int glo = F.mslo[i_first] * F.q;
     const bool overrun = glo + NCH * 8 > F.G;       // window padding reaches past the end of the line
 
@@ -906,7 +906,7 @@ int sumfact_prepare(igx_patch *pt)
 static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 {
     if (*cap >= need) return IGX_OK;
-    if (*buf) { hipFree(*buf); *buf = nullptr; *cap = 0; }
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
     hipError_t e = hipMalloc(buf, (need + 16) * sizeof(double));
     if (e != hipSuccess) {
         set_error("hipMalloc of %.2f GB sum-factorisation workspace failed: %s", need * 8.0 / 1e9, hipGetErrorString(e));
@@ -1010,7 +1010,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
 
     const int nF = (kind == IGX_MASS) ? 1 : dim * (dim + 1) / 2;
-    hipEventRecord(pt->ctx->ev[1], st);
+    (void)hipEventRecord(pt->ctx->ev[1], st);
     // one launch for all fields (blockIdx.y); the types of a field share the field load
     {
         StageAArgs A{};
@@ -1042,7 +1042,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
-    hipEventRecord(pt->ctx->ev[2], st);
+    (void)hipEventRecord(pt->ctx->ev[2], st);
 
     // ---- final-stage input
     FinalArgs F{};
@@ -1090,7 +1090,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         F.N1 = 1; F.S1 = 1; F.Smid = 1; F.Slast = A1.S;
         ngroups = np0;
     }
-    hipEventRecord(pt->ctx->ev[3], st);
+    (void)hipEventRecord(pt->ctx->ev[3], st);
 
     F.V = AL.d_V; F.fa = AL.dev.fa; F.mslo = AL.dev.mslo; F.mshi = AL.dev.mshi;
     F.jlo = AL.dev.jlo; F.jhi = AL.dev.jhi; F.rp = AL.dev.rp;
@@ -1138,7 +1138,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 #undef LAUNCH_M
                 IGX_HIP(hipGetLastError());
                 pt->timing.n_launches++;
-                hipEventRecord(pt->ctx->ev[4], st);
+                (void)hipEventRecord(pt->ctx->ev[4], st);
                 return IGX_OK;
             }
         }
@@ -1193,7 +1193,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
-    hipEventRecord(pt->ctx->ev[4], st);
+    (void)hipEventRecord(pt->ctx->ev[4], st);
     return IGX_OK;
 }
 
