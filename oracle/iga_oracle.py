@@ -219,6 +219,14 @@ def nurbs_grid_jacobian(kvs, coeffs, gridaxes):
     return (Vjac * W - V * Wjac) / (W ** 2)
 
 
+def grid_eval(geo, gridaxes):
+    """BSplineFunc/NurbsFunc.grid_eval: pyiga/bspline.py:874-895, pyiga/geometry.py:103-114."""
+    vals = bspline_grid_eval(geo['kvs'], geo['coeffs'], gridaxes)
+    if geo['nurbs']:
+        return vals[..., :-1] / vals[..., -1:]
+    return vals
+
+
 def grid_jacobian(geo, gridaxes):
     """geo = dict(kvs=[KnotVector...], coeffs=ndarray, nurbs=bool)."""
     if geo['nurbs']:
@@ -329,6 +337,30 @@ def precompute_fields(kind, jac, gw):
     return np.stack(B, axis=-1)
 
 
+def precompute_fields_convdiff(jac, xphys, coeff, gw):
+    """Fields of the generated assembler for the convection-diffusion form (3D): per point
+    [diff_coeff, x, y, z, W, JacInv(9 row-major)] -- layout and arithmetic of the code the reference
+    generates at run time (pyiga/codegen/cython.py:673-701; same cofactor formulas as
+    assemblers.pyx:1420-1441)."""
+    t = jac.reshape(jac.shape[:-2] + (9,))
+    GW = (gw[0][:, None, None] * gw[1][None, :, None]) * gw[2][None, None, :]
+    t6 = t[..., 4] * t[..., 8] - t[..., 5] * t[..., 7]
+    t7 = t[..., 3] * t[..., 8] - t[..., 5] * t[..., 6]
+    t8 = t[..., 3] * t[..., 7] - t[..., 4] * t[..., 6]
+    det = (t[..., 0] * t6 - t[..., 1] * t7) + t[..., 2] * t8
+    i = 1.0 / det
+    JI = [i * t6,
+          i * -(t[..., 1] * t[..., 8] - t[..., 2] * t[..., 7]),
+          i * (t[..., 1] * t[..., 5] - t[..., 2] * t[..., 4]),
+          i * -t7,
+          i * (t[..., 0] * t[..., 8] - t[..., 2] * t[..., 6]),
+          i * -(t[..., 0] * t[..., 5] - t[..., 2] * t[..., 3]),
+          i * t8,
+          i * -(t[..., 0] * t[..., 7] - t[..., 1] * t[..., 6]),
+          i * (t[..., 0] * t[..., 4] - t[..., 1] * t[..., 3])]
+    return np.stack([coeff, xphys[..., 0], xphys[..., 1], xphys[..., 2], GW * np.abs(det)] + JI, axis=-1)
+
+
 # ---------------------------------------------------------------------------
 # sparsity                 pyiga/mlmatrix.py:420-440, mlmatrix_cy.pyx:189-289
 def compute_sparsity_ij(kv1, kv2):
@@ -413,8 +445,8 @@ class Assembler:
     """Restates *Assembler{2,3}D.__init__ (pyiga/assemblers.pyx:38-80,186-228,
     1170-1217,1336-1383) + entry/multi_entries (pyiga/genericasm.pxi:677-758)."""
 
-    def __init__(self, kind, kvs, geo=None, jac=None):
-        assert kind in ('mass', 'stiffness')
+    def __init__(self, kind, kvs, geo=None, jac=None, coeff=None):
+        assert kind in ('mass', 'stiffness', 'convdiff')
         self.kind = kind
         self.kvs = tuple(kvs)
         self.dim = len(kvs)
@@ -428,7 +460,14 @@ class Assembler:
         if jac is None:
             jac = grid_jacobian(geo, self.grid)
         self.jac = np.ascontiguousarray(jac)
-        self.fields = np.ascontiguousarray(precompute_fields(kind, self.jac, self.gw))
+        if kind == 'convdiff':
+            # grid_eval_transformed(diff_coeff, grid, geo): pyiga/utils.py:43-52
+            assert self.dim == 3
+            xphys = grid_eval(geo, self.grid)
+            c = coeff(xphys[..., 0], xphys[..., 1], xphys[..., 2]) * np.ones(xphys.shape[:-1])
+            self.fields = np.ascontiguousarray(precompute_fields_convdiff(self.jac, xphys, c, self.gw))
+        else:
+            self.fields = np.ascontiguousarray(precompute_fields(kind, self.jac, self.gw))
         self.ndofs = np.array([kv.numdofs for kv in kvs], dtype=np.uintp)
         self.ngauss = np.array([g.shape[0] for g in self.grid], dtype=np.uintp)
 
@@ -440,7 +479,7 @@ class Assembler:
         ms = self.meshsupp + [None] * (3 - self.dim)
         C = self.C + [None] * (3 - self.dim)
         p = lambda a: None if a is None else a.ctypes.data
-        rc = lib.orc_entries(self.dim, 0 if self.kind == 'mass' else 1,
+        rc = lib.orc_entries(self.dim, {'mass': 0, 'stiffness': 1, 'convdiff': 2}[self.kind],
                              p(self.ndofs), p(self.ngauss),
                              p(ms[0]), p(ms[1]), p(ms[2]), p(C[0]), p(C[1]), p(C[2]),
                              self.nder, p(self.fields), self.fields.shape[-1],
@@ -510,6 +549,22 @@ def lower_pattern(kvs):
     bidx = [compute_sparsity_ij(kv, kv) for kv in kvs]
     bs = [(kv.numdofs, kv.numdofs) for kv in kvs]
     return ml_nonzero(bidx, bs, lower_tri=True)
+
+
+def full_pattern(kvs):
+    """MLStructure.from_kvs + nonzero(lower_tri=False)."""
+    bidx = [compute_sparsity_ij(kv, kv) for kv in kvs]
+    bs = [(kv.numdofs, kv.numdofs) for kv in kvs]
+    return ml_nonzero(bidx, bs, lower_tri=False)
+
+
+def assemble_nonsymmetric(kind, kvs, geo, coeff=None, nthreads=1):
+    """assemble_entries(asm, symmetric=False): every pattern entry is computed directly."""
+    asm = Assembler(kind, kvs, geo=geo, coeff=coeff)
+    I, J = full_pattern(kvs)
+    entries = asm.multi_entries(np.column_stack((I, J)), nthreads=nthreads)
+    n = int(np.prod([kv.numdofs for kv in kvs]))
+    return scipy.sparse.coo_matrix((entries, (I, J)), shape=(n, n)).tocsr()
 
 
 def assemble(kind, kvs, geo=None, jac=None, nthreads=1, fast=False, return_timing=None):

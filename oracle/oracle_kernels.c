@@ -98,9 +98,22 @@ static double entry3(const orc_ctx *c, const size_t i[3], const size_t j[3])
                     double dv100 = (v0[2 * i0 + 0] * v1[2 * i1 + 0] * v2[2 * i2 + 1]);
                     double dv010 = (v0[2 * i0 + 0] * v1[2 * i1 + 1] * v2[2 * i2 + 0]);
                     double dv001 = (v0[2 * i0 + 1] * v1[2 * i1 + 0] * v2[2 * i2 + 0]);
-                    r += ((((((f[0] * du100) + (f[1] * du010)) + (f[2] * du001)) * dv100)
-                           + ((((f[1] * du100) + (f[3] * du010)) + (f[4] * du001)) * dv010))
-                          + ((((f[2] * du100) + (f[4] * du010)) + (f[5] * du001)) * dv001));
+                    if (c->kind == 1) {
+                        r += ((((((f[0] * du100) + (f[1] * du010)) + (f[2] * du001)) * dv100)
+                               + ((((f[1] * du100) + (f[3] * du010)) + (f[4] * du001)) * dv010))
+                              + ((((f[2] * du100) + (f[4] * du010)) + (f[5] * du001)) * dv001));
+                    } else {
+                        /* physical gradient of u, component r: sum_a JacInv[a][r] * du_a */
+                        const double gu0 = ((f[5] * du100) + (f[8] * du010)) + (f[11] * du001);
+                        const double gu1 = ((f[6] * du100) + (f[9] * du010)) + (f[12] * du001);
+                        const double gu2 = ((f[7] * du100) + (f[10] * du010)) + (f[13] * du001);
+                        const double gv0 = ((f[5] * dv100) + (f[8] * dv010)) + (f[11] * dv001);
+                        const double gv1 = ((f[6] * dv100) + (f[9] * dv010)) + (f[12] * dv001);
+                        const double gv2 = ((f[7] * dv100) + (f[10] * dv010)) + (f[13] * dv001);
+                        const double vv = (v0[2 * i0 + 0] * v1[2 * i1 + 0] * v2[2 * i2 + 0]);
+                        r += ((((((f[0] * gu0) * gv0) + ((f[0] * gu1) * gv1)) + ((f[0] * gu2) * gv2))
+                               + ((((f[2] * gu0) + (-f[1] * gu1)) + gu2) * vv)) * f[4]);
+                    }
                 }
             }
     }

@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'convdiff' not in sys.argv[1:]:
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -251,3 +251,39 @@ if __name__ == '__main__':
     golden_matrices()
     golden_kron()
     print('reference version', pyiga.__version__)
+
+
+# ---------------------------------------------------------------------------
+# (7) custom form of BASELINE config 5 / SURVEY section 8 f1: convection-diffusion, non-symmetric
+#     (assemble.assemble with a run-time compiled vform, pyiga/assemble.py:837-897)
+CONVDIFF = '(inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx'
+
+
+def golden_convdiff():
+    out = {}
+
+    def diff_coeff(x, y, z):
+        return 1.0 + x
+    cyl = cylinder()
+    for name, kvs, geo in (
+            ('d3_p2_n3_cyl', (bspline.make_knots(2, 0.0, 1.0, 3),) * 3, cyl),
+            ('d3_p32_n243_tbox', (bspline.make_knots(3, 0.0, 1.0, 2), bspline.make_knots(2, 0.0, 1.0, 4),
+                                  bspline.make_knots(2, 0.0, 1.0, 3)), geometry.twisted_box()),
+            ('d3_mult_cyl', (bspline.make_knots(2, 0.0, 1.0, 3, mult=2), bspline.make_knots(2, 0.0, 1.0, 3),
+                             bspline.make_knots(3, 0.0, 1.0, 2)), cyl)):
+        A = assemble.assemble(CONVDIFF, kvs, geo=geo, diff_coeff=diff_coeff)
+        put_matrix(out, name, A)
+        asm = assemble.instantiate_assembler(CONVDIFF, kvs, {'geo': geo, 'diff_coeff': diff_coeff}, None)
+        nd = int(np.prod([kv.numdofs for kv in kvs]))
+        rng = np.random.default_rng(3)
+        idx = rng.integers(0, nd, (50, 2)).astype(np.uintp)
+        near = np.arange(0, nd, 5)
+        idx = np.concatenate([idx, np.stack([near, np.minimum(near + 2, nd - 1)], 1).astype(np.uintp),
+                              np.stack([np.minimum(near + 2, nd - 1), near], 1).astype(np.uintp)])
+        out[name + '_idx'] = idx
+        out[name + '_multi'] = np.asarray(asm.multi_entries(idx))
+    save('convdiff', **out)
+
+
+if __name__ == '__main__' and 'convdiff' in sys.argv[1:]:
+    golden_convdiff()

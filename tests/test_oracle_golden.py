@@ -185,3 +185,23 @@ def test_1d_literal_and_kron(oracle, golden):
     assert np.allclose(A.toarray(), oracle.kron_assemble('stiffness', kvs2).toarray(), rtol=0, atol=1e-14)
     A = oracle.assemble('stiffness', kvs3, oracle.geo_unit_cube(3))
     assert np.allclose(A.toarray(), oracle.kron_assemble('stiffness', kvs3).toarray(), rtol=0, atol=1e-14)
+
+
+def test_convdiff_custom_form(oracle, golden):
+    """Row f1 of SURVEY section 8: the run-time compiled convection-diffusion form (non-symmetric)."""
+    g = golden('convdiff')
+    mk = oracle.make_knots
+    cases = [('d3_p2_n3_cyl', (mk(2, 0., 1., 3),) * 3, oracle.geo_cylinder()),
+             ('d3_p32_n243_tbox', (mk(3, 0., 1., 2), mk(2, 0., 1., 4), mk(2, 0., 1., 3)), oracle.geo_twisted_box()),
+             ('d3_mult_cyl', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), oracle.geo_cylinder())]
+    for name, kvs, geo in cases:
+        A = oracle.assemble_nonsymmetric('convdiff', kvs, geo, coeff=lambda x, y, z: 1.0 + x)
+        R = golden_csr(g, name)
+        assert A.shape == R.shape
+        assert rel_maxdiff(A, R) < 1e-14, name
+        assert abs(A - A.T).max() > 1e-3 * abs(A).max()           # genuinely non-symmetric
+        asm = oracle.Assembler('convdiff', kvs, geo, coeff=lambda x, y, z: 1.0 + x)
+        out = asm.multi_entries(g[name + '_idx'])
+        ref = g[name + '_multi']
+        assert np.abs(out - ref).max() <= 1e-14 * np.abs(ref).max()
+        assert np.array_equal(out == 0.0, ref == 0.0)
