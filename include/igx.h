@@ -24,6 +24,8 @@
  *   igx_entries                        <- BaseAssembler{2,3}D.multi_entries / entry
  *                                         pyiga/genericasm.pxi:353-436,677-758
  *                                         (entry_impl + combine, assemblers.pyx:116-172,281-349,1255-1322,1455-1540)
+ *   igx_patch_set_coeff + IGX_CONVDIFF <- the assembler pyiga.compile.compile_vform generates for the form
+ *                                         (pyiga/assemble.py:837-897, pyiga/codegen/cython.py:325-387,673-701)
  *   igx_assemble                       <- assemble_entries(asm, symmetric=True)
  *                                         pyiga/assemble.py:703-754 (multi_entries + COO->CSR + mirror)
  */
@@ -45,7 +47,10 @@ extern "C" {
 typedef struct igx_ctx igx_ctx;       /* one per GPU: device id + HIP stream */
 typedef struct igx_patch igx_patch;   /* device-resident state of one assembler */
 
-enum { IGX_MASS = 0, IGX_STIFFNESS = 1 };
+enum { IGX_MASS = 0, IGX_STIFFNESS = 1,
+       /* (inner(c*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx -- the custom (vform) case of
+          BASELINE config 5, non-symmetric, 3D only; c is set with igx_patch_set_coeff */
+       IGX_CONVDIFF = 2 };
 enum { IGX_GEO_BSPLINE = 0, IGX_GEO_NURBS = 1, IGX_GEO_JACOBIAN = 2 };
 /* algorithm selector for igx_assemble */
 enum { IGX_ALGO_AUTO = 0,      /* sum-factorised when the patch supports it, else entry-wise */
@@ -125,6 +130,10 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *desc);   /* NULL
 void       igx_patch_destroy(igx_patch *patch);
 int        igx_patch_get_info(const igx_patch *patch, igx_patch_info *info);
 
+/* Scalar coefficient field of IGX_CONVDIFF on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
+   pointer; what pyiga.utils.grid_eval_transformed(diff_coeff, gaussgrid, geo) returns).  Copied. */
+int igx_patch_set_coeff(igx_patch *patch, const double *coeff);
+
 /* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
 int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);
 
@@ -134,7 +143,8 @@ int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *wei
 int igx_pattern(igx_patch *patch, int32_t *indptr, int32_t *indices);
 
 /* Assemble all CSR values of the owned rows into device memory (symmetric: lower triangle
-   computed, strict lower part mirrored -> exactly symmetric, as assemble_entries(symmetric=True)).
+   computed, strict lower part mirrored -> exactly symmetric, as assemble_entries(symmetric=True);
+   IGX_CONVDIFF is non-symmetric: every entry is computed, as assemble_entries(symmetric=False)).
    If data_out != NULL the nnz values are also copied to the host buffer. */
 int igx_assemble(igx_patch *patch, int kind, int algo, double *data_out);
 int igx_last_timing(const igx_patch *patch, igx_timing *t);

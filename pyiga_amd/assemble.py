@@ -173,6 +173,58 @@ def assemble_entries(asm, symmetric=False, format='csr', algo='auto'):
 
 
 ################################################################################
+# Custom forms (pyiga/assemble.py:837-897)
+################################################################################
+
+def _normalise_form(problem):
+    return ''.join(str(problem).split())
+
+
+# variational forms with a hand-written device implementation, keyed by their whitespace-free text
+_KNOWN_FORMS = {
+    'inner(grad(u),grad(v))*dx': 'stiffness',
+    'u*v*dx': 'mass',
+    '(inner(diff_coeff*grad(u),grad(v))+inner((x[1],-x[0],1.0),grad(u))*v)*dx': 'convdiff',
+}
+
+
+def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
+    """Assembler object for `problem`.  The reference compiles arbitrary form strings at run time
+    (vform -> Cython -> gcc); here a form must be one of the hand-written device forms, an
+    assembler class, or an assembler object (row f1 of SURVEY section 8: the form compiler is next)."""
+    assert bfuns is None and boundary is None, 'custom basis functions / boundary forms are not supported'
+    if isinstance(problem, str):
+        kind = _KNOWN_FORMS.get(_normalise_form(problem))
+        if kind is None:
+            raise NotImplementedError('no device implementation for the form %r (available: %s)'
+                                      % (problem, ', '.join(sorted(_KNOWN_FORMS))))
+        if 'geo' not in args:
+            raise ValueError("required input parameter 'geo' missing")
+        kvs = tuple(kvs)
+        if kind == 'convdiff':
+            if 'diff_coeff' not in args:
+                raise ValueError("required input parameter 'diff_coeff' missing")
+            assert len(kvs) == 3, 'the convection-diffusion form is three-dimensional'
+            return assemblers.ConvDiffAssembler3D(kvs, args['geo'], args['diff_coeff'])
+        return _ASSEMBLER[(kind, len(kvs))](kvs, args['geo'])
+    if isinstance(problem, type):
+        used = {k: args[k] for k in problem.inputs() if k in args}
+        missing = [k for k in problem.inputs() if k not in args]
+        if missing:
+            raise ValueError("required input parameter '%s' missing" % missing[0])
+        return problem(tuple(kvs), **used)
+    return problem          # already an assembler object
+
+
+def assemble(problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False, format='csr', **kwargs):
+    """Assemble the matrix of a variational form (string, assembler class or assembler object)."""
+    args = dict(args or {})
+    args.update(kwargs)
+    asm = instantiate_assembler(problem, kvs, args, bfuns, boundary)
+    return assemble_entries(asm, symmetric=symmetric, format=format)
+
+
+################################################################################
 # Convenience functions (pyiga/assemble.py:1009-1049)
 ################################################################################
 

@@ -159,6 +159,12 @@ class DevicePatch:
         _lib.check(_lib.load().igx_fields(self.handle, _lib.KINDS[kind], _lib.dptr(out), shp), 'igx_fields')
         return out
 
+    def set_coeff(self, values):
+        """Scalar coefficient on the full tensor Gauss grid (for the convection-diffusion form)."""
+        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        c = _lib.f64(np.broadcast_to(values, G))
+        _lib.check(_lib.load().igx_patch_set_coeff(self.handle, _lib.dptr(c)), 'igx_patch_set_coeff')
+
     def gauss(self, axis):
         n = self.info.ngauss[axis]
         nodes, weights = np.empty(n), np.empty(n)
@@ -239,3 +245,28 @@ class MassAssembler3D(_DeviceAssembler):
 
 class StiffnessAssembler3D(_DeviceAssembler):
     _kind, _dim = 'stiffness', 3
+
+
+class ConvDiffAssembler3D(_DeviceAssembler):
+    """Assembler for the variational form
+
+        (inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx
+
+    -- what the reference compiles at run time from that string (pyiga/assemble.py:837-897,
+    pyiga/vform.py, pyiga/codegen/cython.py).  Non-symmetric.  `diff_coeff` is a function of the
+    physical coordinates (x, y, z), evaluated on the Gauss grid through the geometry exactly like
+    ``pyiga.utils.grid_eval_transformed`` (host numpy, as in the reference); everything else runs on
+    the device.
+    """
+    _kind, _dim = 'convdiff', 3
+
+    @classmethod
+    def inputs(cls):
+        return {'geo': (3,), 'diff_coeff': ()}
+
+    def __init__(self, kvs0, geo, diff_coeff, device=None, row0=None):
+        super().__init__(kvs0, geo, device=device, row0=row0)
+        grid = [self.patch.gauss(k)[0] for k in range(3)]
+        X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
+        vals = diff_coeff(X[..., 0], X[..., 1], X[..., 2]) if callable(diff_coeff) else diff_coeff
+        self.patch.set_coeff(vals)

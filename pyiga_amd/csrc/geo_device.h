@@ -81,6 +81,40 @@ __device__ inline void fields_from_jac(const double t[9], double GW, int kind, d
     }
 }
 
+// Fields of the convection-diffusion form (3D): c*B (upper triangle, as stiffness) and
+// beta_a = W * sum_r JacInv[a][r] * b_r with b = (y, -x, 1) at the physical point ev.
+__device__ inline void fields_convdiff(const double t[9], double GW, const double ev[MAX_COMP], double c,
+                                       double *fields, long long stride, long long pt)
+{
+    const double t3 = t[4] * t[8] - t[5] * t[7];
+    const double t4 = t[3] * t[8] - t[5] * t[6];
+    const double t5 = t[3] * t[7] - t[4] * t[6];
+    const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
+    const double W = GW * fabs(det);
+    const double inv = 1.0 / det;
+    double JI[9];
+    JI[0] = inv * t3;
+    JI[1] = inv * -(t[1] * t[8] - t[2] * t[7]);
+    JI[2] = inv * (t[1] * t[5] - t[2] * t[4]);
+    JI[3] = inv * -t4;
+    JI[4] = inv * (t[0] * t[8] - t[2] * t[6]);
+    JI[5] = inv * -(t[0] * t[5] - t[2] * t[3]);
+    JI[6] = inv * t5;
+    JI[7] = inv * -(t[0] * t[7] - t[1] * t[6]);
+    JI[8] = inv * (t[0] * t[4] - t[1] * t[3]);
+    const double cW = c * W;
+    fields[pt] = cW * ((JI[0] * JI[0] + JI[1] * JI[1]) + JI[2] * JI[2]);
+    fields[stride + pt] = cW * ((JI[0] * JI[3] + JI[1] * JI[4]) + JI[2] * JI[5]);
+    fields[2 * stride + pt] = cW * ((JI[0] * JI[6] + JI[1] * JI[7]) + JI[2] * JI[8]);
+    fields[3 * stride + pt] = cW * ((JI[3] * JI[3] + JI[4] * JI[4]) + JI[5] * JI[5]);
+    fields[4 * stride + pt] = cW * ((JI[3] * JI[6] + JI[4] * JI[7]) + JI[5] * JI[8]);
+    fields[5 * stride + pt] = cW * ((JI[6] * JI[6] + JI[7] * JI[7]) + JI[8] * JI[8]);
+    const double b0 = ev[1], b1 = -ev[0], b2 = 1.0;
+    fields[6 * stride + pt] = W * ((JI[0] * b0 + JI[1] * b1) + JI[2] * b2);
+    fields[7 * stride + pt] = W * ((JI[3] * b0 + JI[4] * b1) + JI[5] * b2);
+    fields[8 * stride + pt] = W * ((JI[6] * b0 + JI[7] * b1) + JI[8] * b2);
+}
+
 inline GeoView make_view(int dim, const GeoAxis gax[3], const double *d_ctrl, int nc)
 {
     GeoView gv{};

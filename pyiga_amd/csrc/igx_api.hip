@@ -164,7 +164,12 @@ static void free_geo_axis(GeoAxis &g) { (void)hipFree(g.d_kv); (void)hipFree(g.d
 static int ensure_fields(igx_patch *pt, int kind)
 {
     if (pt->fields_kind == kind) return IGX_OK;
-    const int nF = (kind == IGX_MASS) ? 1 : pt->dim * (pt->dim + 1) / 2;
+    const int nF = igx_num_fields(pt->dim, kind);
+    if (kind == IGX_CONVDIFF) {
+        if (pt->dim != 3) { set_error("IGX_CONVDIFF is a 3D form"); return IGX_ERR_UNSUPPORTED; }
+        if (!pt->d_coeff) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
+        if (pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("IGX_CONVDIFF needs a spline geometry (physical coordinates)"); return IGX_ERR_UNSUPPORTED; }
+    }
     const size_t need = (size_t)nF * pt->dev.npts_loc;
     if (pt->fields_cap < need) {
         if (pt->d_fields) (void)hipFree(pt->d_fields);
@@ -314,7 +319,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipSetDevice(pt->ctx->device);
     (void)hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
-    (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
+    (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
     delete pt;
@@ -433,6 +438,19 @@ int igx_patch_get_info(const igx_patch *pt, igx_patch_info *info)
     return IGX_OK;
 }
 
+int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
+{
+    if (!pt || !coeff) { set_error("igx_patch_set_coeff: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    const size_t per_plane = (size_t)pt->ax[1].G * pt->ax[2].G;
+    const size_t n = (size_t)pt->dev.G0_loc * per_plane;
+    if (!pt->d_coeff) IGX_HIP(hipMalloc((void **)&pt->d_coeff, std::max<size_t>(1, n) * sizeof(double)));
+    IGX_HIP(hipMemcpyAsync(pt->d_coeff, coeff + (size_t)pt->dev.g0_lo * per_plane, n * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    pt->fields_kind = -1;
+    return IGX_OK;
+}
+
 int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)
 {
     if (!pt || axis < 0 || axis >= pt->dim) { set_error("igx_patch_gauss: bad argument"); return IGX_ERR_ARG; }
@@ -466,10 +484,11 @@ int igx_pattern(igx_patch *pt, int32_t *indptr, int32_t *indices)
 int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
 {
     if (!pt) { set_error("igx_assemble: null patch"); return IGX_ERR_ARG; }
-    if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (kind != IGX_MASS && kind != IGX_STIFFNESS && kind != IGX_CONVDIFF) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
-    if (algo == IGX_ALGO_AUTO) algo = pt->sumfact_ok ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
+    if (algo == IGX_ALGO_AUTO) algo = (pt->sumfact_ok && sumfact_supports_kind(pt, kind)) ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
+    if (algo == IGX_ALGO_SUMFACT && !sumfact_supports_kind(pt, kind)) { set_error("igx_assemble: sum factorisation does not support this form yet"); return IGX_ERR_UNSUPPORTED; }
     if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
     if (algo != IGX_ALGO_SUMFACT && algo != IGX_ALGO_ENTRYWISE) { set_error("igx_assemble: unknown algo %d", algo); return IGX_ERR_ARG; }
     if (!pt->d_data) {
@@ -532,7 +551,7 @@ const int32_t *igx_d_csr_indptr(const igx_patch *pt) { return pt ? pt->d_indptr 
 int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out)
 {
     if (!pt || (M && (!ij || !out))) { set_error("igx_entries: null argument"); return IGX_ERR_ARG; }
-    if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_entries: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (kind != IGX_MASS && kind != IGX_STIFFNESS && kind != IGX_CONVDIFF) { set_error("igx_entries: unknown kind %d", kind); return IGX_ERR_ARG; }
     if (M == 0) return IGX_OK;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
@@ -557,7 +576,7 @@ int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
     IGX_HIP(hipSetDevice(pt->ctx->device));
     int rc = ensure_fields(pt, kind);
     if (rc) return rc;
-    const int nF = (kind == IGX_MASS) ? 1 : pt->dim * (pt->dim + 1) / 2;
+    const int nF = igx_num_fields(pt->dim, kind);
     if (shape4) { shape4[0] = nF; shape4[1] = pt->dev.G0_loc; shape4[2] = pt->ax[1].G; shape4[3] = pt->dim == 3 ? pt->ax[2].G : 1; }
     if (out) {
         IGX_HIP(hipMemcpyAsync(out, pt->d_fields, (size_t)nF * pt->dev.npts_loc * sizeof(double), hipMemcpyDeviceToHost, pt->ctx->stream));

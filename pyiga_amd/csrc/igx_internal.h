@@ -98,6 +98,7 @@ struct igx_patch {
     igx::GeoAxis gax[3];
     double *d_ctrl = nullptr;
     double *d_jac = nullptr;                  // IGX_GEO_JACOBIAN: resident slab of the user array
+    double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     // slab
     int r0_lo = 0, r0_hi = 0, s0_lo = 0, s0_hi = 0;
     long long row_lo = 0, row_hi = 0, nnz = 0, nnz_off = 0, nrows_total = 0, nelem_owned = 0;
@@ -140,7 +141,10 @@ int launch_fields_dump(hipStream_t st, const igx_patch *pt);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
+inline int igx_num_fields(int dim, int kind) { return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : dim * (dim + 1) / 2); }
+inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF; }
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);
+int sumfact_supports_kind(const igx_patch *pt, int kind);
 int sumfact_assemble(igx_patch *pt, int kind, double *d_data);
 } // namespace igx

@@ -243,7 +243,7 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
 // ---------------------------------------------------------------------------------------------
 // geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
 template <int DIM>
-__global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int kind,
+__global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, const double *coeff, int kind,
                              const double *w0, const double *w1, const double *w2,
                              int g0_lo, int G0loc, int G1, int G2, double *fields)
 {
@@ -254,18 +254,20 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int
     if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
     else { g[1] = idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
     double t[9];
+    double ev[MAX_COMP] = {0.0, 0.0, 0.0, 0.0};
     if (geo_kind == IGX_GEO_JACOBIAN) {
         const double *src = jac_in + idx * (DIM * DIM);
         for (int k = 0; k < DIM * DIM; ++k) t[k] = src[k];
     } else {
-        double Jm[MAX_COMP][3], ev[MAX_COMP];
+        double Jm[MAX_COMP][3];
         physical_jacobian<DIM>(gv, geo_kind == IGX_GEO_NURBS, g, DIM, Jm, ev);
         for (int r = 0; r < DIM; ++r)
             for (int c = 0; c < DIM; ++c) t[r * DIM + c] = Jm[r][c];
     }
     double GW = w0[g[0]] * w1[g[1]];
     if (DIM == 3) GW = GW * w2[g[2]];
-    fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
+    if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
+    else fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
 
 // Line-wise variant for spline geometries: the tensor-product structure of the geometry map is
@@ -275,7 +277,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, int
 // (The per-point kernel above costs prod(p_k+1) * ncomp * (DIM+1) FMAs and is memory-latency bound
 // on the control-net gathers.)
 template <int DIM, int NC>
-__global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind,
+__global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind, const double *coeff,
                                                           const double *w0, const double *w1, const double *w2,
                                                           int g0_lo, int G0loc, int G1, int G2, int LPB, double *fields)
 {
@@ -361,7 +363,8 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         else { g0 = g0_lo + (int)line; g1 = gL; }
         double GW = w0[g0] * w1[g1];
         if (DIM == 3) GW = GW * w2[gL];
-        fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
+        if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
+        else fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
     }
 }
 
@@ -382,11 +385,11 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
             dim3 grid((unsigned)((nlines + LPB - 1) / LPB)), block(256);
             const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
             if (dim == 2) {
-                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
-                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
             } else {
-                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
-                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
             }
             IGX_HIP(hipGetLastError());
             return IGX_OK;
@@ -394,10 +397,10 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     }
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     if (dim == 2)
-        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
+        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
                                                 pd.g0_lo, pd.G0_loc, G1, 1, d_fields);
     else
-        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
+        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
                                                 pd.g0_lo, pd.G0_loc, G1, G2, d_fields);
     IGX_HIP(hipGetLastError());
     return IGX_OK;

@@ -84,9 +84,14 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                         const double dv100 = v0[0] * v1[0] * v2[1];
                         const double dv010 = v0[0] * v1[1] * v2[0];
                         const double dv001 = v0[1] * v1[0] * v2[0];
-                        r += ((((((f_0 * du100) + (f_1 * du010)) + (f_2 * du001)) * dv100)
-                               + ((((f_1 * du100) + (f_3 * du010)) + (f_4 * du001)) * dv010))
-                              + ((((f_2 * du100) + (f_4 * du010)) + (f_5 * du001)) * dv001));
+                        double e = ((((((f_0 * du100) + (f_1 * du010)) + (f_2 * du001)) * dv100)
+                                     + ((((f_1 * du100) + (f_3 * du010)) + (f_4 * du001)) * dv010))
+                                    + ((((f_2 * du100) + (f_4 * du010)) + (f_5 * du001)) * dv001));
+                        if (KIND == IGX_CONVDIFF) {      // + (beta . du) * v, fields 6..8 = beta in (x,y,z) order
+                            const double f_6 = fields[6 * stride + pt], f_7 = fields[7 * stride + pt], f_8 = fields[8 * stride + pt];
+                            e += (((f_6 * du100) + (f_7 * du010)) + (f_8 * du001)) * (v0[0] * v1[0] * v2[0]);
+                        }
+                        r += e;
                     }
                 }
             }
@@ -116,6 +121,7 @@ int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const siz
         else k_entries_list<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
     } else {
         if (kind == IGX_MASS) k_entries_list<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        else if (kind == IGX_CONVDIFF) k_entries_list<3, IGX_CONVDIFF><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
         else k_entries_list<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
     }
     IGX_HIP(hipGetLastError());
@@ -213,7 +219,7 @@ int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32
 // (zero-communication multi-GPU scheme, DESIGN.md section "multi-GPU").
 template <int DIM, int KIND>
 __global__ void k_entries_csr(PatchDev pd, const double *fields, long long row_first, long long nrows_scan,
-                              int maxrow, double *data)
+                              int maxrow, bool symmetric, double *data)
 {
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long lr = tid / maxrow;
@@ -233,8 +239,12 @@ __global__ void k_entries_csr(PatchDev pd, const double *fields, long long row_f
     for (int k = 0; k < DIM; ++k) {
         if (j[k] != i[k]) { lower = j[k] < i[k]; diag = false; break; }
     }
-    if (!lower) return;
     const bool own_row = i[0] >= pd.r0_lo && i[0] < pd.r0_hi;
+    if (!symmetric) {                                // non-symmetric form: every entry of the owned rows, no mirror
+        if (own_row) data[entry_pos<DIM>(pd, i, j)] = entry_value<DIM, KIND>(pd, fields, i, j);
+        return;
+    }
+    if (!lower) return;
     const bool own_col = j[0] >= pd.r0_lo && j[0] < pd.r0_hi;
     if (!own_row && !own_col) return;
     const double v = entry_value<DIM, KIND>(pd, fields, i, j);
@@ -256,11 +266,12 @@ int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_
     if (total == 0) return IGX_OK;
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     if (pt->dim == 2) {
-        if (kind == IGX_MASS) k_entries_csr<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
-        else k_entries_csr<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+        if (kind == IGX_MASS) k_entries_csr<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
+        else k_entries_csr<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
     } else {
-        if (kind == IGX_MASS) k_entries_csr<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
-        else k_entries_csr<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, d_data);
+        if (kind == IGX_MASS) k_entries_csr<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
+        else if (kind == IGX_CONVDIFF) k_entries_csr<3, IGX_CONVDIFF><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, false, d_data);
+        else k_entries_csr<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
     }
     IGX_HIP(hipGetLastError());
     return IGX_OK;

@@ -802,6 +802,11 @@ int sumfact_supported(const igx_patch *pt)
     return 1;
 }
 
+int sumfact_supports_kind(const igx_patch *, int kind)
+{
+    return kind == IGX_MASS || kind == IGX_STIFFNESS;
+}
+
 int sumfact_prepare(igx_patch *pt)
 {
     // processed lower pairs of axis 0: j0 <= i0 with the row or the column owned

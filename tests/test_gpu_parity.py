@@ -355,3 +355,37 @@ def test_final_stage_variants_agree(iga, monkeypatch):
                 assert abs(out[sel] - out[sel].T).max() == 0.0
             assert rel_maxdiff(out['mfma'], out['valu']) <= 1e-14
     monkeypatch.delenv('IGX_FINAL')
+
+
+CONVDIFF = '(inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx'
+
+
+@pytest.mark.parametrize('algo', ['auto', 'entrywise'])
+def test_convdiff_custom_form(iga, golden, algo, monkeypatch):
+    """Row f1 of SURVEY section 8 (BASELINE config 5): the run-time compiled convection-diffusion form,
+    non-symmetric, against matrices produced by the real reference."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    g = golden('convdiff')
+    mk = iga.bspline.make_knots
+    cases = [('d3_p2_n3_cyl', (mk(2, 0., 1., 3),) * 3, 'cylinder'),
+             ('d3_p32_n243_tbox', (mk(3, 0., 1., 2), mk(2, 0., 1., 4), mk(2, 0., 1., 3)), 'twisted_box'),
+             ('d3_mult_cyl', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), 'cylinder')]
+    for name, kvs, gname in cases:
+        geo = _geo(iga, gname)
+        asm = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + x)
+        A = iga.assemble.assemble_entries(asm, symmetric=False, algo=algo)
+        R = golden_csr(g, name)
+        assert A.shape == R.shape and A.nnz == R.nnz and not np.isnan(A.data).any()
+        assert rel_maxdiff(A, R) <= RTOL, (name, rel_maxdiff(A, R))
+        out = asm.multi_entries(g[name + '_idx'])
+        ref = g[name + '_multi']
+        assert np.abs(out - ref).max() <= RTOL * np.abs(ref).max()
+        assert np.array_equal(out == 0.0, ref == 0.0)
+    # the reference's string interface
+    kv = mk(2, 0., 1., 3)
+    A = iga.assemble.assemble(CONVDIFF, (kv, kv, kv), geo=_geo(iga, 'cylinder'), diff_coeff=lambda x, y, z: 1.0 + x)
+    assert rel_maxdiff(A, golden_csr(g, 'd3_p2_n3_cyl')) <= RTOL
+    assert rel_maxdiff(iga.assemble.assemble('inner(grad(u), grad(v)) * dx', (kv, kv, kv), geo=_geo(iga, 'cylinder')),
+                       iga.assemble.stiffness((kv, kv, kv), _geo(iga, 'cylinder'))) == 0.0
+    with pytest.raises(NotImplementedError):
+        iga.assemble.assemble('u * dx(v) * dx', (kv, kv, kv), geo=_geo(iga, 'cylinder'))
