@@ -321,6 +321,7 @@ void igx_patch_destroy(igx_patch *pt)
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
     (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
+    (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
     delete pt;
 }

@@ -116,6 +116,9 @@ struct igx_patch {
     int *d_pl0 = nullptr;                     // [npairs0][2] processed lower pairs (i0,j0) of axis 0
     int *d_rl0_of = nullptr;                  // [S0] 1D pair index -> compact processed-pair index or -1
     int npairs0 = 0;
+    // non-symmetric forms (built on first use): all pairs (i0, j0) of the owned rows i0
+    int *d_pl0n = nullptr, *d_stepsn = nullptr;
+    int npairs0n = -1;
     int *d_ldesc = nullptr;                   // [n_ldesc][4] line descriptors of the final stage
     int n_ldesc = 0;
     bool ldesc_ok = false;

@@ -58,6 +58,13 @@ static std::vector<Term> form_terms(int dim, int kind)
             for (int k = 0; k < 3; ++k) t.t[k] = (k < dim) ? ((k == a) ? 1 : 0) + 2 * ((k == b) ? 1 : 0) : 0;
             T.push_back(t);
         }
+    if (kind == IGX_CONVDIFF)              // + (beta . du) v: fields 6.. = beta in (x,y,z) order, v undifferentiated
+        for (int a = 0; a < dim; ++a) {
+            Term t{};
+            t.f = dim * (dim + 1) / 2 + (dim - 1 - a);
+            for (int k = 0; k < 3; ++k) t.t[k] = (k < dim && k == a) ? 1 : 0;
+            T.push_back(t);
+        }
     return T;
 }
 
@@ -94,16 +101,17 @@ struct StageAGroup {
     int t0, t1, nt;
 };
 struct StageAArgs {
-    StageAGroup grp[6];
+    StageAGroup grp[12];
     const double *PI0;          // [G0][4][P][P]
     const int *step_ptr;        // [n0+1] first flush step of each span
-    const int *steps;           // [nsteps][8] K1 slot of pair (leaving dof + a, leaving dof), or -1
+    const int *steps;           // symmetric: [nsteps][8] K1 slot of pair (leaving dof + a, leaving dof), or -1;
+                                // non-symmetric: [nsteps][16], [a] as before and [8+a] = slot of (leaving dof, leaving dof + a)
     int s_lo, s_hi, n0, N0, q, g0_lo;
     int chunk_len;
     long long NPL;
 };
 
-template <int P, int NT, int Q>
+template <int P, int NT, int Q, bool SYM>
 __device__ __forceinline__ void stageA_body(const double *__restrict__ field, double *__restrict__ out0,
                                             double *__restrict__ out1, const int t0, const int t1,
                                             const StageAArgs &A, const long long pt, const bool live, double *pis)
@@ -155,13 +163,13 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b) acc[ty][a][b] = fma(pt_[a * P + b], bv, acc[ty][a][b]);
+                    for (int b = 0; b <= (SYM ? a : P - 1); ++b) acc[ty][a][b] = fma(pt_[a * P + b], bv, acc[ty][a][b]);
                 // keep hipcc from hoisting the LDS reads of every batch to the top (register blow-up):
                 // the next batch's reads may not cross this point, and the FMAs above must precede it
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[ty][a][b]));
+                    for (int b = 0; b <= (SYM ? a : P - 1); ++b) asm volatile("" : "+v"(acc[ty][a][b]));
                 asm volatile("" ::: "memory");
             }
         };
@@ -183,7 +191,7 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
         // per leaving dof; the K1 slots come from a host-built table, one scalar load per step)
         const bool write = live && s >= own_lo;
         for (int st = step_ptr[s]; st < step_ptr[s + 1]; ++st) {
-            cip rec = steps + (size_t)st * 8;
+            cip rec = steps + (size_t)st * (SYM ? 8 : 16);
 #pragma unroll
             for (int a = 0; a < P; ++a) {
                 const int r = rec[a];
@@ -191,21 +199,28 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
                     out0[(long long)r * A.NPL + pt] = acc[0][a][0];
                     if (NT == 2) out1[(long long)r * A.NPL + pt] = acc[NT - 1][a][0];
                 }
+                if (!SYM && a > 0) {
+                    const int ru = rec[8 + a];
+                    if (ru >= 0 && write) {
+                        out0[(long long)ru * A.NPL + pt] = acc[0][0][a];
+                        if (NT == 2) out1[(long long)ru * A.NPL + pt] = acc[NT - 1][0][a];
+                    }
+                }
             }
 #pragma unroll
             for (int ty = 0; ty < NT; ++ty) {
 #pragma unroll
                 for (int a = 0; a < P - 1; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b) acc[ty][a][b] = acc[ty][a + 1][b + 1];
+                    for (int b = 0; b <= (SYM ? a : P - 2); ++b) acc[ty][a][b] = acc[ty][a + 1][b + 1];
 #pragma unroll
-                for (int b = 0; b < P; ++b) acc[ty][P - 1][b] = 0.0;
+                for (int b = 0; b < P; ++b) { acc[ty][P - 1][b] = 0.0; if (!SYM) acc[ty][b][P - 1] = 0.0; }
             }
         }
     }
 }
 
-template <int P, int Q>
+template <int P, int Q, bool SYM>
 __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double pis[];   // [2][q*4*PP]
@@ -213,16 +228,16 @@ __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
     const bool live = pt < A.NPL;
     if (!live) pt = A.NPL - 1;
     const StageAGroup &G = A.grp[blockIdx.y];
-    if (G.nt == 2) stageA_body<P, 2, Q>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
-    else stageA_body<P, 1, Q>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
+    if (G.nt == 2) stageA_body<P, 2, Q, SYM>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
+    else stageA_body<P, 1, Q, SYM>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Stage B (3D): sweep axis 1.  Block = (chunk of g2, processed pair r0, output group y [x span chunk]).
 struct StageBGroup {
     int nterm;
-    int x[4];                   // K1 array index of each term
-    int t1[4];                  // axis-1 type of each term
+    int x[8];                   // K1 array index of each term
+    int t1[8];                  // axis-1 type of each term
 };
 struct StageBArgs {
     StageBGroup grp[4];
@@ -232,6 +247,7 @@ struct StageBArgs {
     const int *pl0;             // [npairs0][2]
     int n1, N1, q, G1, G2, S1, npairs0;
     int ngroups, chunk_len;
+    int symmetric;
 };
 
 template <int P, int NTERM, int Q>
@@ -241,7 +257,7 @@ __device__ __forceinline__ void stageB_body(const double *__restrict__ K1, doubl
 {
     cip step_ptr = (cip)B.step_ptr, steps = (cip)B.steps, pl0 = (cip)B.pl0;
     const int r0 = blockIdx.y;
-    const bool diag0 = pl0[2 * r0] == pl0[2 * r0 + 1];
+    const bool diag0 = B.symmetric && pl0[2 * r0] == pl0[2 * r0 + 1];
     const long long plane = (long long)B.G1 * B.G2;
     const int q = Q ? Q : B.q;
     constexpr int PP = (P * P + 1) & ~1;
@@ -360,7 +376,9 @@ __global__ void __launch_bounds__(256) k_stageB(const double *__restrict__ K1, d
     case 1: stageB_body<P, 1, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 2: stageB_body<P, 2, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 3: stageB_body<P, 3, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
-    default: stageB_body<P, 4, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 4: stageB_body<P, 4, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 5: stageB_body<P, 5, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;     // run-time q: fewer live registers
+    default: stageB_body<P, 6, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     }
 }
 
@@ -393,6 +411,7 @@ struct FinalArgs {
     int CR;                     // rows per wave task
     int NW, GPB;                // waves per block, row groups per block
     long long ngroups;
+    int symmetric;
 };
 
 template <int P, int D>
@@ -525,14 +544,14 @@ __global__ void __launch_bounds__(SIMPLE ? 768 : 384) k_final(const double *__re
         if (F.dim == 3) { r0 = (int)(grp / F.N1); i1 = (int)(grp % F.N1); }
         else r0 = (int)grp;
         const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
-        const bool diag0 = (i0 == j0);
+        const bool diag0 = F.symmetric && (i0 == j0);
         if (F.dim == 3) {
             jl1 = jlo1[i1];
             nl = diag0 ? (i1 - jl1 + 1) : (jhi1[i1] - jl1);    // upper part of a diagonal block is mirrored, not computed
             line0 = (long long)r0 * F.S1 + rp1[i1];
         } else line0 = r0;
         const bool own_row = i0 >= F.r0_lo && i0 < F.r0_hi;
-        const bool own_col = j0 >= F.r0_lo && j0 < F.r0_hi;
+        const bool own_col = F.symmetric && j0 >= F.r0_lo && j0 < F.r0_hi;
         const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
         const int ntask = nl * nchunks;
         const int first = (wave - task_base % F.NW + F.NW) % F.NW;
@@ -802,9 +821,9 @@ int sumfact_supported(const igx_patch *pt)
     return 1;
 }
 
-int sumfact_supports_kind(const igx_patch *, int kind)
+int sumfact_supports_kind(const igx_patch *pt, int kind)
 {
-    return kind == IGX_MASS || kind == IGX_STIFFNESS;
+    return kind == IGX_MASS || kind == IGX_STIFFNESS || (kind == IGX_CONVDIFF && pt->dim == 3);
 }
 
 int sumfact_prepare(igx_patch *pt)
@@ -908,6 +927,44 @@ int sumfact_prepare(igx_patch *pt)
     return IGX_OK;
 }
 
+// Pair list and stage-A flush records of a non-symmetric form: every (i0, j0) of the owned rows i0.
+static int prepare_nonsym(igx_patch *pt)
+{
+    if (pt->npairs0n >= 0) return IGX_OK;
+    const Axis &A0 = pt->ax[0];
+    std::vector<int> pl, rl(A0.S, -1);
+    for (int i0 = std::max(0, pt->r0_lo); i0 < std::min(A0.N, pt->r0_hi); ++i0)
+        for (int j0 = A0.jlo[i0]; j0 < A0.jhi[i0]; ++j0) {
+            rl[A0.rp[i0] + (j0 - A0.jlo[i0])] = (int)(pl.size() / 2);
+            pl.push_back(i0);
+            pl.push_back(j0);
+        }
+    std::vector<int> rec;
+    for (int s = 0; s < A0.n; ++s) {
+        const int base = A0.fa[s];
+        const int m = (s + 1 < A0.n) ? (A0.fa[s + 1] - base) : A0.P;
+        for (int k = 0; k < m; ++k) {
+            const int d = base + k;
+            int r[16];
+            for (int &v : r) v = -1;
+            for (int a = 0; a < A0.P; ++a) {
+                const int o = d + a;
+                if (a > A0.P - 1 - k || o >= A0.N) continue;
+                r[a] = rl[A0.rp[o] + (d - A0.jlo[o])];
+                if (a > 0) r[8 + a] = rl[A0.rp[d] + (o - A0.jlo[d])];
+            }
+            rec.insert(rec.end(), r, r + 16);
+        }
+    }
+    IGX_HIP(hipMalloc(&pt->d_pl0n, std::max<size_t>(1, pl.size()) * sizeof(int)));
+    IGX_HIP(hipMalloc(&pt->d_stepsn, std::max<size_t>(1, rec.size()) * sizeof(int)));
+    IGX_HIP(hipMemcpyAsync(pt->d_pl0n, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipMemcpyAsync(pt->d_stepsn, rec.data(), rec.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    pt->npairs0n = (int)(pl.size() / 2);
+    return IGX_OK;
+}
+
 static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 {
     if (*cap >= need) return IGX_OK;
@@ -925,10 +982,12 @@ static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 }
 
 template <int P>
-static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, dim3 grid, dim3 block, size_t lds)
+static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sym, dim3 grid, dim3 block, size_t lds)
 {
-    if (qeq) k_stageA<P, P><<<grid, block, lds, st>>>(A);
-    else k_stageA<P, 0><<<grid, block, lds, st>>>(A);
+    if (sym) {
+        if (qeq) k_stageA<P, P, true><<<grid, block, lds, st>>>(A);
+        else k_stageA<P, 0, true><<<grid, block, lds, st>>>(A);
+    } else k_stageA<P, 0, false><<<grid, block, lds, st>>>(A);     // full pair window: run-time q keeps the registers down
 }
 
 template <int P>
@@ -992,7 +1051,10 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     std::vector<Term> terms = form_terms(dim, kind);
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
     const long long NPL = (long long)A1.G * (dim == 3 ? A2.G : 1);
-    const int np0 = pt->npairs0;
+    const bool sym = igx_kind_symmetric(kind);
+    if (!sym && prepare_nonsym(pt)) return IGX_ERR_HIP;
+    const int np0 = sym ? pt->npairs0 : pt->npairs0n;
+    const int *d_pl0 = sym ? pt->d_pl0 : pt->d_pl0n;
     if (np0 == 0) return IGX_OK;
 
     // ---- stage-A arrays X = unique (t0, f).  In 2D the final stage wants the arrays ordered by
@@ -1014,7 +1076,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     const int nX = (int)X.size();
     if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
 
-    const int nF = (kind == IGX_MASS) ? 1 : dim * (dim + 1) / 2;
+    const int nF = igx_num_fields(dim, kind);
     (void)hipEventRecord(pt->ctx->ev[1], st);
     // one launch for all fields (blockIdx.y); the types of a field share the field load
     {
@@ -1031,9 +1093,10 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 }
             if (g.nt == 0) continue;
             g.field = pt->d_fields + (size_t)f * pd.npts_loc;
+            if (ng >= 12) { set_error("internal: too many stage-A groups"); return IGX_ERR_UNSUPPORTED; }
             A.grp[ng++] = g;
         }
-        A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
+        A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = sym ? pt->stepA_rec : pt->d_stepsn;
         A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.n0 = A0.n; A.N0 = A0.N; A.q = A0.q; A.g0_lo = pd.g0_lo;
         A.NPL = NPL;
         const int bsA = 256;
@@ -1043,7 +1106,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         const size_t ldsA = (size_t)2 * A0.q * 4 * ((A0.P * A0.P + 1) & ~1) * sizeof(double);
         if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
         dim3 block(bsA), grid((unsigned)bx, ng, ch.nchunks);
-        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, grid, block, ldsA));
+        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, sym, grid, block, ldsA));
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
@@ -1063,6 +1126,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         for (size_t i = 0; i < terms.size(); ++i) {
             const int y = (kind == IGX_MASS) ? 0 : terms[i].t[2];
             StageBGroup &g = B.grp[y];
+            if (g.nterm >= 6) { set_error("internal: too many stage-B terms"); return IGX_ERR_UNSUPPORTED; }
             g.x[g.nterm] = X[term_x[i]].slot;
             g.t1[g.nterm] = terms[i].t[1];
             g.nterm++;
@@ -1071,7 +1135,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         NY = ymax + 1;
         if (ensure(st, &pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
         B.PI1 = A1.d_PI;
-        B.step_ptr = pt->stepB_ptr; B.steps = pt->stepB_rec; B.pl0 = pt->d_pl0;
+        B.step_ptr = pt->stepB_ptr; B.steps = pt->stepB_rec; B.pl0 = d_pl0; B.symmetric = sym;
         B.n1 = A1.n; B.N1 = A1.N; B.q = A1.q; B.G1 = A1.G; B.G2 = A2.G; B.S1 = A1.S; B.npairs0 = np0;
         const int bs = 128;
         const long long bxB = (A2.G + bs - 1) / bs;
@@ -1100,7 +1164,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     F.V = AL.d_V; F.fa = AL.dev.fa; F.mslo = AL.dev.mslo; F.mshi = AL.dev.mshi;
     F.jlo = AL.dev.jlo; F.jhi = AL.dev.jhi; F.rp = AL.dev.rp;
     F.N = AL.N; F.q = AL.q; F.G = AL.G;
-    F.dim = dim; F.pl0 = pt->d_pl0;
+    F.dim = dim; F.pl0 = d_pl0; F.symmetric = sym;
     F.rp0 = A0.dev.rp; F.jlo0 = A0.dev.jlo; F.jhi0 = A0.dev.jhi;
     F.rp1 = A1.dev.rp; F.jlo1 = A1.dev.jlo; F.jhi1 = A1.dev.jhi;
     F.r0_lo = pt->r0_lo; F.r0_hi = pt->r0_hi; F.nnz_off = pt->nnz_off;
@@ -1119,7 +1183,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             const int nch = (wmax + 7) / 8;
             const char *sel = getenv("IGX_FINAL");
             const bool want_mfma = sel && !strcmp(sel, "mfma");
-            if (want_mfma && nch >= 1 && nch <= 6 && pt->ldesc_ok && AL.G >= 2) {
+            if (want_mfma && sym && nch >= 1 && nch <= 6 && pt->ldesc_ok && AL.G >= 2) {
                 FinalMArgs M{};
                 M.desc = (const int4 *)pt->d_ldesc; M.nl = pt->n_ldesc; M.nlines = F.nlines;
                 M.V = AL.d_V; M.fa = AL.dev.fa; M.mslo = AL.dev.mslo; M.mshi = AL.dev.mshi;

@@ -360,7 +360,7 @@ def test_final_stage_variants_agree(iga, monkeypatch):
 CONVDIFF = '(inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx'
 
 
-@pytest.mark.parametrize('algo', ['auto', 'entrywise'])
+@pytest.mark.parametrize('algo', ['auto', 'sumfact', 'entrywise'])
 def test_convdiff_custom_form(iga, golden, algo, monkeypatch):
     """Row f1 of SURVEY section 8 (BASELINE config 5): the run-time compiled convection-diffusion form,
     non-symmetric, against matrices produced by the real reference."""
@@ -389,3 +389,31 @@ def test_convdiff_custom_form(iga, golden, algo, monkeypatch):
                        iga.assemble.stiffness((kv, kv, kv), _geo(iga, 'cylinder'))) == 0.0
     with pytest.raises(NotImplementedError):
         iga.assemble.assemble('u * dx(v) * dx', (kv, kv, kv), geo=_geo(iga, 'cylinder'))
+
+
+@pytest.mark.parametrize('p,n,G', [(2, 9, 2), (3, 7, 3), (4, 6, 2), (1, 8, 3)])
+def test_convdiff_sumfact_vs_oracle_and_slabs(iga, oracle, p, n, G, monkeypatch):
+    """Non-symmetric sum factorisation: against the oracle's entry-wise sums, against the device
+    entry-wise kernels, and slab by slab (bit-identical rows, no exchange)."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    coeff = lambda x, y, z: 1.0 + x * x + 0.5 * z
+    kvs = (iga.bspline.make_knots(p, 0., 1., n), iga.bspline.make_knots(p, 0., 1., n + 1, mult=min(p, 2)),
+           iga.bspline.make_knots(p, 0., 1., n - 1))
+    okvs = tuple(oracle.KnotVector(kv.kv, kv.p) for kv in kvs)
+    asm = iga.assemblers.ConvDiffAssembler3D(kvs, _geo(iga, 'cylinder'), coeff)
+    A = asm.assemble_csr(algo='sumfact')
+    assert asm.patch.timing()['algo_used'] == 2 and not np.isnan(A.data).any()
+    E = asm.assemble_csr(algo='entrywise')
+    R = oracle.assemble_nonsymmetric('convdiff', okvs, oracle.geo_cylinder(), coeff=coeff, nthreads=8)
+    assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices) and np.array_equal(A.indptr, R.indptr)
+    assert rel_maxdiff(A, R) <= RTOL and rel_maxdiff(A, E) <= RTOL
+    assert abs(A - A.T).max() > 1e-3 * abs(A).max()          # really non-symmetric
+    N0 = kvs[0].numdofs
+    bounds = [N0 * g // G for g in range(G + 1)]
+    blocks = []
+    for g in range(G):
+        sl = iga.assemblers.ConvDiffAssembler3D(kvs, _geo(iga, 'cylinder'), coeff, row0=(bounds[g], bounds[g + 1]))
+        blocks.append(sl.assemble_csr(algo='sumfact'))
+        sl.patch.close()
+    S = scipy.sparse.vstack(blocks).tocsr()
+    assert np.array_equal(S.indices, A.indices) and np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
