@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the assembly hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2|c1|tiny] [--algo auto|sumfact|entrywise]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2|c1|c5|tiny] [--algo auto|sumfact|entrywise]
 
 Workload (BASELINE.json): stiffness assembly of a tensor-product B-spline patch over the NURBS
 quarter-annulus cylinder; default C4 = 3D, p=4, 128^3 spans (2.1 M elements, 1.59 G nonzeros).
@@ -33,15 +33,18 @@ CONFIGS = {
     'c2': (2, 3, 256, 'stiffness', 'quarter_annulus'),
     'c1': (2, 3, 15, 'stiffness', 'bspline_quarter_annulus'),
     'tiny': (3, 2, 12, 'stiffness', 'cylinder'),
+    # BASELINE config 5: the run-time compiled (vform) convection-diffusion form, non-symmetric
+    'c5': (3, 5, 96, 'convdiff', 'cylinder'),
 }
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # vector = MFMA FP64 peak on MI355X
 
 
-def algorithmic_bytes_per_element(dim, p, nnz, nelem):
-    """Jacobian in (8 d^2 q^d) + CSR values out (8 nnz / n^d)."""
+def algorithmic_bytes_per_element(dim, p, nnz, nelem, kind='stiffness'):
+    """Jacobian in (8 d^2 q^d) + CSR values out (8 nnz / n^d); the
+    convection-diffusion form also reads its coefficient (8 q^d)."""
     q = p + 1
-    return 8.0 * dim * dim * q ** dim + 8.0 * nnz / nelem
+    return 8.0 * (dim * dim + (1 if kind == 'convdiff' else 0)) * q ** dim + 8.0 * nnz / nelem
 
 
 def measured_traffic(config, world):
@@ -51,6 +54,10 @@ def measured_traffic(config, world):
         return t['chain_bytes'] if world == 1 else None
     except Exception:
         return None
+
+
+def COEFF(x, y, z):
+    return 1.0 + x
 
 
 def make_geo(geometry, name):
@@ -70,7 +77,11 @@ def cpu_baseline(dim, p, kind):
     geo = orc.geo_cylinder() if dim == 3 else orc.geo_quarter_annulus()
     timing = {}
     t0 = time.perf_counter()
-    A = orc.assemble(kind, (kv,) * dim, geo, nthreads=cores, fast=True, return_timing=timing)
+    if kind == 'convdiff':
+        A = orc.assemble_nonsymmetric(kind, (kv,) * dim, geo, coeff=COEFF, nthreads=cores)
+        timing['entries'] = time.perf_counter() - t0
+    else:
+        A = orc.assemble(kind, (kv,) * dim, geo, nthreads=cores, fast=True, return_timing=timing)
     dt = time.perf_counter() - t0
     nel = n ** dim
     return {
@@ -125,7 +136,10 @@ def main():
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
     row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world)
-    patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
+    if kind == 'convdiff':
+        patch = assemblers.ConvDiffAssembler3D(kvs, geo, COEFF, device=local_rank, row0=row0 if part_world > 1 else None).patch
+    else:
+        patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
     if rank == 0 and os.environ.get('BENCH_VERBOSE'):
         print('rank 0 slab', row0, 'nnz', patch.nnz, 'rows', patch.row_range, file=sys.stderr)
     nel_total = n0 * n ** (dim - 1)
@@ -173,7 +187,7 @@ def main():
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
     # roofline on rank 0's slab: algorithmic bytes of one assembly / device time of the kernel chain
     nel_rank = nel_total / world
-    b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total)
+    b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total, kind)
     chain_ms = stage_ms.get('total_ms', ms_per_step)
     achieved = b_el * nel_rank / (chain_ms * 1e-3) / 1e9
     names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_stageA', 'stage1_ms': 'k_stageB', 'final_ms': 'k_final',
@@ -187,8 +201,8 @@ def main():
         'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'strong' if args.strong else 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%dD p=%d stiffness, %s spans, NURBS quarter-annulus %s, uniform open knots'
-                               % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1)),
+        'config': {'workload': '%dD p=%d %s, %s spans, NURBS quarter-annulus %s, uniform open knots'
+                               % (dim, p, kind, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1)),
                                   'cylinder' if dim == 3 else gname),
                    'config': args.config, 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
