@@ -10,7 +10,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libigx.so')
+# IGX_LIB selects another build of the same library (kernel ablation builds); never a fallback
+LIB_PATH = os.environ.get('IGX_LIB') or os.path.join(_HERE, 'libigx.so')
 
 IGX_MASS, IGX_STIFFNESS, IGX_CONVDIFF = 0, 1, 2
 IGX_GEO_BSPLINE, IGX_GEO_NURBS, IGX_GEO_JACOBIAN = 0, 1, 2

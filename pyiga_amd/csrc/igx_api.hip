@@ -321,7 +321,7 @@ void igx_patch_destroy(igx_patch *pt)
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
     (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
-    (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn);
+    (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
     delete pt;
 }
@@ -493,7 +493,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
     if (algo != IGX_ALGO_SUMFACT && algo != IGX_ALGO_ENTRYWISE) { set_error("igx_assemble: unknown algo %d", algo); return IGX_ERR_ARG; }
     if (!pt->d_data) {
-        hipError_t e = hipMalloc((void **)&pt->d_data, std::max<size_t>(1, (size_t)pt->nnz) * sizeof(double));
+        hipError_t e = hipMalloc((void **)&pt->d_data, ((size_t)pt->nnz + IGX_DUMP_PAD) * sizeof(double));   // + dump slots of masked stores
         if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR values failed", pt->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
     }
     if (getenv("IGX_DEBUG_POISON"))               // every value must be written exactly once

@@ -119,6 +119,9 @@ struct igx_patch {
     // non-symmetric forms (built on first use): all pairs (i0, j0) of the owned rows i0
     int *d_pl0n = nullptr, *d_stepsn = nullptr;
     int npairs0n = -1;
+    // 32-byte line descriptors of the quadrature-lane final kernel (symmetric / non-symmetric pair list)
+    int *d_qdesc = nullptr, *d_qdescn = nullptr;
+    long long n_qdesc = 0, n_qdescn = 0;
     int *d_ldesc = nullptr;                   // [n_ldesc][4] line descriptors of the final stage
     int n_ldesc = 0;
     bool ldesc_ok = false;
@@ -145,6 +148,7 @@ int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
 inline int igx_num_fields(int dim, int kind) { return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : dim * (dim + 1) / 2); }
+constexpr size_t IGX_DUMP_PAD = 1024 * 16 + 16;   // doubles behind the CSR values: 1024 dump lines of the final stage
 inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF; }
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);

@@ -665,6 +665,269 @@ __global__ void __launch_bounds__(SIMPLE ? 768 : 384) k_final(const double *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Final stage, quadrature-lane form (single interior knots, q == P; the default for such axes).
+//
+// lane = (row i of the last axis, quadrature point l of a span): a wave owns R = 64/P consecutive rows
+// for its whole life and keeps the basis values it needs in registers --
+//     Vr[k][b] = (value, derivative) of trial function b of the k-th span of row i at point l,
+//     va[k]    = the same for the test function i itself --
+// so the contraction reads no table.  Work is a host-built list of 32-byte line descriptors (scalar
+// loads); a block = FINALQ_WAVES adjacent row chunks going through the same lines in lockstep.
+//   * K windows of a line travel HBM -> LDS by DMA (global_load_lds, no registers), FINALQ_DEPTH lines
+//     ahead; the wave waits with counted vmcnt (loads and stores retire in issue order, so every store
+//     is issued unconditionally -- masked lanes write a dump slot -- to keep the count exact).
+//   * lane (i,l) reads its P x NY K values (consecutive lanes, consecutive LDS words) and accumulates
+//     the contribution of point l to the 2p+1 entries of row i; the P partial sums are added through
+//     a wave-private LDS region into block-shared sums (double-buffered, one s_barrier per line).
+//   * direct CSR runs (2p+1 doubles per row) come from the sums in registers, mirrored runs are
+//     gathered from the shared sums by the wave that owns the TARGET row, so both are whole runs except
+//     next to the block's first and last row.  Store coordinates are precomputed once per wave.
+// Measured at C4 (profiles/): VALU/LDS work 3.6 ms, + K reads 4.7 ms, + direct stores 6.2 ms, all 9.3 ms:
+// the kernel is bound by the HBM write path of 72-byte runs (WRITE_SIZE 1.35 x the CSR bytes).
+struct LineDesc {               // 32 bytes, built by build_qdesc()
+    long long A_d, A_m;         // CSR base of the direct / mirrored run family (relative to the slab)
+    int bc;                     // B_d | C_d<<8 | B_m<<16 | C_m<<24
+    int flags;                  // bit0 row owned, bit1 column owned (mirror), bit2 leading diagonal line
+    long long line;             // K line index
+};
+struct FinalQArgs {
+    const double *V;            // last axis [G][P][2]
+    const int *fa, *mslo, *mshi, *jlo, *jhi, *rp;
+    int N, G;
+    long long nlines;           // lines per K array (stride between types)
+    const LineDesc *desc;
+    long long ndesc;
+    int lpw;                    // lines per block
+    int nchunks;                // row chunks of the last axis (R rows each)
+    int nsuper;                 // blocks per range of lines: ceil(nchunks / FINALQ_WAVES)
+    long long dump;             // element index of a scratch slot behind the CSR values: target of masked-off stores
+    int debug;
+};
+
+#ifndef IGX_Q_WAVES
+#define IGX_Q_WAVES 4
+#endif
+#ifndef IGX_Q_DEPTH
+#define IGX_Q_DEPTH 3
+#endif
+constexpr int FINALQ_WAVES = IGX_Q_WAVES; // adjacent row chunks per block
+constexpr int FINALQ_DEPTH = IGX_Q_DEPTH; // K lines in flight per wave (LDS-DMA)
+constexpr int FINALQ_KWIN = 96;         // doubles per staged K window: >= (64/P + P - 1) * P for P = 2..6, 3 DMA pieces
+#ifndef IGX_Q_DBG
+#define IGX_Q_DBG 0      // compile-time ablation mask (1: no stores, 2: no K loads after the first, 4: no mirror)
+#endif
+typedef const void __attribute__((address_space(1))) *gmem_ptr;
+typedef void __attribute__((address_space(3))) *lds_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int P, int NY>
+__global__ void __launch_bounds__(64 * FINALQ_WAVES) k_final_q(const double *__restrict__ K, double *__restrict__ data, const FinalQArgs F)
+{
+    constexpr int W = 2 * P - 1, R = 64 / P, NJ = R + 2 * (P - 1);
+    constexpr int NIT_D = (R * W + 63) / 64, NIT_M = (NJ * W + 63) / 64;
+    constexpr int NC = (NY == 1) ? 1 : 2;
+    constexpr int D = FINALQ_DEPTH, NSLOT = D + 1, KWIN = FINALQ_KWIN;
+    constexpr int NGL = NY * 3;                         // LDS-DMA instructions per line (64 lanes x 4 B each)
+    constexpr int NST = (IGX_Q_DBG & 1) ? 0 : NIT_D + (IGX_Q_DBG & 4 ? 0 : NIT_M);   // store instructions per line (all unconditional)
+    static_assert((R + P - 1) * P <= KWIN, "K window");
+    static_assert(D * (NGL + NST) < 64, "vmcnt range");
+    constexpr int WAVE_LDS = NSLOT * NY * KWIN + 64 * W;
+    constexpr int SUMS = (FINALQ_WAVES * R + 1) * W;              // sums of one line for all rows of the block (+ a junk row)
+    __shared__ double lds_all[FINALQ_WAVES * WAVE_LDS + 2 * SUMS];   // ONE shared object (K slots, partial sums, sums x 2)
+    typedef const LineDesc __attribute__((address_space(4))) *cdesc;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // XCD-aware order: consecutive logical blocks (the row chunks of one range of lines, which read the
+    // same K lines and complete each other's mirrored runs) run on one XCD and share its L2
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned per = gridDim.x / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    // block = FINALQ_WAVES adjacent row chunks working through the same lines in lockstep (one barrier per
+    // line): the sums of a line are shared, so mirrored runs are written whole by the wave that owns the
+    // target row and only the rows next to the block's ends are completed by the neighbouring block
+    const int super = (int)(bid % F.nsuper);
+    const long long wid = (long long)bid * FINALQ_WAVES + wave;
+    const int chunk = super * FINALQ_WAVES + wave;
+    const long long d_lo = (long long)(bid / F.nsuper) * F.lpw;
+    const long long d_hi = min(d_lo + F.lpw, F.ndesc);
+    if (d_lo >= d_hi || chunk >= F.nchunks) return;     // before any barrier: finished waves do not count
+    double *kslot = lds_all + wave * WAVE_LDS;          // [NSLOT][NY][KWIN]
+    double *out_q = kslot + NSLOT * NY * KWIN;
+    double *sums = lds_all + FINALQ_WAVES * WAVE_LDS;   // [2][block rows + 1][W]
+    const int blk_lo = super * FINALQ_WAVES * R, blk_hi = min(blk_lo + FINALQ_WAVES * R, F.N);
+    // masked-off stores go to a scratch slot behind the CSR values (a line of its own per wave id)
+    double *dump = data + F.dump + (wid & 1023) * 16;
+
+    // ---- per-wave setup: rows, basis registers, store coordinates
+    const int row_lo = chunk * R, row_hi = min(row_lo + R, F.N);
+    const int ntr = row_hi - row_lo;
+    const int r = lane / P, l = lane - r * P;
+    const bool act = r < ntr;
+    const int i = act ? row_lo + r : row_lo;
+    const int slo = F.mslo[i], nsp = act ? F.mshi[i] - slo : 0;
+    const int win0 = __builtin_amdgcn_readfirstlane(F.mslo[row_lo]) * P;   // first element of the chunk's K window
+    const int koff = slo * P + l - win0;                // this lane's element (span 0) inside the window
+    double Vr[P][P][NC], va[P][NC];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const bool live = k < nsp;
+        const int s = live ? slo + k : slo;
+        const int a = min(max(i - F.fa[s], 0), P - 1);
+        const double *vp = F.V + ((size_t)s * P + l) * P * 2;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int b = 0; b < P; ++b) Vr[k][b][c] = live ? vp[2 * b + c] : 0.0;
+            va[k][c] = live ? vp[2 * a + c] : 0.0;
+        }
+    }
+    // direct stores: entry f = (row r_, offset o) of the chunk; element offset = B_d*rp + C_d*c + o
+    int d_rp[NIT_D], d_ci[NIT_D], d_o[NIT_D], d_src[NIT_D], d_dst[NIT_D];
+    bool d_ok[NIT_D], d_up[NIT_D];
+#pragma unroll
+    for (int it = 0; it < NIT_D; ++it) {
+        const int f = lane + 64 * it;
+        const int r_ = f / W, o = f - r_ * W;
+        const bool v = r_ < ntr;
+        const int ii = v ? row_lo + r_ : row_lo;
+        const int jli = F.jlo[ii], ci = F.jhi[ii] - jli;
+        d_ok[it] = v && o < ci;
+        d_up[it] = jli + o > ii;
+        d_rp[it] = F.rp[ii]; d_ci[it] = ci; d_o[it] = o;
+        d_src[it] = v ? (r_ * P) * W + o : 0;
+        d_dst[it] = v ? (ii - blk_lo) * W + o : FINALQ_WAVES * R * W;    // junk slot for lanes past the chunk
+    }
+    // mirrored stores: row j, column i, value from the sums of row i.  This wave writes (j, i) when it owns
+    // row j and row i is in the block, or when row j lies outside the block and it owns row i.
+    const int jmin = F.jlo[row_lo], nj = F.jhi[row_hi - 1] - jmin;
+    int m_rp[NIT_M], m_cj[NIT_M], m_o[NIT_M], m_src[NIT_M];
+    bool m_ok[NIT_M], m_ge[NIT_M];
+#pragma unroll
+    for (int it = 0; it < NIT_M; ++it) {
+        const int f = lane + 64 * it;
+        const int rr = f / W, o = f - rr * W;
+        const bool v = rr < nj;
+        const int j = v ? jmin + rr : jmin;
+        const int jlj = F.jlo[j], cj = F.jhi[j] - jlj;
+        const int ii = jlj + o;
+        const bool own_j = j >= row_lo && j < row_hi, blk_j = j >= blk_lo && j < blk_hi;
+        const bool own_i = ii >= row_lo && ii < row_hi, blk_i = ii >= blk_lo && ii < blk_hi;
+        const bool in = v && o < cj && ((own_j && blk_i) || (!blk_j && own_i));
+        const int iic = in ? ii : row_lo;
+        m_ok[it] = in;
+        m_ge[it] = j >= ii;
+        m_src[it] = (iic - blk_lo) * W + (in ? j - F.jlo[iic] : 0);
+        m_rp[it] = F.rp[j]; m_cj[it] = cj; m_o[it] = o;
+    }
+
+    // ---- K lines: HBM -> LDS by DMA (no registers), FINALQ_DEPTH lines ahead of the arithmetic.
+    // A window is KWIN doubles from element win0 of the line; bytes past the support (or the line) are
+    // finite and meet zero basis values.
+    const long long ystride = F.nlines * (long long)F.G;
+    auto issue_line = [&](const long long line, const int slot) {
+        const char *src = (const char *)(K + line * F.G + win0) + lane * 4;
+        double *dst = kslot + slot * (NY * KWIN);
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                __builtin_amdgcn_global_load_lds((gmem_ptr)(src + y * ystride * 8 + c * 256), (lds_ptr)(dst + y * KWIN + c * 32), 4, 0, 0);
+    };
+    auto do_line = [&](const LineDesc &D_, const int slot, double *out_s) {
+        const double *ks = kslot + slot * (NY * KWIN) + koff;
+        double kv[NY][P];
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int k = 0; k < P; ++k) kv[y][k] = ks[y * KWIN + k * P];
+        double acc[W];
+#pragma unroll
+        for (int o = 0; o < W; ++o) acc[o] = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            double cu0, cu1 = 0.0;
+            if constexpr (NY == 1) cu0 = va[k][0] * kv[0][k];
+            else {
+                cu0 = fma(va[k][1], kv[2][k], va[k][0] * kv[0][k]);     // types 0, 2
+                cu1 = fma(va[k][1], kv[3][k], va[k][0] * kv[1][k]);     // types 1, 3
+            }
+#pragma unroll
+            for (int b = 0; b < P; ++b) {
+                if constexpr (NY == 1) acc[k + b] = fma(Vr[k][b][0], cu0, acc[k + b]);
+                else acc[k + b] = fma(Vr[k][b][0], cu0, fma(Vr[k][b][1], cu1, acc[k + b]));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < W; ++o) out_q[lane * W + o] = acc[o];
+        __builtin_amdgcn_wave_barrier();
+
+        const int B_d = D_.bc & 255, C_d = (D_.bc >> 8) & 255, B_m = (D_.bc >> 16) & 255, C_m = (D_.bc >> 24) & 255;
+        const bool own_row = D_.flags & 1, own_col = D_.flags & 2, diag_lead = D_.flags & 4;
+        double *dst_d = data + D_.A_d, *dst_m = data + D_.A_m;
+        // add the P partial sums of every entry; direct stores.  Masked-off lanes store to the dump slot:
+        // with no branch around a store the number of outstanding memory operations per line is fixed,
+        // which the counted waits on the K windows below rely on.
+#pragma unroll
+        for (int it = 0; it < NIT_D; ++it) {
+            const double *q = out_q + d_src[it];            // entries past the chunk: d_src = 0, masked below
+            double v = q[0];
+#pragma unroll
+            for (int p_ = 1; p_ < P; ++p_) v += q[p_ * W];
+            out_s[d_dst[it]] = v;
+            const bool st = own_row && d_ok[it] && !(diag_lead && d_up[it]);
+            double *p = st ? dst_d + (B_d * d_rp[it] + C_d * d_ci[it] + d_o[it]) : dump;
+            if (!(IGX_Q_DBG & 1)) *p = v;
+        }
+        // every wave's sums of this line are in LDS before any of them is read; the DMA queue stays untouched
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(IGX_Q_DBG & 4)) {
+#pragma unroll
+            for (int it = 0; it < NIT_M; ++it) {
+                const bool st = own_col && m_ok[it] && !(diag_lead && m_ge[it]);
+                double *p = st ? dst_m + (B_m * m_rp[it] + C_m * m_cj[it] + m_o[it]) : dump;
+                if (!(IGX_Q_DBG & 1)) *p = out_s[m_src[it]];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                // out_q reads above precede the next line's writes
+    };
+
+    cdesc desc = (cdesc)F.desc;
+    auto fetch = [&](const long long idx) {             // scalar loads (constant address space)
+        cdesc p = desc + min(idx, d_hi - 1);
+        LineDesc D_;
+        D_.A_d = p->A_d; D_.A_m = p->A_m; D_.bc = p->bc; D_.flags = p->flags; D_.line = p->line;
+        return D_;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_line(desc[min(d_lo + d, d_hi - 1)].line, d);
+    LineDesc cur = fetch(d_lo);
+    int slot = 0;
+    for (long long idx = d_lo; idx < d_hi; ++idx) {
+        // line idx + D into the slot that line idx - 1 has finished with (clamped at the end: harmless re-read)
+        int nslot = slot + D; if (nslot >= NSLOT) nslot -= NSLOT;
+        if (!(IGX_Q_DBG & 2)) issue_line(desc[min(idx + D, d_hi - 1)].line, nslot);
+        const LineDesc nxt = fetch(idx + 1);
+        // the window of line idx is followed in the queue by the D younger windows and the stores of the
+        // (at most D) lines in between
+        const int older = (int)min((long long)D, idx - d_lo);
+        static_assert(D <= 4, "wait ladder");
+        if (older == 0) wait_vm<D * NGL>();
+        else if (older == 1) wait_vm<D * NGL + NST>();
+        else if (older == 2) wait_vm<D * NGL + (D < 2 ? D : 2) * NST>();
+        else if (older == 3) wait_vm<D * NGL + (D < 3 ? D : 3) * NST>();
+        else wait_vm<D * NGL + D * NST>();
+        // the sums ping-pong: a wave can be one line ahead of the slowest one, never two (the barrier)
+        do_line(cur, slot, sums + ((idx - d_lo) & 1) * SUMS);
+        cur = nxt;
+        if (++slot == NSLOT) slot = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Final stage as a banded FP64 GEMM on the matrix cores (v_mfma_f64_16x16x4_f64).
 //
 //   D[line][(i,o)] = sum_t sum_g  K[t][line][g] * PI_last[t][(i,o)][g]
@@ -747,7 +1010,7 @@ __global__ void __launch_bounds__(256) k_final_mfma(const double *__restrict__ K
                 }
             }
             bf[0][c][j2] = u0 * v0;
-            if (NY == 4) { bf[1][c][j2] = u1 * v0; bf[2][c][j2] = u0 * v1; bf[3][c][j2] = u1 * v1; }
+            if constexpr (NY == 4) { bf[1][c][j2] = u1 * v0; bf[2][c][j2] = u0 * v1; bf[3][c][j2] = u1 * v1; }
         }
 
     // ---- stream line tiles
@@ -824,6 +1087,70 @@ int sumfact_supported(const igx_patch *pt)
 int sumfact_supports_kind(const igx_patch *pt, int kind)
 {
     return kind == IGX_MASS || kind == IGX_STIFFNESS || (kind == IGX_CONVDIFF && pt->dim == 3);
+}
+
+// Line descriptors of the quadrature-lane final kernel: one 32-byte record per K line that is contracted,
+// in (r0, i1, j1) order so that consecutive lines of a wave write adjacent CSR runs.
+//   {A_d (int64), A_m (int64), B_d | C_d<<8 | B_m<<16 | C_m<<24, flags, line (int64)}
+// flags: bit0 row owned, bit1 column owned (mirror), bit2 leading diagonal line (i0==j0 [and i1==j1])
+static int build_qdesc(igx_patch *pt, const std::vector<int> &pl, bool sym, int **d_out, long long *n_out)
+{
+    const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
+    const int dim = pt->dim;
+    const long long S1 = A1.S, S2 = A2.S;
+    std::vector<int> ld;
+    auto push = [&](long long Ad, long long Am, int Bd, int Cd, int Bm, int Cm, int flags, long long line) {
+        ld.push_back((int)(Ad & 0xffffffffLL)); ld.push_back((int)(Ad >> 32));
+        ld.push_back((int)(Am & 0xffffffffLL)); ld.push_back((int)(Am >> 32));
+        ld.push_back(Bd | (Cd << 8) | (Bm << 16) | (Cm << 24));
+        ld.push_back(flags);
+        ld.push_back((int)(line & 0xffffffffLL)); ld.push_back((int)(line >> 32));
+    };
+    const int np = (int)(pl.size() / 2);
+    int T = 1;          // measured at C4: 1, 2, 4, 16 within noise of each other (the final stage is bound by its HBM writes)
+    if (const char *e = getenv("IGX_FINALQ_TILE")) T = std::max(1, atoi(e));
+    if (dim == 3) {
+        // group lines by (r0, i1): rows i1 in order, their columns j1 in order
+        for (int r0 = 0; r0 < np; ++r0) {
+            const int i0 = pl[2 * r0], j0 = pl[2 * r0 + 1];
+            const int c0i = A0.jhi[i0] - A0.jlo[i0], c0j = A0.jhi[j0] - A0.jlo[j0];
+            int flags = 0;
+            if (i0 >= pt->r0_lo && i0 < pt->r0_hi) flags |= 1;
+            if (sym && j0 >= pt->r0_lo && j0 < pt->r0_hi) flags |= 2;
+            const bool diag0 = sym && i0 == j0;
+            // rows i1 in blocks of T, columns j1 outermost inside a block.  T = 1: a row's lines follow each
+            // other, so consecutive lines write adjacent direct runs; T > 1 also brings the mirrored runs of
+            // neighbouring rows together in time
+            for (int a1 = 0; a1 < A1.N; a1 += T)
+              for (int j1 = A1.jlo[a1]; j1 < A1.jhi[std::min(a1 + T, A1.N) - 1]; ++j1)
+                for (int i1 = a1; i1 < std::min(a1 + T, A1.N); ++i1) {
+                    if (j1 < A1.jlo[i1] || j1 >= (diag0 ? i1 + 1 : A1.jhi[i1])) continue;
+                    const int r1 = A1.rp[i1] + (j1 - A1.jlo[i1]);
+                    const int c1i = A1.jhi[i1] - A1.jlo[i1], c1j = A1.jhi[j1] - A1.jlo[j1];
+                    const long long Ad = (long long)A0.rp[i0] * S1 * S2 + (long long)c0i * A1.rp[i1] * S2 - pt->nnz_off;
+                    const long long Am = (long long)A0.rp[j0] * S1 * S2 + (long long)c0j * A1.rp[j1] * S2 - pt->nnz_off;
+                    push(Ad, Am, c0i * c1i, (j0 - A0.jlo[i0]) * c1i + (j1 - A1.jlo[i1]),
+                         c0j * c1j, (i0 - A0.jlo[j0]) * c1j + (i1 - A1.jlo[j1]),
+                         flags | ((diag0 && i1 == j1) ? 4 : 0), (long long)r0 * A1.S + r1);
+                }
+        }
+    } else {
+        for (int r0 = 0; r0 < np; ++r0) {
+            const int i0 = pl[2 * r0], j0 = pl[2 * r0 + 1];
+            const int c0i = A0.jhi[i0] - A0.jlo[i0], c0j = A0.jhi[j0] - A0.jlo[j0];
+            int flags = 0;
+            if (i0 >= pt->r0_lo && i0 < pt->r0_hi) flags |= 1;
+            if (sym && j0 >= pt->r0_lo && j0 < pt->r0_hi) flags |= 2;
+            if (sym && i0 == j0) flags |= 4;
+            push((long long)A0.rp[i0] * S1 - pt->nnz_off, (long long)A0.rp[j0] * S1 - pt->nnz_off,
+                 c0i, j0 - A0.jlo[i0], c0j, i0 - A0.jlo[j0], flags, r0);
+        }
+    }
+    *n_out = (long long)(ld.size() / 8);
+    IGX_HIP(hipMalloc(d_out, std::max<size_t>(1, ld.size()) * sizeof(int)));
+    IGX_HIP(hipMemcpyAsync(*d_out, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    return IGX_OK;
 }
 
 int sumfact_prepare(igx_patch *pt)
@@ -919,6 +1246,7 @@ int sumfact_prepare(igx_patch *pt)
         IGX_HIP(hipMemcpyAsync(pt->d_ldesc, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     }
+    if (int rc = build_qdesc(pt, pl, true, &pt->d_qdesc, &pt->n_qdesc)) return rc;
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
     IGX_HIP(hipMalloc(&pt->d_rl0_of, std::max<size_t>(1, rl.size()) * sizeof(int)));
     IGX_HIP(hipMemcpyAsync(pt->d_pl0, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
@@ -961,6 +1289,7 @@ static int prepare_nonsym(igx_patch *pt)
     IGX_HIP(hipMemcpyAsync(pt->d_pl0n, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
     IGX_HIP(hipMemcpyAsync(pt->d_stepsn, rec.data(), rec.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
     IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    if (int rc = build_qdesc(pt, pl, false, &pt->d_qdescn, &pt->n_qdescn)) return rc;
     pt->npairs0n = (int)(pl.size() / 2);
     return IGX_OK;
 }
@@ -969,14 +1298,14 @@ static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 {
     if (*cap >= need) return IGX_OK;
     if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
-    hipError_t e = hipMalloc(buf, (need + 16) * sizeof(double));
+    hipError_t e = hipMalloc(buf, (need + 64) * sizeof(double));
     if (e != hipSuccess) {
         set_error("hipMalloc of %.2f GB sum-factorisation workspace failed: %s", need * 8.0 / 1e9, hipGetErrorString(e));
         return IGX_ERR_NOMEM;
     }
     // lines that are never produced (upper part of diagonal blocks) must stay finite: the final
     // stage multiplies window padding by exact zeros
-    if (hipMemsetAsync(*buf, 0, (need + 16) * sizeof(double), st) != hipSuccess) return IGX_ERR_HIP;   // same stream as the kernels
+    if (hipMemsetAsync(*buf, 0, (need + 64) * sizeof(double), st) != hipSuccess) return IGX_ERR_HIP;   // same stream as the kernels
     *cap = need;
     return IGX_OK;
 }
@@ -1205,6 +1534,45 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                                    case 4: LAUNCH_M(4, 4); break; case 5: LAUNCH_M(4, 5); break; default: LAUNCH_M(4, 6); break; }
                 }
 #undef LAUNCH_M
+                IGX_HIP(hipGetLastError());
+                pt->timing.n_launches++;
+                (void)hipEventRecord(pt->ctx->ev[4], st);
+                return IGX_OK;
+            }
+        }
+        // ---- quadrature-lane kernel: single interior knots and q == P on the last axis
+        {
+            const char *sel = getenv("IGX_FINAL");
+            const bool want_q = !(sel && !strcmp(sel, "valu"));
+            if (want_q && AL.q == AL.P && AL.simple) {
+                FinalQArgs Q{};
+                Q.V = AL.d_V; Q.fa = AL.dev.fa; Q.mslo = AL.dev.mslo; Q.mshi = AL.dev.mshi;
+                Q.jlo = AL.dev.jlo; Q.jhi = AL.dev.jhi; Q.rp = AL.dev.rp;
+                Q.N = AL.N; Q.G = AL.G; Q.nlines = F.nlines;
+                Q.desc = (const LineDesc *)(sym ? pt->d_qdesc : pt->d_qdescn);
+                Q.ndesc = sym ? pt->n_qdesc : pt->n_qdescn;
+                Q.debug = getenv("IGX_DEBUG_Q") ? atoi(getenv("IGX_DEBUG_Q")) : 0;
+                Q.dump = pt->nnz;
+                const int R = 64 / AL.P;
+                Q.nchunks = (AL.N + R - 1) / R;
+                // ~8 waves per CU and a few rounds; at least 16 lines per wave to amortise its set-up
+                long long target_waves = 8192;
+                if (const char *e = getenv("IGX_FINALQ_WAVES")) target_waves = std::max(1, atoi(e));
+                Q.nsuper = (Q.nchunks + FINALQ_WAVES - 1) / FINALQ_WAVES;
+                Q.lpw = (int)std::max<long long>(16, (Q.ndesc * Q.nsuper * FINALQ_WAVES + target_waves - 1) / target_waves);
+                const long long nblocks = ((Q.ndesc + Q.lpw - 1) / Q.lpw) * Q.nsuper;
+                if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
+                dim3 block(64 * FINALQ_WAVES), grid((unsigned)nblocks);
+#define LAUNCH_Q(PV) { if (NY == 1) k_final_q<PV, 1><<<grid, block, 0, st>>>(Kfinal, d_data, Q); \
+                       else k_final_q<PV, 4><<<grid, block, 0, st>>>(Kfinal, d_data, Q); }
+                switch (AL.P) {
+                case 2: LAUNCH_Q(2); break;
+                case 3: LAUNCH_Q(3); break;
+                case 4: LAUNCH_Q(4); break;
+                case 5: LAUNCH_Q(5); break;
+                default: LAUNCH_Q(6); break;
+                }
+#undef LAUNCH_Q
                 IGX_HIP(hipGetLastError());
                 pt->timing.n_launches++;
                 (void)hipEventRecord(pt->ctx->ev[4], st);

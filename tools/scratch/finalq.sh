@@ -1,0 +1,5 @@
+#!/bin/bash
+# ablations of the quadrature-lane final kernel at C4 (timing only; results are wrong with IGX_DEBUG_Q != 0)
+run() { echo "== $*"; env "$@" python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])"; }
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for a in "$@"; do run $a; done
