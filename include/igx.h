@@ -26,6 +26,9 @@
  *                                         (entry_impl + combine, assemblers.pyx:116-172,281-349,1255-1322,1455-1540)
  *   igx_patch_set_coeff + IGX_CONVDIFF <- the assembler pyiga.compile.compile_vform generates for the form
  *                                         (pyiga/assemble.py:837-897, pyiga/codegen/cython.py:325-387,673-701)
+ *   igx_load_vector                    <- inner_products / *FunctionalAssembler*.assemble_vector
+ *                                         pyiga/assemble.py:288-340, pyiga/assemblers.pyx:883-1156,2204-2500,
+ *                                         pyiga/genericasm.pxi:438-456,762-778
  *   igx_assemble                       <- assemble_entries(asm, symmetric=True)
  *                                         pyiga/assemble.py:703-754 (multi_entries + COO->CSR + mirror)
  */
@@ -158,6 +161,12 @@ const int32_t *igx_d_csr_indptr(const igx_patch *patch);
    supports do not intersect.  Works for any pair, inside or outside the owned slab provided the
    fields of the pair's Gauss points are resident (always true for a full patch). */
 int igx_entries(igx_patch *patch, int kind, const size_t *ij, size_t M, double *out);
+
+/* Load vector of the owned rows: out[i] = sum over the Gauss grid of  B_i * f * gw0*gw1*gw2*|det J|
+   (inner_products(kvs, f, geo=geo), L2FunctionalAssembler*.assemble_vector()).  fvals: the function on the
+   FULL tensor Gauss grid (G0 x G1 [x G2], C order, host), i.e. utils.grid_eval(f, gaussgrid) or
+   grid_eval_transformed(f, gaussgrid, geo); out: (row0_hi-row0_lo) x N1 [x N2] doubles (host). */
+int igx_load_vector(igx_patch *patch, const double *fvals, double *out);
 
 /* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */

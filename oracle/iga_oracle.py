@@ -590,6 +590,45 @@ def assemble(kind, kvs, geo=None, jac=None, nthreads=1, fast=False, return_timin
 
 # ---------------------------------------------------------------------------
 # 1D matrices + Kronecker path                   pyiga/assemble.py:125-190,236-282
+def function_grid_eval(f, gridaxes, geo=None):
+    """utils.grid_eval / grid_eval_transformed (pyiga/utils.py:33-52): `f` takes (x, y, z); tuples become
+    a trailing component axis; results are broadcast to the full grid."""
+    shape = tuple(len(g) for g in gridaxes)
+    if geo is None:
+        mesh = list(np.meshgrid(*gridaxes, sparse=True, indexing='ij'))
+        mesh.reverse()
+        vals = f(*mesh)
+    else:
+        X = grid_eval(geo, gridaxes)
+        vals = f(*(X[..., i] for i in range(X.shape[-1])))
+    if isinstance(vals, tuple):
+        vals = np.stack([np.broadcast_to(np.asanyarray(v), shape) for v in vals], axis=-1)
+    vals = np.asanyarray(vals)
+    return np.array(np.broadcast_to(vals, shape + vals.shape[len(shape):]), dtype=float)
+
+
+def inner_products(kvs, f, f_physical=False, geo=None):
+    """Load vector, restating pyiga/assemble.py:288-340 step by step: function values on the Gauss grid,
+    times the tensor quadrature weights, times |det J| when a geometry is given, then the transposed
+    collocation matrices along every axis."""
+    kvs = tuple(kvs)
+    nqp = max(kv.p for kv in kvs) + 1
+    grid, gw = make_tensor_quadrature([kv.mesh for kv in kvs], nqp)
+    if f_physical:
+        assert geo is not None, 'inner_products in physical domain requires geometry'
+        fvals = function_grid_eval(f, grid, geo)
+    else:
+        fvals = function_grid_eval(f, grid)
+    extra = fvals.ndim - len(kvs)
+    for k, w in enumerate(gw):
+        fvals = fvals * w.reshape((1,) * k + (-1,) + (1,) * (len(kvs) - 1 - k + extra))
+    if geo is not None:
+        det = np.abs(np.linalg.det(grid_jacobian(geo, grid)))
+        fvals = fvals * det.reshape(det.shape + (1,) * extra)
+    Ct = [collocation_derivs_dense(kv, g, 0)[0].T for kv, g in zip(kvs, grid)]
+    return apply_tprod_dense(Ct, fvals)
+
+
 def bsp_mixed_deriv_biform_1d(knotvec, du, dv):
     nspans = knotvec.numspans
     nqp = int(math.ceil((2 * knotvec.p - du - dv + 1) / 2.0))

@@ -173,6 +173,44 @@ def assemble_entries(asm, symmetric=False, format='csr', algo='auto'):
 
 
 ################################################################################
+# Right-hand sides (pyiga/assemble.py:288-340)
+################################################################################
+
+def inner_products(kvs, f, f_physical=False, geo=None):
+    """L2 inner products of every basis function of the tensor product basis with `f` (the load
+    vector); array of shape ``ndofs[0] x ... x ndofs[-1]`` (+ the component axes of a non-scalar `f`).
+
+    `f` is a function of (x, y, z) or a spline function object; `f_physical` says whether it is given
+    in physical coordinates (then `geo` is required).  Without `geo` the integrals are over the
+    parameter domain.  2D and 3D run on the device; 1D is a few numpy lines on the host.
+    """
+    from . import geometry, utils
+    from .quadrature import make_tensor_quadrature
+    if isinstance(kvs, bspline.KnotVector):
+        kvs = (kvs,)
+    kvs = tuple(kvs)
+    dim = len(kvs)
+    if f_physical:
+        assert geo is not None, 'inner_products in physical domain requires geometry'
+    if dim == 1:
+        # same steps as the reference: weights, transposed collocation matrix (host; 1D is outside the device path)
+        if geo is not None:
+            raise NotImplementedError('1D inner products with a geometry map are not supported')
+        grid, gw = make_tensor_quadrature([kvs[0].mesh], kvs[0].p + 1)
+        fvals = np.array(utils.grid_eval(f, grid), dtype=float)
+        w = gw[0].reshape((-1,) + (1,) * (fvals.ndim - 1))
+        return bspline.collocation(kvs[0], grid[0]).T @ (fvals * w)
+    assert dim in (2, 3), 'Dimensions higher than 3 are currently not implemented.'
+    g = geo if geo is not None else geometry.unit_cube(dim)     # parameter domain: |det J| = 1
+    patch = assemblers.DevicePatch(kvs, g)
+    grid = tuple(patch.gauss(k)[0] for k in range(dim))
+    fvals = utils.grid_eval_transformed(f, grid, geo) if f_physical else utils.grid_eval(f, grid)
+    out = patch.load_vector(fvals)
+    patch.close()
+    return out
+
+
+################################################################################
 # Custom forms (pyiga/assemble.py:837-897)
 ################################################################################
 

@@ -165,6 +165,27 @@ class DevicePatch:
         c = _lib.f64(np.broadcast_to(values, G))
         _lib.check(_lib.load().igx_patch_set_coeff(self.handle, _lib.dptr(c)), 'igx_patch_set_coeff')
 
+    def load_vector(self, fvals):
+        """Inner products of the owned basis functions with a function given by its values on the full
+        tensor Gauss grid (scalar: shape G; vector-valued: G + trailing component axes)."""
+        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        fvals = np.asarray(fvals, dtype=np.float64)
+        assert fvals.shape[:self.dim] == G, 'function values have the wrong grid shape'
+        lo, hi = int(self.info.row_lo), int(self.info.row_hi)
+        nd = self.ndofs
+        n0 = (hi - lo) // int(np.prod(nd[1:]))
+        comp_shape = fvals.shape[self.dim:]
+        ncomp = int(np.prod(comp_shape)) if comp_shape else 1
+        flat = fvals.reshape(G + (ncomp,))
+        out = np.empty((n0,) + nd[1:] + (ncomp,))
+        lib = _lib.load()
+        for c in range(ncomp):
+            fc = _lib.f64(flat[..., c])
+            oc = np.empty((n0,) + nd[1:])
+            _lib.check(lib.igx_load_vector(self.handle, _lib.dptr(fc), _lib.dptr(oc)), 'igx_load_vector')
+            out[..., c] = oc
+        return out.reshape((n0,) + nd[1:] + comp_shape)
+
     def gauss(self, axis):
         n = self.info.ngauss[axis]
         nodes, weights = np.empty(n), np.empty(n)
@@ -270,3 +291,73 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
         vals = diff_coeff(X[..., 0], X[..., 1], X[..., 2]) if callable(diff_coeff) else diff_coeff
         self.patch.set_coeff(vals)
+
+
+class _FunctionalAssembler:
+    """Arity-1 assemblers: the load vector  (f, v)  over the patch (pyiga/assemblers.pyx:883-1156,
+    2204-2500; base class genericasm.pxi:312-463,631-786).  `f` is sampled on the Gauss grid on the host
+    (it is a Python callable or a spline function, as in the reference); weights, |det J| and the sum
+    over the Gauss grid run on the device."""
+    _dim = None
+    _physical = False
+    arity = 1
+
+    @classmethod
+    def inputs(cls):
+        return {'geo': (cls._dim,), 'f': ()}
+
+    @classmethod
+    def parameters(cls):
+        return {}
+
+    def __init__(self, kvs0, geo, f, device=None, row0=None):
+        from . import utils
+        assert len(kvs0) == self._dim, 'Assembler requires %d knot vectors' % self._dim
+        assert geo.sdim == self._dim, 'Geometry has wrong source dimension'
+        assert geo.dim == self._dim, 'Geometry has wrong dimension'
+        self._geo = geo
+        kvs0 = tuple(kvs0)
+        self.kvs = (kvs0,)
+        self.nqp = max(kv.p for kv in kvs0) + 1
+        self.patch = DevicePatch(kvs0, geo, device=device, row0=row0)
+        self.gaussgrid = tuple(self.patch.gauss(k)[0] for k in range(self._dim))
+        if self._physical:
+            self._fvals = utils.grid_eval_transformed(f, self.gaussgrid, geo)
+        else:
+            self._fvals = utils.grid_eval(f, self.gaussgrid)
+        self._vector = None
+
+    def assemble_vector(self):
+        if self._vector is None:
+            self._vector = self.patch.load_vector(self._fvals)
+        return self._vector.copy()
+
+    # per-entry interface of the reference (genericasm.pxi:353-436,677-758), arity 1
+    def entry1(self, i):
+        return float(self.assemble_vector().ravel()[i])
+
+    def multi_entries1(self, indices):
+        idx = np.asarray(list(indices) if not isinstance(indices, np.ndarray) else indices, dtype=np.intp)
+        return self.assemble_vector().ravel()[idx.ravel()]
+
+    def entry(self, i, j):
+        return self.entry1(i)           # arity 1: the column index is ignored, as in the reference
+
+    def multi_entries(self, indices):
+        return None
+
+
+class L2FunctionalAssembler2D(_FunctionalAssembler):
+    _dim = 2
+
+
+class L2FunctionalAssembler3D(_FunctionalAssembler):
+    _dim = 3
+
+
+class L2FunctionalAssemblerPhys2D(_FunctionalAssembler):
+    _dim, _physical = 2, True
+
+
+class L2FunctionalAssemblerPhys3D(_FunctionalAssembler):
+    _dim, _physical = 3, True

@@ -168,6 +168,17 @@ def collocation_derivs_info(kv, nodes, derivs=1):
     return indices, values.swapaxes(-2, -1)
 
 
+def collocation(kv, nodes):
+    """Sparse collocation matrix ``len(nodes) x numdofs`` of the B-spline basis (pyiga/bspline.py:629-646)."""
+    import scipy.sparse
+    nodes = _lib.f64(nodes)
+    first, values = collocation_derivs_info(kv, nodes, derivs=0)
+    m, P = nodes.shape[0], kv.p + 1
+    indices = (first[:, None] + np.arange(P)[None, :]).ravel()
+    indptr = np.arange(0, m * P + 1, P)
+    return scipy.sparse.csr_matrix((values[0].ravel(), indices, indptr), shape=(m, kv.numdofs))
+
+
 # ---------------------------------------------------------------------------------------------
 def _geo_desc(kvs, coeffs, nurbs):
     """Fill the geometry part of an igx_patch_desc; returns (desc, keepalive)."""

@@ -586,4 +586,38 @@ int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
     return IGX_OK;
 }
 
+int igx_load_vector(igx_patch *pt, const double *fvals, double *out)
+{
+    if (!pt || !fvals || !out) { set_error("igx_load_vector: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab
+    if (rc) return rc;
+    const PatchDev &pd = pt->dev;
+    const int dim = pt->dim;
+    const size_t npts = (size_t)pd.npts_loc, plane = npts / (size_t)pd.G0_loc;
+    const size_t N1 = pt->ax[1].N, N2 = dim == 3 ? pt->ax[2].N : 1, G1 = pt->ax[1].G;
+    const size_t n_out = (size_t)(pt->r0_hi - pt->r0_lo) * N1 * N2;
+    const size_t n_t1 = dim == 3 ? (size_t)pd.G0_loc * G1 * N2 : (size_t)pd.G0_loc * N1;
+    const size_t n_t2 = dim == 3 ? (size_t)pd.G0_loc * N1 * N2 : 1;
+    double *d_f = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_o = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_f); (void)hipFree(d_t1); (void)hipFree(d_t2); (void)hipFree(d_o); };
+    if (hipMalloc((void **)&d_f, npts * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_t1, n_t1 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_t2, n_t2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_o, std::max<size_t>(1, n_out) * sizeof(double)) != hipSuccess) {
+        cleanup();
+        set_error("igx_load_vector: hipMalloc of the workspace failed");
+        return IGX_ERR_NOMEM;
+    }
+    // the function values of the resident Gauss planes are contiguous in the full-grid array (axis 0 is slowest)
+    hipError_t e = hipMemcpyAsync(d_f, fvals + (size_t)pd.g0_lo * plane, npts * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = launch_load_vector(st, pt, d_f, pt->d_fields, d_o, d_t1, d_t2);
+        if (rc == IGX_OK) e = hipMemcpyAsync(out, d_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) { set_error("igx_load_vector: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+    return rc;
+}
+
 } // extern "C"

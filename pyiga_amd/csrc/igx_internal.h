@@ -147,6 +147,8 @@ int launch_fields_dump(hipStream_t st, const igx_patch *pt);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
+int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
+                       double *d_t1, double *d_t2);
 inline int igx_num_fields(int dim, int kind) { return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : dim * (dim + 1) / 2); }
 constexpr size_t IGX_DUMP_PAD = 1024 * 16 + 16;   // doubles behind the CSR values: 1024 dump lines of the final stage
 inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF; }

@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__' and 'convdiff' not in sys.argv[1:]:
+if __name__ == '__main__' and not {'convdiff', 'rhs'} & set(sys.argv[1:]):
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -287,3 +287,66 @@ def golden_convdiff():
 
 if __name__ == '__main__' and 'convdiff' in sys.argv[1:]:
     golden_convdiff()
+
+
+# ---------------------------------------------------------------------------
+# (8) right-hand sides, SURVEY section 8 f3: inner_products / L2Functional assemblers
+#     (pyiga/assemble.py:288-340, test/test_assemble.py:223-245,311,428, test/test_solve.py:6-32)
+def golden_rhs():
+    out = {}
+
+    def f3(x, y, z):
+        return np.cos(x) * np.exp(y) * np.sin(z)
+    kvs = [bspline.make_knots(p, 0.0, 1.0, 8 + p) for p in range(3, 6)]
+    tbox = geometry.twisted_box()
+    out['d3_param'] = assemble.inner_products(kvs, f3)
+    out['d3_tbox'] = assemble.inner_products(kvs, f3, geo=tbox)
+    out['d3_tbox_phys'] = assemble.inner_products(kvs, f3, f_physical=True, geo=tbox)
+    out['d3_tbox_asm'] = assemblers.L2FunctionalAssembler3D(kvs, tbox, f=f3).assemble_vector()
+    out['d3_tbox_phys_asm'] = assemblers.L2FunctionalAssemblerPhys3D(kvs, tbox, f=f3).assemble_vector()
+    cyl = cylinder()
+    kv3 = (bspline.make_knots(2, 0.0, 1.0, 5), bspline.make_knots(3, 0.0, 1.0, 4, mult=2), bspline.make_knots(2, 0.0, 1.0, 6))
+    out['d3_cyl_phys'] = assemble.inner_products(kv3, f3, f_physical=True, geo=cyl)
+
+    def f2(x, y):
+        return np.exp(x + y)
+
+    def fv(x, y):
+        return (x * y, x - y)
+    kv2 = (bspline.make_knots(3, 0.0, 1.0, 6), bspline.make_knots(2, 0.0, 1.0, 5))
+    ann = geometry.quarter_annulus()
+    out['d2_param'] = assemble.inner_products(kv2, f2)
+    out['d2_ann'] = assemble.inner_products(kv2, f2, geo=ann)
+    out['d2_ann_phys'] = assemble.inner_products(kv2, f2, f_physical=True, geo=ann)
+    out['d2_ann_vec_phys'] = assemble.inner_products(kv2, fv, f_physical=True, geo=ann)
+    out['d2_ann_asm'] = assemblers.L2FunctionalAssembler2D(kv2, ann, f=f2).assemble_vector()
+    # spline function as f (parameter domain)
+    g = bspline.BSplineFunc(kv2, np.arange(kv2[0].numdofs * kv2[1].numdofs, dtype=float).reshape(kv2[0].numdofs, -1) / 10.0)
+    out['d2_splinef'] = assemble.inner_products(kv2, g, geo=ann)
+    out['d1_param'] = assemble.inner_products(bspline.make_knots(3, 0.0, 1.0, 7), lambda x: 1 + x ** 2)
+
+    # Poisson problem of test/test_solve.py:6-32 (2D, quarter annulus, Dirichlet data g)
+    from pyiga import solvers, approx
+    kvs = 2 * (bspline.make_knots(3, 0.0, 1.0, 10),)
+
+    def gfun(x, y):
+        return np.cos(x + y) + np.exp(y - x)
+
+    def ffun(x, y):
+        return 2 * (np.cos(x + y) - np.exp(y - x))
+    bcs = assemble.compute_dirichlet_bcs(kvs, ann, ('all', gfun))
+    rhs = assemble.inner_products(kvs, ffun, f_physical=True, geo=ann).ravel()
+    A = assemble.stiffness(kvs, geo=ann)
+    LS = assemble.RestrictedLinearSystem(A, rhs, bcs)
+    u = LS.complete(solvers.make_solver(LS.A, spd=True).dot(LS.b))
+    u_ex = approx.project_L2(kvs, gfun, f_physical=True, geo=ann).ravel()
+    out['poisson2d_bc_idx'] = np.asarray(bcs[0])
+    out['poisson2d_bc_val'] = np.asarray(bcs[1])
+    out['poisson2d_rhs'] = rhs
+    out['poisson2d_u'] = u
+    out['poisson2d_u_ex'] = u_ex
+    save('rhs', **out)
+
+
+if __name__ == '__main__' and 'rhs' in sys.argv[1:]:
+    golden_rhs()

@@ -417,3 +417,94 @@ def test_convdiff_sumfact_vs_oracle_and_slabs(iga, oracle, p, n, G, monkeypatch)
         sl.patch.close()
     S = scipy.sparse.vstack(blocks).tocsr()
     assert np.array_equal(S.indices, A.indices) and np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
+
+
+# ---------------------------------------------------------------------------------------------
+# load vectors
+def _f3(x, y, z):
+    return np.cos(x) * np.exp(y) * np.sin(z)
+
+
+def _f2(x, y):
+    return np.exp(x + y)
+
+
+def _close(a, b, tol=RTOL):
+    return a.shape == b.shape and np.abs(a - b).max() <= tol * np.abs(b).max()
+
+
+def test_inner_products_vs_reference(iga, golden):
+    """inner_products and the L2Functional assemblers against vectors from the real reference
+    (recipes: test/test_assemble.py:223-245)."""
+    g = golden('rhs')
+    mk = iga.bspline.make_knots
+    ip = iga.assemble.inner_products
+    kvs = [mk(p, 0.0, 1.0, 8 + p) for p in range(3, 6)]
+    tbox, ann = _geo(iga, 'twisted_box'), _geo(iga, 'quarter_annulus')
+    assert _close(ip(kvs, _f3), g['d3_param'])
+    assert _close(ip(kvs, _f3, geo=iga.geometry.unit_cube()), g['d3_param'])
+    assert _close(ip(kvs, _f3, geo=tbox), g['d3_tbox'])
+    assert _close(ip(kvs, _f3, f_physical=True, geo=tbox), g['d3_tbox_phys'])
+    asm = iga.assemblers.L2FunctionalAssembler3D(kvs, tbox, f=_f3)
+    assert asm.arity == 1 and _close(asm.assemble_vector(), g['d3_tbox_asm'])
+    v = asm.assemble_vector().ravel()
+    assert asm.entry1(37) == v[37] and np.array_equal(asm.multi_entries1([0, 5, v.size - 1]), v[[0, 5, v.size - 1]])
+    assert _close(iga.assemblers.L2FunctionalAssemblerPhys3D(kvs, tbox, f=_f3).assemble_vector(), g['d3_tbox_phys_asm'])
+    kv3 = (mk(2, 0.0, 1.0, 5), mk(3, 0.0, 1.0, 4, mult=2), mk(2, 0.0, 1.0, 6))
+    assert _close(ip(kv3, _f3, f_physical=True, geo=_geo(iga, 'cylinder')), g['d3_cyl_phys'])
+    kv2 = (mk(3, 0.0, 1.0, 6), mk(2, 0.0, 1.0, 5))
+    assert _close(ip(kv2, _f2), g['d2_param'])
+    assert _close(ip(kv2, _f2, geo=ann), g['d2_ann'])
+    assert _close(ip(kv2, _f2, f_physical=True, geo=ann), g['d2_ann_phys'])
+    assert _close(ip(kv2, lambda x, y: (x * y, x - y), f_physical=True, geo=ann), g['d2_ann_vec_phys'])
+    assert _close(iga.assemblers.L2FunctionalAssembler2D(kv2, ann, f=_f2).assemble_vector(), g['d2_ann_asm'])
+    sp = iga.bspline.BSplineFunc(kv2, np.arange(kv2[0].numdofs * kv2[1].numdofs, dtype=float).reshape(kv2[0].numdofs, -1) / 10.0)
+    assert _close(ip(kv2, sp, geo=ann), g['d2_splinef'])
+    assert _close(ip(mk(3, 0.0, 1.0, 7), lambda x: 1 + x ** 2), g['d1_param'])
+    with pytest.raises(AssertionError):
+        ip(kv2, _f2, f_physical=True)
+
+
+def test_poisson_solve_end_to_end(iga, golden):
+    """test/test_solve.py:6-32 with the two assembled objects (stiffness matrix, load vector) coming from the
+    device and everything else (boundary dofs and values, the reference's solution) from the fixture."""
+    import scipy.sparse.linalg
+    g = golden('rhs')
+    kvs = 2 * (iga.bspline.make_knots(3, 0.0, 1.0, 10),)
+    ann = _geo(iga, 'quarter_annulus')
+    rhs = iga.assemble.inner_products(kvs, lambda x, y: 2 * (np.cos(x + y) - np.exp(y - x)), f_physical=True, geo=ann).ravel()
+    assert np.abs(rhs - g['poisson2d_rhs']).max() <= RTOL * np.abs(g['poisson2d_rhs']).max()
+    A = iga.assemble.stiffness(kvs, geo=ann)
+    bc_idx, bc_val = g['poisson2d_bc_idx'], g['poisson2d_bc_val']
+    free = np.setdiff1d(np.arange(A.shape[0]), bc_idx)
+    u = np.zeros(A.shape[0])
+    u[bc_idx] = bc_val
+    b = rhs[free] - A[free][:, bc_idx] @ bc_val
+    u[free] = scipy.sparse.linalg.spsolve(A[free][:, free].tocsc(), b)
+    assert np.abs(u - g['poisson2d_u']).max() <= 1e-10 * np.abs(g['poisson2d_u']).max()
+    assert np.sqrt(np.mean((u - g['poisson2d_u_ex']) ** 2)) < 5e-5
+
+
+@pytest.mark.parametrize('d,p,n,G', [(3, 2, 9, 2), (3, 4, 6, 3), (2, 3, 20, 4)])
+def test_load_vector_slabs_and_oracle(iga, oracle, d, p, n, G):
+    """Row slabs reproduce their part of the load vector bit for bit; the whole vector matches the oracle."""
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * d
+    geo = _geo(iga, 'quarter_annulus' if d == 2 else 'cylinder')
+    ogeo = oracle.geo_quarter_annulus() if d == 2 else oracle.geo_cylinder()
+    f = _f2 if d == 2 else _f3
+    full = iga.assemble.inner_products(kvs, f, f_physical=True, geo=geo)
+    ref = oracle.inner_products((oracle.make_knots(p, 0., 1., n),) * d, f, f_physical=True, geo=ogeo)
+    assert _close(full, ref)
+    grid = None
+    N0 = kv.numdofs
+    bounds = [N0 * k // G for k in range(G + 1)]
+    parts = []
+    for k in range(G):
+        patch = iga.assemblers.DevicePatch(kvs, geo, row0=(bounds[k], bounds[k + 1]))
+        if grid is None:
+            grid = tuple(patch.gauss(a)[0] for a in range(d))
+            fvals = iga.utils.grid_eval_transformed(f, grid, geo)
+        parts.append(patch.load_vector(fvals))
+        patch.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), full)

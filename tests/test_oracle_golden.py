@@ -205,3 +205,33 @@ def test_convdiff_custom_form(oracle, golden):
         ref = g[name + '_multi']
         assert np.abs(out - ref).max() <= 1e-14 * np.abs(ref).max()
         assert np.array_equal(out == 0.0, ref == 0.0)
+
+
+def test_inner_products_oracle_vs_reference(oracle, golden):
+    """Load vectors: the oracle's restatement of inner_products against vectors produced by
+    the reference (pyiga/assemble.py:288-340; recipes of test/test_assemble.py:223-245)."""
+    g = golden('rhs')
+
+    def f3(x, y, z):
+        return np.cos(x) * np.exp(y) * np.sin(z)
+
+    def f2(x, y):
+        return np.exp(x + y)
+    kvs = [oracle.make_knots(p, 0.0, 1.0, 8 + p) for p in range(3, 6)]
+    tbox, ann, cyl = oracle.geo_twisted_box(), oracle.geo_quarter_annulus(), oracle.geo_cylinder()
+    kv3 = (oracle.make_knots(2, 0.0, 1.0, 5), oracle.make_knots(3, 0.0, 1.0, 4, mult=2), oracle.make_knots(2, 0.0, 1.0, 6))
+    kv2 = (oracle.make_knots(3, 0.0, 1.0, 6), oracle.make_knots(2, 0.0, 1.0, 5))
+    cases = [('d3_param', oracle.inner_products(kvs, f3)),
+             ('d3_tbox', oracle.inner_products(kvs, f3, geo=tbox)),
+             ('d3_tbox_phys', oracle.inner_products(kvs, f3, f_physical=True, geo=tbox)),
+             ('d3_tbox_asm', oracle.inner_products(kvs, f3, geo=tbox)),
+             ('d3_tbox_phys_asm', oracle.inner_products(kvs, f3, f_physical=True, geo=tbox)),
+             ('d3_cyl_phys', oracle.inner_products(kv3, f3, f_physical=True, geo=cyl)),
+             ('d2_param', oracle.inner_products(kv2, f2)),
+             ('d2_ann', oracle.inner_products(kv2, f2, geo=ann)),
+             ('d2_ann_phys', oracle.inner_products(kv2, f2, f_physical=True, geo=ann)),
+             ('d2_ann_vec_phys', oracle.inner_products(kv2, lambda x, y: (x * y, x - y), f_physical=True, geo=ann)),
+             ('d1_param', oracle.inner_products((oracle.make_knots(3, 0.0, 1.0, 7),), lambda x: 1 + x ** 2))]
+    for name, r in cases:
+        assert r.shape == g[name].shape, name
+        assert np.abs(r - g[name]).max() <= 1e-14 * np.abs(g[name]).max(), name
