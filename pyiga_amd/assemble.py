@@ -172,6 +172,40 @@ def assemble_entries(asm, symmetric=False, format='csr', algo='auto'):
     return A.asformat(format)
 
 
+def _nonzeros_for_rows(kvs0, kvs1, row_indices):
+    """(I, J) of all pattern entries in the given rows, rows in the given order and columns ascending
+    (MLStructure.nonzeros_for_rows, pyiga/mlmatrix.py)."""
+    first, last = [], []
+    for kv0, kv1 in zip(kvs0, kvs1):
+        su, sv = kv0.mesh_support_idx_all(), kv1.mesh_support_idx_all()
+        first.append(np.searchsorted(su[:, 1], sv[:, 0], side='right'))
+        last.append(np.searchsorted(su[:, 0], sv[:, 1], side='left'))
+    nd1 = tuple(kv.numdofs for kv in kvs1)
+    nd0 = tuple(kv.numdofs for kv in kvs0)
+    I, J = [], []
+    for r in np.asarray(row_indices, dtype=np.int64).ravel():
+        mi = np.unravel_index(r, nd1)
+        cols = np.zeros(1, dtype=np.int64)
+        for k, ik in enumerate(mi):
+            cols = (cols[:, None] * nd0[k] + np.arange(first[k][ik], last[k][ik])[None, :]).ravel()
+        I.append(np.full(cols.shape[0], r, dtype=np.int64))
+        J.append(cols)
+    if not I:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    return np.concatenate(I), np.concatenate(J)
+
+
+def assemble_partial_rows(asm, row_indices):
+    """Submatrix (full shape, CSR) that contains only the given rows -- what the hierarchical
+    discretisation asks of an assembler (pyiga/_hdiscr.py:5-11): the pattern entries of those rows go
+    through ``asm.multi_entries`` in one batch (on the device for the assemblers of this package)."""
+    kvs0, kvs1 = asm.kvs
+    I, J = _nonzeros_for_rows(kvs0, kvs1, row_indices)
+    data = asm.multi_entries(np.column_stack((I, J)).astype(np.uintp)) if I.size else np.zeros(0)
+    shape = (int(np.prod([kv.numdofs for kv in kvs1])), int(np.prod([kv.numdofs for kv in kvs0])))
+    return scipy.sparse.coo_matrix((data, (I, J)), shape=shape).tocsr()
+
+
 ################################################################################
 # Right-hand sides (pyiga/assemble.py:288-340)
 ################################################################################

@@ -508,3 +508,24 @@ def test_load_vector_slabs_and_oracle(iga, oracle, d, p, n, G):
         parts.append(patch.load_vector(fvals))
         patch.close()
     assert np.array_equal(np.concatenate(parts, axis=0), full)
+
+
+def test_partial_rows(iga):
+    """arbitrary row subsets through batched multi_entries (pyiga/_hdiscr.py:5-11)."""
+    mk = iga.bspline.make_knots
+    for kvs, gname, cls in (((mk(3, 0., 1., 7), mk(2, 0., 1., 9, mult=2)), 'quarter_annulus', iga.assemblers.StiffnessAssembler2D),
+                            ((mk(2, 0., 1., 5), mk(3, 0., 1., 4), mk(2, 0., 1., 6)), 'cylinder', iga.assemblers.MassAssembler3D)):
+        asm = cls(kvs, _geo(iga, gname))
+        A = iga.assemble.assemble_entries(asm, symmetric=True)
+        n = A.shape[0]
+        rows = np.array([0, n - 1, n // 2, 3, n // 3, n // 3 + 1])
+        S = iga.assemble.assemble_partial_rows(asm, rows)
+        assert S.shape == A.shape
+        mask = np.zeros(n, bool)
+        mask[rows] = True
+        assert S[~mask].nnz == 0
+        ref = A[rows]
+        got = S[rows]
+        assert np.array_equal(ref.indices, got.indices) and np.array_equal(ref.indptr, got.indptr)
+        assert np.abs(ref.data - got.data).max() <= RTOL * np.abs(A.data).max()
+        assert iga.assemble.assemble_partial_rows(asm, []).nnz == 0
