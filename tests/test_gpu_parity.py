@@ -529,3 +529,20 @@ def test_partial_rows(iga):
         assert np.array_equal(ref.indices, got.indices) and np.array_equal(ref.indptr, got.indptr)
         assert np.abs(ref.data - got.data).max() <= RTOL * np.abs(A.data).max()
         assert iga.assemble.assemble_partial_rows(asm, []).nnz == 0
+
+
+def test_convdiff_properties_large(iga):
+    """Beyond the oracle's reach: the form annihilates constants (a(1, v) = 0, so every row sums to zero),
+    the sum-factorised stages agree with the entry-wise kernel on scattered rows, nothing is left unwritten."""
+    os.environ['IGX_DEBUG_POISON'] = '1'
+    try:
+        kvs = (iga.bspline.make_knots(3, 0., 1., 20), iga.bspline.make_knots(4, 0., 1., 14), iga.bspline.make_knots(3, 0., 1., 17))
+        asm = iga.assemblers.ConvDiffAssembler3D(kvs, _geo(iga, 'cylinder'), lambda x, y, z: 2.0 + np.sin(x + z))
+        A = asm.assemble_csr(algo='sumfact')
+    finally:
+        del os.environ['IGX_DEBUG_POISON']
+    assert not np.isnan(A.data).any()
+    assert np.abs(A @ np.ones(A.shape[1])).max() <= 1e-11 * np.abs(A.data).max()
+    rows = np.unique(np.linspace(0, A.shape[0] - 1, 40).astype(int))
+    S = iga.assemble.assemble_partial_rows(asm, rows)
+    assert np.abs(S[rows].data - A[rows].data).max() <= RTOL * np.abs(A.data).max()
