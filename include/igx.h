@@ -26,6 +26,8 @@
  *                                         (entry_impl + combine, assemblers.pyx:116-172,281-349,1255-1322,1455-1540)
  *   igx_patch_set_coeff + IGX_CONVDIFF <- the assembler pyiga.compile.compile_vform generates for the form
  *                                         (pyiga/assemble.py:837-897, pyiga/codegen/cython.py:325-387,673-701)
+ *   igx_patch_set_form + IGX_FORM      <- assemble.assemble(<form string>, ...) for scalar forms that are bilinear in
+ *                                         (u, grad u) x (v, grad v): pyiga/assemble.py:837-897, pyiga/vform.py:1804-1885
  *   igx_load_vector                    <- inner_products / *FunctionalAssembler*.assemble_vector
  *                                         pyiga/assemble.py:288-340, pyiga/assemblers.pyx:883-1156,2204-2500,
  *                                         pyiga/genericasm.pxi:438-456,762-778
@@ -53,7 +55,14 @@ typedef struct igx_patch igx_patch;   /* device-resident state of one assembler 
 enum { IGX_MASS = 0, IGX_STIFFNESS = 1,
        /* (inner(c*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx -- the custom (vform) case of
           BASELINE config 5, non-symmetric, 3D only; c is set with igx_patch_set_coeff */
-       IGX_CONVDIFF = 2 };
+       IGX_CONVDIFF = 2,
+       /* general scalar bilinear form in the first-order jets of u and v (3D):
+            a(u,v) = integral of  sum_{r,s=0..3} P_rs(x) * D_r v * D_s u ,   D_0 = identity, D_1..3 = d/dx, d/dy, d/dz (physical)
+          P_rs are coefficient fields set with igx_patch_set_form: the block r,s >= 1 is a diffusion tensor
+          (inner(dot(K,grad(u)),grad(v)): P = K), row 0 a convection vector (inner(b,grad(u))*v), column 0 its
+          adjoint (u*inner(b,grad(v))), P_00 a reaction coefficient (c*u*v).  Non-symmetric.  What the
+          reference compiles from a form string (pyiga/vform.py, pyiga/codegen/cython.py) for this class. */
+       IGX_FORM = 3 };
 enum { IGX_GEO_BSPLINE = 0, IGX_GEO_NURBS = 1, IGX_GEO_JACOBIAN = 2 };
 /* algorithm selector for igx_assemble */
 enum { IGX_ALGO_AUTO = 0,      /* sum-factorised when the patch supports it, else entry-wise */
@@ -136,6 +145,11 @@ int        igx_patch_get_info(const igx_patch *patch, igx_patch_info *info);
 /* Scalar coefficient field of IGX_CONVDIFF on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
    pointer; what pyiga.utils.grid_eval_transformed(diff_coeff, gaussgrid, geo) returns).  Copied. */
 int igx_patch_set_coeff(igx_patch *patch, const double *coeff);
+
+/* Coefficients of IGX_FORM: coef[4*r + s] is P_rs on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
+   pointer) or NULL for an absent (zero) coefficient; r = jet index of the test function v, s = of the trial
+   function u.  Copied.  Replaces the previous form of the patch. */
+int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
 
 /* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
 int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);

@@ -363,6 +363,26 @@ def precompute_fields_convdiff(jac, xphys, coeff, gw):
 
 # ---------------------------------------------------------------------------
 # sparsity                 pyiga/mlmatrix.py:420-440, mlmatrix_cy.pyx:189-289
+def precompute_fields_form(jac, table, gw):
+    """Fields of a general first-order-jet form: [P_rs (16, zeros where absent), W, JacInv (9)] per Gauss
+    point -- what the reference's generated precompute step stores for such a vform: the inputs, W and
+    JacInv (pyiga/vform.py:229-239, pyiga/codegen/cython.py:673-701)."""
+    G = jac.shape[:-2]
+    det = np.linalg.det(jac)
+    W = np.abs(det)
+    for k, w in enumerate(gw):
+        W = W * w.reshape((1,) * k + (-1,) + (1,) * (len(gw) - 1 - k))
+    JI = np.linalg.inv(jac)                    # [param (x,y,z order)][physical]: d xi_a / d x_r
+    F = np.zeros(G + (26,))
+    for r in range(4):
+        for s in range(4):
+            if table[r][s] is not None:
+                F[..., 4 * r + s] = np.broadcast_to(table[r][s], G)
+    F[..., 16] = W
+    F[..., 17:26] = JI.reshape(G + (9,))
+    return F
+
+
 def compute_sparsity_ij(kv1, kv2):
     ms1 = kv1.mesh_support_idx_all()
     ms2 = kv2.mesh_support_idx_all()
@@ -445,8 +465,8 @@ class Assembler:
     """Restates *Assembler{2,3}D.__init__ (pyiga/assemblers.pyx:38-80,186-228,
     1170-1217,1336-1383) + entry/multi_entries (pyiga/genericasm.pxi:677-758)."""
 
-    def __init__(self, kind, kvs, geo=None, jac=None, coeff=None):
-        assert kind in ('mass', 'stiffness', 'convdiff')
+    def __init__(self, kind, kvs, geo=None, jac=None, coeff=None, table=None):
+        assert kind in ('mass', 'stiffness', 'convdiff', 'form')
         self.kind = kind
         self.kvs = tuple(kvs)
         self.dim = len(kvs)
@@ -466,6 +486,14 @@ class Assembler:
             xphys = grid_eval(geo, self.grid)
             c = coeff(xphys[..., 0], xphys[..., 1], xphys[..., 2]) * np.ones(xphys.shape[:-1])
             self.fields = np.ascontiguousarray(precompute_fields_convdiff(self.jac, xphys, c, self.gw))
+        elif kind == 'form':
+            # `table`: 4x4 nested list of functions of the physical coordinates (or constants / None), P[r][s]
+            assert self.dim == 3
+            xphys = grid_eval(geo, self.grid)
+            G = xphys.shape[:-1]
+            vals = [[None if e is None else np.broadcast_to(e(xphys[..., 0], xphys[..., 1], xphys[..., 2]) if callable(e) else e, G)
+                     for e in row] for row in table]
+            self.fields = np.ascontiguousarray(precompute_fields_form(self.jac, vals, self.gw))
         else:
             self.fields = np.ascontiguousarray(precompute_fields(kind, self.jac, self.gw))
         self.ndofs = np.array([kv.numdofs for kv in kvs], dtype=np.uintp)
@@ -479,7 +507,7 @@ class Assembler:
         ms = self.meshsupp + [None] * (3 - self.dim)
         C = self.C + [None] * (3 - self.dim)
         p = lambda a: None if a is None else a.ctypes.data
-        rc = lib.orc_entries(self.dim, {'mass': 0, 'stiffness': 1, 'convdiff': 2}[self.kind],
+        rc = lib.orc_entries(self.dim, {'mass': 0, 'stiffness': 1, 'convdiff': 2, 'form': 3}[self.kind],
                              p(self.ndofs), p(self.ngauss),
                              p(ms[0]), p(ms[1]), p(ms[2]), p(C[0]), p(C[1]), p(C[2]),
                              self.nder, p(self.fields), self.fields.shape[-1],
@@ -558,9 +586,9 @@ def full_pattern(kvs):
     return ml_nonzero(bidx, bs, lower_tri=False)
 
 
-def assemble_nonsymmetric(kind, kvs, geo, coeff=None, nthreads=1):
+def assemble_nonsymmetric(kind, kvs, geo, coeff=None, nthreads=1, table=None):
     """assemble_entries(asm, symmetric=False): every pattern entry is computed directly."""
-    asm = Assembler(kind, kvs, geo=geo, coeff=coeff)
+    asm = Assembler(kind, kvs, geo=geo, coeff=coeff, table=table)
     I, J = full_pattern(kvs)
     entries = asm.multi_entries(np.column_stack((I, J)), nthreads=nthreads)
     n = int(np.prod([kv.numdofs for kv in kvs]))

@@ -98,7 +98,22 @@ static double entry3(const orc_ctx *c, const size_t i[3], const size_t j[3])
                     double dv100 = (v0[2 * i0 + 0] * v1[2 * i1 + 0] * v2[2 * i2 + 1]);
                     double dv010 = (v0[2 * i0 + 0] * v1[2 * i1 + 1] * v2[2 * i2 + 0]);
                     double dv001 = (v0[2 * i0 + 1] * v1[2 * i1 + 0] * v2[2 * i2 + 0]);
-                    if (c->kind == 1) {
+                    if (c->kind == 3) {
+                        /* general first-order-jet form, evaluated the way the generated code of such a vform
+                           does (pyiga/codegen/cython.py:325-387): physical gradients through JacInv, then the
+                           integrand, then the weight.  f = [P(16), W, JacInv(9)], JacInv row-major [param][phys] */
+                        double Gu[4], Gv[4];
+                        Gu[0] = (u0[2 * i0 + 0] * u1[2 * i1 + 0] * u2[2 * i2 + 0]);
+                        Gv[0] = (v0[2 * i0 + 0] * v1[2 * i1 + 0] * v2[2 * i2 + 0]);
+                        for (int r_ = 0; r_ < 3; ++r_) {
+                            Gu[1 + r_] = ((f[17 + r_] * du100) + (f[20 + r_] * du010)) + (f[23 + r_] * du001);
+                            Gv[1 + r_] = ((f[17 + r_] * dv100) + (f[20 + r_] * dv010)) + (f[23 + r_] * dv001);
+                        }
+                        double e = 0.0;
+                        for (int r_ = 0; r_ < 4; ++r_)
+                            for (int s_ = 0; s_ < 4; ++s_) e += (f[4 * r_ + s_] * Gu[s_]) * Gv[r_];
+                        r += e * f[16];
+                    } else if (c->kind == 1) {
                         r += ((((((f[0] * du100) + (f[1] * du010)) + (f[2] * du001)) * dv100)
                                + ((((f[1] * du100) + (f[3] * du010)) + (f[4] * du001)) * dv010))
                               + ((((f[2] * du100) + (f[4] * du010)) + (f[5] * du001)) * dv001));

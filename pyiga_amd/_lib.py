@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IGX_LIB selects another build of the same library (kernel ablation builds); never a fallback
 LIB_PATH = os.environ.get('IGX_LIB') or os.path.join(_HERE, 'libigx.so')
 
-IGX_MASS, IGX_STIFFNESS, IGX_CONVDIFF = 0, 1, 2
+IGX_MASS, IGX_STIFFNESS, IGX_CONVDIFF, IGX_FORM = 0, 1, 2, 3
 IGX_GEO_BSPLINE, IGX_GEO_NURBS, IGX_GEO_JACOBIAN = 0, 1, 2
 IGX_ALGO_AUTO, IGX_ALGO_ENTRYWISE, IGX_ALGO_SUMFACT = 0, 1, 2
 ALGOS = {'auto': IGX_ALGO_AUTO, 'entrywise': IGX_ALGO_ENTRYWISE, 'sumfact': IGX_ALGO_SUMFACT}
-KINDS = {'mass': IGX_MASS, 'stiffness': IGX_STIFFNESS, 'convdiff': IGX_CONVDIFF}
+KINDS = {'mass': IGX_MASS, 'stiffness': IGX_STIFFNESS, 'convdiff': IGX_CONVDIFF, 'form': IGX_FORM}
 
 _dp = C.POINTER(C.c_double)
 
@@ -68,6 +68,7 @@ SYMBOLS = [
     ('igx_patch_destroy', None, [C.c_void_p]),
     ('igx_patch_get_info', C.c_int, [C.c_void_p, C.POINTER(PatchInfo)]),
     ('igx_patch_set_coeff', C.c_int, [C.c_void_p, _dp]),
+    ('igx_patch_set_form', C.c_int, [C.c_void_p, _dp * 16]),
     ('igx_patch_gauss', C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
     ('igx_pattern', C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ('igx_assemble', C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),

@@ -262,17 +262,21 @@ _KNOWN_FORMS = {
 
 def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
     """Assembler object for `problem`.  The reference compiles arbitrary form strings at run time
-    (vform -> Cython -> gcc); here a form must be one of the hand-written device forms, an
-    assembler class, or an assembler object (row f1 of SURVEY section 8: the form compiler is next)."""
+    (vform -> Cython -> gcc).  Here the three built-in forms map to their hand-written kernels, any other
+    3D scalar form in u, v, grad, inner, dot goes through the general device form (``pyiga_amd.forms`` ->
+    ``IGX_FORM``); assembler classes and objects are accepted as in the reference."""
     assert bfuns is None and boundary is None, 'custom basis functions / boundary forms are not supported'
     if isinstance(problem, str):
         kind = _KNOWN_FORMS.get(_normalise_form(problem))
-        if kind is None:
-            raise NotImplementedError('no device implementation for the form %r (available: %s)'
-                                      % (problem, ', '.join(sorted(_KNOWN_FORMS))))
         if 'geo' not in args:
             raise ValueError("required input parameter 'geo' missing")
         kvs = tuple(kvs)
+        if kind is None:
+            # any other scalar form that is bilinear in (u, grad u) x (v, grad v): general device form
+            if len(kvs) != 3:
+                raise NotImplementedError('general form strings are supported for 3D patches; %r is not one of the '
+                                          'built-in forms (%s)' % (problem, ', '.join(sorted(_KNOWN_FORMS))))
+            return assemblers.GeneralFormAssembler3D(kvs, args['geo'], problem, inputs=args)
         if kind == 'convdiff':
             if 'diff_coeff' not in args:
                 raise ValueError("required input parameter 'diff_coeff' missing")

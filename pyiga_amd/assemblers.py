@@ -186,6 +186,21 @@ class DevicePatch:
             out[..., c] = oc
         return out.reshape((n0,) + nd[1:] + comp_shape)
 
+    def set_form(self, table):
+        """Physical coefficient table of IGX_FORM: 4x4 nested list of arrays on the full Gauss grid or None."""
+        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        keep, ptrs = [], (_lib._dp * 16)()
+        for r in range(4):
+            for s in range(4):
+                e = table[r][s]
+                if e is not None:
+                    arr = _lib.f64(np.broadcast_to(e, G))
+                    keep.append(arr)
+                    ptrs[4 * r + s] = _lib.dptr(arr)
+        if not keep:
+            raise ValueError('the form has no non-zero coefficient')
+        _lib.check(_lib.load().igx_patch_set_form(self.handle, ptrs), 'igx_patch_set_form')
+
     def gauss(self, axis):
         n = self.info.ngauss[axis]
         nodes, weights = np.empty(n), np.empty(n)
@@ -291,6 +306,39 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
         vals = diff_coeff(X[..., 0], X[..., 1], X[..., 2]) if callable(diff_coeff) else diff_coeff
         self.patch.set_coeff(vals)
+
+
+class GeneralFormAssembler3D(_DeviceAssembler):
+    """Scalar bilinear form in the first-order jets of u and v,
+
+        a(u, v) = integral of  sum_{r,s=0..3} P_rs(x) D_r v D_s u  dx,   D_0 = id, D_1..3 = d/dx, d/dy, d/dz,
+
+    given either as a form string in the reference's syntax (``'(inner(dot(K, grad(u)), grad(v)) + c*u*v) * dx'``,
+    evaluated by ``pyiga_amd.forms``) or directly as a 4x4 table of coefficient functions/arrays.  This is the
+    class of forms the reference's run-time compiler handles with ``u``, ``v``, ``grad``, ``inner``, ``dot``
+    (pyiga/assemble.py:837-897, pyiga/vform.py:1804-1885); non-symmetric, every pattern entry is computed.
+    Coefficients are sampled on the Gauss grid on the host (they are Python callables, as in the reference),
+    the Jacobian transformation of the coefficients and all sums run on the device.
+    """
+    _kind, _dim = 'form', 3
+
+    def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
+        from . import forms
+        super().__init__(kvs0, geo, device=device, row0=row0)
+        grid = [self.patch.gauss(k)[0] for k in range(3)]
+        G = tuple(len(g) for g in grid)
+        X = np.asarray(geo.grid_eval(grid))                       # shape(grid) x 3, components (x, y, z)
+        if isinstance(form, str):
+            table = forms.coefficient_table(form, G, X, dict(inputs or {}))
+        else:
+            table = [[None] * 4 for _ in range(4)]
+            for r in range(4):
+                for s in range(4):
+                    e = form[r][s]
+                    if e is not None:
+                        table[r][s] = np.broadcast_to(e(X[..., 0], X[..., 1], X[..., 2]) if callable(e) else e, G)
+        self.table_mask = [[e is not None for e in row] for row in table]
+        self.patch.set_form(table)
 
 
 class _FunctionalAssembler:

@@ -164,7 +164,11 @@ static void free_geo_axis(GeoAxis &g) { (void)hipFree(g.d_kv); (void)hipFree(g.d
 static int ensure_fields(igx_patch *pt, int kind)
 {
     if (pt->fields_kind == kind) return IGX_OK;
-    const int nF = igx_num_fields(pt->dim, kind);
+    const int nF = igx_num_fields(pt->dim, kind, pt->dev.form_n);
+    if (kind == IGX_FORM) {
+        if (pt->dim != 3) { set_error("IGX_FORM is a 3D form"); return IGX_ERR_UNSUPPORTED; }
+        if (!pt->d_formc || pt->dev.form_n == 0) { set_error("IGX_FORM needs igx_patch_set_form first"); return IGX_ERR_ARG; }
+    }
     if (kind == IGX_CONVDIFF) {
         if (pt->dim != 3) { set_error("IGX_CONVDIFF is a 3D form"); return IGX_ERR_UNSUPPORTED; }
         if (!pt->d_coeff) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
@@ -319,7 +323,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipSetDevice(pt->ctx->device);
     (void)hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
-    (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
+    (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_formc); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
@@ -333,6 +337,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     if (dim != 2 && dim != 3) { set_error("igx_patch_create: dim must be 2 or 3 (got %d)", dim); return nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     igx_patch *pt = new (std::nothrow) igx_patch();
+    if (pt) for (int k = 0; k < 16; ++k) pt->form_slot[k] = -1;
     if (!pt) return nullptr;
     pt->ctx = ctx;
     pt->dim = dim;
@@ -452,6 +457,38 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     return IGX_OK;
 }
 
+int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
+{
+    if (!pt || !coef) { set_error("igx_patch_set_form: null argument"); return IGX_ERR_ARG; }
+    if (pt->dim != 3) { set_error("igx_patch_set_form: IGX_FORM is a 3D form"); return IGX_ERR_UNSUPPORTED; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    int n = 0;
+    for (int k = 0; k < 16; ++k) pt->form_slot[k] = coef[k] ? n++ : -1;
+    if (n == 0) { set_error("igx_patch_set_form: all coefficients are absent"); return IGX_ERR_ARG; }
+    // parametric terms: the Jacobian mixes the three derivative directions of each jet block
+    bool blk[2][2] = {{false, false}, {false, false}};      // [test is a derivative][trial is a derivative]
+    for (int r = 0; r < 4; ++r)
+        for (int s = 0; s < 4; ++s)
+            if (coef[4 * r + s]) blk[r > 0][s > 0] = true;
+    int nt = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            if (blk[a > 0][b > 0]) pt->dev.form_ab[nt++] = 4 * a + b;
+    pt->dev.form_n = nt;
+    const size_t npts = (size_t)pt->dev.npts_loc, per_plane = npts / (size_t)pt->dev.G0_loc;
+    (void)hipFree(pt->d_formc);
+    pt->d_formc = nullptr;
+    hipError_t e = hipMalloc((void **)&pt->d_formc, std::max<size_t>(1, (size_t)n * npts) * sizeof(double));
+    if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for the form coefficients failed", n * npts * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+    for (int k = 0; k < 16; ++k)
+        if (coef[k])
+            IGX_HIP(hipMemcpyAsync(pt->d_formc + (size_t)pt->form_slot[k] * npts, coef[k] + (size_t)pt->dev.g0_lo * per_plane,
+                                   npts * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    pt->fields_kind = -1;
+    return IGX_OK;
+}
+
 int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)
 {
     if (!pt || axis < 0 || axis >= pt->dim) { set_error("igx_patch_gauss: bad argument"); return IGX_ERR_ARG; }
@@ -485,7 +522,7 @@ int igx_pattern(igx_patch *pt, int32_t *indptr, int32_t *indices)
 int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
 {
     if (!pt) { set_error("igx_assemble: null patch"); return IGX_ERR_ARG; }
-    if (kind != IGX_MASS && kind != IGX_STIFFNESS && kind != IGX_CONVDIFF) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     if (algo == IGX_ALGO_AUTO) algo = (pt->sumfact_ok && sumfact_supports_kind(pt, kind)) ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
@@ -552,7 +589,7 @@ const int32_t *igx_d_csr_indptr(const igx_patch *pt) { return pt ? pt->d_indptr 
 int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out)
 {
     if (!pt || (M && (!ij || !out))) { set_error("igx_entries: null argument"); return IGX_ERR_ARG; }
-    if (kind != IGX_MASS && kind != IGX_STIFFNESS && kind != IGX_CONVDIFF) { set_error("igx_entries: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_entries: unknown kind %d", kind); return IGX_ERR_ARG; }
     if (M == 0) return IGX_OK;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
@@ -577,7 +614,7 @@ int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
     IGX_HIP(hipSetDevice(pt->ctx->device));
     int rc = ensure_fields(pt, kind);
     if (rc) return rc;
-    const int nF = igx_num_fields(pt->dim, kind);
+    const int nF = igx_num_fields(pt->dim, kind, pt->dev.form_n);
     if (shape4) { shape4[0] = nF; shape4[1] = pt->dev.G0_loc; shape4[2] = pt->ax[1].G; shape4[3] = pt->dim == 3 ? pt->ax[2].G : 1; }
     if (out) {
         IGX_HIP(hipMemcpyAsync(out, pt->d_fields, (size_t)nF * pt->dev.npts_loc * sizeof(double), hipMemcpyDeviceToHost, pt->ctx->stream));

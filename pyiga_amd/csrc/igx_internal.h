@@ -48,6 +48,16 @@ struct PatchDev {
     int G0_loc;               // number of resident Gauss planes
     long long npts_loc;       // resident Gauss points = G0_loc * G1 [* G2]
     long long nnz_off;        // global indptr[row_lo]
+    // IGX_FORM: the terms that are present, in field order; ab = 4 * (jet index of v) + (jet index of u),
+    // jet index 0 = value, 1..3 = PARAMETRIC derivative in (x, y, z) order (x = last grid axis)
+    int form_n;
+    int form_ab[16];
+};
+
+// IGX_FORM coefficients on the resident Gauss slab
+struct FormView {
+    const double *c;          // [ncoef][npts_loc]
+    int slot[16];             // physical coefficient 4*r+s -> row of c, or -1
 };
 
 // global CSR row pointer of row (i0,i1,i2); see DESIGN.md "CSR pattern without index arrays"
@@ -98,6 +108,8 @@ struct igx_patch {
     igx::GeoAxis gax[3];
     double *d_ctrl = nullptr;
     double *d_jac = nullptr;                  // IGX_GEO_JACOBIAN: resident slab of the user array
+    double *d_formc = nullptr;                // IGX_FORM: physical coefficient fields [n][npts_loc]
+    int form_slot[16];                        //   4*r+s -> row of d_formc or -1
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     // slab
     int r0_lo = 0, r0_hi = 0, s0_lo = 0, s0_hi = 0;
@@ -149,9 +161,12 @@ int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const siz
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
                        double *d_t1, double *d_t2);
-inline int igx_num_fields(int dim, int kind) { return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : dim * (dim + 1) / 2); }
+inline int igx_num_fields(int dim, int kind, int form_n = 0)
+{
+    return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : (kind == IGX_FORM ? form_n : dim * (dim + 1) / 2));
+}
 constexpr size_t IGX_DUMP_PAD = 1024 * 16 + 16;   // doubles behind the CSR values: 1024 dump lines of the final stage
-inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF; }
+inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF && kind != IGX_FORM; }
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);
 int sumfact_supports_kind(const igx_patch *pt, int kind);

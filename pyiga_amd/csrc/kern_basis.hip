@@ -243,7 +243,7 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
 // ---------------------------------------------------------------------------------------------
 // geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
 template <int DIM>
-__global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, const double *coeff, int kind,
+__global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, const double *coeff, const FormView fv, const PatchDev pd, int kind,
                              const double *w0, const double *w1, const double *w2,
                              int g0_lo, int G0loc, int G1, int G2, double *fields)
 {
@@ -266,7 +266,8 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
     }
     double GW = w0[g[0]] * w1[g[1]];
     if (DIM == 3) GW = GW * w2[g[2]];
-    if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
+    if (DIM == 3 && kind == IGX_FORM) fields_form(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
+    else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
     else fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
 
@@ -277,7 +278,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
 // (The per-point kernel above costs prod(p_k+1) * ncomp * (DIM+1) FMAs and is memory-latency bound
 // on the control-net gathers.)
 template <int DIM, int NC>
-__global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind, const double *coeff,
+__global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind, const double *coeff, const FormView fv, const PatchDev pd,
                                                           const double *w0, const double *w1, const double *w2,
                                                           int g0_lo, int G0loc, int G1, int G2, int LPB, double *fields)
 {
@@ -363,7 +364,8 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         else { g0 = g0_lo + (int)line; g1 = gL; }
         double GW = w0[g0] * w1[g1];
         if (DIM == 3) GW = GW * w2[gL];
-        if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
+        if (DIM == 3 && kind == IGX_FORM) fields_form(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
+        else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
         else fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
     }
 }
@@ -375,6 +377,9 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     const PatchDev &pd = pt->dev;
     const long long total = pd.npts_loc;
     if (total == 0) return IGX_OK;
+    FormView fv{};
+    fv.c = pt->d_formc;
+    for (int k = 0; k < 16; ++k) fv.slot[k] = pt->form_slot[k];
     const int G1 = pd.ax[1].G, G2 = (dim == 3) ? pd.ax[2].G : 1;
     if (pt->geo_kind != IGX_GEO_JACOBIAN) {
         const int LN = (dim == 3) ? G2 : G1;
@@ -385,11 +390,11 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
             dim3 grid((unsigned)((nlines + LPB - 1) / LPB)), block(256);
             const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
             if (dim == 2) {
-                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
-                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
+                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
             } else {
-                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
-                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
+                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
             }
             IGX_HIP(hipGetLastError());
             return IGX_OK;
@@ -397,10 +402,10 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     }
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     if (dim == 2)
-        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
+        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, fv, pd, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
                                                 pd.g0_lo, pd.G0_loc, G1, 1, d_fields);
     else
-        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
+        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, fv, pd, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
                                                 pd.g0_lo, pd.G0_loc, G1, G2, d_fields);
     IGX_HIP(hipGetLastError());
     return IGX_OK;

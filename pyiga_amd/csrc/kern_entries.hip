@@ -75,6 +75,19 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                     const long long pt = ((long long)(g0 - pd.g0_lo) * A1.G + g1) * A2.G + g2;
                     if (KIND == IGX_MASS) {
                         r += (((u0[0] * u1[0] * u2[0]) * (v0[0] * v1[0] * v2[0])) * fields[pt]);
+                    } else if (KIND == IGX_FORM) {
+                        // jets in parametric (x, y, z) order: index 0 = value, 1 = d/dx (last grid axis), 2 = d/dy, 3 = d/dz
+                        const double Du[4] = {u0[0] * u1[0] * u2[0], u0[0] * u1[0] * u2[1], u0[0] * u1[1] * u2[0], u0[1] * u1[0] * u2[0]};
+                        const double Dv[4] = {v0[0] * v1[0] * v2[0], v0[0] * v1[0] * v2[1], v0[0] * v1[1] * v2[0], v0[1] * v1[0] * v2[0]};
+                        double e = 0.0;
+                        for (int t = 0; t < pd.form_n; ++t) {
+                            const int ab = pd.form_ab[t];
+                            double dv = Dv[0], du = Du[0];
+#pragma unroll
+                            for (int c = 1; c < 4; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                            e += (fields[t * stride + pt] * du) * dv;
+                        }
+                        r += e;
                     } else {
                         const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
                         const double f_3 = fields[3 * stride + pt], f_4 = fields[4 * stride + pt], f_5 = fields[5 * stride + pt];
@@ -122,6 +135,7 @@ int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const siz
     } else {
         if (kind == IGX_MASS) k_entries_list<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
         else if (kind == IGX_CONVDIFF) k_entries_list<3, IGX_CONVDIFF><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        else if (kind == IGX_FORM) k_entries_list<3, IGX_FORM><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
         else k_entries_list<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
     }
     IGX_HIP(hipGetLastError());
@@ -271,6 +285,7 @@ int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_
     } else {
         if (kind == IGX_MASS) k_entries_csr<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
         else if (kind == IGX_CONVDIFF) k_entries_csr<3, IGX_CONVDIFF><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, false, d_data);
+        else if (kind == IGX_FORM) k_entries_csr<3, IGX_FORM><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, false, d_data);
         else k_entries_csr<3, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
     }
     IGX_HIP(hipGetLastError());

@@ -43,9 +43,20 @@ static int sym_index(int d, int r, int c)       // row-major upper triangle (pyi
     return idx + (c - r);
 }
 
-static std::vector<Term> form_terms(int dim, int kind)
+static std::vector<Term> form_terms(int dim, int kind, const PatchDev *pd = nullptr)
 {
     std::vector<Term> T;
+    if (kind == IGX_FORM) {
+        // one term per stored field; jet index c >= 1 differentiates grid axis 3 - c (x is the LAST axis)
+        for (int k = 0; k < pd->form_n; ++k) {
+            const int a = pd->form_ab[k] >> 2, b = pd->form_ab[k] & 3;     // a: test function v, b: trial function u
+            Term t{};
+            t.f = k;
+            for (int ax = 0; ax < 3; ++ax) t.t[ax] = ((b >= 1 && ax == 3 - b) ? 1 : 0) + 2 * ((a >= 1 && ax == 3 - a) ? 1 : 0);
+            T.push_back(t);
+        }
+        return T;
+    }
     if (kind == IGX_MASS) {
         T.push_back(Term{0, {0, 0, 0}});
         return T;
@@ -101,7 +112,7 @@ struct StageAGroup {
     int t0, t1, nt;
 };
 struct StageAArgs {
-    StageAGroup grp[12];
+    StageAGroup grp[16];
     const double *PI0;          // [G0][4][P][P]
     const int *step_ptr;        // [n0+1] first flush step of each span
     const int *steps;           // symmetric: [nsteps][8] K1 slot of pair (leaving dof + a, leaving dof), or -1;
@@ -236,8 +247,8 @@ __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
 // Stage B (3D): sweep axis 1.  Block = (chunk of g2, processed pair r0, output group y [x span chunk]).
 struct StageBGroup {
     int nterm;
-    int x[8];                   // K1 array index of each term
-    int t1[8];                  // axis-1 type of each term
+    int x[12];                  // K1 array index of each term
+    int t1[12];                 // axis-1 type of each term
 };
 struct StageBArgs {
     StageBGroup grp[4];
@@ -373,12 +384,16 @@ __global__ void __launch_bounds__(256) k_stageB(const double *__restrict__ K1, d
     const int y = blockIdx.z % B.ngroups, chunk = blockIdx.z / B.ngroups;
     const StageBGroup &G = B.grp[y];
     switch (G.nterm) {
+    case 0: break;                                      // empty group: its K2 array was zero-filled by the host
     case 1: stageB_body<P, 1, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 2: stageB_body<P, 2, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 3: stageB_body<P, 3, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 4: stageB_body<P, 4, Q>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     case 5: stageB_body<P, 5, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;     // run-time q: fewer live registers
-    default: stageB_body<P, 6, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 6: stageB_body<P, 6, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 7: stageB_body<P, 7, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    case 8: stageB_body<P, 8, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
+    default: stageB_body<P, 9, 0>(K1, K2, B, G, y, chunk, g2, live, pis); break;
     }
 }
 
@@ -1086,7 +1101,7 @@ int sumfact_supported(const igx_patch *pt)
 
 int sumfact_supports_kind(const igx_patch *pt, int kind)
 {
-    return kind == IGX_MASS || kind == IGX_STIFFNESS || (kind == IGX_CONVDIFF && pt->dim == 3);
+    return kind == IGX_MASS || kind == IGX_STIFFNESS || ((kind == IGX_CONVDIFF || kind == IGX_FORM) && pt->dim == 3);
 }
 
 // Line descriptors of the quadrature-lane final kernel: one 32-byte record per K line that is contracted,
@@ -1377,7 +1392,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     hipStream_t st = pt->ctx->stream;
     const int dim = pt->dim;
     const PatchDev &pd = pt->dev;
-    std::vector<Term> terms = form_terms(dim, kind);
+    std::vector<Term> terms = form_terms(dim, kind, &pd);
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
     const long long NPL = (long long)A1.G * (dim == 3 ? A2.G : 1);
     const bool sym = igx_kind_symmetric(kind);
@@ -1405,7 +1420,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     const int nX = (int)X.size();
     if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
 
-    const int nF = igx_num_fields(dim, kind);
+    const int nF = igx_num_fields(dim, kind, pd.form_n);
     (void)hipEventRecord(pt->ctx->ev[1], st);
     // one launch for all fields (blockIdx.y); the types of a field share the field load
     {
@@ -1422,7 +1437,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 }
             if (g.nt == 0) continue;
             g.field = pt->d_fields + (size_t)f * pd.npts_loc;
-            if (ng >= 12) { set_error("internal: too many stage-A groups"); return IGX_ERR_UNSUPPORTED; }
+            if (ng >= 16) { set_error("internal: too many stage-A groups"); return IGX_ERR_UNSUPPORTED; }
             A.grp[ng++] = g;
         }
         A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = sym ? pt->stepA_rec : pt->d_stepsn;
@@ -1455,14 +1470,17 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         for (size_t i = 0; i < terms.size(); ++i) {
             const int y = (kind == IGX_MASS) ? 0 : terms[i].t[2];
             StageBGroup &g = B.grp[y];
-            if (g.nterm >= 6) { set_error("internal: too many stage-B terms"); return IGX_ERR_UNSUPPORTED; }
+            if (g.nterm >= 9) { set_error("internal: too many stage-B terms"); return IGX_ERR_UNSUPPORTED; }
             g.x[g.nterm] = X[term_x[i]].slot;
             g.t1[g.nterm] = terms[i].t[1];
             g.nterm++;
             ymax = std::max(ymax, y);
         }
-        NY = ymax + 1;
+        NY = (ymax == 0) ? 1 : 4;                       // the final kernels exist for 1 and 4 K arrays
         if (ensure(st, &pt->d_K2, &pt->K2_cap, (size_t)NY * np0 * A1.S * A2.G)) return IGX_ERR_NOMEM;
+        for (int y = 0; y < NY; ++y)                    // a type of the last axis without terms (general forms): zeros
+            if (B.grp[y].nterm == 0)
+                IGX_HIP(hipMemsetAsync(pt->d_K2 + (size_t)y * np0 * A1.S * A2.G, 0, (size_t)np0 * A1.S * A2.G * sizeof(double), st));
         B.PI1 = A1.d_PI;
         B.step_ptr = pt->stepB_ptr; B.steps = pt->stepB_rec; B.pl0 = d_pl0; B.symmetric = sym;
         B.n1 = A1.n; B.N1 = A1.N; B.q = A1.q; B.G1 = A1.G; B.G2 = A2.G; B.S1 = A1.S; B.npairs0 = np0;

@@ -44,3 +44,78 @@ def rel_maxdiff(A, B):
     """max_ij |A-B| / max_ij |B|  -- the parity norm of SURVEY section 8c."""
     D = abs(A - B)
     return (D.max() if D.nnz else 0.0) / abs(B).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# general form strings (SURVEY 8 f1): the inputs and, written out by hand, the coefficient tables
+# P[r][s] of  sum_rs P_rs D_r v D_s u  (D_0 = id, D_1..3 = d/dx, d/dy, d/dz) the strings stand for
+def form_inputs():
+    import numpy as np
+
+    def c(x, y, z):
+        return 1.0 + x * y
+
+    def K(x, y, z):
+        one = np.ones_like(x * y * z)
+        rows = (((2.0 + x) * one, 0.3 * y * one, 0.0 * one), (-0.2 * one, (1.0 + z) * one, 0.1 * x * one),
+                (0.5 * one, 0.0 * one, 3.0 * one))
+        return np.stack([np.stack(r, -1) for r in rows], -2)
+
+    def b(x, y, z):
+        one = np.ones_like(x * y * z)
+        return (x * one, (1 + z) * one, y * one)
+    return dict(c=c, K=K, b=b)
+
+
+FORMS = {
+    'reactdiff': ('(inner(grad(u), grad(v)) + c*u*v) * dx', ('c',)),
+    'aniso': ('inner(dot(K, grad(u)), grad(v)) * dx', ('K',)),
+    'adjconv': ('(u * inner(b, grad(v)) + 2.5 * u * v) * dx', ('b',)),
+    'full': ('(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v + u * inner(b, grad(v)) + c * u * v) * dx', ('K', 'b', 'c')),
+    'scaled': ('(0.5 * inner(grad(u), 3 * grad(v)) - inner((x[2], 0.0, -x[0]), grad(u)) * v / 4) * dx', ()),
+}
+
+
+def form_tables():
+    inp = form_inputs()
+    Kf, bf, cf = inp['K'], inp['b'], inp['c']
+
+    def Kc(i, j):
+        return lambda x, y, z: Kf(x, y, z)[..., i, j]
+
+    def bc(i):
+        return lambda x, y, z: bf(x, y, z)[i]
+
+    def empty():
+        return [[None] * 4 for _ in range(4)]
+    T = {}
+    t = empty()
+    for k in range(1, 4):
+        t[k][k] = 1.0
+    t[0][0] = cf
+    T['reactdiff'] = t
+    t = empty()
+    for i in range(3):
+        for j in range(3):
+            t[1 + i][1 + j] = Kc(i, j)
+    T['aniso'] = t
+    t = empty()
+    for i in range(3):
+        t[1 + i][0] = bc(i)
+    t[0][0] = 2.5
+    T['adjconv'] = t
+    t = empty()
+    for i in range(3):
+        for j in range(3):
+            t[1 + i][1 + j] = Kc(i, j)
+        t[0][1 + i] = bc(i)
+        t[1 + i][0] = bc(i)
+    t[0][0] = cf
+    T['full'] = t
+    t = empty()
+    for k in range(1, 4):
+        t[k][k] = 1.5
+    t[0][1] = lambda x, y, z: -z / 4
+    t[0][3] = lambda x, y, z: x / 4
+    T['scaled'] = t
+    return T

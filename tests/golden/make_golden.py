@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__' and not {'convdiff', 'rhs'} & set(sys.argv[1:]):
+if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms'} & set(sys.argv[1:]):
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -350,3 +350,51 @@ def golden_rhs():
 
 if __name__ == '__main__' and 'rhs' in sys.argv[1:]:
     golden_rhs()
+
+
+# ---------------------------------------------------------------------------
+# (9) general form strings: scalar forms that are bilinear in (u, grad u) x (v, grad v),
+#     compiled at run time by the reference (pyiga/assemble.py:837-897, pyiga/vform.py:1804-1885)
+def form_inputs():
+    def c(x, y, z):
+        return 1.0 + x * y
+
+    def K(x, y, z):
+        one = np.ones_like(x * y * z)
+        rows = (((2.0 + x) * one, 0.3 * y * one, 0.0 * one), (-0.2 * one, (1.0 + z) * one, 0.1 * x * one),
+                (0.5 * one, 0.0 * one, 3.0 * one))
+        return np.stack([np.stack(r, -1) for r in rows], -2)
+
+    def b(x, y, z):
+        one = np.ones_like(x * y * z)
+        return (x * one, (1 + z) * one, y * one)
+    return dict(c=c, K=K, b=b)
+
+
+FORMS = {
+    'reactdiff': ('(inner(grad(u), grad(v)) + c*u*v) * dx', ('c',)),
+    'aniso': ('inner(dot(K, grad(u)), grad(v)) * dx', ('K',)),
+    'adjconv': ('(u * inner(b, grad(v)) + 2.5 * u * v) * dx', ('b',)),
+    'full': ('(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v + u * inner(b, grad(v)) + c * u * v) * dx', ('K', 'b', 'c')),
+    'scaled': ('(0.5 * inner(grad(u), 3 * grad(v)) - inner((x[2], 0.0, -x[0]), grad(u)) * v / 4) * dx', ()),
+}
+
+
+def golden_forms():
+    out = {}
+    inp = form_inputs()
+    cyl = cylinder()
+    spaces = {
+        'cyl_p2': ((bspline.make_knots(2, 0.0, 1.0, 3),) * 3, cyl),
+        'tbox_mixed': ((bspline.make_knots(3, 0.0, 1.0, 2), bspline.make_knots(2, 0.0, 1.0, 4, mult=2),
+                        bspline.make_knots(1, 0.0, 1.0, 3)), geometry.twisted_box()),
+    }
+    for sname, (kvs, geo) in spaces.items():
+        for fname, (form, names) in FORMS.items():
+            A = assemble.assemble(form, kvs, geo=geo, **{k: inp[k] for k in names})
+            put_matrix(out, '%s_%s' % (sname, fname), A)
+    save('forms', **out)
+
+
+if __name__ == '__main__' and 'forms' in sys.argv[1:]:
+    golden_forms()

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import GOLDEN, golden_csr, rel_maxdiff
+from conftest import GOLDEN, golden_csr, rel_maxdiff, form_inputs, form_tables, FORMS
 
 pytestmark = pytest.mark.gpu
 
@@ -546,3 +546,74 @@ def test_convdiff_properties_large(iga):
     rows = np.unique(np.linspace(0, A.shape[0] - 1, 40).astype(int))
     S = iga.assemble.assemble_partial_rows(asm, rows)
     assert np.abs(S[rows].data - A[rows].data).max() <= RTOL * np.abs(A.data).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# general form strings: front-end (pyiga_amd/forms.py) + IGX_FORM kernels
+def _form_spaces(iga):
+    mk = iga.bspline.make_knots
+    return {'cyl_p2': ((mk(2, 0.0, 1.0, 3),) * 3, 'cylinder'),
+            'tbox_mixed': ((mk(3, 0.0, 1.0, 2), mk(2, 0.0, 1.0, 4, mult=2), mk(1, 0.0, 1.0, 3)), 'twisted_box')}
+
+
+@pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
+def test_general_forms_vs_reference(iga, golden, algo, monkeypatch):
+    """Form strings through the front-end and both device algorithms, against the matrices the reference
+    compiled from the same strings; the same forms given as coefficient tables; multi_entries."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    g = golden('forms')
+    inp = form_inputs()
+    tables = form_tables()
+    for sname, (kvs, gname) in _form_spaces(iga).items():
+        geo = _geo(iga, gname)
+        for fname, (form, names) in FORMS.items():
+            R = golden_csr(g, '%s_%s' % (sname, fname))
+            asm = iga.assemble.instantiate_assembler(form, kvs, dict(geo=geo, **{k: inp[k] for k in names}))
+            assert isinstance(asm, iga.assemblers.GeneralFormAssembler3D)
+            A = asm.assemble_csr(algo=algo)
+            assert asm.patch.timing()['algo_used'] == {'sumfact': 2, 'entrywise': 1}[algo]
+            assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices) and not np.isnan(A.data).any()
+            assert rel_maxdiff(A, R) <= RTOL, (sname, fname, rel_maxdiff(A, R))
+            A2 = iga.assemblers.GeneralFormAssembler3D(kvs, geo, tables[fname]).assemble_csr(algo=algo)
+            assert rel_maxdiff(A2, R) <= RTOL
+            if algo == 'entrywise':
+                rng = np.random.default_rng(5)
+                idx = rng.integers(0, R.shape[0], (60, 2)).astype(np.uintp)
+                assert np.abs(asm.multi_entries(idx) - np.asarray(R[idx[:, 0], idx[:, 1]]).ravel()).max() <= RTOL * np.abs(R.data).max()
+    kv = iga.bspline.make_knots(2, 0.0, 1.0, 3)
+    A = iga.assemble.assemble(FORMS['full'][0], (kv, kv, kv), geo=_geo(iga, 'cylinder'), **inp)
+    assert rel_maxdiff(A, golden_csr(g, 'cyl_p2_full')) <= RTOL
+    for bad in ('u * dx(v) * dx', 'inner(grad(u), grad(u)) * dx', 'u * v', 'inner(grad(u), grad(v)) * u * dx'):
+        with pytest.raises(NotImplementedError):
+            iga.assemble.assemble(bad, (kv, kv, kv), geo=_geo(iga, 'cylinder'))
+
+
+def test_general_form_consistency_and_slabs(iga, oracle):
+    """The general form reproduces the dedicated kernels (stiffness, mass, convection-diffusion) to rounding,
+    matches the oracle at a size with several spans per slab, and row slabs are bit-identical."""
+    kvs = (iga.bspline.make_knots(3, 0., 1., 7), iga.bspline.make_knots(2, 0., 1., 8, mult=2), iga.bspline.make_knots(4, 0., 1., 6))
+    geo = _geo(iga, 'cylinder')
+    G = iga.assemblers.GeneralFormAssembler3D
+    K = iga.assemble.stiffness(kvs, geo)
+    M = iga.assemble.mass(kvs, geo)
+    assert rel_maxdiff(G(kvs, geo, 'inner(grad(u), grad(v)) * dx').assemble_csr(), K) <= RTOL
+    assert rel_maxdiff(G(kvs, geo, 'u * v * dx').assemble_csr(), M) <= RTOL
+    dc = lambda x, y, z: 1.0 + x
+    C = iga.assemblers.ConvDiffAssembler3D(kvs, geo, dc).assemble_csr()
+    F = G(kvs, geo, CONVDIFF, inputs=dict(diff_coeff=dc)).assemble_csr()
+    assert rel_maxdiff(F, C) <= RTOL
+    table = form_tables()['full']
+    asm = G(kvs, geo, table)
+    A = asm.assemble_csr(algo='sumfact')
+    okvs = tuple(oracle.KnotVector(kv.kv, kv.p) for kv in kvs)
+    R = oracle.assemble_nonsymmetric('form', okvs, oracle.geo_cylinder(), table=table, nthreads=8)
+    assert rel_maxdiff(A, R) <= RTOL and rel_maxdiff(asm.assemble_csr(algo='entrywise'), R) <= RTOL
+    N0 = kvs[0].numdofs
+    bounds = [0, N0 // 3, 2 * N0 // 3, N0]
+    parts = []
+    for k in range(3):
+        sl = G(kvs, geo, table, row0=(bounds[k], bounds[k + 1]))
+        parts.append(sl.assemble_csr(algo='sumfact'))
+        sl.patch.close()
+    S = scipy.sparse.vstack(parts).tocsr()
+    assert np.array_equal(S.indices, A.indices) and np.array_equal(S.data, A.data)

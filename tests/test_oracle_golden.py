@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import GOLDEN, golden_csr, rel_maxdiff
+from conftest import GOLDEN, golden_csr, rel_maxdiff, form_tables
 
 
 def test_make_knots_bits(oracle, golden):
@@ -235,3 +235,20 @@ def test_inner_products_oracle_vs_reference(oracle, golden):
     for name, r in cases:
         assert r.shape == g[name].shape, name
         assert np.abs(r - g[name]).max() <= 1e-14 * np.abs(g[name]).max(), name
+
+
+def test_general_forms_oracle_vs_reference(oracle, golden):
+    """General scalar forms in the jets of u and v: the oracle's entry-wise restatement with
+    hand-written coefficient tables against the matrices the reference compiled from the form strings."""
+    g = golden('forms')
+    spaces = {
+        'cyl_p2': ((oracle.make_knots(2, 0.0, 1.0, 3),) * 3, oracle.geo_cylinder()),
+        'tbox_mixed': ((oracle.make_knots(3, 0.0, 1.0, 2), oracle.make_knots(2, 0.0, 1.0, 4, mult=2),
+                        oracle.make_knots(1, 0.0, 1.0, 3)), oracle.geo_twisted_box()),
+    }
+    for sname, (kvs, geo) in spaces.items():
+        for fname, table in form_tables().items():
+            A = oracle.assemble_nonsymmetric('form', kvs, geo, table=table, nthreads=4)
+            R = golden_csr(g, '%s_%s' % (sname, fname))
+            assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
+            assert rel_maxdiff(A, R) <= 1e-14, (sname, fname, rel_maxdiff(A, R))
