@@ -216,9 +216,10 @@ def main():
     }
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(dim, p, kind)
-    print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()        # before the result line: anything RCCL prints comes first
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

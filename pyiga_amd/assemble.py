@@ -271,6 +271,12 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
         if 'geo' not in args:
             raise ValueError("required input parameter 'geo' missing")
         kvs = tuple(kvs)
+        from . import forms
+        if kind is None and forms.arity(problem) == 1:
+            if len(kvs) not in (2, 3):
+                raise NotImplementedError('linear functionals are supported for 2D and 3D patches')
+            cls = assemblers.GeneralFunctionalAssembler2D if len(kvs) == 2 else assemblers.GeneralFunctionalAssembler3D
+            return cls(kvs, args['geo'], problem, inputs=args)
         if kind is None:
             # any other scalar form that is bilinear in (u, grad u) x (v, grad v): general device form
             if len(kvs) != 3:

@@ -395,6 +395,27 @@ class _FunctionalAssembler:
         return None
 
 
+class _FormFunctionalAssembler(_FunctionalAssembler):
+    """Linear functional given as a form string ``F * v * dx`` (pyiga/assemble.py:837-897 with arity 1): the
+    integrand F (inputs, ``x``, numbers) is evaluated on the Gauss grid by ``pyiga_amd.forms``."""
+    _physical = True
+
+    def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
+        from . import forms
+        super().__init__(kvs0, geo, lambda *xyz: 0.0, device=device, row0=row0)
+        G = tuple(len(g) for g in self.gaussgrid)
+        X = np.asarray(geo.grid_eval(list(self.gaussgrid)))
+        self._fvals = forms.functional_coefficient(form, G, X, dict(inputs or {}))
+
+
+class GeneralFunctionalAssembler2D(_FormFunctionalAssembler):
+    _dim = 2
+
+
+class GeneralFunctionalAssembler3D(_FormFunctionalAssembler):
+    _dim = 3
+
+
 class L2FunctionalAssembler2D(_FunctionalAssembler):
     _dim = 2
 

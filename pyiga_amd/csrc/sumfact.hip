@@ -716,7 +716,6 @@ struct FinalQArgs {
     int nchunks;                // row chunks of the last axis (R rows each)
     int nsuper;                 // blocks per range of lines: ceil(nchunks / FINALQ_WAVES)
     long long dump;             // element index of a scratch slot behind the CSR values: target of masked-off stores
-    int debug;
 };
 
 #ifndef IGX_Q_WAVES
@@ -1569,7 +1568,6 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 Q.N = AL.N; Q.G = AL.G; Q.nlines = F.nlines;
                 Q.desc = (const LineDesc *)(sym ? pt->d_qdesc : pt->d_qdescn);
                 Q.ndesc = sym ? pt->n_qdesc : pt->n_qdescn;
-                Q.debug = getenv("IGX_DEBUG_Q") ? atoi(getenv("IGX_DEBUG_Q")) : 0;
                 Q.dump = pt->nnz;
                 const int R = 64 / AL.P;
                 Q.nchunks = (AL.N + R - 1) / R;

@@ -39,10 +39,11 @@ class _Coef:
         a = np.asarray(x, dtype=float)
         if a.ndim == 0:
             return _Coef(a, 0)
-        if a.shape == (3,):
-            return _Coef(np.broadcast_to(a, G + (3,)), 1)
-        if a.shape == (3, 3):
-            return _Coef(np.broadcast_to(a, G + (3, 3)), 2)
+        d = len(G)
+        if d and a.shape == (d,):
+            return _Coef(np.broadcast_to(a, G + (d,)), 1)
+        if d and a.shape == (d, d):
+            return _Coef(np.broadcast_to(a, G + (d, d)), 2)
         rank = a.ndim - len(G)
         assert a.shape[:len(G)] == G and 0 <= rank <= 2, 'coefficient does not fit the Gauss grid'
         return _Coef(a, rank)
@@ -56,7 +57,7 @@ class _Coef:
         return _Coef(self.a[..., k] if self.rank == 1 else self.a[..., k, :], self.rank - 1)
 
     def _bin(self, other, op):
-        if isinstance(other, (_Lin, _Bil)):
+        if isinstance(other, (_Lin, _Bil, _Dx)):
             return NotImplemented
         o = _Coef.wrap(other, ())
         r = max(self.rank, o.rank)
@@ -94,6 +95,8 @@ class _Lin:
         return _Lin(self.who, self.vector, f(self.s, 0), f(self.w, 1), f(self.M, 2), f(self.t, 1))
 
     def __mul__(self, o):
+        if isinstance(o, _Dx):
+            return o.__rmul__(self)
         if isinstance(o, _Lin):
             return _product(self, o)
         if isinstance(o, _Bil):
@@ -118,9 +121,13 @@ class _Bil:
     """Table of physical coefficients P[r][s] (r: jet index of v, s: of u); entries are arrays or None."""
     __array_priority__ = 1000
 
-    def __init__(self, P=None, measured=False):
-        self.P = P if P is not None else [[None] * 4 for _ in range(4)]
+    def __init__(self, P=None, measured=False, n=4):
+        self.P = P if P is not None else [[None] * n for _ in range(n)]
         self.measured = measured
+
+    @property
+    def n(self):
+        return len(self.P)
 
     def _map(self, f):
         return _Bil([[None if e is None else f(e) for e in row] for row in self.P], self.measured)
@@ -145,9 +152,15 @@ class _Bil:
         if not isinstance(o, _Bil) or o.measured != self.measured:
             raise NotImplementedError('sum of incompatible expressions (is every term multiplied by dx?)')
         ad = lambda a, b: b if a is None else (a if b is None else a + b)
-        return _Bil([[ad(self.P[r][s], o.P[r][s]) for s in range(4)] for r in range(4)], self.measured)
+        return _Bil([[ad(self.P[r][s], o.P[r][s]) for s in range(self.n)] for r in range(self.n)], self.measured)
 
     def __sub__(self, o): return self + (-o)
+
+
+class _Functional:
+    """Integrand of a linear functional: scalar-valued expression in the jet of v, times dx."""
+    def __init__(self, lin):
+        self.lin = lin
 
 
 class _Dx:
@@ -157,14 +170,17 @@ class _Dx:
     def __rmul__(self, o):
         if isinstance(o, _Bil):
             return o * self
-        raise NotImplementedError('dx must multiply an expression that contains both u and v')
+        if isinstance(o, _Lin) and not o.vector:
+            return _Functional(o)
+        raise NotImplementedError('dx must multiply a scalar integrand in u and/or v')
     __mul__ = __rmul__
 
 
 def _jet(lin):
     """Scalar-valued linear expression -> list of 4 coefficient arrays (value, d/dx, d/dy, d/dz) or None."""
     assert not lin.vector
-    return [lin.s] + [None if lin.w is None else lin.w[..., k] for k in range(3)]
+    d = (lin.s if lin.w is None else lin.w[..., 0]).ndim
+    return [lin.s] + [None if lin.w is None else lin.w[..., k] for k in range(d)]
 
 
 def _product(a, b):
@@ -174,9 +190,10 @@ def _product(a, b):
         raise NotImplementedError('product of vector-valued expressions: use inner()')
     u, v = (a, b) if a.who == 'u' else (b, a)
     ju, jv = _jet(u), _jet(v)
-    B = _Bil()
-    for r in range(4):
-        for s in range(4):
+    n = len(ju)
+    B = _Bil(n=n)
+    for r in range(n):
+        for s in range(n):
             if jv[r] is not None and ju[s] is not None:
                 B.P[r][s] = jv[r] * ju[s]
     return B
@@ -185,9 +202,10 @@ def _product(a, b):
 def _vec_jet(lin):
     """Vector-valued expression  M grad(phi) + t phi  -> list over components c of the 4 jet coefficients."""
     out = []
-    for c in range(3):
+    d = (lin.M.shape[-1] if lin.M is not None else lin.t.shape[-1])
+    for c in range(d):
         s = None if lin.t is None else lin.t[..., c]
-        w = [None if lin.M is None else lin.M[..., c, k] for k in range(3)]
+        w = [None if lin.M is None else lin.M[..., c, k] for k in range(d)]
         out.append([s] + w)
     return out
 
@@ -195,8 +213,10 @@ def _vec_jet(lin):
 def make_namespace(G, X, inputs):
     """Names available to a form string.  G: grid shape; X: physical coordinates, G + (3,); inputs: dict of
     callables (evaluated at the physical coordinates) or constants."""
+    d = len(G)
+    assert X.shape == G + (d,), 'physical coordinates do not fit the grid'
     one = np.ones(G)
-    eye = np.broadcast_to(np.eye(3), G + (3, 3))
+    eye = np.broadcast_to(np.eye(d), G + (d, d))
 
     def basis(who):
         return _Lin(who, False, s=one)
@@ -216,10 +236,10 @@ def make_namespace(G, X, inputs):
                 raise NotImplementedError('inner() of scalar expressions: use *')
             u, v = (a, b) if a.who == 'u' else (b, a)
             ju, jv = _vec_jet(u), _vec_jet(v)
-            B = _Bil()
-            for c in range(3):
-                for r in range(4):
-                    for s in range(4):
+            B = _Bil(n=d + 1)
+            for c in range(d):
+                for r in range(d + 1):
+                    for s in range(d + 1):
                         if jv[c][r] is not None and ju[c][s] is not None:
                             term = jv[c][r] * ju[c][s]
                             B.P[r][s] = term if B.P[r][s] is None else B.P[r][s] + term
@@ -275,12 +295,12 @@ def make_namespace(G, X, inputs):
         if hasattr(val, 'grid_eval') and not callable(val):
             raise NotImplementedError('spline functions as form inputs')
         if callable(val):
-            vals = val(*(X[..., k] for k in range(3)))
+            vals = val(*(X[..., k] for k in range(d)))
             if not isinstance(vals, (tuple, list)):
                 # a function that ignores some of its arguments returns fewer grid axes: broadcast like the
                 # reference does (pyiga/utils.py:17-31)
                 vals = np.asarray(vals, dtype=float)
-                extra = vals.shape[len(G):] if vals.shape[:len(G)] == G else (vals.shape if vals.shape in ((3,), (3, 3)) else ())
+                extra = vals.shape[len(G):] if vals.shape[:len(G)] == G else (vals.shape if vals.shape in ((d,), (d, d)) else ())
                 vals = np.broadcast_to(vals, G + extra)
             ns[name] = _Coef.wrap(vals, G)
         else:
@@ -297,10 +317,41 @@ def coefficient_table(expr, G, X, inputs):
         raise ValueError('unknown name in the form: %s' % e)
     if not isinstance(res, _Bil) or not res.measured:
         raise NotImplementedError('the form must be a volume integral (... * dx) that is bilinear in u and v')
-    table = [[None] * 4 for _ in range(4)]
-    for r in range(4):
-        for s in range(4):
+    n = len(G) + 1
+    table = [[None] * n for _ in range(n)]
+    for r in range(n):
+        for s in range(n):
             e = res.P[r][s]
             if e is not None and np.any(e != 0.0):
                 table[r][s] = np.ascontiguousarray(np.broadcast_to(e, G), dtype=float)
     return table
+
+
+def functional_coefficient(expr, G, X, inputs):
+    """Evaluate an arity-1 form string ``F * v * dx``; returns the array F on the grid (shape G).
+    Integrands with derivatives of v are not supported."""
+    ns = make_namespace(G, X, inputs)
+    ns.pop('u')
+    try:
+        res = eval(expr, {'__builtins__': {}}, ns)
+    except NameError as e:
+        raise ValueError('unknown name in the form: %s' % e)
+    if not isinstance(res, _Functional) or res.lin.who != 'v':
+        raise NotImplementedError('the form must be a volume integral (... * dx) that is linear in v')
+    if res.lin.w is not None and np.any(res.lin.w != 0.0):
+        raise NotImplementedError('linear functionals with derivatives of v are not supported')
+    return np.ascontiguousarray(np.broadcast_to(res.lin.s, G), dtype=float)
+
+
+def arity(expr):
+    """1 if only v occurs in the form string, 2 if u and v do (as the reference decides: pyiga/vform.py:1818-1825)."""
+    import re
+    words = set(re.findall(r"[^\d\W]\w*", expr))
+    used = words & {'u', 'v'}
+    if used == {'v'}:
+        return 1
+    if used == {'u', 'v'}:
+        return 2
+    if used == {'u'}:
+        raise NotImplementedError('a form that contains u but not v: name the test function v')
+    raise ValueError('arity should be 1 or 2')

@@ -393,6 +393,11 @@ def golden_forms():
         for fname, (form, names) in FORMS.items():
             A = assemble.assemble(form, kvs, geo=geo, **{k: inp[k] for k in names})
             put_matrix(out, '%s_%s' % (sname, fname), A)
+    # arity-1 form strings (test/test_assemble.py:426-429)
+    kv2 = (bspline.make_knots(3, 0.0, 1.0, 6), bspline.make_knots(2, 0.0, 1.0, 5))
+    out['func_d2'] = assemble.assemble('f * v * dx', kv2, geo=geometry.quarter_annulus(), f=lambda x, y: x * y ** 2)
+    out['func_d3'] = assemble.assemble('(2 * f + x[0]) * v * dx', spaces['cyl_p2'][0], geo=cyl,
+                                       f=lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z))
     save('forms', **out)
 
 

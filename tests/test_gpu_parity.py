@@ -617,3 +617,21 @@ def test_general_form_consistency_and_slabs(iga, oracle):
         sl.patch.close()
     S = scipy.sparse.vstack(parts).tocsr()
     assert np.array_equal(S.indices, A.indices) and np.array_equal(S.data, A.data)
+
+
+def test_arity1_form_strings(iga, golden):
+    """Form strings that only contain v assemble a load vector (pyiga/assemble.py:837-897, arity 1;
+    test/test_assemble.py:426-429), against vectors from the reference."""
+    g = golden('forms')
+    mk = iga.bspline.make_knots
+    kv2 = (mk(3, 0.0, 1.0, 6), mk(2, 0.0, 1.0, 5))
+    ann = _geo(iga, 'quarter_annulus')
+    f1 = iga.assemble.assemble('f * v * dx', kv2, geo=ann, f=lambda x, y: x * y ** 2)
+    assert _close(f1, g['func_d2'])
+    assert _close(f1, iga.assemble.inner_products(kv2, lambda x, y: x * y ** 2, geo=ann, f_physical=True), 1e-15)
+    kv = mk(2, 0.0, 1.0, 3)
+    f3 = iga.assemble.assemble('(2 * f + x[0]) * v * dx', (kv, kv, kv), geo=_geo(iga, 'cylinder'),
+                               f=lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z))
+    assert _close(f3, g['func_d3'])
+    with pytest.raises(NotImplementedError):
+        iga.assemble.assemble('inner((1.0, 2.0), grad(v)) * dx', kv2, geo=ann)
