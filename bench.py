@@ -218,6 +218,13 @@ def main():
         out['cpu_baseline'] = cpu_baseline(dim, p, kind)
     if dist is not None:
         dist.destroy_process_group()        # before the result line: anything RCCL prints comes first
+    # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would surface
+    # after this line at exit: flush it first so that the result is the LAST line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
 
