@@ -635,3 +635,25 @@ def test_arity1_form_strings(iga, golden):
     assert _close(f3, g['func_d3'])
     with pytest.raises(NotImplementedError):
         iga.assemble.assemble('inner((1.0, 2.0), grad(v)) * dx', kv2, geo=ann)
+
+
+@pytest.mark.parametrize('d', [2, 3])
+def test_tiny_and_odd_sizes(iga, d, monkeypatch):
+    """Corner sizes of the sum-factorised kernels (one span, fewer rows than a wave chunk, row counts that
+    are not a multiple of the chunk, degree 1, mixed degrees): sum-factorised == entry-wise, all written."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    mk = iga.bspline.make_knots
+    geo = _geo(iga, 'quarter_annulus' if d == 2 else 'cylinder')
+    cases = [(1, 1), (1, 2), (2, 1), (3, 1), (5, 1), (2, 2), (4, 2), (1, 13), (3, 23), (5, 11)]
+    if d == 3:
+        cases = [(1, 1), (2, 1), (4, 1), (5, 2), (1, 9), (3, 13), (5, 7)]
+    for p, n in cases:
+        kvs = tuple(mk(max(1, p - (k == 1)), 0., 1., n + k) for k in range(d))
+        for kind in ('mass', 'stiffness'):
+            patch = iga.assemblers.DevicePatch(kvs, geo)
+            A = patch.csr(kind, algo='sumfact')
+            E = patch.csr(kind, algo='entrywise')
+            patch.close()
+            assert not np.isnan(A.data).any(), (p, n, kind)
+            assert rel_maxdiff(A, E) <= RTOL, (p, n, kind, rel_maxdiff(A, E))
+            assert abs(A - A.T).max() == 0.0
