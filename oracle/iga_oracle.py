@@ -373,13 +373,14 @@ def precompute_fields_form(jac, table, gw):
     for k, w in enumerate(gw):
         W = W * w.reshape((1,) * k + (-1,) + (1,) * (len(gw) - 1 - k))
     JI = np.linalg.inv(jac)                    # [param (x,y,z order)][physical]: d xi_a / d x_r
-    F = np.zeros(G + (26,))
-    for r in range(4):
-        for s in range(4):
+    d = len(G)
+    F = np.zeros(G + (17 + d * d,))
+    for r in range(d + 1):
+        for s in range(d + 1):
             if table[r][s] is not None:
                 F[..., 4 * r + s] = np.broadcast_to(table[r][s], G)
     F[..., 16] = W
-    F[..., 17:26] = JI.reshape(G + (9,))
+    F[..., 17:17 + d * d] = JI.reshape(G + (d * d,))
     return F
 
 
@@ -488,10 +489,9 @@ class Assembler:
             self.fields = np.ascontiguousarray(precompute_fields_convdiff(self.jac, xphys, c, self.gw))
         elif kind == 'form':
             # `table`: 4x4 nested list of functions of the physical coordinates (or constants / None), P[r][s]
-            assert self.dim == 3
             xphys = grid_eval(geo, self.grid)
             G = xphys.shape[:-1]
-            vals = [[None if e is None else np.broadcast_to(e(xphys[..., 0], xphys[..., 1], xphys[..., 2]) if callable(e) else e, G)
+            vals = [[None if e is None else np.broadcast_to(e(*(xphys[..., k] for k in range(self.dim))) if callable(e) else e, G)
                      for e in row] for row in table]
             self.fields = np.ascontiguousarray(precompute_fields_form(self.jac, vals, self.gw))
         else:

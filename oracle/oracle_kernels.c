@@ -50,6 +50,25 @@ static double entry2(const orc_ctx *c, const size_t i[2], const size_t j[2])
                 const double *f = c->fields + ((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * F;
                 r += (((u0[i0] * u1[i1]) * (v0[i0] * v1[i1])) * f[0]);
             }
+    } else if (c->kind == 3) {
+        /* general first-order-jet form in 2D: f = [P(16, rows/cols 0..2 used), W, JacInv(4) row-major [param][phys]] */
+        for (size_t i0 = 0; i0 < n0; ++i0)
+            for (size_t i1 = 0; i1 < n1; ++i1) {
+                const double *f = c->fields + ((sta[0] + i0) * c->ng[1] + (sta[1] + i1)) * F;
+                const double du10 = u0[2 * i0 + 0] * u1[2 * i1 + 1], du01 = u0[2 * i0 + 1] * u1[2 * i1 + 0];
+                const double dv10 = v0[2 * i0 + 0] * v1[2 * i1 + 1], dv01 = v0[2 * i0 + 1] * v1[2 * i1 + 0];
+                double Gu[3], Gv[3];
+                Gu[0] = u0[2 * i0 + 0] * u1[2 * i1 + 0];
+                Gv[0] = v0[2 * i0 + 0] * v1[2 * i1 + 0];
+                for (int r_ = 0; r_ < 2; ++r_) {
+                    Gu[1 + r_] = (f[17 + r_] * du10) + (f[19 + r_] * du01);
+                    Gv[1 + r_] = (f[17 + r_] * dv10) + (f[19 + r_] * dv01);
+                }
+                double e = 0.0;
+                for (int r_ = 0; r_ < 3; ++r_)
+                    for (int s_ = 0; s_ < 3; ++s_) e += (f[4 * r_ + s_] * Gu[s_]) * Gv[r_];
+                r += e * f[16];
+            }
     } else {
         for (size_t i0 = 0; i0 < n0; ++i0)
             for (size_t i1 = 0; i1 < n1; ++i1) {

@@ -279,10 +279,10 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
             return cls(kvs, args['geo'], problem, inputs=args)
         if kind is None:
             # any other scalar form that is bilinear in (u, grad u) x (v, grad v): general device form
-            if len(kvs) != 3:
-                raise NotImplementedError('general form strings are supported for 3D patches; %r is not one of the '
-                                          'built-in forms (%s)' % (problem, ', '.join(sorted(_KNOWN_FORMS))))
-            return assemblers.GeneralFormAssembler3D(kvs, args['geo'], problem, inputs=args)
+            if len(kvs) not in (2, 3):
+                raise NotImplementedError('general form strings are supported for 2D and 3D patches')
+            cls = assemblers.GeneralFormAssembler2D if len(kvs) == 2 else assemblers.GeneralFormAssembler3D
+            return cls(kvs, args['geo'], problem, inputs=args)
         if kind == 'convdiff':
             if 'diff_coeff' not in args:
                 raise ValueError("required input parameter 'diff_coeff' missing")

@@ -308,37 +308,51 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         self.patch.set_coeff(vals)
 
 
-class GeneralFormAssembler3D(_DeviceAssembler):
+class _GeneralFormAssembler(_DeviceAssembler):
     """Scalar bilinear form in the first-order jets of u and v,
 
-        a(u, v) = integral of  sum_{r,s=0..3} P_rs(x) D_r v D_s u  dx,   D_0 = id, D_1..3 = d/dx, d/dy, d/dz,
+        a(u, v) = integral of  sum_{r,s=0..d} P_rs(x) D_r v D_s u  dx,   D_0 = id, D_1..d = d/dx, d/dy[, d/dz],
 
     given either as a form string in the reference's syntax (``'(inner(dot(K, grad(u)), grad(v)) + c*u*v) * dx'``,
-    evaluated by ``pyiga_amd.forms``) or directly as a 4x4 table of coefficient functions/arrays.  This is the
-    class of forms the reference's run-time compiler handles with ``u``, ``v``, ``grad``, ``inner``, ``dot``
+    evaluated by ``pyiga_amd.forms``) or directly as a (d+1)x(d+1) table of coefficient functions/arrays.  This
+    is the class of forms the reference's run-time compiler handles with ``u``, ``v``, ``grad``, ``inner``, ``dot``
     (pyiga/assemble.py:837-897, pyiga/vform.py:1804-1885); non-symmetric, every pattern entry is computed.
     Coefficients are sampled on the Gauss grid on the host (they are Python callables, as in the reference),
-    the Jacobian transformation of the coefficients and all sums run on the device.
+    the Jacobian transformation of the coefficients and all sums run on the device (3D: sum-factorised
+    stages or entry-wise kernel; 2D: entry-wise kernel).
     """
-    _kind, _dim = 'form', 3
+    _kind = 'form'
 
     def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
         from . import forms
         super().__init__(kvs0, geo, device=device, row0=row0)
-        grid = [self.patch.gauss(k)[0] for k in range(3)]
+        d = self._dim
+        grid = [self.patch.gauss(k)[0] for k in range(d)]
         G = tuple(len(g) for g in grid)
-        X = np.asarray(geo.grid_eval(grid))                       # shape(grid) x 3, components (x, y, z)
+        X = np.asarray(geo.grid_eval(grid))                       # shape(grid) x d, components (x, y[, z])
         if isinstance(form, str):
             table = forms.coefficient_table(form, G, X, dict(inputs or {}))
         else:
-            table = [[None] * 4 for _ in range(4)]
-            for r in range(4):
-                for s in range(4):
+            table = [[None] * (d + 1) for _ in range(d + 1)]
+            for r in range(d + 1):
+                for s in range(d + 1):
                     e = form[r][s]
                     if e is not None:
-                        table[r][s] = np.broadcast_to(e(X[..., 0], X[..., 1], X[..., 2]) if callable(e) else e, G)
+                        table[r][s] = np.broadcast_to(e(*(X[..., k] for k in range(d))) if callable(e) else e, G)
+        full = [[None] * 4 for _ in range(4)]
+        for r in range(d + 1):
+            for s in range(d + 1):
+                full[r][s] = table[r][s]
         self.table_mask = [[e is not None for e in row] for row in table]
-        self.patch.set_form(table)
+        self.patch.set_form(full)
+
+
+class GeneralFormAssembler2D(_GeneralFormAssembler):
+    _dim = 2
+
+
+class GeneralFormAssembler3D(_GeneralFormAssembler):
+    _dim = 3
 
 
 class _FunctionalAssembler:

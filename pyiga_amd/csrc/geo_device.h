@@ -117,52 +117,62 @@ __device__ inline void fields_convdiff(const double t[9], double GW, const doubl
 
 // IGX_FORM: parametric jet coefficients  M = W * T P T^t,  T = diag(1, JacInv)  (JacInv[a][r] = d xi_a / d x_r),
 // so that  sum_rs P_rs D_r v D_s u  (physical jets)  =  sum_ab M_ab Dhat_a v Dhat_b u  (parametric jets).
-// Only the terms listed in form_ab are stored (field t <-> form_ab[t]).
+// Only the terms listed in form_ab are stored (field t <-> form_ab[t] = 4 a + b).
+template <int DIM>
 __device__ inline void fields_form(const double t[9], double GW, const FormView &fv, const int form_n, const int *form_ab,
                                    double *fields, long long stride, long long pt)
 {
-    const double t3 = t[4] * t[8] - t[5] * t[7];
-    const double t4 = t[3] * t[8] - t[5] * t[6];
-    const double t5 = t[3] * t[7] - t[4] * t[6];
-    const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
-    const double W = GW * fabs(det);
-    const double inv = 1.0 / det;
+    constexpr int NJ = DIM + 1;
     double T[4][4];
+    for (int r = 0; r < 4; ++r)
+        for (int s = 0; s < 4; ++s) T[r][s] = 0.0;
     T[0][0] = 1.0;
-    for (int k = 1; k < 4; ++k) T[0][k] = T[k][0] = 0.0;
-    T[1][1] = inv * t3;
-    T[1][2] = inv * -(t[1] * t[8] - t[2] * t[7]);
-    T[1][3] = inv * (t[1] * t[5] - t[2] * t[4]);
-    T[2][1] = inv * -t4;
-    T[2][2] = inv * (t[0] * t[8] - t[2] * t[6]);
-    T[2][3] = inv * -(t[0] * t[5] - t[2] * t[3]);
-    T[3][1] = inv * t5;
-    T[3][2] = inv * -(t[0] * t[7] - t[1] * t[6]);
-    T[3][3] = inv * (t[0] * t[4] - t[1] * t[3]);
+    double det;
+    if (DIM == 2) {
+        det = t[0] * t[3] - t[1] * t[2];
+        const double inv = 1.0 / det;
+        T[1][1] = inv * t[3]; T[1][2] = inv * -t[1];
+        T[2][1] = inv * -t[2]; T[2][2] = inv * t[0];
+    } else {
+        const double t3 = t[4] * t[8] - t[5] * t[7];
+        const double t4 = t[3] * t[8] - t[5] * t[6];
+        const double t5 = t[3] * t[7] - t[4] * t[6];
+        det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
+        const double inv = 1.0 / det;
+        T[1][1] = inv * t3;
+        T[1][2] = inv * -(t[1] * t[8] - t[2] * t[7]);
+        T[1][3] = inv * (t[1] * t[5] - t[2] * t[4]);
+        T[2][1] = inv * -t4;
+        T[2][2] = inv * (t[0] * t[8] - t[2] * t[6]);
+        T[2][3] = inv * -(t[0] * t[5] - t[2] * t[3]);
+        T[3][1] = inv * t5;
+        T[3][2] = inv * -(t[0] * t[7] - t[1] * t[6]);
+        T[3][3] = inv * (t[0] * t[4] - t[1] * t[3]);
+    }
+    const double W = GW * fabs(det);
     double P[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < NJ; ++r)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NJ; ++s) {
             const int sl = fv.slot[4 * r + s];
             P[r][s] = sl >= 0 ? fv.c[(long long)sl * stride + pt] : 0.0;
         }
-    // TP = T P  (rows of T act on the test index)
-    double TP[4][4];
+    double TP[4][4];                                   // T P: rows of T act on the test index
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NJ; ++a)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NJ; ++s) {
             double v = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v = fma(T[a][r], P[r][s], v);
+            for (int r = 0; r < NJ; ++r) v = fma(T[a][r], P[r][s], v);
             TP[a][s] = v;
         }
     for (int k = 0; k < form_n; ++k) {
         const int a = form_ab[k] >> 2, b = form_ab[k] & 3;
         double v = 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v = fma(TP[a][s], T[b][s], v);
+        for (int s = 0; s < NJ; ++s) v = fma(TP[a][s], T[b][s], v);
         fields[(long long)k * stride + pt] = W * v;
     }
 }

@@ -166,7 +166,6 @@ static int ensure_fields(igx_patch *pt, int kind)
     if (pt->fields_kind == kind) return IGX_OK;
     const int nF = igx_num_fields(pt->dim, kind, pt->dev.form_n);
     if (kind == IGX_FORM) {
-        if (pt->dim != 3) { set_error("IGX_FORM is a 3D form"); return IGX_ERR_UNSUPPORTED; }
         if (!pt->d_formc || pt->dev.form_n == 0) { set_error("IGX_FORM needs igx_patch_set_form first"); return IGX_ERR_ARG; }
     }
     if (kind == IGX_CONVDIFF) {
@@ -460,7 +459,10 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
 int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
 {
     if (!pt || !coef) { set_error("igx_patch_set_form: null argument"); return IGX_ERR_ARG; }
-    if (pt->dim != 3) { set_error("igx_patch_set_form: IGX_FORM is a 3D form"); return IGX_ERR_UNSUPPORTED; }
+    const int nj = pt->dim + 1;                   // jet size: value + dim derivatives
+    for (int r = 0; r < 4; ++r)
+        for (int s = 0; s < 4; ++s)
+            if (coef[4 * r + s] && (r >= nj || s >= nj)) { set_error("igx_patch_set_form: coefficient (%d,%d) does not exist in %dD", r, s, pt->dim); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     int n = 0;
     for (int k = 0; k < 16; ++k) pt->form_slot[k] = coef[k] ? n++ : -1;
@@ -471,8 +473,8 @@ int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
         for (int s = 0; s < 4; ++s)
             if (coef[4 * r + s]) blk[r > 0][s > 0] = true;
     int nt = 0;
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b)
+    for (int a = 0; a < nj; ++a)
+        for (int b = 0; b < nj; ++b)
             if (blk[a > 0][b > 0]) pt->dev.form_ab[nt++] = 4 * a + b;
     pt->dev.form_n = nt;
     const size_t npts = (size_t)pt->dev.npts_loc, per_plane = npts / (size_t)pt->dev.G0_loc;

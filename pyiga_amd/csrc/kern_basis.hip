@@ -266,7 +266,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
     }
     double GW = w0[g[0]] * w1[g[1]];
     if (DIM == 3) GW = GW * w2[g[2]];
-    if (DIM == 3 && kind == IGX_FORM) fields_form(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
+    if (kind == IGX_FORM) fields_form<DIM>(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
     else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
     else fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         else { g0 = g0_lo + (int)line; g1 = gL; }
         double GW = w0[g0] * w1[g1];
         if (DIM == 3) GW = GW * w2[gL];
-        if (DIM == 3 && kind == IGX_FORM) fields_form(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
+        if (kind == IGX_FORM) fields_form<DIM>(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
         else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
         else fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
     }

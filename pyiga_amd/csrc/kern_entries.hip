@@ -61,6 +61,19 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                 const long long pt = (long long)(g0 - pd.g0_lo) * A1.G + g1;
                 if (KIND == IGX_MASS) {
                     r += (((u0[0] * u1[0]) * (v0[0] * v1[0])) * fields[pt]);
+                } else if (KIND == IGX_FORM) {
+                    // jets in parametric (x, y) order: 0 = value, 1 = d/dx (last grid axis), 2 = d/dy
+                    const double Du[3] = {u0[0] * u1[0], u0[0] * u1[1], u0[1] * u1[0]};
+                    const double Dv[3] = {v0[0] * v1[0], v0[0] * v1[1], v0[1] * v1[0]};
+                    double e = 0.0;
+                    for (int t = 0; t < pd.form_n; ++t) {
+                        const int ab = pd.form_ab[t];
+                        double dv = Dv[0], du = Du[0];
+#pragma unroll
+                        for (int c = 1; c < 3; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                        e += (fields[t * stride + pt] * du) * dv;
+                    }
+                    r += e;
                 } else {
                     const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
                     const double du10 = u0[0] * u1[1], du01 = u0[1] * u1[0];
@@ -131,6 +144,7 @@ int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const siz
     const PatchDev &pd = pt->dev;
     if (pt->dim == 2) {
         if (kind == IGX_MASS) k_entries_list<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        else if (kind == IGX_FORM) k_entries_list<2, IGX_FORM><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
         else k_entries_list<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
     } else {
         if (kind == IGX_MASS) k_entries_list<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
@@ -281,6 +295,7 @@ int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     if (pt->dim == 2) {
         if (kind == IGX_MASS) k_entries_csr<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
+        else if (kind == IGX_FORM) k_entries_csr<2, IGX_FORM><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, false, d_data);
         else k_entries_csr<2, IGX_STIFFNESS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);
     } else {
         if (kind == IGX_MASS) k_entries_csr<3, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, row_first, nrows_scan, maxrow, true, d_data);

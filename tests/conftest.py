@@ -119,3 +119,25 @@ def form_tables():
     t[0][3] = lambda x, y, z: x / 4
     T['scaled'] = t
     return T
+
+
+def form2d_cases():
+    """2D forms of the golden file: name -> (string, inputs, hand-written 3x3 coefficient table)."""
+    import numpy as np
+
+    def K2(x, y):
+        one = np.ones_like(x * y)
+        return np.stack([np.stack(((1.5 + y) * one, 0.4 * x * one), -1), np.stack((-0.3 * one, (2.0 + x * y) * one), -1)], -2)
+
+    def b2(x, y):
+        one = np.ones_like(x * y)
+        return (y * one, (1.0 - x) * one)
+
+    def cc(x, y):
+        return 1.0 + x * y
+    t1 = [[cc, None, None], [None, 1.0, None], [None, None, 1.0]]
+    t2 = [[3.0, lambda x, y: b2(x, y)[0], lambda x, y: b2(x, y)[1]],
+          [lambda x, y: -b2(x, y)[0], lambda x, y: K2(x, y)[..., 0, 0], lambda x, y: K2(x, y)[..., 0, 1]],
+          [lambda x, y: -b2(x, y)[1], lambda x, y: K2(x, y)[..., 1, 0], lambda x, y: K2(x, y)[..., 1, 1]]]
+    return {'reactdiff': ('(inner(grad(u), grad(v)) + c*u*v) * dx', dict(c=cc), t1),
+            'full': ('(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v - u * inner(b, grad(v)) + 3 * u * v) * dx', dict(K=K2, b=b2), t2)}

@@ -393,6 +393,20 @@ def golden_forms():
         for fname, (form, names) in FORMS.items():
             A = assemble.assemble(form, kvs, geo=geo, **{k: inp[k] for k in names})
             put_matrix(out, '%s_%s' % (sname, fname), A)
+    # 2D forms (quarter annulus, unequal degrees)
+    kv2d = (bspline.make_knots(3, 0.0, 1.0, 4), bspline.make_knots(2, 0.0, 1.0, 5, mult=2))
+    ann = geometry.quarter_annulus()
+
+    def K2(x, y):
+        one = np.ones_like(x * y)
+        return np.stack([np.stack(((1.5 + y) * one, 0.4 * x * one), -1), np.stack((-0.3 * one, (2.0 + x * y) * one), -1)], -2)
+
+    def b2(x, y):
+        one = np.ones_like(x * y)
+        return (y * one, (1.0 - x) * one)
+    for fname, form, kw in (('reactdiff', '(inner(grad(u), grad(v)) + c*u*v) * dx', dict(c=lambda x, y: 1.0 + x * y)),
+                            ('full', '(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v - u * inner(b, grad(v)) + 3 * u * v) * dx', dict(K=K2, b=b2))):
+        put_matrix(out, 'd2_%s' % fname, assemble.assemble(form, kv2d, geo=ann, **kw))
     # arity-1 form strings (test/test_assemble.py:426-429)
     kv2 = (bspline.make_knots(3, 0.0, 1.0, 6), bspline.make_knots(2, 0.0, 1.0, 5))
     out['func_d2'] = assemble.assemble('f * v * dx', kv2, geo=geometry.quarter_annulus(), f=lambda x, y: x * y ** 2)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import GOLDEN, golden_csr, rel_maxdiff, form_inputs, form_tables, FORMS
+from conftest import GOLDEN, golden_csr, rel_maxdiff, form_inputs, form_tables, FORMS, form2d_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -657,3 +657,25 @@ def test_tiny_and_odd_sizes(iga, d, monkeypatch):
             assert not np.isnan(A.data).any(), (p, n, kind)
             assert rel_maxdiff(A, E) <= RTOL, (p, n, kind, rel_maxdiff(A, E))
             assert abs(A - A.T).max() == 0.0
+
+
+def test_general_forms_2d(iga, golden):
+    """2D form strings (entry-wise kernel) against the reference's compiled assemblers; the general form
+    against the dedicated 2D stiffness / mass kernels; multi_entries."""
+    g = golden('forms')
+    mk = iga.bspline.make_knots
+    kvs = (mk(3, 0.0, 1.0, 4), mk(2, 0.0, 1.0, 5, mult=2))
+    ann = _geo(iga, 'quarter_annulus')
+    for fname, (form, inputs, table) in form2d_cases().items():
+        R = golden_csr(g, 'd2_%s' % fname)
+        A = iga.assemble.assemble(form, kvs, geo=ann, **inputs)
+        assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
+        assert rel_maxdiff(A, R) <= RTOL, (fname, rel_maxdiff(A, R))
+        asm = iga.assemblers.GeneralFormAssembler2D(kvs, ann, table)
+        assert rel_maxdiff(asm.assemble_csr(), R) <= RTOL
+        idx = np.random.default_rng(2).integers(0, R.shape[0], (40, 2)).astype(np.uintp)
+        assert np.abs(asm.multi_entries(idx) - np.asarray(R[idx[:, 0], idx[:, 1]]).ravel()).max() <= RTOL * np.abs(R.data).max()
+    kv = (mk(3, 0.0, 1.0, 9), mk(4, 0.0, 1.0, 7))
+    G2 = iga.assemblers.GeneralFormAssembler2D
+    assert rel_maxdiff(G2(kv, ann, 'inner(grad(u), grad(v)) * dx').assemble_csr(), iga.assemble.stiffness(kv, ann)) <= RTOL
+    assert rel_maxdiff(G2(kv, ann, '2 * u * v * dx').assemble_csr(), 2 * iga.assemble.mass(kv, ann)) <= RTOL

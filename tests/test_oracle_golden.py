@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import GOLDEN, golden_csr, rel_maxdiff, form_tables
+from conftest import GOLDEN, golden_csr, rel_maxdiff, form_tables, form2d_cases
 
 
 def test_make_knots_bits(oracle, golden):
@@ -252,3 +252,17 @@ def test_general_forms_oracle_vs_reference(oracle, golden):
             R = golden_csr(g, '%s_%s' % (sname, fname))
             assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
             assert rel_maxdiff(A, R) <= 1e-14, (sname, fname, rel_maxdiff(A, R))
+
+
+def test_general_forms_2d_oracle_vs_reference(oracle, golden):
+    g = golden('forms')
+    kvs = (oracle.make_knots(3, 0.0, 1.0, 4), oracle.make_knots(2, 0.0, 1.0, 5, mult=2))
+    for fname, (_, _, table) in form2d_cases().items():
+        full = [[None] * 4 for _ in range(4)]
+        for r in range(3):
+            for s in range(3):
+                full[r][s] = table[r][s]
+        A = oracle.assemble_nonsymmetric('form', kvs, oracle.geo_quarter_annulus(), table=full, nthreads=2)
+        R = golden_csr(g, 'd2_%s' % fname)
+        assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
+        assert rel_maxdiff(A, R) <= 1e-14, (fname, rel_maxdiff(A, R))
