@@ -194,6 +194,18 @@ def main():
              'entry_ms': 'k_entries_csr'}
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
+    # the dominant kernel by itself: the part of the algorithmic bytes that passes through it
+    # (final stage / entry-wise kernel: the CSR values out; stage A: the quadrature input in) over its own time
+    dom = None
+    if dominant in ('k_final', 'k_entries_csr', 'k_stageA', 'k_geo_fields'):
+        q = p + 1
+        if dominant in ('k_final', 'k_entries_csr'):
+            dom_bytes = 8.0 * nnz_total / world
+        else:
+            dom_bytes = 8.0 * (dim * dim + (1 if kind == 'convdiff' else 0)) * q ** dim * nel_rank
+        dom_ach = dom_bytes / (parts[dominant] * 1e-3) / 1e9
+        dom = {'kernel': dominant, 'ms': parts[dominant], 'algorithmic_bytes': dom_bytes, 'achieved': dom_ach,
+               'unit': 'GB/s', 'frac': dom_ach / HBM_PEAK_GBS}
     out = {
         'metric': 'assembled elements/sec (3D p=4, 128^3 spans) + HBM-roofline %; 1/2/4/8 GPU'
                   if args.config == 'c4' else 'assembled elements/sec',
@@ -212,6 +224,7 @@ def main():
             'traffic': measured_traffic(args.config, world),
             'kernel': 'assembly chain (k_geo_fields + k_stageA x fields + k_stageB + k_final), HIP events on the igx stream',
             'algorithmic_bytes_per_element': b_el, 'chain_ms': chain_ms, 'kernel_ms': parts, 'dominant_kernel': dominant,
+            'dominant': dom,
         },
     }
     if not args.no_cpu_baseline:
