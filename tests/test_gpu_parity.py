@@ -679,3 +679,77 @@ def test_general_forms_2d(iga, golden):
     G2 = iga.assemblers.GeneralFormAssembler2D
     assert rel_maxdiff(G2(kv, ann, 'inner(grad(u), grad(v)) * dx').assemble_csr(), iga.assemble.stiffness(kv, ann)) <= RTOL
     assert rel_maxdiff(G2(kv, ann, '2 * u * v * dx').assemble_csr(), 2 * iga.assemble.mass(kv, ann)) <= RTOL
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes, through size-independent properties
+def _axis_ranges(kv):
+    """per dof: first column, number of columns, exclusive prefix sum (the 1D pattern of a knot vector)."""
+    s = kv.mesh_support_idx_all()
+    first = np.searchsorted(s[:, 1], s[:, 0], side='right')
+    last = np.searchsorted(s[:, 0], s[:, 1], side='left')
+    c = (last - first).astype(np.int64)
+    return first.astype(np.int64), c, np.concatenate(([0], np.cumsum(c)))
+
+
+def _positions(kvs, I, J):
+    """CSR position of entry (I, J) from the per-axis tables, for arrays of ravelled indices."""
+    nd = tuple(kv.numdofs for kv in kvs)
+    mi, mj = np.unravel_index(I, nd), np.unravel_index(J, nd)
+    ax = [_axis_ranges(kv) for kv in kvs]
+    S = [a[2][-1] for a in ax]
+    # indptr(I) = rp0*S1*S2 + c0*(rp1*S2 + c1*rp2); offset = ((j0-jlo0)*c1 + (j1-jlo1))*c2 + (j2-jlo2)
+    ind = np.zeros_like(I)
+    cprod = np.ones_like(I)
+    for k in range(len(kvs)):
+        rest = int(np.prod(S[k + 1:])) if k + 1 < len(kvs) else 1
+        ind = ind + cprod * ax[k][2][mi[k]] * rest
+        cprod = cprod * ax[k][1][mi[k]]
+    off = np.zeros_like(I)
+    for k in range(len(kvs)):
+        off = off * ax[k][1][mi[k]] + (mj[k] - ax[k][0][mi[k]])
+    return ind + off, ind
+
+
+def test_full_size_c3(iga, monkeypatch):
+    """BASELINE config 3 at full size (3D p=2 n=64, 34 M nonzeros): mass + stiffness."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(2, 0., 1., 64)
+    geo = _geo(iga, 'cylinder')
+    K = iga.assemble.stiffness((kv,) * 3, geo)
+    M = iga.assemble.mass((kv,) * 3, geo)
+    assert K.nnz == 34012224 and not np.isnan(K.data).any() and not np.isnan(M.data).any()
+    assert abs(K - K.T).max() == 0.0 and abs(M - M.T).max() == 0.0
+    assert np.abs(K @ np.ones(K.shape[0])).max() <= 1e-11 * abs(K).max()
+    assert abs(M.sum() - 0.75 * np.pi) < 1e-9
+
+
+def test_full_size_c4(iga, monkeypatch):
+    """BASELINE config 4 at full size (3D p=4, 128^3 spans, 1.59 G nonzeros), memory-light: the values come
+    back without the index arrays; row sums vanish (K 1 = 0), sampled rows agree with the entry-wise kernel,
+    sampled entry pairs are exactly symmetric, nothing is left unwritten."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(4, 0., 1., 128)
+    kvs = (kv, kv, kv)
+    asm = iga.assemblers.StiffnessAssembler3D(kvs, _geo(iga, 'cylinder'))
+    assert asm.patch.nnz == 1593413632
+    data = asm.patch.assemble('stiffness', algo='sumfact', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 2
+    assert not np.isnan(data).any()
+    n = asm.patch.shape[0]
+    rows = np.arange(n, dtype=np.int64)
+    _, indptr = _positions(kvs, rows, rows)
+    assert indptr[0] == 0 and np.all(np.diff(indptr) > 0)
+    scale = np.abs(data).max()
+    rowsum = np.add.reduceat(data, indptr)
+    assert np.abs(rowsum).max() <= 1e-10 * scale
+    rng = np.random.default_rng(7)
+    sample = np.unique(np.concatenate(([0, n - 1, n // 2], rng.integers(0, n, 60))))
+    S = iga.assemble.assemble_partial_rows(asm, sample)          # entry-wise kernel, 60 rows
+    for r in sample:
+        lo = indptr[r]
+        ref = S.data[S.indptr[r]:S.indptr[r + 1]]
+        assert np.abs(data[lo:lo + ref.size] - ref).max() <= RTOL * scale
+        cols = S.indices[S.indptr[r]:S.indptr[r + 1]].astype(np.int64)
+        pos_t, _ = _positions(kvs, cols, np.full_like(cols, r))
+        assert np.array_equal(data[pos_t], data[lo:lo + ref.size])      # A[J, I] == A[I, J] bit for bit
