@@ -337,3 +337,21 @@ def mass(kvs, geo=None, format='csr'):
 def stiffness(kvs, geo=None, format='csr'):
     """Stiffness matrix for a (tensor product) B-spline basis with an optional geometry map."""
     return _convenience('stiffness', kvs, geo, format)
+
+
+################################################################################
+# Low-rank "fast" variants (pyiga/assemble.py:1063-1101)
+################################################################################
+
+def mass_fast(kvs, geo=None, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=2):
+    """Signature of the reference's low-rank (adaptive cross approximation) mass assembler
+    (pyiga/assemble.py:1063-1081, pyiga/fastasm.cc).  The ACA algorithm exists to avoid most of the
+    entry-wise quadrature sums on a CPU; on the device the exact sum-factorised assembly costs less than
+    the entry sampling ACA needs, so this returns the exact matrix -- inside any `tol` by construction.
+    The approximation parameters are accepted and ignored."""
+    return mass(kvs, geo)
+
+
+def stiffness_fast(kvs, geo=None, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=2):
+    """See :func:`mass_fast` (pyiga/assemble.py:1083-1101)."""
+    return stiffness(kvs, geo)

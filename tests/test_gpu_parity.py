@@ -753,3 +753,37 @@ def test_full_size_c4(iga, monkeypatch):
         cols = S.indices[S.indptr[r]:S.indptr[r + 1]].astype(np.int64)
         pos_t, _ = _positions(kvs, cols, np.full_like(cols, r))
         assert np.array_equal(data[pos_t], data[lo:lo + ref.size])      # A[J, I] == A[I, J] bit for bit
+
+
+def test_fast_variants_match_fixtures(iga):
+    """test/test_assemble.py:187-217: the low-rank entry points against the bundled fixtures (their tolerance
+    there is 1e-9; the exact device path meets the 1e-14 of the exact tests)."""
+    kv = iga.bspline.make_knots(3, 0.0, 1.0, 15)
+    geo = iga.geometry.bspline_quarter_annulus()
+    M_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d2_p3_n15_mass.mtx.gz'))
+    A_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d2_p3_n15_stiff.mtx.gz'))
+    assert abs(iga.assemble.mass_fast((kv, kv), geo, verbose=0) - M_ref).max() < 1e-14
+    assert abs(iga.assemble.stiffness_fast((kv, kv), geo, verbose=0) - A_ref).max() < 1e-14
+    assert abs(iga.assemble.mass_fast((kv, kv)) - iga.assemble.mass((kv, kv))).max() == 0.0
+
+
+def test_full_size_c5(iga, monkeypatch):
+    """BASELINE config 5 at full size (3D p=5 n=96 convection-diffusion form, 1.26 G nonzeros), memory-light:
+    every row sums to zero (a(1, v) = 0), sampled rows agree with the entry-wise kernel, nothing unwritten."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(5, 0., 1., 96)
+    kvs = (kv, kv, kv)
+    asm = iga.assemblers.ConvDiffAssembler3D(kvs, _geo(iga, 'cylinder'), lambda x, y, z: 1.0 + x)
+    assert asm.patch.nnz == 1263214441
+    data = asm.patch.assemble('convdiff', algo='sumfact', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 2 and not np.isnan(data).any()
+    n = asm.patch.shape[0]
+    rows = np.arange(n, dtype=np.int64)
+    _, indptr = _positions(kvs, rows, rows)
+    scale = np.abs(data).max()
+    assert np.abs(np.add.reduceat(data, indptr)).max() <= 1e-10 * scale
+    sample = np.unique(np.concatenate(([0, n - 1], np.random.default_rng(11).integers(0, n, 12))))
+    S = iga.assemble.assemble_partial_rows(asm, sample)
+    for r in sample:
+        ref = S.data[S.indptr[r]:S.indptr[r + 1]]
+        assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
