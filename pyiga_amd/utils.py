@@ -1,46 +1,41 @@
-"""Small helpers mirrored from pyiga/utils.py."""
+"""Host-side helpers with the names and behaviour of the few ``pyiga.utils`` functions this path uses
+(pyiga/utils.py:8-60): sampling a function on a tensor grid and reading the test fixtures."""
 import numpy as np
 import scipy.sparse
 
 
 def read_sparse_matrix(fname):
-    """Read the reference's text fixture format (pyiga/utils.py:54-60): first line skipped,
-    then 1-based ``i j value`` triples."""
-    I, J, vals = np.loadtxt(fname, skiprows=1, unpack=True)
-    I = I.astype(int) - 1
-    J = J.astype(int) - 1
-    return scipy.sparse.coo_matrix((vals, (I, J))).tocsr()
+    """Reference fixture format: a header line, then 1-based ``row col value`` triples; returns CSR."""
+    triples = np.loadtxt(fname, skiprows=1)
+    r = triples[:, 0].astype(np.int64) - 1
+    c = triples[:, 1].astype(np.int64) - 1
+    return scipy.sparse.coo_matrix((triples[:, 2], (r, c))).tocsr()
 
 
-def _broadcast_to_grid(X, grid_shape):
-    X = np.asanyarray(X)
-    target_shape = grid_shape + X.shape[len(grid_shape):]
-    if X.shape != target_shape:
-        X = np.broadcast_to(X, target_shape)
-    return X
-
-
-def _ensure_grid_shape(values, grid):
-    """Tuples become a trailing component axis; results that ignore some arguments are broadcast to
-    the full grid (pyiga/utils.py:17-31)."""
-    grid_shape = tuple(len(g) for g in grid)
+def _on_grid(values, shape):
+    """Array of grid samples ``shape + component axes`` from whatever a user function returned: a scalar, an
+    array that is missing the axes of arguments the function ignored, or a tuple of those (vector-valued)."""
     if isinstance(values, tuple):
-        values = np.stack(tuple(_broadcast_to_grid(v, grid_shape) for v in values), axis=-1)
-    return _broadcast_to_grid(values, grid_shape)
+        comps = [np.broadcast_to(np.asanyarray(c), shape) for c in values]
+        return np.stack(comps, axis=-1)
+    values = np.asanyarray(values)
+    trailing = values.shape[len(shape):]
+    return values if values.shape == shape + trailing else np.broadcast_to(values, shape + trailing)
 
 
 def grid_eval(f, grid):
-    """Evaluate `f` over the tensor grid `grid` (axes in (z, y, x) order; `f` takes (x, y, z)).
-    pyiga/utils.py:33-41."""
+    """Samples of `f` on the tensor grid `grid` (axes in (z, y, x) order).  Spline-like objects evaluate
+    themselves; plain callables take the coordinates as ``f(x, y[, z])`` -- last grid axis first."""
     if hasattr(f, 'grid_eval'):
         return f.grid_eval(grid)
-    mesh = list(np.meshgrid(*grid, sparse=True, indexing='ij'))
-    mesh.reverse()
-    return _ensure_grid_shape(f(*mesh), grid)
+    shape = tuple(len(ax) for ax in grid)
+    d = len(grid)
+    coords = [np.asarray(ax).reshape((1,) * k + (-1,) + (1,) * (d - 1 - k)) for k, ax in enumerate(grid)]
+    return _on_grid(f(*coords[::-1]), shape)
 
 
 def grid_eval_transformed(f, grid, geo):
-    """Evaluate `f` at the images of the grid points under `geo` (pyiga/utils.py:43-52)."""
-    trf_grid = grid_eval(geo, grid)
-    X = tuple(trf_grid[..., i] for i in range(trf_grid.shape[-1]))
-    return _ensure_grid_shape(f(*X), grid)
+    """Samples of `f` at the images of the grid points under the geometry map `geo`."""
+    shape = tuple(len(ax) for ax in grid)
+    pts = grid_eval(geo, grid)                       # shape + (dim,)
+    return _on_grid(f(*np.moveaxis(pts, -1, 0)), shape)
