@@ -1,0 +1,106 @@
+"""CPU tests of the form-string front-end (pyiga_amd/forms.py): pure host logic, no device.
+
+Every string of the golden set must evaluate to exactly the coefficient table written out by hand in
+conftest.py (the tables the oracle is pinned with), and unsupported constructs must be refused."""
+import numpy as np
+import pytest
+
+from conftest import FORMS, form_inputs, form_tables, form2d_cases
+
+
+@pytest.fixture(scope='module')
+def forms():
+    from pyiga_amd import forms
+    return forms
+
+
+def _eval_table(table, X):
+    d = X.shape[-1]
+    G = X.shape[:-1]
+    out = [[None] * (d + 1) for _ in range(d + 1)]
+    for r in range(d + 1):
+        for s in range(d + 1):
+            e = table[r][s]
+            if e is not None:
+                out[r][s] = np.broadcast_to(e(*(X[..., k] for k in range(d))) if callable(e) else e, G)
+    return out
+
+
+def _same(T, H):
+    for r in range(len(H)):
+        for s in range(len(H)):
+            if H[r][s] is None or not np.any(H[r][s]):
+                assert T[r][s] is None, (r, s)
+            else:
+                assert T[r][s] is not None, (r, s)
+                assert np.abs(T[r][s] - H[r][s]).max() <= 1e-15 * max(1.0, np.abs(H[r][s]).max()), (r, s)
+
+
+def test_strings_give_the_hand_written_tables_3d(forms):
+    G = (4, 3, 5)
+    X = np.random.default_rng(0).random(G + (3,)) + 0.5
+    inp = form_inputs()
+    tables = form_tables()
+    for name, (expr, names) in FORMS.items():
+        T = forms.coefficient_table(expr, G, X, {k: inp[k] for k in names})
+        _same(T, _eval_table(tables[name], X))
+        assert forms.arity(expr) == 2
+
+
+def test_strings_give_the_hand_written_tables_2d(forms):
+    G = (6, 4)
+    X = np.random.default_rng(1).random(G + (2,)) + 0.5
+    for name, (expr, inputs, table) in form2d_cases().items():
+        _same(forms.coefficient_table(expr, G, X, inputs), _eval_table(table, X))
+
+
+def test_builtin_strings(forms):
+    G = (3, 3, 3)
+    X = np.random.default_rng(2).random(G + (3,))
+    T = forms.coefficient_table('inner(grad(u), grad(v)) * dx', G, X, {})
+    assert all((T[r][s] is not None) == (r == s and r > 0) for r in range(4) for s in range(4))
+    assert all(np.all(T[k][k] == 1.0) for k in (1, 2, 3))
+    T = forms.coefficient_table('u * v * dx', G, X, {})
+    assert T[0][0] is not None and np.all(T[0][0] == 1.0) and sum(e is not None for row in T for e in row) == 1
+    # the form of BASELINE config 5
+    cd = '(inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx'
+    T = forms.coefficient_table(cd, G, X, dict(diff_coeff=lambda x, y, z: 1.0 + x))
+    assert np.array_equal(T[0][1], X[..., 1]) and np.array_equal(T[0][2], -X[..., 0]) and np.all(T[0][3] == 1.0)
+    assert all(np.array_equal(T[k][k], 1.0 + X[..., 0]) for k in (1, 2, 3)) and T[0][0] is None and T[1][0] is None
+    # constants, parameters, algebra
+    T = forms.coefficient_table('(a * u * v - u * v / 4 + 2 * (u * v)) * dx', G, X, dict(a=3.0))
+    assert np.allclose(T[0][0], 3.0 - 0.25 + 2.0)
+    T = forms.coefficient_table('inner(dot(K, grad(u)), grad(v)) * dx', G, X, dict(K=np.diag([1.0, 2.0, 3.0])))
+    assert all(np.all(T[k][k] == k) for k in (1, 2, 3)) and T[1][2] is None
+
+
+def test_functionals(forms):
+    G = (5, 4)
+    X = np.random.default_rng(3).random(G + (2,))
+    f = lambda x, y: x * y ** 2
+    assert np.array_equal(forms.functional_coefficient('f * v * dx', G, X, dict(f=f)), f(X[..., 0], X[..., 1]))
+    F = forms.functional_coefficient('(2 * f + x[0]) * v * dx', G, X, dict(f=f))
+    assert np.allclose(F, 2 * f(X[..., 0], X[..., 1]) + X[..., 0], rtol=0, atol=1e-15)
+    assert forms.arity('f * v * dx') == 1
+    with pytest.raises(NotImplementedError):
+        forms.functional_coefficient('inner((1.0, 2.0), grad(v)) * dx', G, X, {})
+
+
+@pytest.mark.parametrize('bad', ['u * v', 'inner(grad(u), grad(u)) * dx', 'inner(grad(u), grad(v)) * u * dx',
+                                 'u * dx(v) * dx', 'grad(u) * grad(v) * dx', 'inner(grad(u), v) * dx',
+                                 'grad(c * u) * dx'])
+def test_unsupported_forms_are_refused(forms, bad):
+    G = (3, 3, 3)
+    X = np.random.default_rng(4).random(G + (3,))
+    with pytest.raises(NotImplementedError):
+        forms.arity(bad)
+        forms.coefficient_table(bad, G, X, dict(c=lambda x, y, z: x))
+
+
+def test_unknown_names(forms):
+    G = (2, 2, 2)
+    X = np.zeros(G + (3,))
+    with pytest.raises(ValueError):
+        forms.coefficient_table('q * u * v * dx', G, X, {})
+    with pytest.raises(ValueError):
+        forms.arity('f * dx')
