@@ -242,7 +242,7 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
 
 // ---------------------------------------------------------------------------------------------
 // geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
-template <int DIM>
+template <int DIM, bool FORM>
 __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, const double *coeff, const FormView fv, const PatchDev pd, int kind,
                              const double *w0, const double *w1, const double *w2,
                              int g0_lo, int G0loc, int G1, int G2, double *fields)
@@ -266,7 +266,8 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
     }
     double GW = w0[g[0]] * w1[g[1]];
     if (DIM == 3) GW = GW * w2[g[2]];
-    if (kind == IGX_FORM) fields_form<DIM>(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
+    // FORM is a separate instantiation: its 4x4 products would cost the other kinds a third of their occupancy
+    if (FORM) fields_form<DIM>(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
     else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
     else fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
@@ -277,7 +278,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
 // in LDS, then each thread evaluates its point with only (pL+1) * ncomp * (DIM+1) FMAs.
 // (The per-point kernel above costs prod(p_k+1) * ncomp * (DIM+1) FMAs and is memory-latency bound
 // on the control-net gathers.)
-template <int DIM, int NC>
+template <int DIM, int NC, bool FORM>
 __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs, int kind, const double *coeff, const FormView fv, const PatchDev pd,
                                                           const double *w0, const double *w1, const double *w2,
                                                           int g0_lo, int G0loc, int G1, int G2, int LPB, double *fields)
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         else { g0 = g0_lo + (int)line; g1 = gL; }
         double GW = w0[g0] * w1[g1];
         if (DIM == 3) GW = GW * w2[gL];
-        if (kind == IGX_FORM) fields_form<DIM>(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
+        if (FORM) fields_form<DIM>(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
         else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
         else fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
     }
@@ -389,24 +390,22 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
             const long long nlines = total / LN;
             dim3 grid((unsigned)((nlines + LPB - 1) / LPB)), block(256);
             const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
-            if (dim == 2) {
-                if (nurbs) k_geo_fields_lines<2, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
-                else k_geo_fields_lines<2, 2><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, nullptr, pd.g0_lo, pd.G0_loc, G1, 1, LPB, d_fields);
-            } else {
-                if (nurbs) k_geo_fields_lines<3, 4><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
-                else k_geo_fields_lines<3, 3><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields);
-            }
+#define LAUNCH_LINES(D_, NC_) do { \
+                if (kind == IGX_FORM) k_geo_fields_lines<D_, NC_, true><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, D_ == 3 ? pd.ax[2].w : nullptr, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields); \
+                else k_geo_fields_lines<D_, NC_, false><<<grid, block, lds, st>>>(gv, nurbs, kind, pt->d_coeff, fv, pd, pd.ax[0].w, pd.ax[1].w, D_ == 3 ? pd.ax[2].w : nullptr, pd.g0_lo, pd.G0_loc, G1, G2, LPB, d_fields); } while (0)
+            if (dim == 2) { if (nurbs) LAUNCH_LINES(2, 3); else LAUNCH_LINES(2, 2); }
+            else { if (nurbs) LAUNCH_LINES(3, 4); else LAUNCH_LINES(3, 3); }
+#undef LAUNCH_LINES
             IGX_HIP(hipGetLastError());
             return IGX_OK;
         }
     }
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
-    if (dim == 2)
-        k_geo_fields<2><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, fv, pd, kind, pd.ax[0].w, pd.ax[1].w, nullptr,
-                                                pd.g0_lo, pd.G0_loc, G1, 1, d_fields);
-    else
-        k_geo_fields<3><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, fv, pd, kind, pd.ax[0].w, pd.ax[1].w, pd.ax[2].w,
-                                                pd.g0_lo, pd.G0_loc, G1, G2, d_fields);
+#define LAUNCH_PTS(D_, F_) k_geo_fields<D_, F_><<<grid, block, 0, st>>>(gv, pt->geo_kind, pt->d_jac, pt->d_coeff, fv, pd, kind, pd.ax[0].w, pd.ax[1].w, \
+                                                                    D_ == 3 ? pd.ax[2].w : nullptr, pd.g0_lo, pd.G0_loc, G1, G2, d_fields)
+    if (dim == 2) { if (kind == IGX_FORM) LAUNCH_PTS(2, true); else LAUNCH_PTS(2, false); }
+    else { if (kind == IGX_FORM) LAUNCH_PTS(3, true); else LAUNCH_PTS(3, false); }
+#undef LAUNCH_PTS
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }
