@@ -336,8 +336,8 @@ def test_row_slabs_equal_full(iga, d, p, n, G, algo, monkeypatch):
 
 
 def test_final_stage_variants_agree(iga, monkeypatch):
-    """The matrix-core (MFMA) final stage and the VALU final stage give the same matrix; the MFMA
-    one mirrors too, so both are exactly symmetric."""
+    """The three final-stage kernels (quadrature-lane: default where it applies; LDS-table VALU; matrix-core)
+    give the same matrix, each exactly symmetric."""
     monkeypatch.setenv('IGX_DEBUG_POISON', '1')
     mk = iga.bspline.make_knots
     cases = [((mk(2, 0., 1., 10),) * 3, 'twisted_box'), ((mk(4, 0., 1., 5),) * 3, 'cylinder'),
@@ -346,7 +346,7 @@ def test_final_stage_variants_agree(iga, monkeypatch):
     for kvs, gname in cases:
         for kind in ('mass', 'stiffness'):
             out = {}
-            for sel in ('valu', 'mfma'):
+            for sel in ('q', 'valu', 'mfma'):
                 monkeypatch.setenv('IGX_FINAL', sel)
                 patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
                 out[sel] = patch.csr(kind, algo='sumfact')
@@ -354,6 +354,7 @@ def test_final_stage_variants_agree(iga, monkeypatch):
                 assert not np.isnan(out[sel].data).any()
                 assert abs(out[sel] - out[sel].T).max() == 0.0
             assert rel_maxdiff(out['mfma'], out['valu']) <= 1e-14
+            assert rel_maxdiff(out['q'], out['valu']) <= 1e-14
     monkeypatch.delenv('IGX_FINAL')
 
 
