@@ -1330,7 +1330,8 @@ static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sy
     if (sym) {
         if (qeq) k_stageA<P, P, true><<<grid, block, lds, st>>>(A);
         else k_stageA<P, 0, true><<<grid, block, lds, st>>>(A);
-    } else k_stageA<P, 0, false><<<grid, block, lds, st>>>(A);     // full pair window: run-time q keeps the registers down
+    } else if (qeq) k_stageA<P, P, false><<<grid, block, lds, st>>>(A);   // measured: compile-time q wins for every p (p=5: 16.8 -> 11.0 ms at C5)
+    else k_stageA<P, 0, false><<<grid, block, lds, st>>>(A);
 }
 
 template <int P>
