@@ -737,7 +737,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int P, int NY>
-__global__ void __launch_bounds__(64 * FINALQ_WAVES) k_final_q(const double *__restrict__ K, double *__restrict__ data, const FinalQArgs F)
+__global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves_per_eu(2))) k_final_q(const double *__restrict__ K, double *__restrict__ data, const FinalQArgs F)
 {
     constexpr int W = 2 * P - 1, R = 64 / P, NJ = R + 2 * (P - 1);
     constexpr int NIT_D = (R * W + 63) / 64, NIT_M = (NJ * W + 63) / 64;
