@@ -788,3 +788,18 @@ def test_full_size_c5(iga, monkeypatch):
     for r in sample:
         ref = S.data[S.indptr[r]:S.indptr[r + 1]]
         assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
+
+
+def test_repeatability(iga):
+    """Race hunt: the final stage waits on its LDS-DMA queue with counted vmcnt and exchanges sums between waves
+    through LDS; an under-wait would show up as run-to-run differences.  40 repetitions, bit-identical values
+    (tools/scratch/stress.py runs hundreds, up to the full C4 size)."""
+    import hashlib
+    mk = iga.bspline.make_knots
+    for kvs, gname, kind in (((mk(4, 0., 1., 14),) * 3, 'cylinder', 'stiffness'),
+                             ((mk(2, 0., 1., 30), mk(3, 0., 1., 11), mk(2, 0., 1., 19)), 'twisted_box', 'mass'),
+                             ((mk(3, 0., 1., 200), mk(3, 0., 1., 150)), 'quarter_annulus', 'stiffness')):
+        patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
+        hashes = {hashlib.sha1(patch.assemble(kind, algo='sumfact', to_host=True).tobytes()).hexdigest() for _ in range(40)}
+        patch.close()
+        assert len(hashes) == 1
