@@ -727,6 +727,9 @@ struct FinalQArgs {
 constexpr int FINALQ_WAVES = IGX_Q_WAVES; // adjacent row chunks per block
 constexpr int FINALQ_DEPTH = IGX_Q_DEPTH; // K lines in flight per wave (LDS-DMA)
 constexpr int FINALQ_KWIN = 96;         // doubles per staged K window: >= (64/P + P - 1) * P for P = 2..6, 3 DMA pieces
+#ifndef IGX_Q_NT
+#define IGX_Q_NT 0        // aux bits of the K-window DMA (2 = nt: streaming, do not keep in L2)
+#endif
 #ifndef IGX_Q_DBG
 #define IGX_Q_DBG 0      // compile-time ablation mask (1: no stores, 2: no K loads after the first, 4: no mirror)
 #endif
@@ -849,7 +852,7 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
         for (int y = 0; y < NY; ++y)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                __builtin_amdgcn_global_load_lds((gmem_ptr)(src + y * ystride * 8 + c * 256), (lds_ptr)(dst + y * KWIN + c * 32), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gmem_ptr)(src + y * ystride * 8 + c * 256), (lds_ptr)(dst + y * KWIN + c * 32), 4, 0, IGX_Q_NT);
     };
     auto do_line = [&](const LineDesc &D_, const int slot, double *out_s) {
         const double *ks = kslot + slot * (NY * KWIN) + koff;
