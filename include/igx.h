@@ -183,6 +183,11 @@ int igx_entries(igx_patch *patch, int kind, const size_t *ij, size_t M, double *
    grid_eval_transformed(f, gaussgrid, geo); out: (row0_hi-row0_lo) x N1 [x N2] doubles (host). */
 int igx_load_vector(igx_patch *patch, const double *fvals, double *out);
 
+/* Linear functional in the first-order jet of v:  out[i] = integral of  sum_r F_r(x) D_r v_i  dx  (D_0 = id, D_1.. =
+   physical derivatives).  coef[r]: F_r on the FULL tensor Gauss grid (host) or NULL.  Arity-1 form strings such as
+   'inner(b, grad(v)) * dx' (pyiga/assemble.py:837-897).  Replaces the IGX_FORM coefficients of the patch. */
+int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *out);
+
 /* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */
 int igx_fields(igx_patch *patch, int kind, double *out, int64_t *shape4);

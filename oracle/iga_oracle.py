@@ -657,6 +657,32 @@ def inner_products(kvs, f, f_physical=False, geo=None):
     return apply_tprod_dense(Ct, fvals)
 
 
+def load_vector_jet(kvs, geo, jet):
+    """Load vector of a functional in the first-order jet of v,  sum_r F_r D_r v  (D_0 = id, D_1.. physical
+    derivatives), the way the reference's generated arity-1 assembler evaluates it: physical gradient of the
+    basis function through JacInv, times the coefficients, times W, summed over the Gauss grid.
+    jet: list of d+1 functions of the physical coordinates (or constants / None)."""
+    kvs = tuple(kvs)
+    d = len(kvs)
+    nqp = max(kv.p for kv in kvs) + 1
+    grid, gw = make_tensor_quadrature([kv.mesh for kv in kvs], nqp)
+    X = grid_eval(geo, grid)
+    G = X.shape[:-1]
+    F = [np.zeros(G) if e is None else np.broadcast_to(e(*(X[..., k] for k in range(d))) if callable(e) else e, G) for e in jet]
+    jac = grid_jacobian(geo, grid)
+    W = np.abs(np.linalg.det(jac))
+    for k, w in enumerate(gw):
+        W = W * w.reshape((1,) * k + (-1,) + (1,) * (d - 1 - k))
+    JI = np.linalg.inv(jac)                       # [param (x, y, z order)][physical]
+    C = [collocation_derivs_dense(kv, g, 1) for kv, g in zip(kvs, grid)]
+    out = apply_tprod_dense([c[0].T for c in C], F[0] * W)
+    for a in range(d):                            # parametric direction a (x first) <-> grid axis d-1-a
+        Ga = W * sum(JI[..., a, r] * F[1 + r] for r in range(d))
+        ops = [C[ax][1 if ax == d - 1 - a else 0].T for ax in range(d)]
+        out = out + apply_tprod_dense(ops, Ga)
+    return out
+
+
 def bsp_mixed_deriv_biform_1d(knotvec, du, dv):
     nspans = knotvec.numspans
     nqp = int(math.ceil((2 * knotvec.p - du - dv + 1) / 2.0))

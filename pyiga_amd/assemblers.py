@@ -201,6 +201,22 @@ class DevicePatch:
             raise ValueError('the form has no non-zero coefficient')
         _lib.check(_lib.load().igx_patch_set_form(self.handle, ptrs), 'igx_patch_set_form')
 
+    def load_vector_jet(self, jet):
+        """Load vector of  sum_r F_r D_r v  (jet[0]: coefficient of v, jet[1..d]: of its physical derivatives;
+        arrays on the full Gauss grid or None)."""
+        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        keep, ptrs = [], (_lib._dp * 4)()
+        for r, e in enumerate(jet):
+            if e is not None:
+                arr = _lib.f64(np.broadcast_to(e, G))
+                keep.append(arr)
+                ptrs[r] = _lib.dptr(arr)
+        lo, hi = int(self.info.row_lo), int(self.info.row_hi)
+        nd = self.ndofs
+        out = np.empty(((hi - lo) // int(np.prod(nd[1:])),) + nd[1:])
+        _lib.check(_lib.load().igx_load_vector_jet(self.handle, ptrs, _lib.dptr(out)), 'igx_load_vector_jet')
+        return out
+
     def gauss(self, axis):
         n = self.info.ngauss[axis]
         nodes, weights = np.empty(n), np.empty(n)
@@ -410,8 +426,10 @@ class _FunctionalAssembler:
 
 
 class _FormFunctionalAssembler(_FunctionalAssembler):
-    """Linear functional given as a form string ``F * v * dx`` (pyiga/assemble.py:837-897 with arity 1): the
-    integrand F (inputs, ``x``, numbers) is evaluated on the Gauss grid by ``pyiga_amd.forms``."""
+    """Linear functional given as a form string, e.g. ``'f * v * dx'`` or ``'(f * v + inner(b, grad(v))) * dx'``
+    (pyiga/assemble.py:837-897 with arity 1): the coefficients of v and grad(v) (inputs, ``x``, numbers) are
+    evaluated on the Gauss grid by ``pyiga_amd.forms``; weights, the Jacobian transformation and the sums
+    run on the device."""
     _physical = True
 
     def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
@@ -419,7 +437,15 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
         super().__init__(kvs0, geo, lambda *xyz: 0.0, device=device, row0=row0)
         G = tuple(len(g) for g in self.gaussgrid)
         X = np.asarray(geo.grid_eval(list(self.gaussgrid)))
-        self._fvals = forms.functional_coefficient(form, G, X, dict(inputs or {}))
+        self._jet = forms.functional_jet(form, G, X, dict(inputs or {}))
+
+    def assemble_vector(self):
+        if self._vector is None:
+            if all(e is None for e in self._jet[1:]):
+                self._vector = self.patch.load_vector(self._jet[0] if self._jet[0] is not None else np.zeros(1))
+            else:
+                self._vector = self.patch.load_vector_jet(self._jet)
+        return self._vector.copy()
 
 
 class GeneralFunctionalAssembler2D(_FormFunctionalAssembler):

@@ -659,4 +659,48 @@ int igx_load_vector(igx_patch *pt, const double *fvals, double *out)
     return rc;
 }
 
+int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
+{
+    if (!pt || !coef || !out) { set_error("igx_load_vector_jet: null argument"); return IGX_ERR_ARG; }
+    const int dim = pt->dim;
+    for (int r = dim + 1; r < 4; ++r)
+        if (coef[r]) { set_error("igx_load_vector_jet: coefficient %d does not exist in %dD", r, dim); return IGX_ERR_ARG; }
+    // the linear functional  sum_r F_r D_r v  is column 0 of a jet form: its parametric coefficients
+    // G_a = W * sum_r T[a][r] F_r come out of the same field kernel (fields_form)
+    const double *table[16];
+    for (int k = 0; k < 16; ++k) table[k] = nullptr;
+    bool any = false;
+    for (int r = 0; r < 4; ++r) { table[4 * r] = coef[r]; any = any || coef[r]; }
+    if (!any) { set_error("igx_load_vector_jet: all coefficients are absent"); return IGX_ERR_ARG; }
+    int rc = igx_patch_set_form(pt, table);
+    if (rc) return rc;
+    rc = ensure_fields(pt, IGX_FORM);
+    if (rc) return rc;
+    hipStream_t st = pt->ctx->stream;
+    const PatchDev &pd = pt->dev;
+    const size_t npts = (size_t)pd.npts_loc;
+    const size_t N1 = pt->ax[1].N, N2 = dim == 3 ? pt->ax[2].N : 1, G1 = pt->ax[1].G;
+    const size_t n_out = (size_t)(pt->r0_hi - pt->r0_lo) * N1 * N2;
+    const size_t n_t1 = dim == 3 ? (size_t)pd.G0_loc * G1 * N2 : (size_t)pd.G0_loc * N1;
+    const size_t n_t2 = dim == 3 ? (size_t)pd.G0_loc * N1 * N2 : 1;
+    double *d_t1 = nullptr, *d_t2 = nullptr, *d_o = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_t1); (void)hipFree(d_t2); (void)hipFree(d_o); };
+    if (hipMalloc((void **)&d_t1, n_t1 * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_t2, n_t2 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_o, std::max<size_t>(1, n_out) * sizeof(double)) != hipSuccess) {
+        cleanup();
+        set_error("igx_load_vector_jet: hipMalloc of the workspace failed");
+        return IGX_ERR_NOMEM;
+    }
+    for (int k = 0; k < pd.form_n && rc == IGX_OK; ++k) {
+        const int a = pd.form_ab[k] >> 2;                  // jet index of v; derivative a >= 1 acts on grid axis dim - a
+        rc = launch_load_vector(st, pt, pt->d_fields + (size_t)k * npts, nullptr, d_o, d_t1, d_t2, a >= 1 ? dim - a : -1, k > 0);
+    }
+    hipError_t e = hipSuccess;
+    if (rc == IGX_OK) e = hipMemcpyAsync(out, d_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) { set_error("igx_load_vector_jet: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+    return rc;
+}
+
 } // extern "C"

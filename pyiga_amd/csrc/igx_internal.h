@@ -160,7 +160,7 @@ int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
-                       double *d_t1, double *d_t2);
+                       double *d_t1, double *d_t2, int deriv_axis = -1, int accumulate = 0);
 inline int igx_num_fields(int dim, int kind, int form_n = 0)
 {
     return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : (kind == IGX_FORM ? form_n : dim * (dim + 1) / 2));

@@ -15,7 +15,8 @@ namespace igx {
 template <bool WEIGHT>
 __global__ void __launch_bounds__(256) k_contract_axis(const double *__restrict__ in, const double *__restrict__ wfield,
                                                        double *__restrict__ out, const AxisDev ax,
-                                                       long long A, long long B, int i_lo, int i_hi, int g_off)
+                                                       long long A, long long B, int i_lo, int i_hi, int g_off,
+                                                       int deriv, int accumulate)
 {
     const int Nout = i_hi - i_lo;
     const long long total = A * Nout * B;
@@ -37,16 +38,19 @@ __global__ void __launch_bounds__(256) k_contract_axis(const double *__restrict_
             const long long idx = (a * Gin + (g - g_off)) * B + b;
             double v = in[idx];
             if (WEIGHT) v *= wfield[idx];
-            r = fma(ax.V[((size_t)g * P + aloc) * 2], v, r);
+            r = fma(ax.V[((size_t)g * P + aloc) * 2 + deriv], v, r);      // deriv = 1: derivative of the basis function
         }
     }
-    out[(a * Nout + (i - i_lo)) * B + b] = r;
+    double *dst = out + (a * Nout + (i - i_lo)) * B + b;
+    *dst = accumulate ? *dst + r : r;
 }
 
 // d_f: function values on the RESIDENT Gauss slab (G0_loc x G1 [x G2]); d_W: mass field on the same slab;
 // d_out: (r0_hi - r0_lo) x N1 [x N2]; tmp1/tmp2: workspaces (sizes below)
+// deriv_axis: grid axis whose basis functions are differentiated (-1: none); accumulate: add to d_out;
+// d_W == nullptr: d_f already contains the weights
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
-                       double *d_t1, double *d_t2)
+                       double *d_t1, double *d_t2, int deriv_axis, int accumulate)
 {
     const PatchDev &pd = pt->dev;
     const int dim = pd.dim;
@@ -59,30 +63,32 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
         // [G0,G1,G2] -> [G0,G1,N2]
         {
             const long long A = G0 * a1.G, n = A * a2.N;
-            k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a2, A, 1, 0, a2.N, 0);
+            if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a2, A, 1, 0, a2.N, 0, deriv_axis == 2, 0);
+            else k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_f, nullptr, d_t1, a2, A, 1, 0, a2.N, 0, deriv_axis == 2, 0);
         }
         // [G0,G1,N2] -> [G0,N1,N2]
         {
             const long long n = G0 * a1.N * a2.N;
-            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t1, nullptr, d_t2, a1, G0, a2.N, 0, a1.N, 0);
+            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t1, nullptr, d_t2, a1, G0, a2.N, 0, a1.N, 0, deriv_axis == 1, 0);
         }
         // [G0,N1,N2] -> [n0,N1,N2]   (axis 0: only the owned dof planes; the slab starts at Gauss index g0_lo)
         {
             const long long B = (long long)a1.N * a2.N, n = (long long)n0 * B;
             AxisDev ax0 = a0;
             ax0.G = (int)G0;
-            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo);
+            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv_axis == 0, accumulate);
         }
     } else {
         {
             const long long n = G0 * a1.N;
-            k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a1, G0, 1, 0, a1.N, 0);
+            if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a1, G0, 1, 0, a1.N, 0, deriv_axis == 1, 0);
+            else k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_f, nullptr, d_t1, a1, G0, 1, 0, a1.N, 0, deriv_axis == 1, 0);
         }
         {
             const long long B = a1.N, n = (long long)n0 * B;
             AxisDev ax0 = a0;
             ax0.G = (int)G0;
-            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t1, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo);
+            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t1, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv_axis == 0, accumulate);
         }
     }
     IGX_HIP(hipGetLastError());

@@ -327,9 +327,9 @@ def coefficient_table(expr, G, X, inputs):
     return table
 
 
-def functional_coefficient(expr, G, X, inputs):
-    """Evaluate an arity-1 form string ``F * v * dx``; returns the array F on the grid (shape G).
-    Integrands with derivatives of v are not supported."""
+def functional_jet(expr, G, X, inputs):
+    """Evaluate an arity-1 form string ``(F0 * v + inner(F, grad(v))) * dx``; returns the list
+    ``[F0, F_1, ..., F_d]`` of coefficient arrays on the grid (shape G) or None."""
     ns = make_namespace(G, X, inputs)
     ns.pop('u')
     try:
@@ -338,9 +338,18 @@ def functional_coefficient(expr, G, X, inputs):
         raise ValueError('unknown name in the form: %s' % e)
     if not isinstance(res, _Functional) or res.lin.who != 'v':
         raise NotImplementedError('the form must be a volume integral (... * dx) that is linear in v')
-    if res.lin.w is not None and np.any(res.lin.w != 0.0):
-        raise NotImplementedError('linear functionals with derivatives of v are not supported')
-    return np.ascontiguousarray(np.broadcast_to(res.lin.s, G), dtype=float)
+    out = []
+    for e in _jet(res.lin):
+        out.append(None if e is None or not np.any(e != 0.0) else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float))
+    return out
+
+
+def functional_coefficient(expr, G, X, inputs):
+    """Value coefficient of an arity-1 form string ``F * v * dx`` (no derivatives of v allowed)."""
+    jet = functional_jet(expr, G, X, inputs)
+    if any(e is not None for e in jet[1:]):
+        raise NotImplementedError('this functional contains derivatives of v: use functional_jet')
+    return jet[0] if jet[0] is not None else np.zeros(G)
 
 
 def arity(expr):

@@ -412,6 +412,10 @@ def golden_forms():
     out['func_d2'] = assemble.assemble('f * v * dx', kv2, geo=geometry.quarter_annulus(), f=lambda x, y: x * y ** 2)
     out['func_d3'] = assemble.assemble('(2 * f + x[0]) * v * dx', spaces['cyl_p2'][0], geo=cyl,
                                        f=lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z))
+    # arity-1 forms with derivatives of v
+    out['funcgrad_d2'] = assemble.assemble('(f * v + inner(b, grad(v))) * dx', kv2, geo=geometry.quarter_annulus(),
+                                           f=lambda x, y: x * y ** 2, b=b2)
+    out['funcgrad_d3'] = assemble.assemble('inner(b, grad(v)) * dx', spaces['tbox_mixed'][0], geo=geometry.twisted_box(), b=inp['b'])
     save('forms', **out)
 
 

@@ -84,6 +84,10 @@ def test_functionals(forms):
     assert forms.arity('f * v * dx') == 1
     with pytest.raises(NotImplementedError):
         forms.functional_coefficient('inner((1.0, 2.0), grad(v)) * dx', G, X, {})
+    jet = forms.functional_jet('(f * v + inner((1.0, x[0]), grad(v))) * dx', G, X, dict(f=f))
+    assert np.array_equal(jet[0], f(X[..., 0], X[..., 1])) and np.all(jet[1] == 1.0) and np.array_equal(jet[2], X[..., 0])
+    jet = forms.functional_jet('inner((0.0, 2.0), grad(v)) * dx', G, X, {})
+    assert jet[0] is None and jet[1] is None and np.all(jet[2] == 2.0)
 
 
 @pytest.mark.parametrize('bad', ['u * v', 'inner(grad(u), grad(u)) * dx', 'inner(grad(u), grad(v)) * u * dx',

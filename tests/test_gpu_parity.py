@@ -634,8 +634,27 @@ def test_arity1_form_strings(iga, golden):
     f3 = iga.assemble.assemble('(2 * f + x[0]) * v * dx', (kv, kv, kv), geo=_geo(iga, 'cylinder'),
                                f=lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z))
     assert _close(f3, g['func_d3'])
-    with pytest.raises(NotImplementedError):
-        iga.assemble.assemble('inner((1.0, 2.0), grad(v)) * dx', kv2, geo=ann)
+    # derivatives of v in the functional
+    inp = form_inputs()
+    b2 = form2d_cases()['full'][1]['b']
+    fg2 = iga.assemble.assemble('(f * v + inner(b, grad(v))) * dx', kv2, geo=ann, f=lambda x, y: x * y ** 2, b=b2)
+    assert _close(fg2, g['funcgrad_d2'])
+    kvm = (mk(3, 0.0, 1.0, 2), mk(2, 0.0, 1.0, 4, mult=2), mk(1, 0.0, 1.0, 3))
+    fg3 = iga.assemble.assemble('inner(b, grad(v)) * dx', kvm, geo=_geo(iga, 'twisted_box'), b=inp['b'])
+    assert _close(fg3, g['funcgrad_d3'])
+    # divergence theorem on the unit cube: integral of grad(v).e_x = v(1,.,.) - v(0,.,.) integrated over the face -> sums to 0 over
+    # interior functions, and the whole vector sums to 0 because the basis is a partition of unity
+    fz = iga.assemble.assemble('inner((1.0, 2.0, -3.0), grad(v)) * dx', (kv, kv, kv), geo=iga.geometry.unit_cube())
+    assert abs(fz.sum()) <= 1e-13
+    # slabs reproduce their rows bit for bit
+    from pyiga_amd import forms
+    full = iga.assemblers.GeneralFunctionalAssembler3D(kvm, _geo(iga, 'twisted_box'), 'inner(b, grad(v)) * dx', inputs=dict(b=inp['b']))
+    parts = []
+    N0 = kvm[0].numdofs
+    for lo, hi in ((0, 2), (2, N0)):
+        sl = iga.assemblers.GeneralFunctionalAssembler3D(kvm, _geo(iga, 'twisted_box'), 'inner(b, grad(v)) * dx', inputs=dict(b=inp['b']), row0=(lo, hi))
+        parts.append(sl.assemble_vector())
+    assert np.array_equal(np.concatenate(parts, axis=0), full.assemble_vector())
 
 
 @pytest.mark.parametrize('d', [2, 3])

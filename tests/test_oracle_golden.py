@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import GOLDEN, golden_csr, rel_maxdiff, form_tables, form2d_cases
+from conftest import GOLDEN, golden_csr, rel_maxdiff, form_tables, form2d_cases, form_inputs
 
 
 def test_make_knots_bits(oracle, golden):
@@ -266,3 +266,17 @@ def test_general_forms_2d_oracle_vs_reference(oracle, golden):
         R = golden_csr(g, 'd2_%s' % fname)
         assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
         assert rel_maxdiff(A, R) <= 1e-14, (fname, rel_maxdiff(A, R))
+
+
+def test_functionals_with_gradients_oracle_vs_reference(oracle, golden):
+    """Arity-1 forms with derivatives of v ('inner(b, grad(v)) * dx'): oracle restatement vs the reference."""
+    g = golden('forms')
+    b3 = form_inputs()['b']
+    kvs = (oracle.make_knots(3, 0.0, 1.0, 2), oracle.make_knots(2, 0.0, 1.0, 4, mult=2), oracle.make_knots(1, 0.0, 1.0, 3))
+    r = oracle.load_vector_jet(kvs, oracle.geo_twisted_box(), [None] + [(lambda x, y, z, i=i: b3(x, y, z)[i]) for i in range(3)])
+    assert np.abs(r - g['funcgrad_d3']).max() <= 1e-14 * np.abs(g['funcgrad_d3']).max()
+    b2 = form2d_cases()['full'][1]['b']
+    kv2 = (oracle.make_knots(3, 0.0, 1.0, 6), oracle.make_knots(2, 0.0, 1.0, 5))
+    r = oracle.load_vector_jet(kv2, oracle.geo_quarter_annulus(),
+                               [lambda x, y: x * y ** 2, lambda x, y: b2(x, y)[0], lambda x, y: b2(x, y)[1]])
+    assert np.abs(r - g['funcgrad_d2']).max() <= 1e-14 * np.abs(g['funcgrad_d2']).max()
