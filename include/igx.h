@@ -56,8 +56,7 @@ enum { IGX_MASS = 0, IGX_STIFFNESS = 1,
        /* (inner(c*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx -- the custom (vform) case of
           BASELINE config 5, non-symmetric, 3D only; c is set with igx_patch_set_coeff */
        IGX_CONVDIFF = 2,
-       /* general scalar bilinear form in the first-order jets of u and v (2D: r,s = 0..2, entry-wise kernels; 3D: also
-          the sum-factorised stages):
+       /* general scalar bilinear form in the first-order jets of u and v (2D: r,s = 0..2):
             a(u,v) = integral of  sum_{r,s=0..3} P_rs(x) * D_r v * D_s u ,   D_0 = identity, D_1..3 = d/dx, d/dy, d/dz (physical)
           P_rs are coefficient fields set with igx_patch_set_form: the block r,s >= 1 is a diffusion tensor
           (inner(dot(K,grad(u)),grad(v)): P = K), row 0 a convection vector (inner(b,grad(u))*v), column 0 its

@@ -334,8 +334,8 @@ class _GeneralFormAssembler(_DeviceAssembler):
     is the class of forms the reference's run-time compiler handles with ``u``, ``v``, ``grad``, ``inner``, ``dot``
     (pyiga/assemble.py:837-897, pyiga/vform.py:1804-1885); non-symmetric, every pattern entry is computed.
     Coefficients are sampled on the Gauss grid on the host (they are Python callables, as in the reference),
-    the Jacobian transformation of the coefficients and all sums run on the device (3D: sum-factorised
-    stages or entry-wise kernel; 2D: entry-wise kernel).
+    the Jacobian transformation of the coefficients and all sums run on the device (sum-factorised stages
+    or entry-wise kernel).
     """
     _kind = 'form'
 

@@ -47,12 +47,12 @@ static std::vector<Term> form_terms(int dim, int kind, const PatchDev *pd = null
 {
     std::vector<Term> T;
     if (kind == IGX_FORM) {
-        // one term per stored field; jet index c >= 1 differentiates grid axis 3 - c (x is the LAST axis)
+        // one term per stored field; jet index c >= 1 differentiates grid axis dim - c (x is the LAST axis)
         for (int k = 0; k < pd->form_n; ++k) {
             const int a = pd->form_ab[k] >> 2, b = pd->form_ab[k] & 3;     // a: test function v, b: trial function u
             Term t{};
             t.f = k;
-            for (int ax = 0; ax < 3; ++ax) t.t[ax] = ((b >= 1 && ax == 3 - b) ? 1 : 0) + 2 * ((a >= 1 && ax == 3 - a) ? 1 : 0);
+            for (int ax = 0; ax < 3; ++ax) t.t[ax] = ax < dim ? ((b >= 1 && ax == dim - b) ? 1 : 0) + 2 * ((a >= 1 && ax == dim - a) ? 1 : 0) : 0;
             T.push_back(t);
         }
         return T;
@@ -1092,6 +1092,18 @@ __global__ void __launch_bounds__(256) k_final_mfma(const double *__restrict__ K
     }
 }
 
+// sum of up to 16 arrays (2D general forms: the stage-A arrays of one last-axis type); n == 0 gives zeros
+struct CombineArgs { const double *src[16]; double *dst; long long len; int n; };
+__global__ void __launch_bounds__(256) k_combine(const CombineArgs C)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < C.len; i += stride) {
+        double v = 0.0;
+        for (int k = 0; k < C.n; ++k) v += C.src[k][i];
+        C.dst[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 int sumfact_supported(const igx_patch *pt)
@@ -1103,7 +1115,7 @@ int sumfact_supported(const igx_patch *pt)
 
 int sumfact_supports_kind(const igx_patch *pt, int kind)
 {
-    return kind == IGX_MASS || kind == IGX_STIFFNESS || ((kind == IGX_CONVDIFF || kind == IGX_FORM) && pt->dim == 3);
+    return kind == IGX_MASS || kind == IGX_STIFFNESS || kind == IGX_FORM || (kind == IGX_CONVDIFF && pt->dim == 3);
 }
 
 // Line descriptors of the quadrature-lane final kernel: one 32-byte record per K line that is contracted,
@@ -1416,7 +1428,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 if (X[x].t0 == terms[i].t[0] && X[x].f == terms[i].f) found = (int)x;
         if (found < 0) {
             found = (int)X.size();
-            X.push_back(XA{terms[i].t[0], terms[i].f, dim == 2 ? (kind == IGX_MASS ? 0 : terms[i].t[1]) : found});
+            X.push_back(XA{terms[i].t[0], terms[i].f, (dim == 2 && kind != IGX_FORM) ? (kind == IGX_MASS ? 0 : terms[i].t[1]) : found});
         }
         term_x[i] = found;
     }
@@ -1505,6 +1517,26 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     } else {
         NY = (kind == IGX_MASS) ? 1 : 4;
         Kfinal = pt->d_K1;
+        if (kind == IGX_FORM) {
+            // general 2D form: several terms share a last-axis type; their stage-A arrays are summed into the
+            // array of that type (2D intermediates are small: one extra pass over them)
+            int ymax = 0;
+            for (const Term &t : terms) ymax = std::max(ymax, t.t[1]);
+            NY = (ymax == 0) ? 1 : 4;
+            const size_t per = (size_t)np0 * NPL;
+            if (ensure(st, &pt->d_K2, &pt->K2_cap, (size_t)NY * per)) return IGX_ERR_NOMEM;
+            for (int y = 0; y < NY; ++y) {
+                CombineArgs C{};
+                for (size_t i = 0; i < terms.size(); ++i)
+                    if (terms[i].t[1] == y) C.src[C.n++] = pt->d_K1 + (size_t)X[term_x[i]].slot * per;
+                C.dst = pt->d_K2 + (size_t)y * per;
+                C.len = (long long)per;
+                k_combine<<<dim3((unsigned)std::min<size_t>((per + 255) / 256, 65535u * 16u)), 256, 0, st>>>(C);
+            }
+            IGX_HIP(hipGetLastError());
+            pt->timing.n_launches += NY;
+            Kfinal = pt->d_K2;
+        }
         F.nlines = np0;
         F.N1 = 1; F.S1 = 1; F.Smid = 1; F.Slast = A1.S;
         ngroups = np0;

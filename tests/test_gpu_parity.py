@@ -692,13 +692,29 @@ def test_general_forms_2d(iga, golden):
         assert A.nnz == R.nnz and np.array_equal(A.indices, R.indices)
         assert rel_maxdiff(A, R) <= RTOL, (fname, rel_maxdiff(A, R))
         asm = iga.assemblers.GeneralFormAssembler2D(kvs, ann, table)
-        assert rel_maxdiff(asm.assemble_csr(), R) <= RTOL
+        for algo, code in (('sumfact', 2), ('entrywise', 1), ('auto', 2)):
+            B = asm.assemble_csr(algo=algo)
+            assert asm.patch.timing()['algo_used'] == code
+            assert rel_maxdiff(B, R) <= RTOL, (fname, algo, rel_maxdiff(B, R))
         idx = np.random.default_rng(2).integers(0, R.shape[0], (40, 2)).astype(np.uintp)
         assert np.abs(asm.multi_entries(idx) - np.asarray(R[idx[:, 0], idx[:, 1]]).ravel()).max() <= RTOL * np.abs(R.data).max()
     kv = (mk(3, 0.0, 1.0, 9), mk(4, 0.0, 1.0, 7))
     G2 = iga.assemblers.GeneralFormAssembler2D
     assert rel_maxdiff(G2(kv, ann, 'inner(grad(u), grad(v)) * dx').assemble_csr(), iga.assemble.stiffness(kv, ann)) <= RTOL
     assert rel_maxdiff(G2(kv, ann, '2 * u * v * dx').assemble_csr(), 2 * iga.assemble.mass(kv, ann)) <= RTOL
+    # larger, non-uniform knots, slabs: sum-factorised == entry-wise, rows bit-identical
+    kvl = (mk(3, 0.0, 1.0, 37), mk(2, 0.0, 1.0, 23, mult=2))
+    form, inputs, _ = form2d_cases()['full']
+    full = G2(kvl, ann, form, inputs=inputs)
+    A = full.assemble_csr(algo='sumfact')
+    assert rel_maxdiff(A, full.assemble_csr(algo='entrywise')) <= RTOL
+    N0 = kvl[0].numdofs
+    parts = []
+    for lo, hi in ((0, N0 // 2), (N0 // 2, N0)):
+        sl = G2(kvl, ann, form, inputs=inputs, row0=(lo, hi))
+        parts.append(sl.assemble_csr(algo='sumfact'))
+    S = scipy.sparse.vstack(parts).tocsr()
+    assert np.array_equal(S.indices, A.indices) and np.array_equal(S.data, A.data)
 
 
 # ---------------------------------------------------------------------------------------------
