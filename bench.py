@@ -93,6 +93,42 @@ def cpu_baseline(dim, p, kind):
     }
 
 
+def bench_rhs(args, patch, kvs, geo, dim, p, n0, n, nel_total, world, rank, dist, barrier):
+    """Load vector of the same patch.  The function values are host data by definition (a Python
+    callable sampled on the Gauss grid), so a call includes their upload; `value` uses the device time of the
+    three contractions (inputs resident, HIP events inside igx_load_vector), the PCIe-inclusive rate is noted."""
+    import pyiga_amd
+    from pyiga_amd import utils
+    grid = tuple(patch.gauss(k)[0] for k in range(dim))
+    fvals = np.ascontiguousarray(utils.grid_eval(lambda *x: np.cos(x[0]) * np.exp(x[1]) * (np.sin(x[2]) if dim == 3 else 1.0), grid))
+    for _ in range(args.warmup):
+        patch.load_vector(fvals)
+    barrier()
+    dev_ms, t0 = 0.0, time.perf_counter()
+    for _ in range(args.steps):
+        patch.load_vector(fvals)
+        dev_ms += patch.timing()['total_ms']
+    barrier()
+    wall = time.perf_counter() - t0
+    if rank != 0:
+        return
+    dev_ms /= args.steps
+    q = p + 1
+    b_el = 8.0 * q ** dim + 8.0 * np.prod([k.numdofs for k in kvs]) / nel_total      # f in + vector out (W is resident)
+    nel_rank = nel_total / world
+    achieved = b_el * nel_rank / (dev_ms * 1e-3) / 1e9
+    out = {'metric': 'load-vector elements/sec', 'value': nel_total / (dev_ms * 1e-3), 'unit': 'elements/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%dD p=%d load vector (inner_products), %s spans' % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
+                      'config': args.config, 'elements': nel_total,
+                      'note': 'value = device time of the contractions; a whole call incl. the upload of the function values took %.1f ms' % (1e3 * wall / args.steps)},
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': None, 'kernel': 'k_contract_axis x %d' % dim, 'algorithmic_bytes_per_element': b_el}}
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,6 +138,7 @@ def main():
     ap.add_argument('--n', type=int, default=0, help='override spans per axis (testing)')
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs'], help='rhs: the load vector (inner_products) of the same patch instead of the matrix')
     ap.add_argument('--strong', action='store_true', help='strong scaling: keep the patch fixed, split its rows')
     ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank weak-scaling run on this one GPU (no collectives)')
     args = ap.parse_args()
@@ -154,6 +191,8 @@ def main():
             torch.cuda.synchronize()
         patch.ctx.sync()
 
+    if args.op == 'rhs':
+        return bench_rhs(args, patch, kvs, geo, dim, p, n0, n, nel_total, world, rank, dist, barrier)
     for _ in range(args.warmup):
         patch.assemble(kind, algo=args.algo, to_host=False)
     stage_ms = {}

@@ -109,7 +109,7 @@ typedef struct {
 typedef struct {                       /* device time of the last igx_assemble, HIP events on the ctx stream */
     float total_ms;
     float fields_ms, stage0_ms, stage1_ms, final_ms, entry_ms;
-    int32_t algo_used;
+    int32_t algo_used;                 /* IGX_ALGO_ENTRYWISE / IGX_ALGO_SUMFACT; 3 after igx_load_vector (total_ms = its contractions) */
     int32_t n_launches;
 } igx_timing;
 

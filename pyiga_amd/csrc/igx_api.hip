@@ -650,10 +650,18 @@ int igx_load_vector(igx_patch *pt, const double *fvals, double *out)
     // the function values of the resident Gauss planes are contiguous in the full-grid array (axis 0 is slowest)
     hipError_t e = hipMemcpyAsync(d_f, fvals + (size_t)pd.g0_lo * plane, npts * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
+        (void)hipEventRecord(pt->ctx->ev[6], st);        // device time of the contractions, inputs resident
         rc = launch_load_vector(st, pt, d_f, pt->d_fields, d_o, d_t1, d_t2);
+        (void)hipEventRecord(pt->ctx->ev[7], st);
         if (rc == IGX_OK) e = hipMemcpyAsync(out, d_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && rc == IGX_OK) {
+        memset(&pt->timing, 0, sizeof(pt->timing));
+        (void)hipEventElapsedTime(&pt->timing.total_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
+        pt->timing.algo_used = 3;                        // load vector
+        pt->timing.n_launches = pt->dim;
+    }
     cleanup();
     if (e != hipSuccess) { set_error("igx_load_vector: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
     return rc;

@@ -45,6 +45,60 @@ __global__ void __launch_bounds__(256) k_contract_axis(const double *__restrict_
     *dst = accumulate ? *dst + r : r;
 }
 
+// Last (contiguous) axis: a block walks LPB consecutive grid lines.  Thread i keeps the basis values of dof i on its
+// support in registers (they do not depend on the line); each line (times its weights) is staged in LDS with
+// coalesced loads (double-buffered), then thread i sums over its support.
+//   out[a][i] = sum_g V[g][i - fa][deriv] * in[a][g] (* w[a][g])
+constexpr int VEC_MAXSUP = 36;                           // (p+1) * q for p <= 5
+template <bool WEIGHT>
+__global__ void __launch_bounds__(256) k_contract_last(const double *__restrict__ in, const double *__restrict__ wfield,
+                                                       double *__restrict__ out, const AxisDev ax, long long A, int LPB, int deriv)
+{
+    extern __shared__ double line[];                     // [2][G]
+    const int G = ax.G, q = ax.q, P = ax.P;
+    const long long a_lo = (long long)blockIdx.x * LPB, a_hi = min(a_lo + LPB, A);
+    // per-thread basis values (threads beyond N idle in the compute phase, all threads help loading)
+    const int i = threadIdx.x;
+    double vreg[VEC_MAXSUP];
+    int g_first = 0, nsup = 0;
+    if (i < ax.N) {
+        const int s_lo = ax.mslo[i], s_hi = ax.mshi[i];
+        g_first = s_lo * q;
+        nsup = (s_hi - s_lo) * q;
+#pragma unroll
+        for (int k = 0; k < VEC_MAXSUP; ++k) {
+            double v = 0.0;
+            if (k < nsup) {
+                const int g = g_first + k, s = g / q;
+                v = ax.V[((size_t)g * P + (i - ax.fa[s])) * 2 + deriv];
+            }
+            vreg[k] = v;
+        }
+    }
+    auto stage = [&](const long long a, double *dst) {
+        const double *src = in + a * G;
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            double v = src[g];
+            if (WEIGHT) v *= wfield[a * G + g];
+            dst[g] = v;
+        }
+    };
+    if (a_lo < a_hi) stage(a_lo, line);
+    __syncthreads();
+    for (long long a = a_lo; a < a_hi; ++a) {
+        double *cur = line + ((a - a_lo) & 1) * G, *nxt = line + ((a - a_lo + 1) & 1) * G;
+        if (a + 1 < a_hi) stage(a + 1, nxt);
+        if (i < ax.N) {
+            double r = 0.0;
+#pragma unroll
+            for (int k = 0; k < VEC_MAXSUP; ++k)
+                if (k < nsup) r = fma(vreg[k], cur[g_first + k], r);
+            out[a * ax.N + i] = r;
+        }
+        __syncthreads();
+    }
+}
+
 // d_f: function values on the RESIDENT Gauss slab (G0_loc x G1 [x G2]); d_W: mass field on the same slab;
 // d_out: (r0_hi - r0_lo) x N1 [x N2]; tmp1/tmp2: workspaces (sizes below)
 // deriv_axis: grid axis whose basis functions are differentiated (-1: none); accumulate: add to d_out;
@@ -55,6 +109,9 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
     const PatchDev &pd = pt->dev;
     const int dim = pd.dim;
     const int bs = 256;
+    // the register/LDS kernel needs one thread per dof of the line, the support in VEC_MAXSUP registers and the
+    // double-buffered line in LDS; anything else takes the generic kernel
+    auto last_axis_fast = [](const AxisDev &ax) { return ax.N <= 256 && ax.P * ax.q <= VEC_MAXSUP && (size_t)2 * ax.G * sizeof(double) <= 48 * 1024; };
     auto blocks = [&](long long n) { return dim3((unsigned)((n + bs - 1) / bs)); };
     const long long G0 = pd.G0_loc;
     const AxisDev &a0 = pd.ax[0], &a1 = pd.ax[1], &a2 = pd.ax[2];
@@ -63,7 +120,12 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
         // [G0,G1,G2] -> [G0,G1,N2]
         {
             const long long A = G0 * a1.G, n = A * a2.N;
-            if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a2, A, 1, 0, a2.N, 0, deriv_axis == 2, 0);
+            if (last_axis_fast(a2)) {
+                const int tb = a2.N > 128 ? 256 : 128, LPB = 16;
+                const dim3 grid((unsigned)((A + LPB - 1) / LPB));
+                if (d_W) k_contract_last<true><<<grid, tb, (size_t)2 * a2.G * sizeof(double), st>>>(d_f, d_W, d_t1, a2, A, LPB, deriv_axis == 2);
+                else k_contract_last<false><<<grid, tb, (size_t)2 * a2.G * sizeof(double), st>>>(d_f, nullptr, d_t1, a2, A, LPB, deriv_axis == 2);
+            } else if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a2, A, 1, 0, a2.N, 0, deriv_axis == 2, 0);
             else k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_f, nullptr, d_t1, a2, A, 1, 0, a2.N, 0, deriv_axis == 2, 0);
         }
         // [G0,G1,N2] -> [G0,N1,N2]
@@ -81,7 +143,12 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
     } else {
         {
             const long long n = G0 * a1.N;
-            if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a1, G0, 1, 0, a1.N, 0, deriv_axis == 1, 0);
+            if (last_axis_fast(a1)) {
+                const int tb = a1.N > 128 ? 256 : 128, LPB = 4;
+                const dim3 grid((unsigned)((G0 + LPB - 1) / LPB));
+                if (d_W) k_contract_last<true><<<grid, tb, (size_t)2 * a1.G * sizeof(double), st>>>(d_f, d_W, d_t1, a1, G0, LPB, deriv_axis == 1);
+                else k_contract_last<false><<<grid, tb, (size_t)2 * a1.G * sizeof(double), st>>>(d_f, nullptr, d_t1, a1, G0, LPB, deriv_axis == 1);
+            } else if (d_W) k_contract_axis<true><<<blocks(n), bs, 0, st>>>(d_f, d_W, d_t1, a1, G0, 1, 0, a1.N, 0, deriv_axis == 1, 0);
             else k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_f, nullptr, d_t1, a1, G0, 1, 0, a1.N, 0, deriv_axis == 1, 0);
         }
         {
