@@ -326,6 +326,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
+    (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
     delete pt;
 }
 
@@ -381,6 +382,9 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         pt->row_hi = pt->r0_hi * plane;
         pt->nnz_off = (long long)A0.rp[pt->r0_lo] * Srest;
         pt->nnz = (long long)(A0.rp[pt->r0_hi] - A0.rp[pt->r0_lo]) * Srest;
+        // the fused stage forms only the lower triangle: the rows of the p0 dof planes above the slab hold the sources
+        // of the slab's upper-triangle entries (mirror pass), behind the owned values in the same buffer
+        pt->nnz_ext = (long long)(A0.rp[std::min(pt->r0_hi + A0.p, A0.N)] - A0.rp[pt->r0_lo]) * Srest;
         // elements attributed to this slab: spans of axis 0 split proportionally to the owned dofs
         const long long sp_lo = (long long)A0.n * pt->r0_lo / A0.N, sp_hi = (long long)A0.n * pt->r0_hi / A0.N;
         pt->nelem_owned = (sp_hi - sp_lo) * A1.n * A2.n;
@@ -532,7 +536,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
     if (algo != IGX_ALGO_SUMFACT && algo != IGX_ALGO_ENTRYWISE) { set_error("igx_assemble: unknown algo %d", algo); return IGX_ERR_ARG; }
     if (!pt->d_data) {
-        hipError_t e = hipMalloc((void **)&pt->d_data, ((size_t)pt->nnz + IGX_DUMP_PAD) * sizeof(double));   // + dump slots of masked stores
+        hipError_t e = hipMalloc((void **)&pt->d_data, ((size_t)std::max(pt->nnz, pt->nnz_ext) + IGX_DUMP_PAD) * sizeof(double));   // + halo rows of the mirror pass / dump slots of masked stores
         if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR values failed", pt->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
     }
     if (getenv("IGX_DEBUG_POISON"))               // every value must be written exactly once

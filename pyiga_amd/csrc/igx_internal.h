@@ -141,6 +141,12 @@ struct igx_patch {
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
     double *d_K1 = nullptr, *d_K2 = nullptr;
     size_t K1_cap = 0, K2_cap = 0;
+    // fused sweep + final stage (fused.hip)
+    long long nnz_ext = 0;                    // values of the owned rows + the p0 halo planes above them (mirror sources)
+    double *d_zeros = nullptr;                // a row of zeros: input of absent sweep slots
+    int *d_triv = nullptr;                    // one-dof outer axis of the 2D case: pl0 {0,0} | rp0 {0,1} | jlo0 {0} | jhi0 {1}
+    int *d_tpairs = nullptr;                  // [ntp][2] mirror targets: outer pairs (i0 owned, j0 >= i0)
+    int ntp = 0;
     igx_timing timing{};
 };
 
@@ -167,6 +173,30 @@ inline int igx_num_fields(int dim, int kind, int form_n = 0)
 }
 constexpr size_t IGX_DUMP_PAD = 1024 * 16 + 16;   // doubles behind the CSR values: 1024 dump lines of the final stage
 inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF && kind != IGX_FORM; }
+// fused sweep + final stage and mirror pass (fused.hip)
+struct BFInputs {
+    const Axis *mid, *last;                   // swept axis, last (contiguous) axis
+    int slot_n[4][4];                         // [last-axis type y][mid-axis type t1]: number of input arrays (<= 2)
+    const double *slot_ptr[4][4][2];          // their device pointers: array[slice][g_mid - gmid_lo][g_last]
+    long long slice_stride;                   // doubles between slices (outer pairs)
+    const double *zeros;                      // >= G_last zeros
+    int gmid_lo;
+    const int *pl0;                           // [npairs][2] outer pairs (device)
+    int npairs;
+    const int *rp0, *jlo0, *jhi0;             // outer axis tables (device)
+    int sym, mid_lo, mid_hi;
+    int span_hi;                              // resident spans of the mid axis end here
+};
+struct MirrorInputs {
+    const Axis *mid, *last;
+    const int *rp0, *jlo0, *jhi0;
+    const int *tpairs;
+    int ntp;
+    int i1_lo, i1_hi;                         // target rows of the mid axis
+};
+int fused_rows_per_tile(int P);
+int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
+int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);
 int sumfact_supports_kind(const igx_patch *pt, int kind);

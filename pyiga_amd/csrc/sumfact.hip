@@ -1276,6 +1276,24 @@ int sumfact_prepare(igx_patch *pt)
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     }
     if (int rc = build_qdesc(pt, pl, true, &pt->d_qdesc, &pt->n_qdesc)) return rc;
+    // fused stage (fused.hip): a row of zeros, the one-dof outer axis of the 2D case, the mirror targets
+    {
+        const Axis &AL = pt->ax[pt->dim - 1];
+        IGX_HIP(hipMalloc(&pt->d_zeros, ((size_t)AL.G + 256) * sizeof(double)));
+        IGX_HIP(hipMemsetAsync(pt->d_zeros, 0, ((size_t)AL.G + 256) * sizeof(double), pt->ctx->stream));
+        const int triv[6] = {0, 0, 0, 1, 0, 1};        // pl0 {0,0} | rp0 {0,1} | jlo0 {0} | jhi0 {1}
+        IGX_HIP(hipMalloc(&pt->d_triv, sizeof(triv)));
+        IGX_HIP(hipMemcpyAsync(pt->d_triv, triv, sizeof(triv), hipMemcpyHostToDevice, pt->ctx->stream));
+        std::vector<int> tp;
+        if (pt->dim == 3) {
+            for (int i0 = pt->r0_lo; i0 < pt->r0_hi; ++i0)
+                for (int j0 = i0; j0 < A0.jhi[i0]; ++j0) { tp.push_back(i0); tp.push_back(j0); }
+        } else { tp.push_back(0); tp.push_back(0); }
+        pt->ntp = (int)(tp.size() / 2);
+        IGX_HIP(hipMalloc(&pt->d_tpairs, std::max<size_t>(1, tp.size()) * sizeof(int)));
+        IGX_HIP(hipMemcpyAsync(pt->d_tpairs, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    }
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
     IGX_HIP(hipMalloc(&pt->d_rl0_of, std::max<size_t>(1, rl.size()) * sizeof(int)));
     IGX_HIP(hipMemcpyAsync(pt->d_pl0, pl.data(), pl.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
@@ -1327,14 +1345,15 @@ static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 {
     if (*cap >= need) return IGX_OK;
     if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
-    hipError_t e = hipMalloc(buf, (need + 64) * sizeof(double));
+    constexpr size_t PAD = 256;     // >= FINALQ_KWIN doubles: the last K window of k_final_q and the tile window of k_bf may read past the last line
+    hipError_t e = hipMalloc(buf, (need + PAD) * sizeof(double));
     if (e != hipSuccess) {
         set_error("hipMalloc of %.2f GB sum-factorisation workspace failed: %s", need * 8.0 / 1e9, hipGetErrorString(e));
         return IGX_ERR_NOMEM;
     }
     // lines that are never produced (upper part of diagonal blocks) must stay finite: the final
     // stage multiplies window padding by exact zeros
-    if (hipMemsetAsync(*buf, 0, (need + 64) * sizeof(double), st) != hipSuccess) return IGX_ERR_HIP;   // same stream as the kernels
+    if (hipMemsetAsync(*buf, 0, (need + PAD) * sizeof(double), st) != hipSuccess) return IGX_ERR_HIP;   // same stream as the kernels
     *cap = need;
     return IGX_OK;
 }
@@ -1402,6 +1421,60 @@ static int launch_final(hipStream_t st, const double *K, double *data, const Fin
     case 6: { constexpr int PP = 6; CALL; } break;             \
     default: set_error("sum factorisation: degree %d unsupported", (Pv) - 1); return IGX_ERR_UNSUPPORTED; }
 
+// The fused sweep + final stage (fused.hip) needs single interior knots, equal degrees and q = p + 1 on the swept and
+// the last axis.  IGX_PATH=unfused (or a choice of IGX_FINAL) selects the round-1 kernels (K2 through HBM), which also
+// serve every other case.
+static bool fused_applicable(const igx_patch *pt)
+{
+    if (const char *e = getenv("IGX_PATH"))
+        if (!strcmp(e, "unfused")) return false;
+    if (getenv("IGX_FINAL")) return false;
+    const int dim = pt->dim;
+    const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
+    if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 6) return false;
+    return true;
+}
+
+// slot table of the fused stage: input array `ptr` enters the sweep with mid-axis type t1 and last-axis type y
+static bool bf_add_slot(BFInputs &in, int y, int t1, const double *ptr)
+{
+    int &n = in.slot_n[y][t1];
+    if (n >= 2) return false;
+    in.slot_ptr[y][t1][n++] = ptr;
+    return true;
+}
+
+static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
+{
+    hipStream_t st = pt->ctx->stream;
+    const int dim = pt->dim;
+    const Axis &A0 = pt->ax[0];
+    in.mid = &pt->ax[dim - 2]; in.last = &pt->ax[dim - 1];
+    in.zeros = pt->d_zeros; in.sym = sym ? 1 : 0;
+    if (dim == 3) { in.rp0 = A0.dev.rp; in.jlo0 = A0.dev.jlo; in.jhi0 = A0.dev.jhi; }
+    else { in.pl0 = pt->d_triv; in.npairs = 1; in.rp0 = pt->d_triv + 2; in.jlo0 = pt->d_triv + 4; in.jhi0 = pt->d_triv + 5; }
+    int i1_lo = 0, i1_hi = in.mid->N;
+    if (dim == 3) { in.mid_lo = 0; in.mid_hi = in.mid->N; in.span_hi = in.mid->n; }
+    else {
+        // 2D: the swept axis carries the row slab; symmetric forms also produce the lower entries of the p halo rows
+        // above it (mirror sources), as far as the resident spans reach
+        i1_lo = pt->r0_lo; i1_hi = pt->r0_hi;
+        in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
+    }
+    if (int rc = launch_bf(st, pt, in, d_data)) return rc;
+    pt->timing.n_launches++;
+    (void)hipEventRecord(pt->ctx->ev[3], st);
+    if (sym) {
+        MirrorInputs mi{};
+        mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
+        mi.tpairs = pt->d_tpairs; mi.ntp = pt->ntp; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
+        if (int rc = launch_mirror(st, pt, mi, d_data)) return rc;
+        pt->timing.n_launches++;
+    }
+    (void)hipEventRecord(pt->ctx->ev[4], st);
+    return IGX_OK;
+}
+
 int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 {
     hipStream_t st = pt->ctx->stream;
@@ -1415,6 +1488,20 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     const int np0 = sym ? pt->npairs0 : pt->npairs0n;
     const int *d_pl0 = sym ? pt->d_pl0 : pt->d_pl0n;
     if (np0 == 0) return IGX_OK;
+    const bool fused = fused_applicable(pt);
+    if (fused && dim == 2) {
+        // 2D: the fields ARE the sweep input (axis 0 swept, axis 1 contracted by the contractors): one kernel + mirror
+        BFInputs in{};
+        bool ok = true;
+        for (const Term &t : terms)
+            ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : t.t[1], t.t[0], pt->d_fields + (size_t)t.f * pd.npts_loc);
+        if (ok) {
+            in.slice_stride = 0; in.gmid_lo = pd.g0_lo;
+            (void)hipEventRecord(pt->ctx->ev[1], st);
+            (void)hipEventRecord(pt->ctx->ev[2], st);
+            return run_fused(pt, in, sym, d_data);
+        }
+    }
 
     // ---- stage-A arrays X = unique (t0, f).  In 2D the final stage wants the arrays ordered by
     // the last-axis type of their (single) consuming term; in 3D any order works.
@@ -1470,6 +1557,18 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         pt->timing.n_launches++;
     }
     (void)hipEventRecord(pt->ctx->ev[2], st);
+
+    if (fused && dim == 3) {
+        BFInputs in{};
+        bool ok = true;
+        for (size_t i = 0; i < terms.size(); ++i)
+            ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : terms[i].t[2], terms[i].t[1],
+                                   pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPL);
+        if (ok) {
+            in.slice_stride = NPL; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
+            return run_fused(pt, in, sym, d_data);
+        }
+    }
 
     // ---- final-stage input
     FinalArgs F{};

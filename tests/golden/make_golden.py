@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms'} & set(sys.argv[1:]):
+if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms', 'fullsize'} & set(sys.argv[1:]):
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -421,3 +421,72 @@ def golden_forms():
 
 if __name__ == '__main__' and 'forms' in sys.argv[1:]:
     golden_forms()
+
+
+# ---------------------------------------------------------------------------
+# (10) full-size parity pins (BASELINE configs 2 and 3 at their real sizes; p=4 / p=5 at the largest size the
+#      build container holds comfortably): sampled in-pattern entries through multi_entries
+#      (pyiga/genericasm.pxi:722-758) and, for config 2, the product of the whole matrix with a fixed vector.
+def sample_pairs(ndofs, p, M, seed):
+    """M seeded (row, col) pairs inside the sparsity pattern (|i_k - j_k| <= p per axis): random rows plus
+    every corner of the dof box, both triangles."""
+    rng = np.random.default_rng(seed)
+    d = len(ndofs)
+    I = np.stack([rng.integers(0, n, M) for n in ndofs], 1)
+    corners = np.array(np.meshgrid(*[(0, n - 1) for n in ndofs], indexing='ij')).reshape(d, -1).T
+    I[:len(corners)] = corners
+    off = rng.integers(-p, p + 1, (M, d))
+    J = np.clip(I + off, 0, np.array(ndofs) - 1)
+    row = np.ravel_multi_index(I.T, ndofs)
+    col = np.ravel_multi_index(J.T, ndofs)
+    return np.stack([row, col], 1).astype(np.uintp)
+
+
+def golden_fullsize():
+    out = {}
+    ann = geometry.quarter_annulus()
+    cyl = cylinder()
+    # config 2: 2D p=3 n=256, NURBS quarter annulus, stiffness
+    kv = bspline.make_knots(3, 0.0, 1.0, 256)
+    kvs = (kv, kv)
+    asm = assemblers.StiffnessAssembler2D(kvs, ann)
+    idx = sample_pairs([k.numdofs for k in kvs], 3, 20000, 11)
+    out['c2_idx'] = idx.astype(np.uint32)
+    out['c2_val'] = np.asarray(asm.multi_entries(idx))
+    A = assemble.stiffness(kvs, geo=ann)
+    x = np.sin(0.37 * np.arange(A.shape[0]) + 0.1)
+    out['c2_Ax'] = A @ x
+    out['c2_nnz'] = np.array(A.nnz)
+    out['c2_absmax'] = np.array(abs(A).max())
+    print('c2 done', A.shape, A.nnz)
+    # config 3: 3D p=2 n=64, cylinder, mass + stiffness
+    kv = bspline.make_knots(2, 0.0, 1.0, 64)
+    kvs = (kv, kv, kv)
+    idx = sample_pairs([k.numdofs for k in kvs], 2, 10000, 12)
+    out['c3_idx'] = idx.astype(np.uint32)
+    out['c3_stiff'] = np.asarray(assemblers.StiffnessAssembler3D(kvs, cyl).multi_entries(idx))
+    out['c3_mass'] = np.asarray(assemblers.MassAssembler3D(kvs, cyl).multi_entries(idx))
+    print('c3 done')
+    # config-4 degree on 32^3 spans, config-5 degree on 24^3 spans (the entry sums are the same code path at any n)
+    kv = bspline.make_knots(4, 0.0, 1.0, 32)
+    kvs = (kv, kv, kv)
+    idx = sample_pairs([k.numdofs for k in kvs], 4, 10000, 13)
+    out['p4n32_idx'] = idx.astype(np.uint32)
+    out['p4n32_stiff'] = np.asarray(assemblers.StiffnessAssembler3D(kvs, cyl).multi_entries(idx))
+    print('p4 done')
+    kv = bspline.make_knots(5, 0.0, 1.0, 24)
+    kvs = (kv, kv, kv)
+    idx = sample_pairs([k.numdofs for k in kvs], 5, 6000, 14)
+    out['p5n24_idx'] = idx.astype(np.uint32)
+    out['p5n24_stiff'] = np.asarray(assemblers.StiffnessAssembler3D(kvs, cyl).multi_entries(idx))
+
+    def diff_coeff(x, y, z):
+        return 1.0 + x
+    asm = assemble.instantiate_assembler(CONVDIFF, kvs, {'geo': cyl, 'diff_coeff': diff_coeff}, None)
+    out['p5n24_convdiff'] = np.asarray(asm.multi_entries(idx))
+    print('p5 done')
+    save('fullsize', **out)
+
+
+if __name__ == '__main__' and 'fullsize' in sys.argv[1:]:
+    golden_fullsize()

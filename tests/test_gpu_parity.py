@@ -838,3 +838,77 @@ def test_repeatability(iga):
         hashes = {hashlib.sha1(patch.assemble(kind, algo='sumfact', to_host=True).tobytes()).hexdigest() for _ in range(40)}
         patch.close()
         assert len(hashes) == 1
+
+
+# ------------------------------------------------------------------------------------------
+# Full-size parity pinned to the REFERENCE (tests/golden/golden_fullsize.npz, make_golden.py 'fullsize'):
+# multi_entries of the reference at seeded in-pattern pairs of BASELINE configs 2 and 3 at their real sizes and of the
+# config-4 / config-5 degrees on 32^3 / 24^3 spans, compared with the device-assembled CSR at those positions.
+def _csr_at(A, idx):
+    """values of the CSR matrix at the (row, col) pairs (all inside the pattern)."""
+    rows, cols = idx[:, 0].astype(np.int64), idx[:, 1].astype(np.int64)
+    out = np.empty(len(rows))
+    for k in range(len(rows)):
+        lo, hi = A.indptr[rows[k]], A.indptr[rows[k] + 1]
+        pos = lo + np.searchsorted(A.indices[lo:hi], cols[k])
+        assert pos < hi and A.indices[pos] == cols[k]
+        out[k] = A.data[pos]
+    return out
+
+
+@pytest.mark.parametrize('path', ['fused', 'unfused'])
+def test_fullsize_vs_reference_c2(iga, golden, path, monkeypatch):
+    """BASELINE config 2: 2D p=3 n=256 NURBS quarter annulus, 'CSR vs reference within 1e-12'."""
+    monkeypatch.setenv('IGX_PATH', path)
+    g = golden('fullsize')
+    kv = iga.bspline.make_knots(3, 0., 1., 256)
+    A = iga.assemble.stiffness((kv, kv), iga.geometry.quarter_annulus())
+    assert A.nnz == int(g['c2_nnz'])
+    scale = float(g['c2_absmax'])
+    assert abs(abs(A).max() - scale) <= 1e-12 * scale
+    assert np.abs(_csr_at(A, g['c2_idx']) - g['c2_val']).max() <= RTOL * scale
+    # the whole matrix through a fixed vector: every entry takes part
+    x = np.sin(0.37 * np.arange(A.shape[0]) + 0.1)
+    assert np.abs(A @ x - g['c2_Ax']).max() <= 1e-11 * scale
+    assert abs(A - A.T).max() == 0.0
+
+
+@pytest.mark.parametrize('path', ['fused', 'unfused'])
+def test_fullsize_vs_reference_3d(iga, golden, path, monkeypatch):
+    """BASELINE config 3 at full size (3D p=2 n=64, mass + stiffness) and the config-4 / config-5 degrees at the largest
+    size the reference was run at (p=4 n=32, p=5 n=24; stiffness and the convection-diffusion form)."""
+    monkeypatch.setenv('IGX_PATH', path)
+    g = golden('fullsize')
+    geo = _geo(iga, 'cylinder')
+    for tag, p, n, kinds in (('c3', 2, 64, ('stiff', 'mass')), ('p4n32', 4, 32, ('stiff',)), ('p5n24', 5, 24, ('stiff', 'convdiff'))):
+        kv = iga.bspline.make_knots(p, 0., 1., n)
+        kvs = (kv, kv, kv)
+        idx = g[tag + '_idx']
+        for kind in kinds:
+            if kind == 'convdiff':
+                A = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + x).assemble_csr()
+            else:
+                A = (iga.assemble.stiffness if kind == 'stiff' else iga.assemble.mass)(kvs, geo)
+            ref = g['%s_%s' % (tag, kind)]
+            err = np.abs(_csr_at(A, idx) - ref).max()
+            assert err <= RTOL * abs(A).max(), (tag, kind, err / abs(A).max())
+            del A
+
+
+@pytest.mark.parametrize('d,p,n', [(2, 1, 9), (2, 2, 33), (2, 3, 70), (2, 4, 37), (2, 5, 21), (3, 1, 7), (3, 2, 13),
+                                   (3, 3, 11), (3, 4, 9), (3, 5, 8)])
+def test_fused_equals_unfused(iga, d, p, n, monkeypatch):
+    """The fused sweep + final stage + mirror pass against the round-1 kernels (K2 through HBM) for every degree of
+    the fast path, mass and stiffness: same matrix to rounding, exactly symmetric, every value written."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * d
+    geo = iga.geometry.quarter_annulus() if d == 2 else _geo(iga, 'cylinder')
+    for kind in ('mass', 'stiffness'):
+        monkeypatch.setenv('IGX_PATH', 'fused')
+        A = iga.assemblers.DevicePatch(kvs, geo).csr(kind, algo='sumfact')
+        monkeypatch.setenv('IGX_PATH', 'unfused')
+        B = iga.assemblers.DevicePatch(kvs, geo).csr(kind, algo='sumfact')
+        assert not np.isnan(A.data).any()
+        assert abs(A - A.T).max() == 0.0
+        assert rel_maxdiff(A, B) <= RTOL, (kind, rel_maxdiff(A, B))
