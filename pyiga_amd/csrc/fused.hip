@@ -27,6 +27,7 @@
 // knots, the same degree and q = p + 1 Gauss points per span.
 #include "igx_internal.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -36,13 +37,49 @@ typedef const double __attribute__((address_space(4))) *cdp;
 typedef const int __attribute__((address_space(4))) *cip;
 
 constexpr int BF_TL = 128;            // Gauss points of the last axis per block = lanes of the sweep (2 waves per role)
+constexpr int BF_NCW = 4;             // contractor waves
+constexpr int BF_NSTW = 0;            // dedicated store waves (0: the contractor waves also store the segments)
 
+// Sweeper roles: one per last-axis type y that occurs.  The arrays entering the sweep are grouped by (y, mid-axis type
+// t1 = tu + 2 tv); MASK has bit 4 y + t1 set for the groups that exist.  Per Gauss point a role accumulates
+//   shape 0 (one tu = f):   acc[a][b] += V[b][f] * (V[a][0] * K[f] + V[a][1] * K[f + 2])                 30..35 FMAs
+//   shape 1 (one tv = f):   acc[a][b] += V[a][f] * (V[b][0] * K[2 f] + V[b][1] * K[2 f + 1])             30..35 FMAs
+//   shape 2 (all four t1):  acc[a][b] += sum_tu V[b][tu] * (V[a][0] * K[tu] + V[a][1] * K[tu + 2])       70 FMAs
+// (a: test function = row, b: trial function; PI[t1][a][b] = V[b][tu] V[a][tv]) instead of 25 FMAs per array with 25
+// coefficients each.  has[t1] says which K exist.
+struct BFRole { int y, shape, f, has[4]; };
+constexpr int bf_roles_of_y(int m) { return m == 0 ? 0 : 1; }
+constexpr int bf_nroles(int MASK)
+{
+    return bf_roles_of_y(MASK & 15) + bf_roles_of_y((MASK >> 4) & 15) + bf_roles_of_y((MASK >> 8) & 15) + bf_roles_of_y((MASK >> 12) & 15);
+}
+constexpr BFRole bf_role_y(int y, int m)
+{
+    if ((m & 10) == 0) return BFRole{y, 0, 0, {m & 1, 0, (m >> 2) & 1, 0}};                // only tu = 0
+    if ((m & 5) == 0) return BFRole{y, 0, 1, {0, (m >> 1) & 1, 0, (m >> 3) & 1}};          // only tu = 1
+    if ((m & 12) == 0) return BFRole{y, 1, 0, {m & 1, (m >> 1) & 1, 0, 0}};                // only tv = 0
+    if ((m & 3) == 0) return BFRole{y, 1, 1, {0, 0, (m >> 2) & 1, (m >> 3) & 1}};          // only tv = 1
+    return BFRole{y, 2, 0, {m & 1, (m >> 1) & 1, (m >> 2) & 1, (m >> 3) & 1}};
+}
+constexpr BFRole bf_role(int MASK, int r)
+{
+    for (int y = 0; y < 4; ++y) {
+        const int m = (MASK >> (4 * y)) & 15, n = bf_roles_of_y(m);
+        if (r < n) return bf_role_y(y, m);
+        r -= n;
+    }
+    return BFRole{0, 0, 0, {0, 0, 0, 0}};
+}
 template <int P>
 struct BFGeom {
     static constexpr int p = P - 1, W = 2 * P - 1;
     static constexpr int SPANS = BF_TL / P;                // spans of a tile window
-    static constexpr int RMAX = SPANS - p;                 // rows of the last axis per tile
-    static constexpr int NCW = (RMAX * W + 63) / 64;       // contractor waves: one lane per (row, line)
+    static constexpr int RGEO = SPANS - p;                 // rows of the last axis whose support fits the window
+    static constexpr int LPL = P <= 5 ? 2 : 1;             // lines per contractor lane (two share the reads of the basis values; registers allow it up to p = 3)
+    static constexpr int LG = (W + LPL - 1) / LPL;         // line groups: a contractor lane pair takes LPL lines of a row
+    static constexpr int RCAP = (BF_NCW * 32) / LG;        // rows the contractors cover: one lane PAIR per (row, line group)
+    static constexpr int RMAX = RGEO < RCAP ? RGEO : RCAP; // rows per tile
+    static constexpr int KR = (RMAX + BF_NCW - 1) / BF_NCW;   // rows per contractor wave in the store phase
 };
 
 struct BFArgs {
@@ -65,119 +102,286 @@ struct BFArgs {
     int mid_lo, mid_hi;           // rows of the mid axis to produce
     int span_hi;                  // spans of the mid axis below this one are resident (2D row slabs; else n1)
     int npairs;
+    int dbg;                      // ablation mask (IGX_BF_DBG; timing experiments only): 1 no contraction, 2 no segment stores,
+                                  //   4 no sweep arithmetic
 };
 
+// Diagnostic build (-DIGX_BF_STAMP, never the shipped library): every wave adds up the shader cycles it spends waiting
+// at the two barriers of a step; wave 0 lane 0 of each role group of block 0.. writes {wait, total} per wave at the end.
+#ifdef IGX_BF_STAMP
+__device__ unsigned long long g_bf_stamp[64 * 1024];
+#define BF_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#define BF_STAMP_END(w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+        g_bf_stamp[(blockIdx.x * 16 + (w)) * 2] = st_wait; g_bf_stamp[(blockIdx.x * 16 + (w)) * 2 + 1] = t1_ - st_t0; } } while (0)
+#define bar_lds() do { const unsigned long long a_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        st_wait += __builtin_amdgcn_s_memtime() - a_; } while (0)
+#else
+#define BF_STAMP_DECL
+#define BF_STAMP_END(w)
 __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
-// One Gauss point of the sweep for the role whose mid-axis types are MASKY (bit t1 = tu + 2 tv):
-//   acc[a][b] += sum_{tu} V[b][tu] * (sum_{tv} V[a][tv] * kt[tu + 2 tv])
-template <int P, int MASKY>
-__device__ __forceinline__ void sweep_point(double (&acc)[P][P], const double (&kt)[4], const double (&v)[P][2])
+// exchange between the two lanes of a pair (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double pair_swap(double x)
 {
-#pragma unroll
-    for (int tu = 0; tu < 2; ++tu) {
-        const bool h0 = (MASKY >> tu) & 1, h1 = (MASKY >> (tu + 2)) & 1;
-        if (!h0 && !h1) continue;
-#pragma unroll
-        for (int a = 0; a < P; ++a) {
-            double c;
-            if (h0 && h1) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
-            else if (h0) c = v[a][0] * kt[tu];
-            else c = v[a][1] * kt[tu + 2];
-#pragma unroll
-            for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
-        }
-    }
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
-template <int P, int NY, int MASKY, int NA>
-__device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int y, const int r0, const int g2l, const int g2,
-                                           const int s_begin, const int rhi, double *lines, const int LS)
+// ---- sweeper: role R of MASK, lane = Gauss point g2 of the tile window.  The values of one span live in registers; each
+// is reloaded for the next span right after its use, so a load has a whole step to land and the waits are counted
+// (no branch around a load inside the loops: hipcc answers those with vmcnt(0)).
+template <int P, int MASK, int RI, int NA>
+__device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
+                                           const int rhi, double *lines, const int LS)
 {
+    constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = BF_TL;
+    BF_STAMP_DECL
     cdp V1 = (cdp)A.V1;
     double acc[P][P];
 #pragma unroll
     for (int a = 0; a < P; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
-    // uniform row pointers of the present slots
+    // per-lane row pointers of the slots that exist
     const double *base[4][NA];
-    int rs[4][NA];
+    long long rs[4][NA];
 #pragma unroll
     for (int t1 = 0; t1 < 4; ++t1)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            base[t1][i] = A.sp[y][t1][i] + (long long)r0 * A.ss[y][t1][i] - (long long)A.gmid_lo * A.rs[y][t1][i];
-            rs[t1][i] = A.rs[y][t1][i];
+            rs[t1][i] = A.rs[R.y][t1][i];
+            base[t1][i] = A.sp[R.y][t1][i] + (long long)r0 * A.ss[R.y][t1][i] - (long long)A.gmid_lo * rs[t1][i] + g2;
         }
-    const int n_sw = min(A.n1, A.span_hi);           // spans that exist and are resident
-    const int t_lastc = min(n_sw, rhi) - 1;          // last span that is swept
-    double kv[P][4][NA];                             // values of one span; each is reloaded right after its use
+    const int n_sw = min(A.n1, A.span_hi);               // spans that exist and are resident
+    const int t_sw = min(n_sw, rhi);                     // sweeping steps end here
+    double kv[P][4][NA];
     {
-        const int s = min(s_begin, t_lastc);
+        const int s = min(s_begin, t_sw - 1);
 #pragma unroll
         for (int l = 0; l < P; ++l)
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1)
-                if ((MASKY >> t1) & 1)
+                if (R.has[t1])
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = (base[t1][i] + (long long)(s * P + l) * rs[t1][i])[g2];
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = base[t1][i][(long long)(s * P + l) * rs[t1][i]];
     }
-    for (int t = s_begin; t < rhi + 2; ++t) {
-        bar_lds();                                   // B1
-        if (t < rhi && t < n_sw) {
-            const int tn = min(t + 1, t_lastc);
-            cdp cf = V1 + (size_t)t * P * P * 2;
+    auto flush = [&]() {
+        // dof t leaves: column (t+a, t) and row (t, t+a) of the pair window are complete
+        double *ln = lines + RI * TL + g2l;
 #pragma unroll
-            for (int l = 0; l < P; ++l) {
-                double v[P][2];
+        for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
 #pragma unroll
-                for (int b = 0; b < P; ++b) { v[b][0] = cf[(l * P + b) * 2]; v[b][1] = cf[(l * P + b) * 2 + 1]; }
-                double kt[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
 #pragma unroll
-                for (int t1 = 0; t1 < 4; ++t1)
-                    if ((MASKY >> t1) & 1) {
-                        kt[t1] = kv[l][t1][0];
-                        if (NA == 2) kt[t1] += kv[l][t1][1];
+        for (int a = 0; a < P - 1; ++a)
 #pragma unroll
-                        for (int i = 0; i < NA; ++i) kv[l][t1][i] = (base[t1][i] + (long long)(tn * P + l) * rs[t1][i])[g2];
+            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+        for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
+    };
+    int t = s_begin;
+    for (; t < t_sw; ++t) {
+        bar_lds();                                       // B1
+        const int tn = min(t + 1, t_sw - 1);
+        cdp cf = V1 + (size_t)t * P * P * 2;
+        double v[P][2];
+#pragma unroll
+        for (int b = 0; b < P; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
+#pragma unroll
+        for (int l = 0; l < P; ++l) {
+            // coefficients of the next point are requested before this point's arithmetic
+            double vn[P][2];
+            const int ln_ = l + 1 < P ? l + 1 : l;
+#pragma unroll
+            for (int b = 0; b < P; ++b) { vn[b][0] = cf[(ln_ * P + b) * 2]; vn[b][1] = cf[(ln_ * P + b) * 2 + 1]; }
+            double kt[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1)
+                if (R.has[t1]) {
+                    kt[t1] = kv[l][t1][0];
+                    if (NA == 2) kt[t1] += kv[l][t1][1];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = base[t1][i][(long long)(tn * P + l) * rs[t1][i]];
+                }
+            if (!(A.dbg & 4)) {
+                if (R.shape == 1) {
+                    // one tv = f: w[b] = sum_tu V[b][tu] K[tu + 2 f]
+#pragma unroll
+                    for (int b = 0; b < P; ++b) {
+                        double w;
+                        if (R.has[2 * R.f] && R.has[2 * R.f + 1]) w = fma(v[b][1], kt[2 * R.f + 1], v[b][0] * kt[2 * R.f]);
+                        else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
+                        else w = v[b][1] * kt[2 * R.f + 1];
+#pragma unroll
+                        for (int a = 0; a < P; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
                     }
-                sweep_point<P, MASKY>(acc, kt, v);
-                // keep the points apart: the coefficient loads of point l+1 may not be hoisted above the FMAs of point l
+                } else {
+                    // c[a] = sum_tv V[a][tv] K[tu + 2 tv] for the tu that occur
 #pragma unroll
-                for (int a = 0; a < P; ++a)
+                    for (int tu = 0; tu < 2; ++tu) {
+                        if (!(R.has[tu] || R.has[tu + 2])) continue;
 #pragma unroll
-                    for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+                        for (int a = 0; a < P; ++a) {
+                            double c;
+                            if (R.has[tu] && R.has[tu + 2]) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
+                            else if (R.has[tu]) c = v[a][0] * kt[tu];
+                            else c = v[a][1] * kt[tu + 2];
+#pragma unroll
+                            for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                        }
+                    }
+                }
+            } else acc[0][0] += kt[0] + kt[1] + kt[2] + kt[3];
+            // keep the points apart (the FMAs of point l precede the coefficient use of point l+1)
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+#pragma unroll
+            for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
+        }
+        bar_lds();                                       // B2: the contractors have read the previous lines
+        flush();
+    }
+    for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
+        bar_lds();
+        bar_lds();
+        flush();
+    }
+    for (; t < rhi + 2; ++t) { bar_lds(); bar_lds(); }   // the contractors finish the last two rows
+    BF_STAMP_END(threadIdx.x >> 6);
+}
+
+template <int P, int MASK, int NA, int RI, bool END = (RI >= bf_nroles(MASK))>
+struct BFSweepDispatch {
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    {
+        if (role == RI) bf_sweeper<P, MASK, RI, NA>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
+        else BFSweepDispatch<P, MASK, NA, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+    }
+};
+template <int P, int MASK, int NA, int RI>
+struct BFSweepDispatch<P, MASK, NA, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+};
+
+// K values by last-axis type: the lines of the roles of one type are added (R: the raw role values of one Gauss point)
+template <int MASK, int RI, bool END = (RI >= bf_nroles(MASK))>
+struct BFKSum {
+    template <int NR>
+    __device__ static __forceinline__ void run(double (&K)[4], const double (&R)[NR])
+    {
+        constexpr int y = bf_role(MASK, RI).y;
+        constexpr bool first = RI == 0 || bf_role(MASK, RI > 0 ? RI - 1 : 0).y != y;      // roles are ordered by y
+        if (first) K[y] = R[RI]; else K[y] += R[RI];
+        BFKSum<MASK, RI + 1>::run(K, R);
+    }
+};
+template <int MASK, int RI>
+struct BFKSum<MASK, RI, true> {
+    template <int NR>
+    __device__ static __forceinline__ void run(double (&)[4], const double (&)[NR]) {}
+};
+
+// Contraction of LPL K2 lines (ln[q]: window images, all roles) with the last axis for one row: accv[q][o] = partial sums
+// of this lane half (Gauss points l = h, h + 2, ...) of the 2p+1 entries of line q.  vs: basis values from the first point
+// of the row's support; nsp spans in the support; irel = row - first span (INNER: the row's function is function p - k of
+// its k-th span, true for every row >= p).
+template <int P, int NY, int MASK, int LPL, bool INNER>
+__device__ __forceinline__ void bf_contract(double (&accv)[LPL][2 * P - 1], const double *const (&ln)[LPL], const double *vs,
+                                            const int h, const int nsp, const int irel)
+{
+    constexpr int p = P - 1, W = 2 * P - 1, NLH = (P + 1) / 2, NR = bf_nroles(MASK);
+#pragma unroll
+    for (int q = 0; q < LPL; ++q)
+#pragma unroll
+        for (int o = 0; o < W; ++o) accv[q][o] = 0.0;
+    // NIT = P * NLH (span, point) steps per lane.  Every value read from LDS is replaced by the one of the next step
+    // right after its last use, so the reads of step n+1 are in flight under the arithmetic of step n.
+    constexpr int NIT = P * NLH;
+    auto gof = [&](const int it) { const int kk = it / NLH, l = 2 * (it - kk * NLH) + h; return kk * P + min(l, P - 1); };
+    double R[LPL][NR], V[P][2];                          // role values (one role per type) of the lines, basis values
+    auto load_K = [&](const int it) {
+        const int g = gof(it);
+#pragma unroll
+        for (int q = 0; q < LPL; ++q)
+#pragma unroll
+            for (int ri = 0; ri < NR; ++ri) R[q][ri] = ln[q][ri * BF_TL + g];
+    };
+    auto load_V = [&](const int it, const int b) {
+        const double *vg = vs + (size_t)gof(it) * P * 2;
+        V[b][0] = vg[2 * b]; V[b][1] = vg[2 * b + 1];
+    };
+    load_K(0);
+#pragma unroll
+    for (int b = 0; b < P; ++b) load_V(0, b);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int kk = it / NLH, j = it - kk * NLH;
+        const bool pv = kk < nsp && 2 * j + h < P;
+        double va0, va1;
+        if (INNER) { va0 = V[p - kk][0]; va1 = V[p - kk][1]; }         // test function = function p - kk of the span
+        else {
+            const int a2 = min(max(irel - kk, 0), p);
+            const double *vg = vs + (size_t)gof(it) * P * 2;
+            va0 = vg[2 * a2]; va1 = vg[2 * a2 + 1];
+        }
+        if (!pv) { va0 = 0.0; va1 = 0.0; }
+        double cu[LPL][2];
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) {
+            double KK[4] = {0.0, 0.0, 0.0, 0.0};
+            BFKSum<MASK, 0>::run(KK, R[q]);               // by type (one role per type: a copy)
+            if (NY == 1) { cu[q][0] = va0 * KK[0]; cu[q][1] = 0.0; }
+            else {
+                cu[q][0] = fma(va1, KK[2], va0 * KK[0]);  // types 0, 2
+                cu[q][1] = fma(va1, KK[3], va0 * KK[1]);  // types 1, 3
             }
         }
-        bar_lds();                                   // B2: the contractors have read the previous lines
-        if (t < rhi) {
-            // dof t leaves: column (t+a, t) and row (t, t+a) of the pair window are complete
-            double *ln = lines + y * TL + g2l;
+        if (it + 1 < NIT) {
 #pragma unroll
-            for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
-#pragma unroll
-            for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
-#pragma unroll
-            for (int a = 0; a < P - 1; ++a)
-#pragma unroll
-                for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
-#pragma unroll
-            for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
+            for (int q = 0; q < LPL; ++q) asm volatile("" : "+v"(cu[q][0]), "+v"(cu[q][1]));   // R is dead from here
+            load_K(it + 1);
+            __builtin_amdgcn_sched_barrier(0);            // the refill stays here, a whole step ahead of its use
         }
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+#pragma unroll
+            for (int q = 0; q < LPL; ++q) {
+                if (NY == 1) accv[q][kk + b] = fma(V[b][0], cu[q][0], accv[q][kk + b]);
+                else accv[q][kk + b] = fma(V[b][0], cu[q][0], fma(V[b][1], cu[q][1], accv[q][kk + b]));
+            }
+            if (it + 1 < NIT) {
+#pragma unroll
+                for (int q = 0; q < LPL; ++q) asm volatile("" : "+v"(accv[q][kk + b]));      // V[b] is dead from here
+                load_V(it + 1, b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the reads of step n+2 may not be hoisted above this point (register blow-up)
+#pragma unroll
+        for (int q = 0; q < LPL; ++q)
+#pragma unroll
+            for (int b = 0; b < P; ++b) asm volatile("" : "+v"(accv[q][kk + b]));
+        asm volatile("" ::: "memory");
     }
 }
 
 template <int P, int NY, int MASK, int NA>
-__global__ void __launch_bounds__((NY * (BF_TL / 64) + BFGeom<P>::NCW) * 64) k_bf(const BFArgs A)
+__global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW) * 64) k_bf(const BFArgs A)
 {
     using Gm = BFGeom<P>;
-    constexpr int p = P - 1, W = 2 * P - 1, TL = BF_TL, NLG = TL / 64, NSW = NY * NLG, NCW = Gm::NCW, RMAX = Gm::RMAX;
-    constexpr int LS = NY * TL + 2;                       // doubles per line (all types), padded against bank conflicts
+    constexpr int p = P - 1, W = 2 * P - 1, TL = BF_TL, NLG = TL / 64, NR = bf_nroles(MASK), NSW = NR * NLG, NCW = BF_NCW;
+    constexpr int RMAX = Gm::RMAX, KR = Gm::KR;
+    constexpr int LS = NR * TL + 2;                       // doubles per line (all roles), padded against bank conflicts
     constexpr int OFF_RING = (W * LS + 1) & ~1;
     constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * RMAX * W + 1) & ~1;
     constexpr int OFF_V2 = (OFF_CUR + 2 * P * RMAX * W + 1) & ~1;
+    constexpr int OFF_RT = OFF_V2 + TL * P * 2;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lines = lds;                 // [W][LS]: lines 0..p = pairs (d+a, d), lines p+a = pairs (d, d+a) of the last flush
     double *ring = lds + OFF_RING;       // [P+1][p][RMAX][W]: entries of the pairs (i1, j1 < i1), row slot i1 mod (P+1)
@@ -203,101 +407,125 @@ __global__ void __launch_bounds__((NY * (BF_TL / 64) + BFGeom<P>::NCW) * 64) k_b
     const int rlo = A.mid_lo + mch * A.mrows, rhi = min(rlo + A.mrows, A.mid_hi);
     const int s_begin = max(rlo - p, 0);
 
-    for (int idx = threadIdx.x; idx < nwin * P * 2; idx += blockDim.x) V2s[idx] = A.V2[(size_t)win0 * P * 2 + idx];
+    for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) V2s[idx] = idx < nwin * P * 2 ? A.V2[(size_t)win0 * P * 2 + idx] : 0.0;
     // the barrier B1 of the first iteration orders these writes before their first use
 
-    if (wave < NSW) {
-        // ---------------- sweepers: role y, lane group lg
-        const int y = wave % NY, lg = wave / NY;
+    // wave -> task.  A workgroup's waves go to the four SIMDs cyclically, so every SIMD gets one contractor and (for
+    // four roles) one wave of each half of the roles: 0,1: role 0 | 2,3: role 1 | 4..7: contractors | 8,9: role 2 | 10,11: role 3.
+    // Task ids: sweepers 0..NSW-1 (role = id / 2, lane group = id % 2), contractors NSW..
+    int task = wave;
+    if (NR == 4 && NCW == 4) {
+        if (wave >= 4 && wave < 8) task = NSW + (wave - 4);
+        else if (wave >= 8) task = wave - 4;
+    }
+    if (task < NSW) {
+        // ---------------- sweepers: role, lane group lg
+        const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
-        const int g2 = min(win0 + g2l, A.G2 - 1);
-        if (NY == 1) bf_sweeper<P, NY, MASK & 15, NA>(A, 0, r0, g2l, g2, s_begin, rhi, lines, LS);
-        else {
-            switch (y) {
-            case 0: bf_sweeper<P, NY, MASK & 15, NA>(A, 0, r0, g2l, g2, s_begin, rhi, lines, LS); break;
-            case 1: bf_sweeper<P, NY, (MASK >> 4) & 15, NA>(A, 1, r0, g2l, g2, s_begin, rhi, lines, LS); break;
-            case 2: bf_sweeper<P, NY, (MASK >> 8) & 15, NA>(A, 2, r0, g2l, g2, s_begin, rhi, lines, LS); break;
-            default: bf_sweeper<P, NY, (MASK >> 12) & 15, NA>(A, 3, r0, g2l, g2, s_begin, rhi, lines, LS); break;
-            }
-        }
+        const int g2 = min(win0 + min(g2l, nwin - 1), A.G2 - 1);     // lanes past the window re-read its last point
+        BFSweepDispatch<P, MASK, NA, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
         return;
     }
 
-    // ---------------- contractors: lane = (row r of the tile, line k9)
-    const int cw = wave - NSW;
-    const int idx = cw * 64 + lane;
-    const bool cval = idx < nrows * W;
-    const int r = cval ? idx / W : 0, k9 = cval ? idx - r * W : 0;
+    // ---------------- contractors: a lane PAIR per (row r of the tile, group of two lines); the halves take the Gauss
+    // points l = h, h + 2, ... of every span and add their sums through DPP.  Two lines per lane share the reads of
+    // the basis values: the stage is bound by LDS reads, not by arithmetic.
+    constexpr int LG = Gm::LG, LPL = Gm::LPL;
+    BF_STAMP_DECL
+    const int cw = task - NSW;
+    const int idx = cw * 32 + (lane >> 1), h = lane & 1;
+    const bool cval = idx < nrows * LG;
+    const int r = cval ? idx / LG : 0, lgp = cval ? idx - r * LG : 0;
     const int i2 = row_lo + r;
     const int slo = max(i2 - p, 0), nsp = min(i2, A.n2 - 1) + 1 - slo;
     const int gl0 = (slo - sp_lo) * P;                    // window index of the first Gauss point of row i2's support
-    const int la = k9 <= p ? k9 : k9 - p;                 // line k9: pair (d + la, d) for k9 <= p, else (d, d + la)
     const int c0i = jhi0[i0] - jlo0[i0];
     const long long S12 = A.S1 * A.S2;
+    constexpr int NLH = (P + 1) / 2;                      // Gauss points per span and half
+    const bool inner = row_lo >= p;                       // rows >= p: in span k of its support, row i is function p - k
 
+    // ---- segment stores: whole CSR segments of the row completed two steps ago, from the entry rings.  The contractor
+    // waves share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
+    // q = (rr * W + m) * W + o, lane-consecutive -> consecutive lanes write consecutive doubles.  What does not depend on the
+    // step is worked out once per lane.
+            constexpr int NSL = (RMAX * W * W + 64 * NCW - 1) / (64 * NCW);
+            int pl_rp[NSL], pl_src[NSL], pl_mo[NSL];          // rp2[row] | rr * W + o | m, o, c2, flags
+    #pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                const int q = (k * NCW + cw) * 64 + lane;
+                const int rr = min(q / (W * W), RMAX - 1), e2 = q - (q / (W * W)) * (W * W);
+                const int m = e2 / W, o = e2 - m * W;
+                const int2 rt = make_int2(rp2[min(row_lo + rr, A.N2 - 1)], min(row_lo + rr + p, A.N2 - 1) + 1 - max(row_lo + rr - p, 0));
+                const int i2r = row_lo + rr;
+                const bool ok = q < nrows * W * W && o < rt.y;
+                const bool dg = o <= i2r - max(i2r - p, 0);   // entry of the diagonal line of a diagonal block that is stored (j2 <= i2)
+                pl_rp[k] = rt.x; pl_src[k] = rr * W + o;
+                pl_mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0);   // (rows past the axis have a negative run length)
+            }
     for (int t = s_begin; t < rhi + 2; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
-        // ---- whole segments of row dd2 = t - 2 (its entries were completed in the previous iteration)
-        const int dd2 = t - 2;
-        if (dd2 >= rlo && dd2 < rhi) {
-            const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
-            const double *rg = ring + (size_t)((dd2 % (P + 1)) * p) * RMAX * W;
-            const double *cu = cur + (size_t)((dd2 & 1) * P) * RMAX * W;
-            for (int rr = cw; rr < nrows; rr += NCW) {
-                const int i2r = row_lo + rr;
-                const int jl2 = max(i2r - p, 0), c2r = min(i2r + p, A.N2 - 1) + 1 - jl2;
-                const int ne = diag0 ? (dd2 - jl1) * c2r + (i2r - jl2 + 1) : c1 * c2r;
-                double *dst = A.data + ((long long)rp0[i0] * S12 + (long long)c0i * ((long long)rp1[dd2] * A.S2 + (long long)c1 * rp2[i2r])
-                                        - A.nnz_off + (long long)(j0 - jlo0[i0]) * c1 * c2r);
-                for (int e = lane; e < ne; e += 64) {
-                    const int m = e / c2r, o = e - m * c2r;
-                    const int j1 = jl1 + m;
-                    const double v = (j1 < dd2) ? rg[((p - (dd2 - j1)) * RMAX + rr) * W + o] : cu[((j1 - dd2) * RMAX + rr) * W + o];
-                    dst[e] = v;
-                }
-            }
-        }
-        // ---- contract the lines of flush dd = t - 1 with the last axis
-        const int dd = t - 1;
-        if (dd >= s_begin && dd < rhi) {
-            const int row1 = k9 <= p ? dd + la : dd, col1 = k9 <= p ? dd : dd + la;
-            const bool lv = cval && row1 >= rlo && row1 < rhi && col1 < A.N1 && !(diag0 && col1 > row1);
-            if (lv) {
-                double accv[W];
-#pragma unroll
-                for (int o = 0; o < W; ++o) accv[o] = 0.0;
-                const double *ln = lines + k9 * LS + gl0;
-                const double *vs = V2s + gl0 * P * 2;
-#pragma unroll
-                for (int kk = 0; kk < P; ++kk) {
-                    if (kk < nsp) {
-                        const int a2 = i2 - (slo + kk);   // local index of the test function in this span
-#pragma unroll
-                        for (int l = 0; l < P; ++l) {
-                            const int g = kk * P + l;
-                            const double va0 = vs[(g * P + a2) * 2], va1 = vs[(g * P + a2) * 2 + 1];
-                            double cu0, cu1 = 0.0;
-                            if (NY == 1) cu0 = va0 * ln[g];
-                            else {
-                                cu0 = fma(va1, ln[2 * TL + g], va0 * ln[g]);           // types 0, 2
-                                cu1 = fma(va1, ln[3 * TL + g], va0 * ln[TL + g]);      // types 1, 3
-                            }
-#pragma unroll
-                            for (int b = 0; b < P; ++b) {
-                                if (NY == 1) accv[kk + b] = fma(vs[(g * P + b) * 2], cu0, accv[kk + b]);
-                                else accv[kk + b] = fma(vs[(g * P + b) * 2], cu0, fma(vs[(g * P + b) * 2 + 1], cu1, accv[kk + b]));
-                            }
+                    const int dd2 = t - 2;
+                    if (dd2 >= rlo && dd2 < rhi && !(A.dbg & 2)) {
+                        const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
+                        const int nm = diag0 ? dd2 - jl1 + 1 : c1;    // lines of the segment
+                        const int koff = p - (dd2 - jl1);             // line m of the segment is pair index m + koff: < p ring, >= p cur
+                        const double *rg = ring + (size_t)((dd2 % (P + 1)) * p) * RMAX * W;
+                        const double *cu = cur + (size_t)((dd2 & 1) * P) * RMAX * W;
+                        double *rowp = A.data + ((long long)rp0[i0] * S12 + (long long)c0i * (long long)rp1[dd2] * A.S2 - A.nnz_off);
+                        const int colb = (j0 - jlo0[i0]) * c1, rsc = c0i * c1;
+                        double val[NSL];
+        #pragma unroll
+                        for (int k = 0; k < NSL; ++k) {
+                            const int kx = min((pl_mo[k] & 15) + koff, 2 * p);
+                            val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl_src[k]];     // always inside the rings
+                        }
+        #pragma unroll
+                        for (int k = 0; k < NSL; ++k) {
+                            const int m = pl_mo[k] & 15, o = (pl_mo[k] >> 4) & 15, c2r = (pl_mo[k] >> 8) & 15;
+                            const bool ok = ((pl_mo[k] >> 12) & 1) && m < nm && !(diag0 && m == nm - 1 && !((pl_mo[k] >> 13) & 1));
+                            if (ok) rowp[(long long)rsc * pl_rp[k] + (colb + m) * c2r + o] = val[k];
                         }
                     }
-                }
-                double *dste = (col1 < row1) ? ring + (size_t)((((row1 % (P + 1)) * p + (p - la)) * RMAX + r)) * W
-                                             : cur + (size_t)((((dd & 1) * P + (col1 - row1)) * RMAX + r)) * W;
+        // ---- contract the lines of flush dd = t - 1 with the last axis
+        const int dd = t - 1;
+        if (dd >= s_begin && dd < rhi && !(A.dbg & 1)) {
+            // line k9: pair (dd + la, dd) for k9 <= p, else (dd, dd + la)
+            // per-lane constants pass through an opaque statement each step: hipcc would otherwise hoist the address arithmetic
+            // of all NIT contraction steps out of the step loop (dozens of registers, spilled)
+            int gl0s = gl0, irel = i2 - slo;
+            asm volatile("" : "+v"(gl0s), "+v"(irel));
+            bool lv[LPL], any = false;
+            int row1[LPL], col1[LPL];
+            const double *lnp[LPL];
 #pragma unroll
-                for (int o = 0; o < W; ++o) dste[o] = accv[o];
+            for (int q = 0; q < LPL; ++q) {
+                const int k9 = LPL * lgp + q, la = k9 <= p ? k9 : k9 - p;
+                row1[q] = k9 <= p ? dd + la : dd; col1[q] = k9 <= p ? dd : dd + la;
+                lv[q] = cval && k9 < W && row1[q] >= rlo && row1[q] < rhi && col1[q] < A.N1 && !(diag0 && col1[q] > row1[q]);
+                any = any || lv[q];
+                lnp[q] = lines + min(k9, W - 1) * LS + gl0s;
+            }
+            if (any) {
+                double accv[LPL][W];
+                if (inner) bf_contract<P, NY, MASK, LPL, true>(accv, lnp, V2s + gl0s * P * 2, h, nsp, irel);
+                else bf_contract<P, NY, MASK, LPL, false>(accv, lnp, V2s + gl0s * P * 2, h, nsp, irel);
+#pragma unroll
+                for (int q = 0; q < LPL; ++q) {
+#pragma unroll
+                    for (int o = 0; o < W; ++o) accv[q][o] += pair_swap(accv[q][o]);
+                    if (h == 0 && lv[q]) {
+                        const int la = row1[q] - col1[q];
+                        double *dste = (la > 0) ? ring + (size_t)((((row1[q] % (P + 1)) * p + (p - la)) * RMAX + r)) * W
+                                                : cur + (size_t)((((dd & 1) * P - la) * RMAX + r)) * W;
+#pragma unroll
+                        for (int o = 0; o < W; ++o) dste[o] = accv[q][o];
+                    }
+                }
             }
         }
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
     }
+    BF_STAMP_END(wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -342,22 +570,39 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
     for (int i1 = M.i1_lo; i1 < M.i1_hi; ++i1) {
         const int jl1i = jlo1[i1], c1i = jhi1[i1] - jl1i;
         const int a1 = diag ? i1 : jl1i, b1 = jhi1[i1], nj1 = b1 - a1;
-        // ---- gather: T[j1 - a1][j2 - j2lo][i2' - jlo2[j2]]
+        // ---- gather: T[j1 - a1][j2 - j2lo][i2' - jlo2[j2]]; GU loads in flight per thread
         const int total = nj1 * nj2 * W2;
-        for (int f = threadIdx.x; f < total; f += blockDim.x) {
-            const int op = f % W2, rest = f / W2;
-            const int j2r = rest % nj2, j1i = rest / nj2;
-            const int j1 = a1 + j1i, j2 = j2lo + j2r;
-            const int jl2 = t_jlo2[j2], c2 = t_c2[j2];
-            const int i2p = jl2 + op;
-            double v = 0.0;
-            if (op < c2 && i2p >= cl && i2p < ch && !(diag && j1 == i1 && j2 <= i2p)) {
-                const int c1j = jhi1[j1] - jlo1[j1];
-                const long long src = (long long)rp0[j0] * S12 + (long long)c0j * ((long long)rp1[j1] * M.S2 + (long long)c1j * t_rp2[j2])
-                                      + ((long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1])) * c2 + op - M.nnz_off;
-                v = M.data[src];
+        constexpr int GU = 8;
+        for (int f0 = threadIdx.x; f0 < total; f0 += blockDim.x * GU) {
+            double v[GU];
+            const double *src[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * blockDim.x;
+                src[u] = nullptr;
+                if (f < total) {
+                    const int op = f % W2, rest = f / W2;
+                    const int j2r = rest % nj2, j1i = rest / nj2;
+                    const int j1 = a1 + j1i, j2 = j2lo + j2r;
+                    const int jl2 = t_jlo2[j2], c2 = t_c2[j2];
+                    const int i2p = jl2 + op;
+                    if (op < c2 && i2p >= cl && i2p < ch && !(diag && j1 == i1 && j2 <= i2p)) {
+                        const int c1j = jhi1[j1] - jlo1[j1];
+                        src[u] = M.data + ((long long)rp0[j0] * S12 + (long long)c0j * ((long long)rp1[j1] * M.S2 + (long long)c1j * t_rp2[j2])
+                                           + ((long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1])) * c2 + op - M.nnz_off);
+                    }
+                }
             }
-            T[(j1i * NJ2 + j2r) * W2 + op] = v;
+#pragma unroll
+            for (int u = 0; u < GU; ++u) v[u] = src[u] ? *src[u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * blockDim.x;
+                if (f < total) {
+                    const int op = f % W2, rest = f / W2;
+                    T[((rest / nj2) * NJ2 + rest % nj2) * W2 + op] = v[u];
+                }
+            }
         }
         __syncthreads();
         // ---- whole target segments
@@ -383,19 +628,32 @@ template <int P, int NY, int MASK, int NA>
 static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
     using Gm = BFGeom<P>;
-    constexpr int W = 2 * P - 1, p = P - 1, LS = NY * BF_TL + 2;
+    constexpr int W = 2 * P - 1, p = P - 1, LS = bf_nroles(MASK) * BF_TL + 2;
     constexpr int OFF_RING = (W * LS + 1) & ~1;
     constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * Gm::RMAX * W + 1) & ~1;
     constexpr int OFF_V2 = (OFF_CUR + 2 * P * Gm::RMAX * W + 1) & ~1;
-    constexpr size_t lds = (size_t)(OFF_V2 + BF_TL * P * 2) * sizeof(double);
+    constexpr size_t lds = (size_t)(OFF_V2 + BF_TL * P * 2 + (Gm::RMAX + 1) / 2 * 2) * sizeof(double);
     static_assert(lds <= 160 * 1024, "k_bf: LDS");
     IGX_HIP(hipFuncSetAttribute((const void *)k_bf<P, NY, MASK, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_bf<P, NY, MASK, NA><<<dim3(nblocks), dim3((NY * (BF_TL / 64) + Gm::NCW) * 64), lds, st>>>(A);
+    k_bf<P, NY, MASK, NA><<<dim3(nblocks), dim3((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW) * 64), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
+#ifdef IGX_BF_STAMP
+    {
+        static std::vector<unsigned long long> h(64 * 1024);
+        IGX_HIP(hipStreamSynchronize(st));
+        IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bf_stamp), h.size() * sizeof(unsigned long long)));
+        const int nw = bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW, nb = std::min<unsigned>(nblocks, 2048);
+        for (int w = 0; w < nw; ++w) {
+            double wt = 0, tot = 0;
+            for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
+            fprintf(stderr, "k_bf stamp: wave %2d  wait %.0f  total %.0f cycles/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
+        }
+    }
+#endif
     return IGX_OK;
 }
 
-constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248, BF_MASK_ALL = 0xFFFF;
+constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
 template <int P>
 static int launch_bf_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
@@ -404,28 +662,51 @@ static int launch_bf_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny
     if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf_k<P, 4, BF_MASK_STIFF3, 1>(st, A, nblocks);
     if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf_k<P, 4, BF_MASK_STIFF3, 2>(st, A, nblocks);
     if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf_k<P, 4, BF_MASK_STIFF2, 1>(st, A, nblocks);
-    return launch_bf_k<P, 4, BF_MASK_ALL, 2>(st, A, nblocks);
+    set_error("fused stage: no kernel for this set of types");
+    return IGX_ERR_UNSUPPORTED;
 }
 
-int fused_rows_per_tile(int P) { return BF_TL / P - (P - 1); }
+static void bf_signature(const BFInputs &in, int &ny, int &mask, int &na)
+{
+    int ymax = 0;
+    mask = 0; na = 1;
+    for (int y = 0; y < 4; ++y)
+        for (int t1 = 0; t1 < 4; ++t1)
+            if (in.slot_n[y][t1] > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); na = std::max(na, in.slot_n[y][t1]); }
+    ny = ymax == 0 ? 1 : 4;
+}
+
+// the fused kernel is compiled for the sets of types of the BASELINE forms: mass, stiffness (2D, 3D) and the 3D
+// convection-diffusion form; other forms run the unfused kernels
+int fused_supported(const BFInputs &in)
+{
+    int ny, mask, na;
+    bf_signature(in, ny, mask, na);
+    return (ny == 1 && mask == 0x0001 && na == 1) || (ny == 4 && mask == 0x135F && na <= 2) || (ny == 4 && mask == 0x1248 && na == 1);
+}
+
+int fused_rows_per_tile(int P)
+{
+    const int W = 2 * P - 1, lpl = P <= 5 ? 2 : 1, lg = (W + lpl - 1) / lpl;
+    return std::min(BF_TL / P - (P - 1), (BF_NCW * 32) / lg);
+}
 
 // slots[y][t1]: input arrays (device pointers) of the sweep with their strides; see BFArgs
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data)
 {
     const Axis &AM = *in.mid, &AL = *in.last;
     BFArgs A{};
-    int ymax = 0, mask = 0, na = 1;
+    int ny, mask, na;
+    bf_signature(in, ny, mask, na);
+    if (!fused_supported(in)) { set_error("fused stage: no kernel for this set of types"); return IGX_ERR_UNSUPPORTED; }
     for (int y = 0; y < 4; ++y)
         for (int t1 = 0; t1 < 4; ++t1) {
             const int n = in.slot_n[y][t1];
-            if (n > 2) { set_error("fused stage: more than two arrays per slot"); return IGX_ERR_UNSUPPORTED; }
-            if (n > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); na = std::max(na, n); }
             for (int i = 0; i < 2; ++i) {
                 if (i < n) { A.sp[y][t1][i] = in.slot_ptr[y][t1][i]; A.ss[y][t1][i] = in.slice_stride; A.rs[y][t1][i] = AL.G; }
                 else { A.sp[y][t1][i] = in.zeros; A.ss[y][t1][i] = 0; A.rs[y][t1][i] = 0; }
             }
         }
-    const int ny = ymax == 0 ? 1 : 4;
     A.gmid_lo = in.gmid_lo; A.G2 = AL.G;
     A.V1 = AM.d_V; A.V2 = AL.d_V;
     A.n1 = AM.n; A.N1 = AM.N; A.n2 = AL.n; A.N2 = AL.N;
@@ -447,6 +728,7 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     A.mrows = (mid_rows + nmch - 1) / nmch;
     A.nmchunks = (mid_rows + A.mrows - 1) / A.mrows;
     A.npairs = in.npairs;
+    A.dbg = getenv("IGX_BF_DBG") ? atoi(getenv("IGX_BF_DBG")) : 0;
     blocks = (long long)in.npairs * A.ntiles * A.nmchunks;
     if (blocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (blocks == 0) return IGX_OK;

@@ -195,6 +195,7 @@ struct MirrorInputs {
     int i1_lo, i1_hi;                         // target rows of the mid axis
 };
 int fused_rows_per_tile(int P);
+int fused_supported(const BFInputs &in);
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
 int sumfact_supported(const igx_patch *pt);

@@ -1464,7 +1464,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
     if (int rc = launch_bf(st, pt, in, d_data)) return rc;
     pt->timing.n_launches++;
     (void)hipEventRecord(pt->ctx->ev[3], st);
-    if (sym) {
+    if (sym && !getenv("IGX_NO_MIRROR")) {
         MirrorInputs mi{};
         mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
         mi.tpairs = pt->d_tpairs; mi.ntp = pt->ntp; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
@@ -1495,7 +1495,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         bool ok = true;
         for (const Term &t : terms)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : t.t[1], t.t[0], pt->d_fields + (size_t)t.f * pd.npts_loc);
-        if (ok) {
+        if (ok && fused_supported(in)) {
             in.slice_stride = 0; in.gmid_lo = pd.g0_lo;
             (void)hipEventRecord(pt->ctx->ev[1], st);
             (void)hipEventRecord(pt->ctx->ev[2], st);
@@ -1564,7 +1564,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         for (size_t i = 0; i < terms.size(); ++i)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : terms[i].t[2], terms[i].t[1],
                                    pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPL);
-        if (ok) {
+        if (ok && fused_supported(in)) {
             in.slice_stride = NPL; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
             return run_fused(pt, in, sym, d_data);
         }
