@@ -376,12 +376,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
 {
     using Gm = BFGeom<P>;
     constexpr int p = P - 1, W = 2 * P - 1, TL = BF_TL, NLG = TL / 64, NR = bf_nroles(MASK), NSW = NR * NLG, NCW = BF_NCW;
-    constexpr int RMAX = Gm::RMAX, KR = Gm::KR;
+    constexpr int RMAX = Gm::RMAX;
     constexpr int LS = NR * TL + 2;                       // doubles per line (all roles), padded against bank conflicts
     constexpr int OFF_RING = (W * LS + 1) & ~1;
     constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * RMAX * W + 1) & ~1;
     constexpr int OFF_V2 = (OFF_CUR + 2 * P * RMAX * W + 1) & ~1;
-    constexpr int OFF_RT = OFF_V2 + TL * P * 2;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lines = lds;                 // [W][LS]: lines 0..p = pairs (d+a, d), lines p+a = pairs (d, d+a) of the last flush
     double *ring = lds + OFF_RING;       // [P+1][p][RMAX][W]: entries of the pairs (i1, j1 < i1), row slot i1 mod (P+1)
@@ -441,7 +440,6 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     const int gl0 = (slo - sp_lo) * P;                    // window index of the first Gauss point of row i2's support
     const int c0i = jhi0[i0] - jlo0[i0];
     const long long S12 = A.S1 * A.S2;
-    constexpr int NLH = (P + 1) / 2;                      // Gauss points per span and half
     const bool inner = row_lo >= p;                       // rows >= p: in span k of its support, row i is function p - k
 
     // ---- segment stores: whole CSR segments of the row completed two steps ago, from the entry rings.  The contractor
@@ -530,93 +528,111 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
 
 // ---------------------------------------------------------------------------------------------
 // Mirror pass: upper-triangle entries from the lower triangle.  Block = (target outer pair (i0, j0 >= i0), chunk of
-// rows i2 of the last axis); it walks the rows i1 of the mid axis.  Per step the source runs
+// rows i2 of the last axis, range of rows i1 of the mid axis); it walks its rows i1.  Per step the source runs
 //     row (j0, j1, j2), columns (i0, i1, i2' in chunk)        for the j1 of the segment and j2 around the chunk
-// are gathered into an LDS tile (reads: 72-byte runs whose neighbours in memory are the runs of the next steps, served
-// by the XCD's L2), and the target segments  row (i0, i1, i2), columns (j0, j1, j2)  are written whole.
+// are gathered into an LDS tile (reads: runs of 2p+1 doubles whose neighbours in memory are the runs of the next steps,
+// served by the XCD's L2), and the target segments  row (i0, i1, i2), columns (j0, j1, j2)  are written whole.
+// Everything about an element that does not depend on i1 -- which (j2, i2') it is, its place in the tile, the row
+// terms of its CSR position -- is worked out once per thread; a step costs two multiply-adds per element.
+// (Both axes have single interior knots and the same degree here: the pass follows k_bf.)
 struct MirrorArgs {
     double *data;
     long long nnz_off, S1, S2;
-    const int *rp0, *jlo0, *jhi0, *rp1, *jlo1, *jhi1, *rp2, *jlo2, *jhi2;
-    int N1, N2;
+    const int *rp0, *jlo0, *jhi0, *rp1, *rp2;
+    int N1, N2, p;
     int i1_lo, i1_hi;            // target rows of the mid axis
+    int i1_rows, ni1;            // rows i1 per block, blocks per (pair, chunk)
     const int *tpairs;           // [ntp][2] target pairs
     int ntp, RC, nchunks;
-    int W2max, NJ2max;           // LDS tile geometry
 };
 
+template <int WW> struct MirrorGeom {
+    static constexpr int RCM = WW == 3 ? 128 : WW == 5 ? 128 : WW == 7 ? 112 : WW == 9 ? 66 : 40;   // rows i2 per block (tile <= 48 KB)
+    static constexpr int NJ2 = RCM + WW - 1;                           // source rows j2 around a chunk
+    static constexpr int SG = (NJ2 * WW + 255) / 256;                  // gather elements (j2, offset) per thread and j1
+    static constexpr int SS = (RCM * WW * WW + 255) / 256;             // target elements per thread
+};
+
+template <int WW>
 __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1, jlo1 = (cip)M.jlo1, jhi1 = (cip)M.jhi1;
-    int *t_jlo2 = (int *)lds, *t_c2 = t_jlo2 + M.N2, *t_rp2 = t_c2 + M.N2;
-    double *T = lds + ((3 * M.N2 + 1) / 2 + 1);
-    for (int i = threadIdx.x; i < M.N2; i += blockDim.x) { t_jlo2[i] = M.jlo2[i]; t_c2[i] = M.jhi2[i] - M.jlo2[i]; t_rp2[i] = M.rp2[i]; }
-    __syncthreads();
+    using Gm = MirrorGeom<WW>;
+    constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS;
+    extern __shared__ __attribute__((aligned(16))) double T[];           // [WW][NJ2][WW]
+    cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1;
     unsigned bid = blockIdx.x;
     {
         const unsigned per = gridDim.x / 8;
         if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
     }
-    const int chunk = (int)(bid % M.nchunks), tp = (int)(bid / M.nchunks);
+    const int ib = (int)(bid % M.ni1), chunk = (int)((bid / M.ni1) % M.nchunks), tp = (int)(bid / ((unsigned)M.ni1 * M.nchunks));
     const int i0 = ((cip)M.tpairs)[2 * tp], j0 = ((cip)M.tpairs)[2 * tp + 1];
     const bool diag = i0 == j0;
     const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
     const int cl = chunk * M.RC, ch = min(cl + M.RC, M.N2);
-    const int j2lo = t_jlo2[cl], j2hi = t_jlo2[ch - 1] + t_c2[ch - 1], nj2 = j2hi - j2lo;
-    const int W2 = M.W2max, NJ2 = M.NJ2max;
+    const int j2lo = max(cl - p, 0), j2hi = min(ch - 1 + p, M.N2 - 1) + 1, nj2 = j2hi - j2lo;
     const long long S12 = M.S1 * M.S2;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (int i1 = M.i1_lo; i1 < M.i1_hi; ++i1) {
-        const int jl1i = jlo1[i1], c1i = jhi1[i1] - jl1i;
-        const int a1 = diag ? i1 : jl1i, b1 = jhi1[i1], nj1 = b1 - a1;
-        // ---- gather: T[j1 - a1][j2 - j2lo][i2' - jlo2[j2]]; GU loads in flight per thread
-        const int total = nj1 * nj2 * W2;
-        constexpr int GU = 8;
-        for (int f0 = threadIdx.x; f0 < total; f0 += blockDim.x * GU) {
-            double v[GU];
-            const double *src[GU];
+    auto jlo = [&](const int i) { return max(i - p, 0); };
+    auto cnt = [&](const int i, const int N) { return min(i + p, N - 1) + 1 - max(i - p, 0); };
+    // ---- gather plan: element (j2, op) of a source run = column i2' = jlo2[j2] + op
+    int g_rp[SG], g_pk[SG];              // rp2[j2] | c2, op, flags (1: valid, 2: j2 <= i2'), tile offset
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int f = f0 + u * blockDim.x;
-                src[u] = nullptr;
-                if (f < total) {
-                    const int op = f % W2, rest = f / W2;
-                    const int j2r = rest % nj2, j1i = rest / nj2;
-                    const int j1 = a1 + j1i, j2 = j2lo + j2r;
-                    const int jl2 = t_jlo2[j2], c2 = t_c2[j2];
-                    const int i2p = jl2 + op;
-                    if (op < c2 && i2p >= cl && i2p < ch && !(diag && j1 == i1 && j2 <= i2p)) {
-                        const int c1j = jhi1[j1] - jlo1[j1];
-                        src[u] = M.data + ((long long)rp0[j0] * S12 + (long long)c0j * ((long long)rp1[j1] * M.S2 + (long long)c1j * t_rp2[j2])
-                                           + ((long long)(i0 - jlo0[j0]) * c1j + (i1 - jlo1[j1])) * c2 + op - M.nnz_off);
-                    }
-                }
-            }
+    for (int s_ = 0; s_ < SG; ++s_) {
+        const int f = threadIdx.x + 256 * s_;
+        const int j2r = min(f / WW, nj2 - 1), op = f - (f / WW) * WW;
+        const int j2 = j2lo + j2r, c2 = cnt(j2, M.N2), i2p = jlo(j2) + op;
+        const bool ok = f < nj2 * WW && op < c2 && i2p >= cl && i2p < ch;
+        g_rp[s_] = M.rp2[j2];
+        g_pk[s_] = c2 | (op << 4) | (ok ? 256 : 0) | (j2 <= i2p ? 512 : 0) | ((j2r * WW + op) << 10);
+    }
+    // ---- target plan: element (i2, j1 index m, offset o) of a target segment
+    int t_rp[SS], t_pk[SS], t_off[SS];    // rp2[i2] | c2, m, o, flags (1: valid, 2: j2 <= i2) | tile offset
 #pragma unroll
-            for (int u = 0; u < GU; ++u) v[u] = src[u] ? *src[u] : 0.0;
+    for (int s_ = 0; s_ < SS; ++s_) {
+        const int q = threadIdx.x + 256 * s_;
+        const int rr = q / (WW * WW), e2 = q - rr * (WW * WW);
+        const int m = e2 / WW, o = e2 - m * WW;
+        const int i2 = min(cl + rr, M.N2 - 1), c2 = cnt(i2, M.N2), j2 = min(jlo(i2) + o, M.N2 - 1);
+        const bool ok = cl + rr < ch && o < c2;
+        t_rp[s_] = M.rp2[i2];
+        t_pk[s_] = c2 | (m << 4) | (o << 8) | (ok ? 4096 : 0) | (j2 <= i2 ? 8192 : 0);
+        t_off[s_] = (m * NJ2 + (j2 - j2lo)) * WW + (i2 - jlo(j2));
+    }
+    const int i1b = M.i1_lo + ib * M.i1_rows, i1e = min(i1b + M.i1_rows, M.i1_hi);
+    for (int i1 = i1b; i1 < i1e; ++i1) {
+        const int jl1i = jlo(i1), c1i = cnt(i1, M.N1);
+        const int a1 = diag ? i1 : jl1i, nj1 = jl1i + c1i - a1;
+        // ---- gather: all loads of the step are in flight before the first value is used
+        double v[WW][SG];
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int f = f0 + u * blockDim.x;
-                if (f < total) {
-                    const int op = f % W2, rest = f / W2;
-                    T[((rest / nj2) * NJ2 + rest % nj2) * W2 + op] = v[u];
-                }
+        for (int m = 0; m < WW; ++m) {
+            const int j1 = min(a1 + m, M.N1 - 1), c1j = cnt(j1, M.N1);
+            const long long Rj = (long long)rp0[j0] * S12 + (long long)c0j * rp1[j1] * M.S2 - M.nnz_off;
+            const long long A1 = (long long)c0j * c1j;
+            const int B1 = (i0 - jlo0[j0]) * c1j + (i1 - jlo(j1));
+#pragma unroll
+            for (int s_ = 0; s_ < SG; ++s_) {
+                const int pk = g_pk[s_], c2 = pk & 15, op = (pk >> 4) & 15;
+                const bool ok = m < nj1 && (pk & 256) && !(diag && m == 0 && (pk & 512));
+                const long long src = ok ? Rj + A1 * g_rp[s_] + B1 * c2 + op : 0;
+                v[m][s_] = M.data[src];
             }
         }
+#pragma unroll
+        for (int m = 0; m < WW; ++m)
+#pragma unroll
+            for (int s_ = 0; s_ < SG; ++s_)
+                if (threadIdx.x + 256 * s_ < nj2 * WW) T[m * (NJ2 * WW) + (g_pk[s_] >> 10)] = v[m][s_];     // (elements past the chunk alias its last row)
         __syncthreads();
         // ---- whole target segments
-        for (int i2 = cl + wave; i2 < ch; i2 += nwaves) {
-            const int jl2 = t_jlo2[i2], c2 = t_c2[i2];
-            const long long dst0 = (long long)rp0[i0] * S12 + (long long)c0i * ((long long)rp1[i1] * M.S2 + (long long)c1i * t_rp2[i2])
-                                   + ((long long)(j0 - jlo0[i0]) * c1i + (a1 - jl1i)) * c2 - M.nnz_off;
-            const int ne = nj1 * c2;
-            for (int e = lane; e < ne; e += 64) {
-                const int j1i = e / c2, o = e - j1i * c2;
-                const int j2 = jl2 + o;
-                if (diag && j1i == 0 && j2 <= i2) continue;
-                M.data[dst0 + e] = T[(j1i * NJ2 + (j2 - j2lo)) * W2 + (i2 - t_jlo2[j2])];
-            }
+        const long long Ri = (long long)rp0[i0] * S12 + (long long)c0i * rp1[i1] * M.S2 - M.nnz_off;
+        const long long A = (long long)c0i * c1i;
+        const int B = (j0 - jlo0[i0]) * c1i + (a1 - jl1i);
+#pragma unroll
+        for (int s_ = 0; s_ < SS; ++s_) {
+            const int pk = t_pk[s_], c2 = pk & 15, m = (pk >> 4) & 15, o = (pk >> 8) & 15;
+            if ((pk & 4096) && m < nj1 && !(diag && m == 0 && (pk & 8192)))
+                M.data[Ri + A * t_rp[s_] + (B + m) * c2 + o] = T[t_off[s_]];
         }
         __syncthreads();
     }
@@ -743,44 +759,47 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     }
 }
 
+template <int WW>
+static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
+{
+    using Gm = MirrorGeom<WW>;
+    M.nchunks = (N2 + Gm::RCM - 1) / Gm::RCM;
+    M.RC = (N2 + M.nchunks - 1) / M.nchunks;
+    // a launch wants >= ~1536 blocks: split the rows i1 of a (pair, chunk)
+    const int rows = M.i1_hi - M.i1_lo;
+    long long base = (long long)M.ntp * M.nchunks;
+    M.ni1 = (int)std::max<long long>(1, std::min<long long>((1536 + base - 1) / base, std::max(1, rows / 8)));
+    M.i1_rows = (rows + M.ni1 - 1) / M.ni1;
+    M.ni1 = (rows + M.i1_rows - 1) / M.i1_rows;
+    const long long blocks = base * M.ni1;
+    if (blocks > 0x7fffffffLL) { set_error("mirror pass: too many blocks"); return IGX_ERR_UNSUPPORTED; }
+    if (blocks == 0) return IGX_OK;
+    constexpr size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
+    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mirror<WW><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data)
 {
     if (in.ntp == 0) return IGX_OK;
     const Axis &AM = *in.mid, &AL = *in.last;
+    if (!AM.simple || !AL.simple || AM.P != AL.P) { set_error("mirror pass: axes must have single knots and equal degree"); return IGX_ERR_UNSUPPORTED; }
     MirrorArgs M{};
     M.data = d_data; M.nnz_off = pt->nnz_off; M.S1 = AM.S; M.S2 = AL.S;
     M.rp0 = in.rp0; M.jlo0 = in.jlo0; M.jhi0 = in.jhi0;
-    M.rp1 = AM.dev.rp; M.jlo1 = AM.dev.jlo; M.jhi1 = AM.dev.jhi;
-    M.rp2 = AL.dev.rp; M.jlo2 = AL.dev.jlo; M.jhi2 = AL.dev.jhi;
-    M.N1 = AM.N; M.N2 = AL.N; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
+    M.rp1 = AM.dev.rp; M.rp2 = AL.dev.rp;
+    M.N1 = AM.N; M.N2 = AL.N; M.p = AL.p; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
     M.tpairs = in.tpairs; M.ntp = in.ntp;
-    int w1 = 0, w2 = 0;
-    for (int i = 0; i < AM.N; ++i) w1 = std::max(w1, AM.jhi[i] - AM.jlo[i]);
-    for (int i = 0; i < AL.N; ++i) w2 = std::max(w2, AL.jhi[i] - AL.jlo[i]);
-    // rows of the last axis per block: the whole axis when its tile fits ~48 KB of LDS, else equal chunks
-    int nch = 1, RC, nj2;
-    for (;; ++nch) {
-        RC = (AL.N + nch - 1) / nch;
-        nj2 = 0;
-        for (int cl = 0; cl < AL.N; cl += RC) nj2 = std::max(nj2, AL.jhi[std::min(cl + RC, AL.N) - 1] - AL.jlo[cl]);
-        if ((size_t)w1 * nj2 * w2 * sizeof(double) <= 48 * 1024 || RC <= 8) break;
+    switch (2 * AL.p + 1) {
+    case 3: return launch_mirror_k<3>(st, M, AL.N);
+    case 5: return launch_mirror_k<5>(st, M, AL.N);
+    case 7: return launch_mirror_k<7>(st, M, AL.N);
+    case 9: return launch_mirror_k<9>(st, M, AL.N);
+    case 11: return launch_mirror_k<11>(st, M, AL.N);
+    default: set_error("mirror pass: degree %d unsupported", AL.p); return IGX_ERR_UNSUPPORTED;
     }
-    // a launch wants >= ~1024 blocks
-    while ((long long)in.ntp * nch < 1024 && RC > 16) {
-        ++nch;
-        RC = (AL.N + nch - 1) / nch;
-        nj2 = 0;
-        for (int cl = 0; cl < AL.N; cl += RC) nj2 = std::max(nj2, AL.jhi[std::min(cl + RC, AL.N) - 1] - AL.jlo[cl]);
-    }
-    M.RC = RC; M.nchunks = (AL.N + RC - 1) / RC; M.W2max = w2; M.NJ2max = nj2;
-    const size_t lds = ((size_t)(3 * AL.N + 1) / 2 + 1 + (size_t)w1 * nj2 * w2) * sizeof(double);
-    if (lds > 160 * 1024) { set_error("mirror pass: tile does not fit LDS"); return IGX_ERR_UNSUPPORTED; }
-    const long long blocks = (long long)in.ntp * M.nchunks;
-    if (blocks > 0x7fffffffLL) { set_error("mirror pass: too many blocks"); return IGX_ERR_UNSUPPORTED; }
-    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mirror<<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
-    IGX_HIP(hipGetLastError());
-    return IGX_OK;
 }
 
 } // namespace igx
