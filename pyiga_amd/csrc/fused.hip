@@ -73,13 +73,10 @@ constexpr BFRole bf_role(int MASK, int r)
 template <int P>
 struct BFGeom {
     static constexpr int p = P - 1, W = 2 * P - 1;
-    static constexpr int SPANS = BF_TL / P;                // spans of a tile window
-    static constexpr int RGEO = SPANS - p;                 // rows of the last axis whose support fits the window
-    static constexpr int LPL = P <= 5 ? 2 : 1;             // lines per contractor lane (two share the reads of the basis values; registers allow it up to p = 3)
-    static constexpr int LG = (W + LPL - 1) / LPL;         // line groups: a contractor lane pair takes LPL lines of a row
-    static constexpr int RCAP = (BF_NCW * 32) / LG;        // rows the contractors cover: one lane PAIR per (row, line group)
-    static constexpr int RMAX = RGEO < RCAP ? RGEO : RCAP; // rows per tile
-    static constexpr int KR = (RMAX + BF_NCW - 1) / BF_NCW;   // rows per contractor wave in the store phase
+    static constexpr int LW = (W + BF_NCW - 1) / BF_NCW;   // K2 lines per contractor wave and step
+    static constexpr int SPW = (BF_TL / P) < (64 / LW) ? (BF_TL / P) : (64 / LW);   // spans of a tile window: one lane per (line, span)
+    static constexpr int RMAX = SPW - p;                   // rows of the last axis per tile (their supports fit the window)
+    static constexpr int XB = LW * SPW * P * P;            // doubles of a contractor wave's exchange buffer
 };
 
 struct BFArgs {
@@ -110,25 +107,22 @@ struct BFArgs {
 // at the two barriers of a step; wave 0 lane 0 of each role group of block 0.. writes {wait, total} per wave at the end.
 #ifdef IGX_BF_STAMP
 __device__ unsigned long long g_bf_stamp[64 * 1024];
-#define BF_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#define BF_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_seg[3] = {0, 0, 0}, st_a = 0;
+#define BF_SEG_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BF_SEG_END(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory"); st_seg[i] += __builtin_amdgcn_s_memtime() - st_a; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BF_SEG_DUMP(w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) for (int i_ = 0; i_ < 3; ++i_) g_bf_stamp[32768 + (blockIdx.x * 4 + (w)) * 3 + i_] = st_seg[i_]; } while (0)
 #define BF_STAMP_END(w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
         g_bf_stamp[(blockIdx.x * 16 + (w)) * 2] = st_wait; g_bf_stamp[(blockIdx.x * 16 + (w)) * 2 + 1] = t1_ - st_t0; } } while (0)
 #define bar_lds() do { const unsigned long long a_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         st_wait += __builtin_amdgcn_s_memtime() - a_; } while (0)
 #else
 #define BF_STAMP_DECL
+#define BF_SEG_BEGIN()
+#define BF_SEG_END(i)
+#define BF_SEG_DUMP(w)
 #define BF_STAMP_END(w)
 __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
-
-// exchange between the two lanes of a pair (lane ^ 1): DPP quad_perm [1,0,3,2]
-__device__ __forceinline__ double pair_swap(double x)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
 
 // ---- sweeper: role R of MASK, lane = Gauss point g2 of the tile window.  The values of one span live in registers; each
 // is reloaded for the next span right after its use, so a load has a whole step to land and the waits are counted
@@ -140,6 +134,8 @@ __device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const 
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = BF_TL;
     BF_STAMP_DECL
+    // the sweepers feed the memory pipeline: they issue first, the contractors take the remaining slots of the SIMD
+    __builtin_amdgcn_s_setprio(3);
     cdp V1 = (cdp)A.V1;
     double acc[P][P];
 #pragma unroll
@@ -269,104 +265,71 @@ struct BFSweepDispatch<P, MASK, NA, RI, true> {
     __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
 };
 
-// K values by last-axis type: the lines of the roles of one type are added (R: the raw role values of one Gauss point)
-template <int MASK, int RI, bool END = (RI >= bf_nroles(MASK))>
-struct BFKSum {
-    template <int NR>
-    __device__ static __forceinline__ void run(double (&K)[4], const double (&R)[NR])
-    {
-        constexpr int y = bf_role(MASK, RI).y;
-        constexpr bool first = RI == 0 || bf_role(MASK, RI > 0 ? RI - 1 : 0).y != y;      // roles are ordered by y
-        if (first) K[y] = R[RI]; else K[y] += R[RI];
-        BFKSum<MASK, RI + 1>::run(K, R);
-    }
-};
-template <int MASK, int RI>
-struct BFKSum<MASK, RI, true> {
-    template <int NR>
-    __device__ static __forceinline__ void run(double (&)[4], const double (&)[NR]) {}
-};
-
-// Contraction of LPL K2 lines (ln[q]: window images, all roles) with the last axis for one row: accv[q][o] = partial sums
-// of this lane half (Gauss points l = h, h + 2, ...) of the 2p+1 entries of line q.  vs: basis values from the first point
-// of the row's support; nsp spans in the support; irel = row - first span (INNER: the row's function is function p - k of
-// its k-th span, true for every row >= p).
-template <int P, int NY, int MASK, int LPL, bool INNER>
-__device__ __forceinline__ void bf_contract(double (&accv)[LPL][2 * P - 1], const double *const (&ln)[LPL], const double *vs,
-                                            const int h, const int nsp, const int irel)
+// Element matrices of one K2 line on one span of the last axis (the contractors' first half): with K[y][l] the line's values
+// of type y = tu + 2 tv at the span's Gauss points and V[l][.][.] the basis values there,
+//     loc[a][b] = sum_l sum_tu V[l][b][tu] * (sum_tv V[l][a][tv] * K[tu + 2 tv][l])        (a: test function, b: trial function)
+// -- every K and V value is read from LDS once per (line, span), not once per row.  The values of point l+1 are requested
+// before the arithmetic of point l.  One role per type: role index = position of the type among those that occur.
+template <int P, int NY, int MASK>
+__device__ __forceinline__ void bf_element(double (&loc)[P][P], const double *kl, const double *vl)
 {
-    constexpr int p = P - 1, W = 2 * P - 1, NLH = (P + 1) / 2, NR = bf_nroles(MASK);
+    constexpr int TL = BF_TL;
+    // LDS row of type y inside the line image (roles are ordered by type)
+    constexpr int ry0 = 0;
+    constexpr int ry1 = bf_roles_of_y(MASK & 15);
+    constexpr int ry2 = ry1 + bf_roles_of_y((MASK >> 4) & 15);
+    constexpr int ry3 = ry2 + bf_roles_of_y((MASK >> 8) & 15);
+    constexpr bool h0 = (MASK & 15) != 0, h1 = ((MASK >> 4) & 15) != 0, h2 = ((MASK >> 8) & 15) != 0, h3 = ((MASK >> 12) & 15) != 0;
 #pragma unroll
-    for (int q = 0; q < LPL; ++q)
+    for (int a = 0; a < P; ++a)
 #pragma unroll
-        for (int o = 0; o < W; ++o) accv[q][o] = 0.0;
-    // NIT = P * NLH (span, point) steps per lane.  Every value read from LDS is replaced by the one of the next step
-    // right after its last use, so the reads of step n+1 are in flight under the arithmetic of step n.
-    constexpr int NIT = P * NLH;
-    auto gof = [&](const int it) { const int kk = it / NLH, l = 2 * (it - kk * NLH) + h; return kk * P + min(l, P - 1); };
-    double R[LPL][NR], V[P][2];                          // role values (one role per type) of the lines, basis values
-    auto load_K = [&](const int it) {
-        const int g = gof(it);
-#pragma unroll
-        for (int q = 0; q < LPL; ++q)
-#pragma unroll
-            for (int ri = 0; ri < NR; ++ri) R[q][ri] = ln[q][ri * BF_TL + g];
+        for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
+    double K[4], V[P][2];
+    auto load_K = [&](const int l) {
+        K[0] = h0 ? kl[ry0 * TL + l] : 0.0;
+        if (NY == 4) { K[1] = h1 ? kl[ry1 * TL + l] : 0.0; K[2] = h2 ? kl[ry2 * TL + l] : 0.0; K[3] = h3 ? kl[ry3 * TL + l] : 0.0; }
     };
-    auto load_V = [&](const int it, const int b) {
-        const double *vg = vs + (size_t)gof(it) * P * 2;
-        V[b][0] = vg[2 * b]; V[b][1] = vg[2 * b + 1];
-    };
+    auto load_V = [&](const int l, const int b) { V[b][0] = vl[(l * P + b) * 2]; V[b][1] = vl[(l * P + b) * 2 + 1]; };
     load_K(0);
 #pragma unroll
     for (int b = 0; b < P; ++b) load_V(0, b);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int kk = it / NLH, j = it - kk * NLH;
-        const bool pv = kk < nsp && 2 * j + h < P;
-        double va0, va1;
-        if (INNER) { va0 = V[p - kk][0]; va1 = V[p - kk][1]; }         // test function = function p - kk of the span
-        else {
-            const int a2 = min(max(irel - kk, 0), p);
-            const double *vg = vs + (size_t)gof(it) * P * 2;
-            va0 = vg[2 * a2]; va1 = vg[2 * a2 + 1];
-        }
-        if (!pv) { va0 = 0.0; va1 = 0.0; }
-        double cu[LPL][2];
+    for (int l = 0; l < P; ++l) {
+        // every value is replaced by the one of the next point right after its last use (one register set)
+        double c0[P], c1[P];
 #pragma unroll
-        for (int q = 0; q < LPL; ++q) {
-            double KK[4] = {0.0, 0.0, 0.0, 0.0};
-            BFKSum<MASK, 0>::run(KK, R[q]);               // by type (one role per type: a copy)
-            if (NY == 1) { cu[q][0] = va0 * KK[0]; cu[q][1] = 0.0; }
+        for (int a = 0; a < P; ++a) {
+            if (NY == 1) { c0[a] = V[a][0] * K[0]; c1[a] = 0.0; }
             else {
-                cu[q][0] = fma(va1, KK[2], va0 * KK[0]);  // types 0, 2
-                cu[q][1] = fma(va1, KK[3], va0 * KK[1]);  // types 1, 3
+                c0[a] = fma(V[a][1], K[2], V[a][0] * K[0]);      // types 0, 2
+                c1[a] = fma(V[a][1], K[3], V[a][0] * K[1]);      // types 1, 3
             }
         }
-        if (it + 1 < NIT) {
+        if (l + 1 < P) {
 #pragma unroll
-            for (int q = 0; q < LPL; ++q) asm volatile("" : "+v"(cu[q][0]), "+v"(cu[q][1]));   // R is dead from here
-            load_K(it + 1);
-            __builtin_amdgcn_sched_barrier(0);            // the refill stays here, a whole step ahead of its use
+            for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c0[a]), "+v"(c1[a]));     // K is dead from here
+            load_K(l + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < P; ++b) {
 #pragma unroll
-            for (int q = 0; q < LPL; ++q) {
-                if (NY == 1) accv[q][kk + b] = fma(V[b][0], cu[q][0], accv[q][kk + b]);
-                else accv[q][kk + b] = fma(V[b][0], cu[q][0], fma(V[b][1], cu[q][1], accv[q][kk + b]));
+            for (int a = 0; a < P; ++a) {
+                if (NY == 1) loc[a][b] = fma(V[b][0], c0[a], loc[a][b]);
+                else loc[a][b] = fma(V[b][0], c0[a], fma(V[b][1], c1[a], loc[a][b]));
             }
-            if (it + 1 < NIT) {
+            if (l + 1 < P) {
 #pragma unroll
-                for (int q = 0; q < LPL; ++q) asm volatile("" : "+v"(accv[q][kk + b]));      // V[b] is dead from here
-                load_V(it + 1, b);
+                for (int a = 0; a < P; ++a) asm volatile("" : "+v"(loc[a][b]));          // V[b] is dead from here
+                load_V(l + 1, b);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the reads of step n+2 may not be hoisted above this point (register blow-up)
+        // the reads of point l+2 may not be hoisted above this point (register blow-up)
 #pragma unroll
-        for (int q = 0; q < LPL; ++q)
+        for (int a = 0; a < P; ++a)
 #pragma unroll
-            for (int b = 0; b < P; ++b) asm volatile("" : "+v"(accv[q][kk + b]));
+            for (int b = 0; b < P; ++b) asm volatile("" : "+v"(loc[a][b]));
         asm volatile("" ::: "memory");
     }
 }
@@ -381,11 +344,13 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     constexpr int OFF_RING = (W * LS + 1) & ~1;
     constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * RMAX * W + 1) & ~1;
     constexpr int OFF_V2 = (OFF_CUR + 2 * P * RMAX * W + 1) & ~1;
+    constexpr int OFF_XB = OFF_V2 + TL * P * 2;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lines = lds;                 // [W][LS]: lines 0..p = pairs (d+a, d), lines p+a = pairs (d, d+a) of the last flush
     double *ring = lds + OFF_RING;       // [P+1][p][RMAX][W]: entries of the pairs (i1, j1 < i1), row slot i1 mod (P+1)
     double *cur = lds + OFF_CUR;         // [2][P][RMAX][W]:   entries of the pairs (d, d .. d+p), slot d & 1
     double *V2s = lds + OFF_V2;          // [TL][P][2]: last-axis basis values on the tile window
+    double *xbuf = lds + OFF_XB;         // [NCW][LW][SPW][P][P]: element matrices of the lines a contractor wave is working on
 
     cip pl0 = (cip)A.pl0, rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0, rp1 = (cip)A.rp1, rp2 = (cip)A.rp2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -409,13 +374,16 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) V2s[idx] = idx < nwin * P * 2 ? A.V2[(size_t)win0 * P * 2 + idx] : 0.0;
     // the barrier B1 of the first iteration orders these writes before their first use
 
-    // wave -> task.  A workgroup's waves go to the four SIMDs cyclically, so every SIMD gets one contractor and (for
-    // four roles) one wave of each half of the roles: 0,1: role 0 | 2,3: role 1 | 4..7: contractors | 8,9: role 2 | 10,11: role 3.
-    // Task ids: sweepers 0..NSW-1 (role = id / 2, lane group = id % 2), contractors NSW..
+    // wave -> task.  A workgroup's waves go to the four SIMDs cyclically (wave % 4), and the stage is bound by vector issue:
+    // for four roles the FP64 work per step (role 0: 70 FMAs per point, roles 1..3: 30..35, contractor: ~75 per point) is
+    // spread as  SIMD 0: contractor 0 + both waves of role 1 | 1: contractor 1 + role 2 | 2: contractor 2 + role 3 |
+    // 3: both waves of role 0 + contractor 3 (few lines, stores).  Task ids: sweepers 0..NSW-1 (role = id / 2, lane group = id % 2),
+    // contractors NSW..
     int task = wave;
     if (NR == 4 && NCW == 4) {
-        if (wave >= 4 && wave < 8) task = NSW + (wave - 4);
-        else if (wave >= 8) task = wave - 4;
+        const int sd = wave & 3, k = wave >> 2;           // SIMD residue, position
+        if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
+        else task = k < 2 ? k : NSW + 3;
     }
     if (task < NSW) {
         // ---------------- sweepers: role, lane group lg
@@ -426,21 +394,24 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
         return;
     }
 
-    // ---------------- contractors: a lane PAIR per (row r of the tile, group of two lines); the halves take the Gauss
-    // points l = h, h + 2, ... of every span and add their sums through DPP.  Two lines per lane share the reads of
-    // the basis values: the stage is bound by LDS reads, not by arithmetic.
-    constexpr int LG = Gm::LG, LPL = Gm::LPL;
+    // ---------------- contractors.  Per step and contractor wave LW lines of the last flush:
+    //   1. lane = (line, span of the window): element matrices loc[a][b] of the line on that span (bf_element) -> wave-private
+    //      exchange buffer;
+    //   2. lane = (line, row of the tile): the 2p+1 entries of the row are gathered from the element matrices of the spans
+    //      of its support, entry o = b - a + p from (span i2 - a, a, b), in a fixed order -> entry rings.
+    constexpr int LW = Gm::LW, SPW = Gm::SPW, PP = P * P;
     BF_STAMP_DECL
     const int cw = task - NSW;
-    const int idx = cw * 32 + (lane >> 1), h = lane & 1;
-    const bool cval = idx < nrows * LG;
-    const int r = cval ? idx / LG : 0, lgp = cval ? idx - r * LG : 0;
-    const int i2 = row_lo + r;
-    const int slo = max(i2 - p, 0), nsp = min(i2, A.n2 - 1) + 1 - slo;
-    const int gl0 = (slo - sp_lo) * P;                    // window index of the first Gauss point of row i2's support
+    double *xb = xbuf + cw * Gm::XB;
+    const int nsw = sp_hi - sp_lo;                        // spans of the window
+    const int ln1 = lane / SPW, s1 = lane - ln1 * SPW;    // step 1: line slot, span
+    const bool v1 = ln1 < LW && s1 < nsw;
+    const int ln3 = lane / RMAX, r3 = lane - ln3 * RMAX;  // step 2: line slot, row
+    const bool v3 = ln3 < LW && r3 < nrows;
+    const int i2 = row_lo + r3;
+    const int osh = max(p - i2, 0);                       // rows < p: the run starts at column 0, entry o sits at o - osh
     const int c0i = jhi0[i0] - jlo0[i0];
     const long long S12 = A.S1 * A.S2;
-    const bool inner = row_lo >= p;                       // rows >= p: in span k of its support, row i is function p - k
 
     // ---- segment stores: whole CSR segments of the row completed two steps ago, from the entry rings.  The contractor
     // waves share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
@@ -462,6 +433,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
             }
     for (int t = s_begin; t < rhi + 2; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
+        BF_SEG_BEGIN();
                     const int dd2 = t - 2;
                     if (dd2 >= rlo && dd2 < rhi && !(A.dbg & 2)) {
                         const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
@@ -484,45 +456,63 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
                             if (ok) rowp[(long long)rsc * pl_rp[k] + (colb + m) * c2r + o] = val[k];
                         }
                     }
+        BF_SEG_END(0);
         // ---- contract the lines of flush dd = t - 1 with the last axis
         const int dd = t - 1;
         if (dd >= s_begin && dd < rhi && !(A.dbg & 1)) {
             // line k9: pair (dd + la, dd) for k9 <= p, else (dd, dd + la)
-            // per-lane constants pass through an opaque statement each step: hipcc would otherwise hoist the address arithmetic
-            // of all NIT contraction steps out of the step loop (dozens of registers, spilled)
-            int gl0s = gl0, irel = i2 - slo;
-            asm volatile("" : "+v"(gl0s), "+v"(irel));
-            bool lv[LPL], any = false;
-            int row1[LPL], col1[LPL];
-            const double *lnp[LPL];
+            auto line_ok = [&](const int k9, int &row1, int &col1) {
+                const int la = k9 <= p ? k9 : k9 - p;
+                row1 = k9 <= p ? dd + la : dd; col1 = k9 <= p ? dd : dd + la;
+                return k9 < W && row1 >= rlo && row1 < rhi && col1 < A.N1 && !(diag0 && col1 > row1);
+            };
+            BF_SEG_BEGIN();
+            {
+                int row1, col1;
+                const int k9 = cw * LW + ln1;
+                if (v1 && line_ok(k9, row1, col1)) {
+                    double loc[P][P];
+                    bf_element<P, NY, MASK>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
+                    double *xo = xb + (ln1 * SPW + s1) * PP;
 #pragma unroll
-            for (int q = 0; q < LPL; ++q) {
-                const int k9 = LPL * lgp + q, la = k9 <= p ? k9 : k9 - p;
-                row1[q] = k9 <= p ? dd + la : dd; col1[q] = k9 <= p ? dd : dd + la;
-                lv[q] = cval && k9 < W && row1[q] >= rlo && row1[q] < rhi && col1[q] < A.N1 && !(diag0 && col1[q] > row1[q]);
-                any = any || lv[q];
-                lnp[q] = lines + min(k9, W - 1) * LS + gl0s;
-            }
-            if (any) {
-                double accv[LPL][W];
-                if (inner) bf_contract<P, NY, MASK, LPL, true>(accv, lnp, V2s + gl0s * P * 2, h, nsp, irel);
-                else bf_contract<P, NY, MASK, LPL, false>(accv, lnp, V2s + gl0s * P * 2, h, nsp, irel);
+                    for (int a = 0; a < P; ++a)
 #pragma unroll
-                for (int q = 0; q < LPL; ++q) {
-#pragma unroll
-                    for (int o = 0; o < W; ++o) accv[q][o] += pair_swap(accv[q][o]);
-                    if (h == 0 && lv[q]) {
-                        const int la = row1[q] - col1[q];
-                        double *dste = (la > 0) ? ring + (size_t)((((row1[q] % (P + 1)) * p + (p - la)) * RMAX + r)) * W
-                                                : cur + (size_t)((((dd & 1) * P - la) * RMAX + r)) * W;
-#pragma unroll
-                        for (int o = 0; o < W; ++o) dste[o] = accv[q][o];
-                    }
+                        for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
                 }
             }
+            BF_SEG_END(1);
+            __builtin_amdgcn_wave_barrier();              // LDS operations of one wave execute in order
+            BF_SEG_BEGIN();
+            {
+                int row1, col1;
+                const int k9 = cw * LW + ln3;
+                if (v3 && line_ok(k9, row1, col1)) {
+                    double accv[W];
+#pragma unroll
+                    for (int o = 0; o < W; ++o) accv[o] = 0.0;
+                    const double *xi = xb + (ln3 * SPW - sp_lo) * PP;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        const int sp = i2 - a;            // the span in which row i2 is test function a
+                        if (sp >= 0 && sp < A.n2) {
+#pragma unroll
+                            for (int b = 0; b < P; ++b) accv[b - a + p] += xi[sp * PP + a * P + b];
+                        }
+                    }
+                    const int la = row1 - col1;
+                    double *dste = ((la > 0) ? ring + (size_t)((((row1 % (P + 1)) * p + (p - la)) * RMAX + r3)) * W
+                                             : cur + (size_t)((((dd & 1) * P - la) * RMAX + r3)) * W) - osh;
+#pragma unroll
+                    for (int o = 0; o < W; ++o)
+                        if (o >= osh) dste[o] = accv[o];
+                }
+            }
+            BF_SEG_END(2);
+            __builtin_amdgcn_wave_barrier();              // the gather precedes the next step's element matrices
         }
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
     }
+    BF_SEG_DUMP(cw);
     BF_STAMP_END(wave);
 }
 
@@ -648,7 +638,7 @@ static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
     constexpr int OFF_RING = (W * LS + 1) & ~1;
     constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * Gm::RMAX * W + 1) & ~1;
     constexpr int OFF_V2 = (OFF_CUR + 2 * P * Gm::RMAX * W + 1) & ~1;
-    constexpr size_t lds = (size_t)(OFF_V2 + BF_TL * P * 2 + (Gm::RMAX + 1) / 2 * 2) * sizeof(double);
+    constexpr size_t lds = (size_t)(OFF_V2 + BF_TL * P * 2 + BF_NCW * Gm::XB) * sizeof(double);
     static_assert(lds <= 160 * 1024, "k_bf: LDS");
     IGX_HIP(hipFuncSetAttribute((const void *)k_bf<P, NY, MASK, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_bf<P, NY, MASK, NA><<<dim3(nblocks), dim3((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW) * 64), lds, st>>>(A);
@@ -663,6 +653,11 @@ static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
             double wt = 0, tot = 0;
             for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
             fprintf(stderr, "k_bf stamp: wave %2d  wait %.0f  total %.0f cycles/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
+        }
+        for (int w = 0; w < BF_NCW; ++w) {
+            double sg[3] = {0, 0, 0};
+            for (int b = 0; b < nb; ++b) for (int i = 0; i < 3; ++i) sg[i] += h[32768 + (b * 4 + w) * 3 + i];
+            fprintf(stderr, "k_bf stamp: contractor %d  stores %.0f  elements %.0f  gather %.0f cycles/block\n", w, sg[0] / nb, sg[1] / nb, sg[2] / nb);
         }
     }
 #endif
@@ -703,8 +698,8 @@ int fused_supported(const BFInputs &in)
 
 int fused_rows_per_tile(int P)
 {
-    const int W = 2 * P - 1, lpl = P <= 5 ? 2 : 1, lg = (W + lpl - 1) / lpl;
-    return std::min(BF_TL / P - (P - 1), (BF_NCW * 32) / lg);
+    const int W = 2 * P - 1, lw = (W + BF_NCW - 1) / BF_NCW;
+    return std::min(BF_TL / P, 64 / lw) - (P - 1);
 }
 
 // slots[y][t1]: input arrays (device pointers) of the sweep with their strides; see BFArgs
@@ -754,7 +749,6 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     case 3: return launch_bf_p<3>(st, A, nb, ny, mask, na);
     case 4: return launch_bf_p<4>(st, A, nb, ny, mask, na);
     case 5: return launch_bf_p<5>(st, A, nb, ny, mask, na);
-    case 6: return launch_bf_p<6>(st, A, nb, ny, mask, na);
     default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
     }
 }

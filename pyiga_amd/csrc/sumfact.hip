@@ -1422,16 +1422,18 @@ static int launch_final(hipStream_t st, const double *K, double *data, const Fin
     default: set_error("sum factorisation: degree %d unsupported", (Pv) - 1); return IGX_ERR_UNSUPPORTED; }
 
 // The fused sweep + final stage (fused.hip) needs single interior knots, equal degrees and q = p + 1 on the swept and
-// the last axis.  IGX_PATH=unfused (or a choice of IGX_FINAL) selects the round-1 kernels (K2 through HBM), which also
-// serve every other case.
+// the last axis.  It is the default in 3D (C4: 12.1 + 3.7 ms against 6.9 + 9.4..10.7 ms for stage B + final, K2 never in
+// HBM); in 2D the unfused kernels are faster (C2: 0.105 against 0.141 ms) and stay the default.  IGX_PATH=fused / unfused
+// forces a path (a choice of IGX_FINAL implies unfused); the unfused kernels also serve every other case.
 static bool fused_applicable(const igx_patch *pt)
 {
-    if (const char *e = getenv("IGX_PATH"))
-        if (!strcmp(e, "unfused")) return false;
+    const char *e = getenv("IGX_PATH");
+    if (e && !strcmp(e, "unfused")) return false;
     if (getenv("IGX_FINAL")) return false;
     const int dim = pt->dim;
+    if (dim == 2 && !(e && !strcmp(e, "fused"))) return false;
     const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
-    if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 6) return false;
+    if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 5) return false;      // (p = 5: the exchange buffers of k_bf do not fit LDS yet)
     return true;
 }
 
