@@ -2,22 +2,26 @@
 """Throughput of the assembly hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c3|c2|c1|c5|tiny] [--algo auto|sumfact|entrywise]
+                    [--weak] [--emulate R/W] [--op matrix|rhs|entries]
 
-Workload (BASELINE.json): stiffness assembly of a tensor-product B-spline patch over the NURBS
-quarter-annulus cylinder; default C4 = 3D, p=4, 128^3 spans (2.1 M elements, 1.59 G nonzeros).
-One "step" = one complete assembly of the CSR values on the device (quadrature fields from the
-control net, the sum-factorisation stages, CSR write-out + mirror), inputs resident in HBM.
+Workload (BASELINE.json): stiffness assembly of a tensor-product B-spline patch over the NURBS quarter-annulus
+cylinder; default C4 = 3D, p=4, 128^3 spans (2.1 M elements, 1.59 G nonzeros).  One "step" = one complete assembly of
+the CSR values on the device (quadrature fields from the control net, the sum-factorisation stages, CSR write-out +
+mirror), inputs resident in HBM.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- the patch grows
-along axis 0 to N*128 spans and rank r owns the r-th slab of axis-0 dof planes.  The row-owner
-computes everything it needs (DESIGN.md "multi-GPU"), so there is no collective on the data
-path; torch.distributed (RCCL) is only used for the timing barrier / max-reduce.
+Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL).  Launched by torch.distributed.run the
+script reads RANK/LOCAL_RANK/WORLD_SIZE; started plainly with --gpus N > 1 it spawns the N ranks itself BEFORE
+anything touches the GPU and relays rank 0's line.  The default is STRONG scaling of the named patch (BASELINE config 4
+fixes 128^3 spans): rank r owns the r-th slab of axis-0 dof planes and computes everything it needs itself
+(DESIGN.md "multi-GPU"), so there is no collective on the data path; RCCL carries the barrier and the reductions of
+the timing.  --weak grows axis 0 with the rank count instead (each rank a 128-span slab) and says so in `scaling`.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 (the last line of stdout).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -47,11 +51,47 @@ def algorithmic_bytes_per_element(dim, p, nnz, nelem, kind='stiffness'):
     return 8.0 * (dim * dim + (1 if kind == 'convdiff' else 0)) * q ** dim + 8.0 * nnz / nelem
 
 
+def algorithmic_flops(dim, p, kvs, kind):
+    """FP64 operations of ONE assembly with the global sum factorisation, by stage -- the
+    useful ones: no tile halos, no warm-up spans.  Counts follow the kernels: fields ~150 flop per Gauss point;
+    stage A: 2 flops per (array, lower pair of the span, point); stage B in rank-1 form (fused stage) 2 * 170 per
+    (axis-0 pair, g1, g2) for the 9 stiffness terms; last contraction 2 * 70 q per (line, row)."""
+    P = p + 1
+    q = P
+    N = [kv.numdofs for kv in kvs]
+    n = [kv.numspans for kv in kvs]
+    G = [k * q for k in n]
+    npts = float(np.prod(G))
+    S = [Nk * (2 * p + 1) - p * (p + 1) for Nk in N]          # 1D pairs (single interior knots)
+    Slow = (S[0] + N[0]) // 2                                   # lower pairs of axis 0
+    sym = kind != 'convdiff'
+    nX = {('stiffness', 3): 8, ('stiffness', 2): 3, ('convdiff', 3): 11}.get((kind, dim), 1)
+    nterm = {('stiffness', 3): 9, ('stiffness', 2): 4, ('convdiff', 3): 12}.get((kind, dim), 1)
+    out = {'fields': 150.0 * npts}
+    pairs_span = P * (P + 1) / 2 if sym else P * P
+    out['stage_a'] = 2.0 * nX * pairs_span * npts
+    np0 = Slow if sym else S[0]
+    if dim == 3:
+        per_pt = 2.0 * {9: 170, 12: 225, 1: 30}.get(nterm, 25 * nterm)
+        out['stage_b'] = per_pt * np0 * G[1] * G[2]
+        lines = np0 * S[1]
+        out['contraction'] = 2.0 * (70 if nterm > 1 else 30) * q * lines * N[2]
+    else:
+        out['contraction'] = 2.0 * (70 if nterm > 1 else 30) * q * np0 * N[1]
+    return out
+
+
 def measured_traffic(config, world):
-    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/), or None."""
+    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/<round>_traffic.json) with the git
+    commit they were taken at -- or None when the kernels have changed since (stale numbers are not reported)."""
     try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))[config]
-        return t['chain_bytes'] if world == 1 else None
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')))[config]
+        if world != 1:
+            return None
+        head = subprocess.run(['git', '-C', ROOT, 'log', '-1', '--format=%H', '--', 'pyiga_amd/csrc'], capture_output=True, text=True).stdout.strip()
+        if head and t.get('kernels_commit') and not head.startswith(t['kernels_commit']):
+            return None
+        return {'bytes': t['chain_bytes'], 'profile_commit': t.get('kernels_commit'), 'source': 'profiles/r02_traffic.json'}
     except Exception:
         return None
 
@@ -68,10 +108,10 @@ def make_geo(geometry, name):
 
 def cpu_baseline(dim, p, kind):
     """Oracle (C port of the reference's entry-wise loops, reference compile flags) timed on the
-    host cores on a bounded sample of the same workload."""
+    host cores on a bounded sample of the same workload.  Runs BEFORE anything touches the GPU (it may start gcc)."""
     from oracle import iga_oracle as orc
     orc.build()
-    n = {(3, 4): 24, (3, 2): 48, (2, 3): 256}.get((dim, p), 12)
+    n = {(3, 4): 24, (3, 2): 48, (2, 3): 256, (3, 5): 14}.get((dim, p), 12)
     cores = os.cpu_count() or 1
     kv = orc.make_knots(p, 0.0, 1.0, n)
     geo = orc.geo_cylinder() if dim == 3 else orc.geo_quarter_annulus()
@@ -93,82 +133,88 @@ def cpu_baseline(dim, p, kind):
     }
 
 
-def bench_rhs(args, patch, kvs, geo, dim, p, n0, n, nel_total, world, rank, dist, barrier):
-    """Load vector of the same patch.  The function values are host data by definition (a Python
-    callable sampled on the Gauss grid), so a call includes their upload; `value` uses the device time of the
-    three contractions (inputs resident, HIP events inside igx_load_vector), the PCIe-inclusive rate is noted."""
-    import pyiga_amd
-    from pyiga_amd import utils
-    grid = tuple(patch.gauss(k)[0] for k in range(dim))
-    fvals = np.ascontiguousarray(utils.grid_eval(lambda *x: np.cos(x[0]) * np.exp(x[1]) * (np.sin(x[2]) if dim == 3 else 1.0), grid))
-    for _ in range(args.warmup):
-        patch.load_vector(fvals)
-    barrier()
-    dev_ms, t0 = 0.0, time.perf_counter()
-    for _ in range(args.steps):
-        patch.load_vector(fvals)
-        dev_ms += patch.timing()['total_ms']
-    barrier()
-    wall = time.perf_counter() - t0
-    if rank != 0:
-        return
-    dev_ms /= args.steps
-    q = p + 1
-    b_el = 8.0 * q ** dim + 8.0 * np.prod([k.numdofs for k in kvs]) / nel_total      # f in + vector out (W is resident)
-    nel_rank = nel_total / world
-    achieved = b_el * nel_rank / (dev_ms * 1e-3) / 1e9
-    out = {'metric': 'load-vector elements/sec', 'value': nel_total / (dev_ms * 1e-3), 'unit': 'elements/s', 'n_gpus': world,
-           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-           'config': {'workload': '%dD p=%d load vector (inner_products), %s spans' % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
-                      'config': args.config, 'elements': nel_total,
-                      'note': 'value = device time of the contractions; a whole call incl. the upload of the function values took %.1f ms' % (1e3 * wall / args.steps)},
-           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': None, 'kernel': 'k_contract_axis x %d' % dim, 'algorithmic_bytes_per_element': b_el}}
+def flush_c_stdio():
+    # RCCL writes its banner through C stdio, which is block-buffered on a pipe: flush it so that the result is the LAST line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as children (nothing here has touched the GPU), relay rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit('bench.py: ranks exited with %s' % rcs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='c4', choices=sorted(CONFIGS))
     ap.add_argument('--n', type=int, default=0, help='override spans per axis (testing)')
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs'], help='rhs: the load vector (inner_products) of the same patch instead of the matrix')
-    ap.add_argument('--strong', action='store_true', help='strong scaling: keep the patch fixed, split its rows')
-    ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank weak-scaling run on this one GPU (no collectives)')
+    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries'],
+                    help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs')
+    ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
+    ap.add_argument('--strong', action='store_true', help='(default) strong scaling: the patch is fixed, its rows are split')
+    ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank run on this one GPU (no collectives)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    emu = None
-    if args.emulate:
-        emu = tuple(int(x) for x in args.emulate.split('/'))
+    if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+        return self_launch(args)
+    rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    emu = tuple(int(x) for x in args.emulate.split('/')) if args.emulate else None
+    dim, p, n, kind, gname = CONFIGS[args.config]
+    if args.n:
+        n = args.n
+
+    # the CPU baseline first: it may compile the oracle (child processes only before the GPU is initialised)
+    cpu = None
+    if rank == 0 and world == 1 and emu is None and not args.no_cpu_baseline and args.op == 'matrix':
+        cpu = cpu_baseline(dim, p, kind)
+
     dist = None
     if world > 1 or os.environ.get('BENCH_FORCE_DIST'):      # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('RCCL world size %d != --gpus %d' % (dist.get_world_size(), args.gpus))
 
     import pyiga_amd
     from pyiga_amd import bspline, geometry, assemblers, distributed
     os.environ['IGX_DEVICE'] = str(local_rank)
 
-    dim, p, n, kind, gname = CONFIGS[args.config]
-    if args.n:
-        n = args.n
     geo = make_geo(geometry, gname)
-    # weak scaling: axis 0 grows with the number of ranks; each rank owns one slab of dof planes
     part_rank, part_world = (rank, world) if emu is None else emu
-    n0 = n if (args.strong or part_world == 1) else n * part_world
+    weak = args.weak and part_world > 1
+    n0 = n * part_world if weak else n
+    t_setup = time.perf_counter()
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
@@ -177,8 +223,8 @@ def main():
         patch = assemblers.ConvDiffAssembler3D(kvs, geo, COEFF, device=local_rank, row0=row0 if part_world > 1 else None).patch
     else:
         patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
-    if rank == 0 and os.environ.get('BENCH_VERBOSE'):
-        print('rank 0 slab', row0, 'nnz', patch.nnz, 'rows', patch.row_range, file=sys.stderr)
+    patch.ctx.sync()
+    setup_s = time.perf_counter() - t_setup                 # knots, tables, plan, coefficient sampling + upload
     nel_total = n0 * n ** (dim - 1)
     if emu is not None:
         nel_total //= part_world        # one slab's share
@@ -192,20 +238,25 @@ def main():
         patch.ctx.sync()
 
     if args.op == 'rhs':
-        return bench_rhs(args, patch, kvs, geo, dim, p, n0, n, nel_total, world, rank, dist, barrier)
+        return bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, barrier)
+    if args.op == 'entries':
+        return bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank)
     for _ in range(args.warmup):
         patch.assemble(kind, algo=args.algo, to_host=False)
-    stage_ms = {}
+    stage_ms, steps_ms = {}, []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         patch.assemble(kind, algo=args.algo, to_host=False)     # returns after the ctx stream has drained
-        for k, v in patch.timing().items():
+        tm = patch.timing()
+        for k, v in tm.items():
             if k.endswith('_ms'):
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
-        algo_used = patch.timing()['algo_used']
+        steps_ms.append(tm['total_ms'])
+        algo_used = tm['algo_used']
     barrier()
     dt = time.perf_counter() - t0
+    slab_ms = [float(np.median(steps_ms))]
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -214,6 +265,9 @@ def main():
         z = torch.tensor([float(nnz_local)], dtype=torch.float64, device='cuda')
         dist.all_reduce(z, op=dist.ReduceOp.SUM)
         nnz_total = int(z.item())
+        sl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
+        dist.all_gather(sl, torch.tensor([slab_ms[0]], dtype=torch.float64, device='cuda'))
+        slab_ms = [float(x.item()) for x in sl]
     else:
         nnz_total = nnz_local
     if rank != 0:
@@ -224,60 +278,130 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = nel_total * args.steps / dt
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-    # roofline on rank 0's slab: algorithmic bytes of one assembly / device time of the kernel chain
+    # roofline on rank 0's slab: algorithmic bytes of one assembly / device time of the kernel chain (median step)
     nel_rank = nel_total / world
     b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total, kind)
-    chain_ms = stage_ms.get('total_ms', ms_per_step)
+    chain_ms = float(np.median(steps_ms))
     achieved = b_el * nel_rank / (chain_ms * 1e-3) / 1e9
-    names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_stageA', 'stage1_ms': 'k_stageB', 'final_ms': 'k_final',
-             'entry_ms': 'k_entries_csr'}
+    fused = stage_ms.get('stage1_ms', 0) > 0 and os.environ.get('IGX_PATH', 'fused' if dim == 3 else 'unfused') != 'unfused' and not os.environ.get('IGX_FINAL')
+    names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_stageA', 'stage1_ms': 'k_bf' if fused else 'k_stageB',
+             'final_ms': 'k_mirror' if fused else 'k_final', 'entry_ms': 'k_entries_csr'}
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
-    # the dominant kernel by itself: the part of the algorithmic bytes that passes through it
-    # (final stage / entry-wise kernel: the CSR values out; stage A: the quadrature input in) over its own time
-    dom = None
-    if dominant in ('k_final', 'k_entries_csr', 'k_stageA', 'k_geo_fields'):
-        q = p + 1
-        if dominant in ('k_final', 'k_entries_csr'):
-            dom_bytes = 8.0 * nnz_total / world
-        else:
-            dom_bytes = 8.0 * (dim * dim + (1 if kind == 'convdiff' else 0)) * q ** dim * nel_rank
-        dom_ach = dom_bytes / (parts[dominant] * 1e-3) / 1e9
-        dom = {'kernel': dominant, 'ms': parts[dominant], 'algorithmic_bytes': dom_bytes, 'achieved': dom_ach,
-               'unit': 'GB/s', 'frac': dom_ach / HBM_PEAK_GBS}
+    flops = algorithmic_flops(dim, p, kvs, kind) if algo_used == 2 else None
+    fp64 = None
+    if flops:
+        share = part_world if emu is not None else world    # flops of ONE slab (approximately: halo planes not counted)
+        tot = sum(flops.values()) / share
+        nel_patch = nel_total * (part_world if emu is not None else 1)
+        fp64 = {'flops_per_element': {k: round(v / nel_patch, 1) for k, v in flops.items()}, 'total_gflop': round(tot / 1e9, 2),
+                'achieved': tot / (chain_ms * 1e-3) / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tot / (chain_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 'algorithm': 'global sum factorisation, useful flops only'}
     out = {
         'metric': 'assembled elements/sec (3D p=4, 128^3 spans) + HBM-roofline %; 1/2/4/8 GPU'
                   if args.config == 'c4' else 'assembled elements/sec',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'strong' if args.strong else 'weak',
+        'scaling': 'weak' if weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%dD p=%d %s, %s spans, NURBS quarter-annulus %s, uniform open knots'
                                % (dim, p, kind, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1)),
                                   'cylinder' if dim == 3 else gname),
-                   'config': args.config, 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
+                   'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
+                   'path': 'fused sweep+final (k_bf) + mirror' if fused else 'stage kernels',
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
+        'step_ms': {'median': chain_ms, 'min': float(np.min(steps_ms)), 'max': float(np.max(steps_ms))},
+        'slab_ms': [round(x, 3) for x in slab_ms],
+        'setup_s': round(setup_s, 3),
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': measured_traffic(args.config, world),
-            'kernel': 'assembly chain (k_geo_fields + k_stageA x fields + k_stageB + k_final), HIP events on the igx stream',
+            'kernel': 'assembly chain (' + ' + '.join(parts) + '), HIP events on the igx stream; median step',
             'algorithmic_bytes_per_element': b_el, 'chain_ms': chain_ms, 'kernel_ms': parts, 'dominant_kernel': dominant,
-            'dominant': dom,
+            'fp64': fp64,
         },
     }
-    if not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(dim, p, kind)
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
     if dist is not None:
         dist.destroy_process_group()        # before the result line: anything RCCL prints comes first
-    # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would surface
-    # after this line at exit: flush it first so that the result is the LAST line of stdout
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
+def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, barrier):
+    """Load vector of the same patch.  `value` uses the device time of the contractions with the
+    function values resident in HBM (igx_load_vector_d); the whole host-pointer call incl. the upload is noted."""
+    from pyiga_amd import utils
+    grid = tuple(patch.gauss(k)[0] for k in range(dim))
+    fvals = np.ascontiguousarray(utils.grid_eval(lambda *x: np.cos(x[0]) * np.exp(x[1]) * (np.sin(x[2]) if dim == 3 else 1.0), grid))
+    t0 = time.perf_counter()
+    patch.load_vector(fvals)
+    host_call_ms = 1e3 * (time.perf_counter() - t0)
+    patch.upload_function(fvals)                      # resident from here on
+    for _ in range(args.warmup):
+        patch.load_vector_resident()
+    barrier()
+    dev, t0 = [], time.perf_counter()
+    for _ in range(args.steps):
+        patch.load_vector_resident()
+        dev.append(patch.timing()['total_ms'])
+    barrier()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    dev_ms = float(np.median(dev))
+    if dist is not None:
+        import torch
+        t = torch.tensor([dev_ms, wall_ms], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dev_ms, wall_ms = float(t[0].item()), float(t[1].item())
+    if rank != 0:
+        return
+    q = p + 1
+    b_el = 8.0 * q ** dim + 8.0 * np.prod([k.numdofs for k in kvs]) / nel_total      # f in + vector out (W is resident)
+    nel_rank = nel_total / world
+    achieved = b_el * nel_rank / (dev_ms * 1e-3) / 1e9
+    out = {'metric': 'load-vector elements/sec', 'value': nel_total / (dev_ms * 1e-3), 'unit': 'elements/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%dD p=%d load vector (inner_products), %s spans' % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
+                      'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total,
+                      'note': 'value = device time of the contractions, function values resident (igx_load_vector_d); whole resident call '
+                              '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms' % (wall_ms, host_call_ms)},
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': None, 'kernel': 'k_contract_axis x %d' % dim, 'algorithmic_bytes_per_element': b_el}}
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
+def bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank):
+    """Batched multi_entries: 1 M seeded in-pattern pairs, index pairs and results resident on the device."""
+    rng = np.random.default_rng(5)
+    nd = [k.numdofs for k in kvs]
+    M = 1 << 20
+    I = np.stack([rng.integers(0, x, M) for x in nd], 1)
+    J = np.clip(I + rng.integers(-p, p + 1, (M, dim)), 0, np.array(nd) - 1)
+    idx = np.stack([np.ravel_multi_index(I.T, nd), np.ravel_multi_index(J.T, nd)], 1).astype(np.uintp)
+    for _ in range(max(1, args.warmup)):
+        patch.entries(kind, idx[:1024])
+    t0 = time.perf_counter()
+    patch.entries(kind, idx)
+    host_ms = 1e3 * (time.perf_counter() - t0)
+    patch.upload_pairs(idx)
+    dev = []
+    for _ in range(args.steps):
+        patch.entries_resident(kind)
+        dev.append(patch.timing()['entry_ms'])
+    dev_ms = float(np.median(dev))
+    q = p + 1
+    # bytes one entry must read: its fields on the support intersection (avg ((p+1) q / 2)^d points x d(d+1)/2 fields) -- L2-resident reuse aside
+    out = {'metric': 'multi_entries pairs/sec', 'value': M / (dev_ms * 1e-3), 'unit': 'entries/s', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic',
+           'config': {'workload': '%dD p=%d %s multi_entries, %d random in-pattern pairs, %s spans' % (dim, p, kind, M, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
+                      'config': args.config, 'note': 'device time with resident pairs; host-pointer call (upload pairs, download values) %.1f ms' % host_ms},
+           'roofline': {'bound': 'fp64', 'note': 'the entry-wise sum is arithmetic: ~33 flop per Gauss point of the support intersection',
+                        'achieved': None, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}}
     print(json.dumps(out), flush=True)
 
 

@@ -154,6 +154,10 @@ int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
 /* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
 int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);
 
+/* Resident Gauss planes of axis 0: a row slab keeps only the planes its rows touch, [*g0_lo, *g0_lo + *g0_n).
+   Device-side inputs (igx_load_vector_d) are laid out on this slab. */
+int igx_patch_gauss_slab(const igx_patch *patch, int64_t *g0_lo, int64_t *g0_n);
+
 /* Canonical CSR pattern of the owned rows.  indptr has (row_hi-row_lo+1) entries, LOCAL
    (indptr[0] = 0); indices has nnz entries (global column ids).  Either may be NULL.
    The pattern is also kept on the device. */
@@ -176,11 +180,25 @@ const int32_t *igx_d_csr_indptr(const igx_patch *patch);
    fields of the pair's Gauss points are resident (always true for a full patch). */
 int igx_entries(igx_patch *patch, int kind, const size_t *ij, size_t M, double *out);
 
+/* The same with the index pairs and the results in device memory (no copies; pyiga/genericasm.pxi:722-758). */
+int igx_entries_d(igx_patch *patch, int kind, const size_t *d_ij, size_t M, double *d_out);
+
+/* Device buffers that stay resident between calls (function values, index pairs, results): plain hipMalloc'ed memory on the
+   context's GPU; uploads / downloads are synchronous on the context's stream. */
+void *igx_dev_alloc(igx_ctx *ctx, size_t bytes);                               /* NULL on failure */
+void  igx_dev_free(igx_ctx *ctx, void *d_ptr);
+int   igx_dev_upload(igx_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int   igx_dev_download(igx_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
 /* Load vector of the owned rows: out[i] = sum over the Gauss grid of  B_i * f * gw0*gw1*gw2*|det J|
    (inner_products(kvs, f, geo=geo), L2FunctionalAssembler*.assemble_vector()).  fvals: the function on the
    FULL tensor Gauss grid (G0 x G1 [x G2], C order, host), i.e. utils.grid_eval(f, gaussgrid) or
    grid_eval_transformed(f, gaussgrid, geo); out: (row0_hi-row0_lo) x N1 [x N2] doubles (host). */
 int igx_load_vector(igx_patch *patch, const double *fvals, double *out);
+
+/* The same with the function values of the RESIDENT Gauss slab (G0_local x G1 [x G2], C order) and the result in device
+   memory: no transfer, workspace owned by the patch (pyiga/assemble.py:288-340 with f already sampled). */
+int igx_load_vector_d(igx_patch *patch, const double *d_fvals, double *d_out);
 
 /* Linear functional in the first-order jet of v:  out[i] = integral of  sum_r F_r(x) D_r v_i  dx  (D_0 = id, D_1.. =
    physical derivatives).  coef[r]: F_r on the FULL tensor Gauss grid (host) or NULL.  Arity-1 form strings such as

@@ -91,8 +91,79 @@ class DevicePatch:
 
     def close(self):
         if getattr(self, 'handle', None):
+            for name in ('_d_f', '_d_vec', '_d_ij', '_d_val'):
+                self._dev_free(name)
             _lib.load().igx_patch_destroy(self.handle)
             self.handle = None
+
+    # -- device-resident buffers (function values, index pairs, results stay in HBM between calls)
+    def _dev_free(self, name):
+        buf = getattr(self, name, None)
+        if buf:
+            _lib.load().igx_dev_free(self.ctx.handle, buf[0])
+            setattr(self, name, None)
+
+    def _dev_buffer(self, name, nbytes):
+        buf = getattr(self, name, None)
+        if buf and buf[1] >= nbytes:
+            return buf[0]
+        self._dev_free(name)
+        ptr = _lib.load().igx_dev_alloc(self.ctx.handle, nbytes)
+        if not ptr:
+            raise _lib.IgxError('igx_dev_alloc failed: ' + _lib.last_error())
+        setattr(self, name, (ptr, nbytes))
+        return ptr
+
+    def gauss_slab(self):
+        """(first plane, number of planes) of the Gauss planes of axis 0 that are resident for this row slab."""
+        lo, n = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().igx_patch_gauss_slab(self.handle, C.byref(lo), C.byref(n)), 'igx_patch_gauss_slab')
+        return int(lo.value), int(n.value)
+
+    def upload_function(self, fvals):
+        """Copy the function values (full tensor Gauss grid) of the resident Gauss slab to the device; load_vector_resident()
+        then works without any transfer."""
+        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        fvals = np.asarray(fvals, dtype=np.float64)
+        assert fvals.shape == G, 'function values have the wrong grid shape'
+        g0_lo, g0_n = self.gauss_slab()
+        part = np.ascontiguousarray(fvals[g0_lo:g0_lo + g0_n])
+        ptr = self._dev_buffer('_d_f', part.nbytes)
+        _lib.check(_lib.load().igx_dev_upload(self.ctx.handle, ptr, part.ctypes.data, part.nbytes), 'igx_dev_upload')
+
+    def load_vector_resident(self, to_host=False):
+        """Load vector from the function values uploaded with upload_function(); the result stays on the device unless asked for."""
+        assert getattr(self, '_d_f', None), 'upload_function() first'
+        lo, hi = int(self.info.row_lo), int(self.info.row_hi)
+        nd = self.ndofs
+        n0 = (hi - lo) // int(np.prod(nd[1:]))
+        n_out = n0 * int(np.prod(nd[1:]))
+        d_out = self._dev_buffer('_d_vec', 8 * n_out)
+        _lib.check(_lib.load().igx_load_vector_d(self.handle, self._d_f[0], d_out), 'igx_load_vector_d')
+        if not to_host:
+            return None
+        out = np.empty((n0,) + nd[1:])
+        _lib.check(_lib.load().igx_dev_download(self.ctx.handle, out.ctypes.data, d_out, out.nbytes), 'igx_dev_download')
+        return out
+
+    def upload_pairs(self, idx):
+        """Index pairs (M, 2) of a batched multi_entries request, kept on the device for entries_resident()."""
+        idx = np.ascontiguousarray(idx, dtype=np.uintp)
+        assert idx.ndim == 2 and idx.shape[1] == 2
+        ptr = self._dev_buffer('_d_ij', idx.nbytes)
+        _lib.check(_lib.load().igx_dev_upload(self.ctx.handle, ptr, idx.ctypes.data, idx.nbytes), 'igx_dev_upload')
+        self._npairs = idx.shape[0]
+
+    def entries_resident(self, kind, to_host=False):
+        assert getattr(self, '_d_ij', None), 'upload_pairs() first'
+        M = self._npairs
+        d_val = self._dev_buffer('_d_val', 8 * M)
+        _lib.check(_lib.load().igx_entries_d(self.handle, _lib.KINDS[kind], self._d_ij[0], M, d_val), 'igx_entries_d')
+        if not to_host:
+            return None
+        out = np.empty(M)
+        _lib.check(_lib.load().igx_dev_download(self.ctx.handle, out.ctypes.data, d_val, out.nbytes), 'igx_dev_download')
+        return out
 
     def __del__(self):
         try:

@@ -188,6 +188,21 @@ static int ensure_fields(igx_patch *pt, int kind)
     return IGX_OK;
 }
 
+// grow-only device workspace owned by the patch
+template <class T>
+static int ws_reserve(T **buf, size_t *cap, size_t n, const char *what)
+{
+    if (*cap >= n) return IGX_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    if (hipMalloc((void **)buf, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) {
+        *buf = nullptr;
+        set_error("hipMalloc of %.3f GB for %s failed", n * sizeof(T) / 1e9, what);
+        return IGX_ERR_NOMEM;
+    }
+    *cap = n;
+    return IGX_OK;
+}
+
 } // namespace igx
 
 using namespace igx;
@@ -327,6 +342,8 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
     (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
+    (void)hipFree(pt->d_ws_ij); (void)hipFree(pt->d_ws_out);
+    (void)hipFree(pt->d_lv_f); (void)hipFree(pt->d_lv_t1); (void)hipFree(pt->d_lv_t2); (void)hipFree(pt->d_lv_o);
     delete pt;
 }
 
@@ -592,6 +609,28 @@ const double *igx_d_csr_data(const igx_patch *pt) { return pt ? pt->d_data : nul
 const int32_t *igx_d_csr_indices(const igx_patch *pt) { return pt ? pt->d_indices : nullptr; }
 const int32_t *igx_d_csr_indptr(const igx_patch *pt) { return pt ? pt->d_indptr : nullptr; }
 
+int igx_entries_d(igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out)
+{
+    if (!pt || (M && (!d_ij || !d_out))) { set_error("igx_entries_d: null argument"); return IGX_ERR_ARG; }
+    if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_entries_d: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (M == 0) return IGX_OK;
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc = ensure_fields(pt, kind);
+    if (rc) return rc;
+    (void)hipEventRecord(pt->ctx->ev[6], st);
+    rc = launch_entries_list(st, pt, kind, d_ij, M, d_out);
+    (void)hipEventRecord(pt->ctx->ev[7], st);
+    if (rc) return rc;
+    IGX_HIP(hipStreamSynchronize(st));
+    memset(&pt->timing, 0, sizeof(pt->timing));
+    (void)hipEventElapsedTime(&pt->timing.entry_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
+    pt->timing.total_ms = pt->timing.entry_ms;
+    pt->timing.algo_used = IGX_ALGO_ENTRYWISE;
+    pt->timing.n_launches = 1;
+    return IGX_OK;
+}
+
 int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out)
 {
     if (!pt || (M && (!ij || !out))) { set_error("igx_entries: null argument"); return IGX_ERR_ARG; }
@@ -599,19 +638,14 @@ int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out
     if (M == 0) return IGX_OK;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
-    int rc = ensure_fields(pt, kind);
-    if (rc) return rc;
-    size_t *d_ij = nullptr;
-    double *d_out = nullptr;
-    if ((rc = dev_alloc_copy(&d_ij, ij, 2 * M, st))) return rc;
-    IGX_HIP(hipMalloc((void **)&d_out, M * sizeof(double)));
-    rc = launch_entries_list(st, pt, kind, d_ij, M, d_out);
-    if (!rc) {
-        IGX_HIP(hipMemcpyAsync(out, d_out, M * sizeof(double), hipMemcpyDeviceToHost, st));
-        IGX_HIP(hipStreamSynchronize(st));
-    }
-    (void)hipFree(d_ij); (void)hipFree(d_out);
-    return rc;
+    int rc;
+    if ((rc = ws_reserve(&pt->d_ws_ij, &pt->ws_ij_cap, 2 * M, "index pairs"))) return rc;
+    if ((rc = ws_reserve(&pt->d_ws_out, &pt->ws_out_cap, M, "entry values"))) return rc;
+    IGX_HIP(hipMemcpyAsync(pt->d_ws_ij, ij, 2 * M * sizeof(size_t), hipMemcpyHostToDevice, st));
+    if ((rc = igx_entries_d(pt, kind, pt->d_ws_ij, M, pt->d_ws_out))) return rc;
+    IGX_HIP(hipMemcpyAsync(out, pt->d_ws_out, M * sizeof(double), hipMemcpyDeviceToHost, st));
+    IGX_HIP(hipStreamSynchronize(st));
+    return IGX_OK;
 }
 
 int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
@@ -629,46 +663,102 @@ int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
     return IGX_OK;
 }
 
+static int lv_workspace(igx_patch *pt, size_t *n_out)
+{
+    const PatchDev &pd = pt->dev;
+    const int dim = pt->dim;
+    const size_t N1 = pt->ax[1].N, N2 = dim == 3 ? pt->ax[2].N : 1, G1 = pt->ax[1].G;
+    *n_out = (size_t)(pt->r0_hi - pt->r0_lo) * N1 * N2;
+    const size_t n_t1 = dim == 3 ? (size_t)pd.G0_loc * G1 * N2 : (size_t)pd.G0_loc * N1;
+    const size_t n_t2 = dim == 3 ? (size_t)pd.G0_loc * N1 * N2 : 1;
+    int rc;
+    if ((rc = ws_reserve(&pt->d_lv_t1, &pt->lv_t1_cap, n_t1, "load-vector workspace"))) return rc;
+    if ((rc = ws_reserve(&pt->d_lv_t2, &pt->lv_t2_cap, n_t2, "load-vector workspace"))) return rc;
+    return ws_reserve(&pt->d_lv_o, &pt->lv_o_cap, *n_out, "load vector");
+}
+
+int igx_load_vector_d(igx_patch *pt, const double *d_fvals, double *d_out)
+{
+    if (!pt || !d_fvals || !d_out) { set_error("igx_load_vector_d: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab
+    if (rc) return rc;
+    size_t n_out;
+    if ((rc = lv_workspace(pt, &n_out))) return rc;
+    (void)hipEventRecord(pt->ctx->ev[6], st);        // device time of the contractions, inputs resident
+    rc = launch_load_vector(st, pt, d_fvals, pt->d_fields, d_out, pt->d_lv_t1, pt->d_lv_t2);
+    (void)hipEventRecord(pt->ctx->ev[7], st);
+    if (rc) return rc;
+    IGX_HIP(hipStreamSynchronize(st));
+    memset(&pt->timing, 0, sizeof(pt->timing));
+    (void)hipEventElapsedTime(&pt->timing.total_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
+    pt->timing.algo_used = 3;                        // load vector
+    pt->timing.n_launches = pt->dim;
+    return IGX_OK;
+}
+
+int igx_patch_gauss_slab(const igx_patch *pt, int64_t *g0_lo, int64_t *g0_n)
+{
+    if (!pt) { set_error("igx_patch_gauss_slab: null patch"); return IGX_ERR_ARG; }
+    if (g0_lo) *g0_lo = pt->dev.g0_lo;
+    if (g0_n) *g0_n = pt->dev.G0_loc;
+    return IGX_OK;
+}
+
 int igx_load_vector(igx_patch *pt, const double *fvals, double *out)
 {
     if (!pt || !fvals || !out) { set_error("igx_load_vector: null argument"); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
-    int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab
-    if (rc) return rc;
     const PatchDev &pd = pt->dev;
-    const int dim = pt->dim;
     const size_t npts = (size_t)pd.npts_loc, plane = npts / (size_t)pd.G0_loc;
-    const size_t N1 = pt->ax[1].N, N2 = dim == 3 ? pt->ax[2].N : 1, G1 = pt->ax[1].G;
-    const size_t n_out = (size_t)(pt->r0_hi - pt->r0_lo) * N1 * N2;
-    const size_t n_t1 = dim == 3 ? (size_t)pd.G0_loc * G1 * N2 : (size_t)pd.G0_loc * N1;
-    const size_t n_t2 = dim == 3 ? (size_t)pd.G0_loc * N1 * N2 : 1;
-    double *d_f = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_o = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_f); (void)hipFree(d_t1); (void)hipFree(d_t2); (void)hipFree(d_o); };
-    if (hipMalloc((void **)&d_f, npts * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_t1, n_t1 * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_t2, n_t2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_o, std::max<size_t>(1, n_out) * sizeof(double)) != hipSuccess) {
-        cleanup();
-        set_error("igx_load_vector: hipMalloc of the workspace failed");
-        return IGX_ERR_NOMEM;
-    }
+    int rc;
+    size_t n_out;
+    if ((rc = ws_reserve(&pt->d_lv_f, &pt->lv_f_cap, npts, "function values"))) return rc;
+    if ((rc = lv_workspace(pt, &n_out))) return rc;
     // the function values of the resident Gauss planes are contiguous in the full-grid array (axis 0 is slowest)
-    hipError_t e = hipMemcpyAsync(d_f, fvals + (size_t)pd.g0_lo * plane, npts * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        (void)hipEventRecord(pt->ctx->ev[6], st);        // device time of the contractions, inputs resident
-        rc = launch_load_vector(st, pt, d_f, pt->d_fields, d_o, d_t1, d_t2);
-        (void)hipEventRecord(pt->ctx->ev[7], st);
-        if (rc == IGX_OK) e = hipMemcpyAsync(out, d_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && rc == IGX_OK) {
-        memset(&pt->timing, 0, sizeof(pt->timing));
-        (void)hipEventElapsedTime(&pt->timing.total_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
-        pt->timing.algo_used = 3;                        // load vector
-        pt->timing.n_launches = pt->dim;
-    }
-    cleanup();
-    if (e != hipSuccess) { set_error("igx_load_vector: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
-    return rc;
+    IGX_HIP(hipMemcpyAsync(pt->d_lv_f, fvals + (size_t)pd.g0_lo * plane, npts * sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = igx_load_vector_d(pt, pt->d_lv_f, pt->d_lv_o))) return rc;
+    IGX_HIP(hipMemcpyAsync(out, pt->d_lv_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    IGX_HIP(hipStreamSynchronize(st));
+    return IGX_OK;
+}
+
+// device buffers that stay resident between calls (function values, index pairs, results)
+void *igx_dev_alloc(igx_ctx *ctx, size_t bytes)
+{
+    if (!ctx) { set_error("igx_dev_alloc: null context"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(1, bytes)) != hipSuccess) { set_error("hipMalloc of %.3f GB failed", bytes / 1e9); return nullptr; }
+    return p;
+}
+
+void igx_dev_free(igx_ctx *ctx, void *d_ptr)
+{
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_ptr);
+}
+
+int igx_dev_upload(igx_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !src))) { set_error("igx_dev_upload: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(ctx->device));
+    IGX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    IGX_HIP(hipStreamSynchronize(ctx->stream));
+    return IGX_OK;
+}
+
+int igx_dev_download(igx_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !d_src))) { set_error("igx_dev_download: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(ctx->device));
+    IGX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    IGX_HIP(hipStreamSynchronize(ctx->stream));
+    return IGX_OK;
 }
 
 int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
@@ -691,18 +781,10 @@ int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
     hipStream_t st = pt->ctx->stream;
     const PatchDev &pd = pt->dev;
     const size_t npts = (size_t)pd.npts_loc;
-    const size_t N1 = pt->ax[1].N, N2 = dim == 3 ? pt->ax[2].N : 1, G1 = pt->ax[1].G;
-    const size_t n_out = (size_t)(pt->r0_hi - pt->r0_lo) * N1 * N2;
-    const size_t n_t1 = dim == 3 ? (size_t)pd.G0_loc * G1 * N2 : (size_t)pd.G0_loc * N1;
-    const size_t n_t2 = dim == 3 ? (size_t)pd.G0_loc * N1 * N2 : 1;
-    double *d_t1 = nullptr, *d_t2 = nullptr, *d_o = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_t1); (void)hipFree(d_t2); (void)hipFree(d_o); };
-    if (hipMalloc((void **)&d_t1, n_t1 * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_t2, n_t2 * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_o, std::max<size_t>(1, n_out) * sizeof(double)) != hipSuccess) {
-        cleanup();
-        set_error("igx_load_vector_jet: hipMalloc of the workspace failed");
-        return IGX_ERR_NOMEM;
-    }
+    size_t n_out;
+    if ((rc = lv_workspace(pt, &n_out))) return rc;
+    double *d_t1 = pt->d_lv_t1, *d_t2 = pt->d_lv_t2, *d_o = pt->d_lv_o;
+    auto cleanup = [&]() {};
     for (int k = 0; k < pd.form_n && rc == IGX_OK; ++k) {
         const int a = pd.form_ab[k] >> 2;                  // jet index of v; derivative a >= 1 acts on grid axis dim - a
         rc = launch_load_vector(st, pt, pt->d_fields + (size_t)k * npts, nullptr, d_o, d_t1, d_t2, a >= 1 ? dim - a : -1, k > 0);

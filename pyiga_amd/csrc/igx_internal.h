@@ -141,6 +141,11 @@ struct igx_patch {
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
     double *d_K1 = nullptr, *d_K2 = nullptr;
     size_t K1_cap = 0, K2_cap = 0;
+    // persistent workspaces of the batched-entry and load-vector entry points (grow-only, freed with the patch)
+    size_t *d_ws_ij = nullptr; double *d_ws_out = nullptr;
+    size_t ws_ij_cap = 0, ws_out_cap = 0;
+    double *d_lv_f = nullptr, *d_lv_t1 = nullptr, *d_lv_t2 = nullptr, *d_lv_o = nullptr;
+    size_t lv_f_cap = 0, lv_t1_cap = 0, lv_t2_cap = 0, lv_o_cap = 0;
     // fused sweep + final stage (fused.hip)
     long long nnz_ext = 0;                    // values of the owned rows + the p0 halo planes above them (mirror sources)
     double *d_zeros = nullptr;                // a row of zeros: input of absent sweep slots

@@ -11,6 +11,9 @@
 // These kernels accept any degree <= IGX_MAX_DEGREE and any open knot vector (repeated interior
 // knots included); they are the general path and the parity anchor for the sum-factorised path.
 #include "igx_internal.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace igx {
 
@@ -137,11 +140,101 @@ __global__ void k_entries_list(PatchDev pd, const double *fields, const size_t *
     out[k] = ok ? entry_value<DIM, KIND>(pd, fields, i, j) : 0.0;
 }
 
+// Wave-per-entry form for batched requests at p >= 2 (multi_entries on arbitrary pairs): the 64 lanes of a
+// wave split the Gauss points of the support intersection -- lane = point of the (axis 1 [, axis 2]) box, contiguous along
+// the last axis, so the field loads of a wave are runs of (overlap * q) doubles -- and walk axis 0 together; the partial
+// sums are added with wave shuffles.  The summation order differs from entry_value (one thread, the reference's order);
+// k_entries_list keeps that order for p = 1 and as the parity anchor (IGX_ENTRIES=thread).
+template <int DIM, int KIND>
+__global__ void __launch_bounds__(256) k_entries_wave(PatchDev pd, const double *fields, const size_t *ij, size_t M, double *out)
+{
+    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= M) return;
+    int i[3], j[3];
+    const bool ok = unravel<DIM>(pd, ij[2 * k], i) && unravel<DIM>(pd, ij[2 * k + 1], j);
+    int glo[3] = {0, 0, 0}, ng[3] = {1, 1, 1};
+    bool empty = !ok;
+    if (ok)
+        for (int a = 0; a < DIM; ++a) {
+            const AxisDev &A = pd.ax[a];
+            const int lo = max(A.mslo[i[a]], A.mslo[j[a]]), hi = min(A.mshi[i[a]], A.mshi[j[a]]);
+            if (lo >= hi) empty = true;
+            glo[a] = lo * A.q; ng[a] = (hi - lo) * A.q;
+        }
+    if (empty) { if (lane == 0) out[k] = 0.0; return; }
+    if (glo[0] < pd.g0_lo || glo[0] + ng[0] > pd.g0_lo + pd.G0_loc) { if (lane == 0) out[k] = __builtin_nan(""); return; }
+    const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1], &A2 = pd.ax[2];
+    const long long stride = pd.npts_loc;
+    const int nbox = ng[1] * (DIM == 3 ? ng[2] : 1);
+    double r = 0.0;
+    for (int idx = lane; idx < nbox; idx += 64) {
+        const int g1 = glo[1] + (DIM == 3 ? idx / ng[2] : idx), g2 = DIM == 3 ? glo[2] + idx % ng[2] : 0;
+        const int f1 = A1.fa[g1 / A1.q];
+        const double *u1 = A1.V + ((size_t)g1 * A1.P + (j[1] - f1)) * 2, *v1 = A1.V + ((size_t)g1 * A1.P + (i[1] - f1)) * 2;
+        double u2v = 1.0, u2d = 0.0, v2v = 1.0, v2d = 0.0;
+        if (DIM == 3) {
+            const int f2 = A2.fa[g2 / A2.q];
+            const double *u2 = A2.V + ((size_t)g2 * A2.P + (j[2] - f2)) * 2, *v2 = A2.V + ((size_t)g2 * A2.P + (i[2] - f2)) * 2;
+            u2v = u2[0]; u2d = u2[1]; v2v = v2[0]; v2d = v2[1];
+        }
+        for (int g0 = glo[0]; g0 < glo[0] + ng[0]; ++g0) {
+            const int f0 = A0.fa[g0 / A0.q];
+            const double *u0 = A0.V + ((size_t)g0 * A0.P + (j[0] - f0)) * 2, *v0 = A0.V + ((size_t)g0 * A0.P + (i[0] - f0)) * 2;
+            const long long pt = DIM == 3 ? ((long long)(g0 - pd.g0_lo) * A1.G + g1) * A2.G + g2 : (long long)(g0 - pd.g0_lo) * A1.G + g1;
+            if (DIM == 2) {
+                if (KIND == IGX_MASS) r += (((u0[0] * u1[0]) * (v0[0] * v1[0])) * fields[pt]);
+                else {
+                    const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
+                    const double du10 = u0[0] * u1[1], du01 = u0[1] * u1[0], dv10 = v0[0] * v1[1], dv01 = v0[1] * v1[0];
+                    r += ((((f_0 * du10) + (f_1 * du01)) * dv10) + (((f_1 * du10) + (f_2 * du01)) * dv01));
+                }
+            } else {
+                if (KIND == IGX_MASS) r += (((u0[0] * u1[0] * u2v) * (v0[0] * v1[0] * v2v)) * fields[pt]);
+                else {
+                    const double f_0 = fields[pt], f_1 = fields[stride + pt], f_2 = fields[2 * stride + pt];
+                    const double f_3 = fields[3 * stride + pt], f_4 = fields[4 * stride + pt], f_5 = fields[5 * stride + pt];
+                    const double du100 = u0[0] * u1[0] * u2d, du010 = u0[0] * u1[1] * u2v, du001 = u0[1] * u1[0] * u2v;
+                    const double dv100 = v0[0] * v1[0] * v2d, dv010 = v0[0] * v1[1] * v2v, dv001 = v0[1] * v1[0] * v2v;
+                    double e = ((((((f_0 * du100) + (f_1 * du010)) + (f_2 * du001)) * dv100)
+                                 + ((((f_1 * du100) + (f_3 * du010)) + (f_4 * du001)) * dv010))
+                                + ((((f_2 * du100) + (f_4 * du010)) + (f_5 * du001)) * dv001));
+                    if (KIND == IGX_CONVDIFF) {
+                        const double f_6 = fields[6 * stride + pt], f_7 = fields[7 * stride + pt], f_8 = fields[8 * stride + pt];
+                        e += (((f_6 * du100) + (f_7 * du010)) + (f_8 * du001)) * (v0[0] * v1[0] * v2v);
+                    }
+                    r += e;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) r += __shfl_xor(r, sft);
+    if (lane == 0) out[k] = r;
+}
+
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out)
 {
     if (M == 0) return IGX_OK;
-    dim3 grid((unsigned)((M + 127) / 128)), block(128);
     const PatchDev &pd = pt->dev;
+    // wave-per-entry for the fixed forms at p >= 2 (IGX_ENTRIES=thread keeps the one-thread form, the reference's summation order)
+    int pmax = 0;
+    for (int k = 0; k < pt->dim; ++k) pmax = std::max(pmax, pt->ax[k].p);
+    const char *sel = getenv("IGX_ENTRIES");
+    if (kind != IGX_FORM && pmax >= 2 && !(sel && !strcmp(sel, "thread")) && M < (1ull << 25)) {
+        dim3 gridw((unsigned)((M + 3) / 4)), blockw(256);
+        if (pt->dim == 2) {
+            if (kind == IGX_MASS) k_entries_wave<2, IGX_MASS><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+            else k_entries_wave<2, IGX_STIFFNESS><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        } else {
+            if (kind == IGX_MASS) k_entries_wave<3, IGX_MASS><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+            else if (kind == IGX_CONVDIFF) k_entries_wave<3, IGX_CONVDIFF><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+            else k_entries_wave<3, IGX_STIFFNESS><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
+        }
+        IGX_HIP(hipGetLastError());
+        return IGX_OK;
+    }
+    dim3 grid((unsigned)((M + 127) / 128)), block(128);
     if (pt->dim == 2) {
         if (kind == IGX_MASS) k_entries_list<2, IGX_MASS><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);
         else if (kind == IGX_FORM) k_entries_list<2, IGX_FORM><<<grid, block, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);

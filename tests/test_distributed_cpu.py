@@ -1,7 +1,6 @@
 """N>1 path on CPU: two gloo ranks shard the rows, each produces its block, rank 0 gathers and the
 result equals the single-process matrix.  The block producer is the CPU oracle here (no GPU in
-this container); on the GPU box test_gpu_parity.py::test_row_slabs_equal_full checks that the HIP
-path produces exactly these blocks."""
+this container); on the GPU box tests/test_distributed_gpu.py runs the same worker with the HIP path."""
 import os
 import socket
 
@@ -18,40 +17,16 @@ def _free_port():
     return port
 
 
-def _oracle_block(kind, kvs, geo, row0, device, algo):
-    """CPU stand-in for the device block: rows of the oracle matrix."""
-    from oracle import iga_oracle as orc
-    okvs = tuple(orc.KnotVector(kv.kv, kv.p) for kv in kvs)
-    A = orc.assemble(kind, okvs, orc.geo_cylinder() if len(kvs) == 3 else orc.geo_quarter_annulus())
-    plane = int(np.prod([kv.numdofs for kv in kvs[1:]]))
-    return A[row0[0] * plane:row0[1] * plane].tocsr()
-
-
-def _worker(rank, world, port, out):
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    from pyiga_amd import bspline, distributed
-    kv = bspline.make_knots(2, 0.0, 1.0, 5)
-    kvs = (kv, kv, kv)
-    blk = distributed.assemble_rows('stiffness', kvs, None, rank, world, block_fn=_oracle_block)
-    lo, hi = distributed.row_range(kvs, rank, world)
-    assert blk.shape == (hi - lo, kv.numdofs ** 3)
-    full = distributed.gather_matrix(blk, dst=0)
-    dist.barrier()
-    if rank == 0:
-        np.savez(out, data=full.data, indices=full.indices, indptr=full.indptr, shape=np.array(full.shape))
-    dist.destroy_process_group()
-
-
 def test_two_rank_row_sharding(tmp_path, oracle):
-    import torch.multiprocessing as mp
+    """Same worker as the GPU test (tests/_dist_worker.py): slab ranges, assemble_rows, gather_matrix are the product's."""
+    import subprocess
+    import sys
     out = str(tmp_path / 'full.npz')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    port = str(_free_port())
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, '_dist_worker.py'), str(r), '2', port, 'cpu', out])
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
     z = np.load(out)
     full = scipy.sparse.csr_matrix((z['data'], z['indices'], z['indptr']), shape=tuple(z['shape']))
     kv = oracle.make_knots(2, 0.0, 1.0, 5)

@@ -1,0 +1,34 @@
+"""Two ranks on ONE MI355X (both on device 0; the GPU box has a single GPU): each runs the product path
+pyiga_amd.distributed.assemble_rows for its row slab, rank 0 gathers, and the stacked result equals the single-process
+matrix bit for bit.  The ranks are child processes started before this process touches the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from test_distributed_cpu import _free_port
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_two_ranks_one_gpu(tmp_path):
+    out = str(tmp_path / 'full.npz')
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_dist_worker.py'), str(r), '2', port, 'gpu', out], env=env)
+             for r in range(2)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0, 0]
+    z = np.load(out)
+    full = scipy.sparse.csr_matrix((z['data'], z['indices'], z['indptr']), shape=tuple(z['shape']))
+    import pyiga_amd as iga
+    kv = iga.bspline.make_knots(3, 0.0, 1.0, 11)
+    geo = iga.geometry.tensor_product(iga.geometry.line_segment(0.0, 1.0), iga.geometry.quarter_annulus())
+    ref = iga.assemble.stiffness((kv,) * 3, geo)
+    assert full.shape == ref.shape and full.nnz == ref.nnz
+    assert np.array_equal(full.indptr, ref.indptr) and np.array_equal(full.indices, ref.indices)
+    assert np.array_equal(full.data, ref.data)

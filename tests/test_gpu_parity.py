@@ -912,3 +912,65 @@ def test_fused_equals_unfused(iga, d, p, n, monkeypatch):
         assert not np.isnan(A.data).any()
         assert abs(A - A.T).max() == 0.0
         assert rel_maxdiff(A, B) <= RTOL, (kind, rel_maxdiff(A, B))
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,p,n,G', [(3, 2, 9, 2), (3, 4, 6, 3), (2, 3, 20, 4), (2, 1, 11, 1)])
+def test_resident_load_vector(iga, d, p, n, G):
+    """igx_load_vector_d on device-resident function values == the host-buffer entry point, bit for bit, per slab."""
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * d
+    geo = _geo(iga, 'quarter_annulus' if d == 2 else 'cylinder')
+    f = _f2 if d == 2 else _f3
+    N0 = kv.numdofs
+    bounds = [N0 * k // G for k in range(G + 1)]
+    fvals = None
+    for k in range(G):
+        patch = iga.assemblers.DevicePatch(kvs, geo, row0=(bounds[k], bounds[k + 1]))
+        if fvals is None:
+            grid = tuple(patch.gauss(a)[0] for a in range(d))
+            fvals = iga.utils.grid_eval_transformed(f, grid, geo)
+        ref = patch.load_vector(fvals)
+        lo, cnt = patch.gauss_slab()
+        assert 0 <= lo and lo + cnt <= fvals.shape[0] and (G > 1 or cnt == fvals.shape[0])
+        patch.upload_function(fvals)
+        assert patch.load_vector_resident() is None          # result stays in HBM
+        out = patch.load_vector_resident(to_host=True)
+        assert np.array_equal(out, ref)
+        assert np.array_equal(patch.load_vector_resident(to_host=True), ref)     # persistent buffers: repeatable
+        patch.close()
+
+
+@pytest.mark.parametrize('d,p,n', [(3, 2, 8), (3, 4, 6), (2, 3, 30), (2, 5, 12), (3, 1, 9)])
+def test_entries_wave_vs_thread_and_resident(iga, d, p, n, monkeypatch):
+    """Wave-per-entry kernel (default for p >= 2) against the one-thread-per-entry kernel (the reference's summation order)
+    and against the assembled matrix; device-resident index pairs give the same bits as the host entry point."""
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * d
+    geo = _geo(iga, 'quarter_annulus' if d == 2 else 'cylinder')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    N = patch.shape[0]
+    rng = np.random.default_rng(7 + d + p)
+    indptr, indices = patch.pattern()
+    rows = np.repeat(np.arange(N), np.diff(indptr))
+    pick = rng.choice(len(indices), size=min(4000, len(indices)), replace=False)
+    idx = np.stack([rows[pick], indices[pick]], axis=1)
+    idx = np.concatenate([idx, rng.integers(0, N, size=(500, 2))])          # + arbitrary pairs (mostly outside the pattern)
+    kinds = ['mass', 'stiffness'] + (['convdiff'] if d == 3 else [])
+    if d == 3:
+        patch.set_coeff(1.5)
+    for kind in kinds:
+        monkeypatch.setenv('IGX_ENTRIES', 'thread')
+        e_thread = patch.entries(kind, idx)
+        monkeypatch.delenv('IGX_ENTRIES')
+        e_wave = patch.entries(kind, idx)
+        scale = np.abs(e_thread).max()
+        assert np.abs(e_wave - e_thread).max() <= RTOL * scale
+        assert np.array_equal(e_wave == 0.0, e_thread == 0.0)
+        A = patch.csr(kind)
+        ref = np.asarray(A[idx[:, 0], idx[:, 1]]).ravel()
+        assert np.abs(e_wave - ref).max() <= RTOL * scale
+        patch.upload_pairs(idx)
+        assert patch.entries_resident(kind) is None
+        assert np.array_equal(patch.entries_resident(kind, to_host=True), e_wave)
+    patch.close()
