@@ -1,5 +1,5 @@
 // Device helpers shared by the geometry/fields kernels (kern_basis.hip) and the fused
-// geometry + stage-A sweep (sumfact.hip).
+// geometry + stage-A sweep (geoa.hip).
 #pragma once
 #include "igx_internal.h"
 
@@ -41,26 +41,28 @@ __device__ inline void finish_jacobian(const double val[MAX_COMP], const double 
     }
 }
 
-// quadrature fields of one point from its Jacobian (row-major t[]): fields[f*stride + pt]
+// quadrature fields of one point from its Jacobian (row-major t[]): f[0] = W for the mass form, the upper
+// triangle of  W * JacInv JacInv^T  (row-major) for the stiffness form.  Returns the number of fields.
 template <int DIM>
-__device__ inline void fields_from_jac(const double t[9], double GW, int kind, double *fields, long long stride, long long pt)
+__device__ inline int fields_values(const double t[9], double GW, int kind, double f[6])
 {
     if (DIM == 2) {
         const double det = t[0] * t[3] - t[1] * t[2];
         const double W = GW * fabs(det);
-        if (kind == IGX_MASS) { fields[pt] = W; return; }
+        if (kind == IGX_MASS) { f[0] = W; return 1; }
         const double inv = 1.0 / det;
         const double J0 = inv * t[3], J1 = inv * -t[1], J2 = inv * -t[2], J3 = inv * t[0];
-        fields[pt] = W * (J0 * J0 + J1 * J1);
-        fields[stride + pt] = W * (J0 * J2 + J1 * J3);
-        fields[2 * stride + pt] = W * (J2 * J2 + J3 * J3);
+        f[0] = W * (J0 * J0 + J1 * J1);
+        f[1] = W * (J0 * J2 + J1 * J3);
+        f[2] = W * (J2 * J2 + J3 * J3);
+        return 3;
     } else {
         const double t3 = t[4] * t[8] - t[5] * t[7];
         const double t4 = t[3] * t[8] - t[5] * t[6];
         const double t5 = t[3] * t[7] - t[4] * t[6];
         const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
         const double W = GW * fabs(det);
-        if (kind == IGX_MASS) { fields[pt] = W; return; }
+        if (kind == IGX_MASS) { f[0] = W; return 1; }
         const double inv = 1.0 / det;
         double JI[9];
         JI[0] = inv * t3;
@@ -72,13 +74,25 @@ __device__ inline void fields_from_jac(const double t[9], double GW, int kind, d
         JI[6] = inv * t5;
         JI[7] = inv * -(t[0] * t[7] - t[1] * t[6]);
         JI[8] = inv * (t[0] * t[4] - t[1] * t[3]);
-        fields[pt] = W * ((JI[0] * JI[0] + JI[1] * JI[1]) + JI[2] * JI[2]);
-        fields[stride + pt] = W * ((JI[0] * JI[3] + JI[1] * JI[4]) + JI[2] * JI[5]);
-        fields[2 * stride + pt] = W * ((JI[0] * JI[6] + JI[1] * JI[7]) + JI[2] * JI[8]);
-        fields[3 * stride + pt] = W * ((JI[3] * JI[3] + JI[4] * JI[4]) + JI[5] * JI[5]);
-        fields[4 * stride + pt] = W * ((JI[3] * JI[6] + JI[4] * JI[7]) + JI[5] * JI[8]);
-        fields[5 * stride + pt] = W * ((JI[6] * JI[6] + JI[7] * JI[7]) + JI[8] * JI[8]);
+        f[0] = W * ((JI[0] * JI[0] + JI[1] * JI[1]) + JI[2] * JI[2]);
+        f[1] = W * ((JI[0] * JI[3] + JI[1] * JI[4]) + JI[2] * JI[5]);
+        f[2] = W * ((JI[0] * JI[6] + JI[1] * JI[7]) + JI[2] * JI[8]);
+        f[3] = W * ((JI[3] * JI[3] + JI[4] * JI[4]) + JI[5] * JI[5]);
+        f[4] = W * ((JI[3] * JI[6] + JI[4] * JI[7]) + JI[5] * JI[8]);
+        f[5] = W * ((JI[6] * JI[6] + JI[7] * JI[7]) + JI[8] * JI[8]);
+        return 6;
     }
+}
+
+// ... stored as fields[f*stride + pt]
+template <int DIM>
+__device__ inline void fields_from_jac(const double t[9], double GW, int kind, double *fields, long long stride, long long pt)
+{
+    double f[6];
+    const int nf = fields_values<DIM>(t, GW, kind, f);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (k < nf) fields[k * stride + pt] = f[k];
 }
 
 // Fields of the convection-diffusion form (3D): c*B (upper triangle, as stiffness) and

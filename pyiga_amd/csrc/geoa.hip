@@ -1,0 +1,439 @@
+// Fused geometry + stage A (3D, spline/NURBS geometry, symmetric fixed forms).
+//
+// Stage A sweeps axis 0:   K1[x][pair (i0,j0)][g1][g2] = sum_{g0} PI0[g0][t_x][a][b] * field_{f_x}(g0, g1, g2)
+// and the fields are pointwise functions of the geometry Jacobian.  The separate kernels wrote the fields
+// (6 x npts doubles at 3D stiffness) and read them back; here a block evaluates them on the fly:
+//
+//   block  = NS waves on the SAME 64 points (g1, g2) of the plane; wave w owns sweep slot x = w (one K1 array:
+//            15 accumulators for the lower triangle of the (p+1)^2 pair window)
+//   batch  = NS consecutive Gauss planes of axis 0: wave w evaluates the geometry of plane base + w for the 64 points
+//            and puts the fields into LDS; after the barrier every wave sweeps its slot over the NS planes
+//            (double-buffered LDS: one barrier per batch)
+//   geometry: G(g0, g1, g2) = sum_a0 N_a0(g0) C_a0(g1, g2): the column coefficients C (value, d/d1, d/d2 of the
+//            homogeneous control net contracted along axes 1, 2) of the block's 64 points live in LDS and change only
+//            when the axis-0 span of the GEOMETRY changes; a point costs (p0g+1) * nc * 4 FMAs + the Jacobian algebra
+//            (a batch that straddles a span boundary is evaluated span by span)
+//   coefficients PI0 and the flush tables are wave-uniform: scalar loads
+//
+// HBM traffic: the K1 arrays, written once (17 GB at C4 instead of 12.6 + 12.6 + 17).
+// Reference: pyiga/assemble_tools_cy.pyx (vform kernels evaluate the same fields per quadrature point),
+// geometry evaluation pyiga/bspline.py:917-921, pyiga/geometry.py:17-25.
+#include <cstdlib>
+#include <cstdio>
+#include <algorithm>
+#include "geo_device.h"
+
+namespace igx {
+
+constexpr int GA_MAXS = 8;
+typedef const double __attribute__((address_space(4))) *cdp;      // uniform tables: scalar loads
+typedef const int __attribute__((address_space(4))) *cip;
+
+struct GeoAArgs {
+    GeoView gv;
+    const double *w0, *w1, *w2;
+    int nurbs, kind;
+    int G1, G2;
+    long long NPL, stride;      // points of a plane; doubles between the K1 slices of consecutive pairs
+    const double *PI0;          // [G0][4][P][P]
+    const int *step_ptr;        // [n0+1]
+    const int *steps;           // [nsteps][8]
+    int s_lo, s_hi, q, chunk_len;
+    int ntiles;                 // 64-point tiles of the plane
+    int dbg;                    // ablation (IGX_GEOA_DBG): 1 no geometry, 2 no stores, 4 no sweep arithmetic
+    int field[GA_MAXS], type[GA_MAXS];
+    double *out[GA_MAXS];
+};
+
+typedef int int8v __attribute__((ext_vector_type(8)));
+
+// Diagnostic build (-DIGX_GA_STAMP, never the shipped library): shader cycles per wave in the sections of the loop
+#ifdef IGX_GA_STAMP
+__device__ unsigned long long g_ga_stamp[2048 * 8 * 6];
+#define GA_T(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define GA_T(i)
+#endif
+
+// Uniform tables (sweep coefficients, axis-0 geometry basis, flush records) are NOT read with scalar loads inside the loop:
+// the scalar cache holds 16 KB, the tables are larger, and a scalar load that misses it queues in the L2 behind the K1
+// store stream -- tools/ubench/k1_store.hip: 3.1 ms of arithmetic with such loads become 9.4 ms when the stores are on,
+// while the same arithmetic without them overlaps the stores completely.  The block stages the table rows of a batch in
+// LDS with vector loads issued a whole batch ahead.
+template <int P, int NS, int P0G, int NC>
+__global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_geoA(const GeoAArgs A)
+{
+    constexpr int NL = P * (P + 1) / 2;                   // lower triangle of the pair window
+    constexpr int NLP = (NL + 1) & ~1;                    // 16-byte rows
+    constexpr int NT = NS * 64;                           // threads
+    constexpr int NPI = NS * 4 * NL;                      // coefficient values of a batch
+    constexpr int KPI = (NPI + NT - 1) / NT;              // ... per thread
+    __shared__ double fld[2][NS][6][64];                  // fields of two batches of planes
+    __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
+    __shared__ __attribute__((aligned(16))) double pis[2][NS][4][NLP];   // sweep coefficients PI0[g][t][a][b], b <= a
+    __shared__ double gts[2][NS][8];                      // axis-0 geometry basis at the plane: (N, N') x P0G | w0 | first active index
+    __shared__ int fts[2][NS][12];                        // plane ends a span: number of flush steps | first step | 8 slots of the first step
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // consecutive block ids go to different XCDs: give each XCD a contiguous range of point tiles
+    const int per_xcd = gridDim.x >> 3;                   // the grid is padded to a multiple of 8 blocks
+    int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (A.dbg & 8) tile = blockIdx.x;
+    if (tile >= A.ntiles) tile = A.ntiles - 1;            // surplus blocks redo the last tile (same values again: harmless)
+    long long pt = (long long)tile * 64 + lane;
+    if (pt >= A.NPL) pt = A.NPL - 1;                      // lanes past the end redo the last point (and store it again: harmless)
+    const int g1 = (int)(pt / A.G2), g2 = (int)(pt - (long long)g1 * A.G2);
+    const int q = A.q;
+    const int own_lo = A.s_lo + blockIdx.y * A.chunk_len;
+    const int own_hi = min(own_lo + A.chunk_len, A.s_hi);
+    const int s_begin = max(A.s_lo, own_lo - (P - 1));
+    const int g_begin = s_begin * q, g_end = own_hi * q, g_last = g_end - 1;
+
+    // ---- table staging (vector loads; the values wait in registers until the end of the iteration)
+    const GeoView &gv = A.gv;
+    int pi_src[KPI], pi_dst[KPI];                         // per-thread element of the coefficient rows: source offset (plane j in the
+                                                          // top byte), LDS slot
+#pragma unroll
+    for (int k = 0; k < KPI; ++k) {
+        const int i = tid + k * NT;
+        const int j = i / (4 * NL), r = i - j * (4 * NL), t = r / NL, e = r - t * NL;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= e) ++a;
+        const int bb = e - a * (a + 1) / 2;
+        pi_src[k] = i < NPI ? (j << 24) | (t * (P * P) + a * P + bb) : -1;
+        pi_dst[k] = (j * 4 + t) * NLP + e;
+    }
+    double pi_reg[KPI], gt_reg = 0.0;
+    int ft_reg[2 + P];
+    auto stage_pi_load = [&](const int gb) {              // coefficient rows of the batch that starts at plane gb
+#pragma unroll
+        for (int k = 0; k < KPI; ++k)
+            if (pi_src[k] >= 0) pi_reg[k] = A.PI0[(size_t)min(gb + (pi_src[k] >> 24), g_last) * (4 * P * P) + (pi_src[k] & 0xffffff)];
+    };
+    auto stage_pi_store = [&](const int buf) {
+#pragma unroll
+        for (int k = 0; k < KPI; ++k)
+            if (pi_src[k] >= 0) (&pis[buf][0][0][0])[pi_dst[k]] = pi_reg[k];
+    };
+    auto stage_gt_load = [&](const int gb) {
+        if (tid < NS * 8) {
+            const int j = tid >> 3, e = tid & 7, g = min(gb + j, g_last);
+            if (e < 2 * P0G) gt_reg = gv.V[0][(size_t)g * P0G * 2 + e];
+            else if (e == 6) gt_reg = A.w0[g];
+            else if (e == 7) gt_reg = (double)gv.fa[0][g];
+        }
+    };
+    auto stage_gt_store = [&](const int buf) {
+        if (tid < NS * 8) (&gts[buf][0][0])[tid] = gt_reg;
+    };
+    auto stage_ft_load = [&](const int gb) {              // one thread per plane of the batch
+        if (tid < NS) {
+            const int g = gb + tid, sp_ = g / q;
+            ft_reg[0] = 0; ft_reg[1] = 0;
+            if (g < g_end && g - sp_ * q == q - 1) {
+                const int st0 = A.step_ptr[sp_], st1 = A.step_ptr[sp_ + 1];
+                ft_reg[0] = st1 - st0; ft_reg[1] = st0;
+                if (st1 > st0) {
+#pragma unroll
+                    for (int a = 0; a < P; ++a) ft_reg[2 + a] = A.steps[(size_t)st0 * 8 + a];
+                }
+            }
+        }
+    };
+    auto stage_ft_store = [&](const int buf) {
+        if (tid < NS) {
+#pragma unroll
+            for (int k = 0; k < 2 + P; ++k) fts[buf][tid][k] = ft_reg[k];
+        }
+    };
+
+    // ---- geometry
+    const double GW1 = A.w1[g1], GW2 = A.w2[g2];
+    // the prologue loads are complete before the loop: a wait for them inside it would also drain the K1 stores
+    asm volatile("" :: "v"(GW1), "v"(GW2));
+    int f0_blk = -1;
+    // the block's waves share the work: wave w contracts the control net along axes 1, 2 for its (a0, component) pairs
+    auto columns = [&](const int f0) {
+        const double *V1 = gv.V[1] + (size_t)g1 * gv.P[1] * 2, *V2 = gv.V[2] + (size_t)g2 * gv.P[2] * 2;
+        const int f1 = gv.fa[1][g1], f2 = gv.fa[2][g2];
+        for (int e = w; e < P0G * NC; e += NS) {
+            const int a0 = e / NC, c = e - a0 * NC;
+            double sv = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int a1 = 0; a1 < gv.P[1]; ++a1)
+                for (int a2 = 0; a2 < gv.P[2]; ++a2) {
+                    const double cf = gv.ctrl[(((size_t)(f0 + a0) * gv.N[1] + (f1 + a1)) * gv.N[2] + (f2 + a2)) * NC + c];
+                    sv = fma(V1[a1 * 2] * V2[a2 * 2], cf, sv);
+                    s1 = fma(V1[a1 * 2 + 1] * V2[a2 * 2], cf, s1);
+                    s2 = fma(V1[a1 * 2] * V2[a2 * 2 + 1], cf, s2);
+                }
+            Cs[e][0][lane] = sv; Cs[e][1][lane] = s1; Cs[e][2][lane] = s2;
+        }
+    };
+    // fields of plane j of the batch in buffer gbuf at this lane's point -> fld[buf][j]
+    auto evaluate = [&](const int gbuf, const int buf) {
+        const double *gt = gts[gbuf][w];
+        double V0[2 * P0G];
+#pragma unroll
+        for (int e = 0; e < 2 * P0G; ++e) V0[e] = gt[e];
+        const double gw0 = gt[6];
+        double val[MAX_COMP], jac[MAX_COMP][3];
+#pragma unroll
+        for (int c = 0; c < MAX_COMP; ++c) { val[c] = 0.0; jac[c][0] = jac[c][1] = jac[c][2] = 0.0; }
+#pragma unroll
+        for (int a0 = 0; a0 < P0G; ++a0) {
+            const double n = V0[a0 * 2], d = V0[a0 * 2 + 1];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double c0 = Cs[a0 * NC + c][0][lane], c1 = Cs[a0 * NC + c][1][lane], c2 = Cs[a0 * NC + c][2][lane];
+                val[c] = fma(n, c0, val[c]);
+                jac[c][0] = fma(d, c0, jac[c][0]);
+                jac[c][1] = fma(n, c1, jac[c][1]);
+                jac[c][2] = fma(n, c2, jac[c][2]);
+            }
+        }
+        double Jm[MAX_COMP][3], ev[MAX_COMP];
+        finish_jacobian<3>(val, jac, NC == 4, 3, NC, Jm, ev);
+        double tt[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tt[r * 3 + c] = Jm[r][c];
+        double GW = gw0 * GW1;
+        GW = GW * GW2;
+        double f[6];
+        fields_values<3>(tt, GW, A.kind, f);
+        const int nf = A.kind == IGX_MASS ? 1 : 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < nf) fld[buf][w][k][lane] = f[k];
+    };
+    // all waves: evaluate the batch that starts at plane gn (table rows in gts[gbuf]).  The column coefficients belong to
+    // one span of the geometry's axis 0; a batch that straddles span boundaries is evaluated span by span (uniform control:
+    // every wave of the block takes the same way)
+    auto next_batch = [&](const int gn, const int gbuf, const int buf) {
+        if (gn >= g_end) return;
+        const int jl = min(NS - 1, g_last - gn);
+        const int mine = w <= jl ? __builtin_amdgcn_readfirstlane((int)gts[gbuf][w][7]) : -1;
+        const int last = __builtin_amdgcn_readfirstlane((int)gts[gbuf][jl][7]);
+        int cur = __builtin_amdgcn_readfirstlane((int)gts[gbuf][0][7]);
+        for (;;) {
+            if (cur != f0_blk) {
+                columns(cur);
+                f0_blk = cur;
+                __syncthreads();
+            }
+            if (mine == cur && !(A.dbg & 1)) evaluate(gbuf, buf);
+            if (cur == last) break;
+            int nxt = last;
+            for (int j = jl; j >= 0; --j) {
+                const int v = __builtin_amdgcn_readfirstlane((int)gts[gbuf][j][7]);
+                if (v > cur) nxt = v;
+            }
+            cur = nxt;
+            __syncthreads();                              // the columns are rewritten next
+        }
+    };
+
+    // ---- sweep state of this wave
+    const int t = A.type[w], fi = A.field[w];
+    double *const out = A.out[w] + pt;
+    double acc[P][P];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NH = (NLP / 2 + 1) / 2 * 2;             // first half of the coefficient row (doubles, even)
+    auto coefficients = [&](double (&cf)[NLP], const int buf, const int j, const int k0, const int k1) {
+        const d2 *row = (const d2 *)&pis[buf][j][t][0];
+#pragma unroll
+        for (int k = k0 / 2; k < k1 / 2; ++k) { const d2 v = row[k]; cf[2 * k] = v.x; cf[2 * k + 1] = v.y; }
+    };
+
+#ifdef IGX_GA_STAMP
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
+    // prologue: tables of batches 0 (all) and 1 (geometry), fields of batch 0
+    stage_gt_load(g_begin); stage_gt_store(0);
+    stage_gt_load(g_begin + NS); stage_gt_store(1);
+    stage_pi_load(g_begin); stage_pi_store(0);
+    stage_ft_load(g_begin); stage_ft_store(0);
+    __syncthreads();
+    next_batch(g_begin, 0, 0);
+    __syncthreads();
+    GA_T(0);
+    int it = 0, l = 0, sp = s_begin;                      // plane gb + j = point l of span sp
+    for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+        const int buf = it & 1;
+        next_batch(gb + NS, buf ^ 1, buf ^ 1);
+        GA_T(0);                                          // geometry
+        // table rows of the next iteration: requested now, stored to LDS after the sweep
+        stage_pi_load(gb + NS);
+        stage_ft_load(gb + NS);
+        stage_gt_load(gb + 2 * NS);
+        double bv = fld[buf][0][fi][lane];
+        double cf[NLP];
+        coefficients(cf, buf, 0, 0, NLP);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (gb + j >= g_end) break;
+            // the row of the next plane replaces this one half by half, each half right after its last use: the LDS reads
+            // are in flight under the other half's FMAs and one register set serves
+            const int jn = j + 1 < NS ? j + 1 : j;
+            const double bvn = fld[buf][jn][fi][lane];
+            double *af = &acc[0][0];
+            (void)af;
+            if (!(A.dbg & 4)) {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b, ++k)
+                        if (k < NH) acc[a][b] = fma(cf[k], bv, acc[a][b]);
+            } else acc[0][0] += cf[0] + bv;
+            {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b, ++k)
+                        if (k < NH) asm volatile("" : "+v"(acc[a][b]));
+            }
+            asm volatile("" ::: "memory");
+            coefficients(cf, buf, jn, 0, NH);
+            if (!(A.dbg & 4)) {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b, ++k)
+                        if (k >= NH) acc[a][b] = fma(cf[k], bv, acc[a][b]);
+            }
+            {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b, ++k)
+                        if (k >= NH) asm volatile("" : "+v"(acc[a][b]));
+            }
+            asm volatile("" ::: "memory");
+            coefficients(cf, buf, jn, NH, NLP);
+            bv = bvn;
+            GA_T(1);                                      // sweep arithmetic (+ parked stores)
+            if (++l < q) continue;
+            // dofs that leave the active set after span sp: their pairs are complete
+            const bool write = sp >= own_lo && !(A.dbg & 2);
+            const int nst = __builtin_amdgcn_readfirstlane(fts[buf][j][0]), st0 = __builtin_amdgcn_readfirstlane(fts[buf][j][1]);
+            for (int st = st0; st < st0 + nst; ++st) {
+                int pr[P];
+                if (st == st0) {
+#pragma unroll
+                    for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(fts[buf][j][2 + a]);
+                } else {                                  // (several dofs leave at the end of the axis)
+                    const int8v rec = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 8);
+#pragma unroll
+                    for (int a = 0; a < P; ++a) pr[a] = rec[a];
+                }
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+                    if (pr[a] >= 0 && write) out[(long long)pr[a] * A.stride] = acc[a][0];
+#pragma unroll
+                for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+                for (int b = 0; b < P; ++b) acc[P - 1][b] = 0.0;
+            }
+            l = 0; ++sp;
+            GA_T(2);                                      // flush
+        }
+        GA_T(1);
+        stage_pi_store(buf ^ 1);
+        stage_ft_store(buf ^ 1);
+        stage_gt_store(buf);                              // batch it + 2
+        __syncthreads();
+        GA_T(3);                                          // barrier
+    }
+#ifdef IGX_GA_STAMP
+    if (lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0)
+        for (int i = 0; i < 4; ++i) g_ga_stamp[(blockIdx.x * 8 + (w & 7)) * 6 + i] = st_[i];
+#endif
+}
+
+template <int P, int NS, int P0G>
+static int launch_geoA_k(hipStream_t st, const GeoAArgs &A, int nc, dim3 grid)
+{
+    if (nc == 4) k_geoA<P, NS, P0G, 4><<<grid, dim3(NS * 64), 0, st>>>(A);
+    else k_geoA<P, NS, P0G, 3><<<grid, dim3(NS * 64), 0, st>>>(A);
+    IGX_HIP(hipGetLastError());
+#ifdef IGX_GA_STAMP
+    {
+        static std::vector<unsigned long long> h(2048 * 8 * 6);
+        IGX_HIP(hipStreamSynchronize(st));
+        IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ga_stamp), h.size() * sizeof(unsigned long long)));
+        const int nb = std::min<unsigned>(grid.x, 2048);
+        for (int w = 0; w < NS; ++w) {
+            double t[4] = {0, 0, 0, 0};
+            for (int b = 0; b < nb; ++b) for (int i = 0; i < 4; ++i) t[i] += h[(b * 8 + w) * 6 + i];
+            fprintf(stderr, "k_geoA stamp: wave %d  geometry %.0f  sweep %.0f  flush %.0f  barrier %.0f  (x100 ns per block)\n", w, t[0] / nb, t[1] / nb, t[2] / nb, t[3] / nb);
+        }
+    }
+#endif
+    return IGX_OK;
+}
+
+template <int P, int NS>
+static int launch_geoA_g(hipStream_t st, const GeoAArgs &A, int nc, int p0g, dim3 grid)
+{
+    switch (p0g) {
+    case 2: return launch_geoA_k<P, NS, 2>(st, A, nc, grid);
+    case 3: return launch_geoA_k<P, NS, 3>(st, A, nc, grid);
+    }
+    return IGX_ERR_UNSUPPORTED;
+}
+
+bool geoA_supported(const igx_patch *pt, int kind, int nslots)
+{
+    if (pt->dim != 3 || (kind != IGX_STIFFNESS && kind != IGX_MASS)) return false;
+    if (pt->geo_kind != IGX_GEO_BSPLINE && pt->geo_kind != IGX_GEO_NURBS) return false;
+    if (nslots != (kind == IGX_MASS ? 1 : 8)) return false;
+    const int P = pt->ax[0].P;
+    if (P < 2 || P > 6) return false;
+    const int p0g = pt->gax[0].P;
+    if (p0g < 2 || p0g > 3) return false;
+    // the column coefficients are recomputed at every span change of the geometry's axis 0: keep that rare
+    const long long gspans = pt->gax[0].N - pt->gax[0].P + 1;
+    const long long redo = gspans * p0g * pt->gax[1].P * pt->gax[2].P * pt->ncomp * 3;
+    return redo <= 24LL * pt->dev.G0_loc;
+}
+
+int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks)
+{
+    const PatchDev &pd = pt->dev;
+    const Axis &A0 = pt->ax[0];
+    GeoAArgs A{};
+    A.gv = make_view(3, pt->gax, pt->d_ctrl, pt->ncomp);
+    A.w0 = pd.ax[0].w; A.w1 = pd.ax[1].w; A.w2 = pd.ax[2].w;
+    A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
+    A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
+    A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
+    A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
+    A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.q = A0.q; A.chunk_len = chunk_len;
+    { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
+    for (int x = 0; x < nslots; ++x) { A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x]; }
+    A.ntiles = (int)((A.NPL + 63) / 64);
+    dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs
+    const int nc = pt->ncomp, p0g = pt->gax[0].P;
+#define GEOA_P(PV) case PV: return nslots == 1 ? launch_geoA_g<PV, 1>(st, A, nc, p0g, grid) : launch_geoA_g<PV, 8>(st, A, nc, p0g, grid)
+    switch (A0.P) {
+        GEOA_P(2); GEOA_P(3); GEOA_P(4); GEOA_P(5); GEOA_P(6);
+    }
+#undef GEOA_P
+    set_error("fused geometry + stage A: unsupported degree %d", A0.p);
+    return IGX_ERR_UNSUPPORTED;
+}
+
+} // namespace igx

@@ -563,7 +563,8 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     hipEvent_t *ev = pt->ctx->ev;
     IGX_HIP(hipEventRecord(ev[0], st));
     pt->fields_kind = -1;                           // the timed path always recomputes the fields
-    int rc = ensure_fields(pt, kind);
+    int rc = IGX_OK;
+    if (algo != IGX_ALGO_SUMFACT || sumfact_needs_fields(pt, kind)) rc = ensure_fields(pt, kind);
     if (rc) return rc;
     pt->timing.n_launches = 1;
     IGX_HIP(hipEventRecord(ev[1], st));

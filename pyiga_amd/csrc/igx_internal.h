@@ -203,6 +203,11 @@ int fused_rows_per_tile(int P);
 int fused_supported(const BFInputs &in);
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
+// fused geometry + stage A (geoa.hip)
+bool geoA_supported(const igx_patch *pt, int kind, int nslots);
+int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks);
+bool sumfact_needs_fields(const igx_patch *pt, int kind);
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);
 int sumfact_supports_kind(const igx_patch *pt, int kind);

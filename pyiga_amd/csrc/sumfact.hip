@@ -1425,6 +1425,20 @@ static int launch_final(hipStream_t st, const double *K, double *data, const Fin
 // the last axis.  It is the default in 3D (C4: 12.1 + 3.7 ms against 6.9 + 9.4..10.7 ms for stage B + final, K2 never in
 // HBM); in 2D the unfused kernels are faster (C2: 0.105 against 0.141 ms) and stay the default.  IGX_PATH=fused / unfused
 // forces a path (a choice of IGX_FINAL implies unfused); the unfused kernels also serve every other case.
+// geometry + stage A in one kernel (IGX_GEOA=0: separate field and sweep kernels)
+static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
+{
+    const char *e = getenv("IGX_GEOA");
+    if (e && !strcmp(e, "0")) return false;
+    return igx_kind_symmetric(kind) && geoA_supported(pt, kind, nslots);
+}
+
+bool sumfact_needs_fields(const igx_patch *pt, int kind)
+{
+    if (pt->dim != 3 || !igx_kind_symmetric(kind)) return true;
+    return !geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 8);
+}
+
 static bool fused_applicable(const igx_patch *pt)
 {
     const char *e = getenv("IGX_PATH");
@@ -1522,10 +1536,24 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         term_x[i] = found;
     }
     const int nX = (int)X.size();
-    if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPL)) return IGX_ERR_NOMEM;
+    // K1 slice stride: padded when both producer (geoA) and consumer (k_bf) take a stride (experiment: IGX_K1PAD doubles)
+    const bool use_geoA = geoA_wanted(pt, kind, nX);
+    long long NPLs = NPL;
+    if (use_geoA && fused && dim == 3) { const char *e = getenv("IGX_K1PAD"); NPLs = NPL + (e ? atoi(e) : 0); }
+    if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPLs)) return IGX_ERR_NOMEM;
 
     const int nF = igx_num_fields(dim, kind, pd.form_n);
     (void)hipEventRecord(pt->ctx->ev[1], st);
+    if (use_geoA) {
+        // geometry evaluated inside the sweep: no field arrays (geoa.hip)
+        int sf[8], stp[8];
+        double *so[8];
+        for (int x = 0; x < nX; ++x) { sf[x] = X[x].f; stp[x] = X[x].t0; so[x] = pt->d_K1 + (size_t)X[x].slot * np0 * NPLs; }
+        const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P);
+        int rc = launch_geoA(st, pt, kind, nX, sf, stp, so, NPLs, ch.len, ch.nchunks);
+        if (rc) return rc;
+        pt->timing.n_launches++;
+    } else
     // one launch for all fields (blockIdx.y); the types of a field share the field load
     {
         StageAArgs A{};
@@ -1565,9 +1593,9 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         bool ok = true;
         for (size_t i = 0; i < terms.size(); ++i)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : terms[i].t[2], terms[i].t[1],
-                                   pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPL);
+                                   pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPLs);
         if (ok && fused_supported(in)) {
-            in.slice_stride = NPL; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
+            in.slice_stride = NPLs; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
             return run_fused(pt, in, sym, d_data);
         }
     }
