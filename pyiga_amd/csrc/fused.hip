@@ -409,7 +409,6 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     const int ln3 = lane / RMAX, r3 = lane - ln3 * RMAX;  // step 2: line slot, row
     const bool v3 = ln3 < LW && r3 < nrows;
     const int i2 = row_lo + r3;
-    const int osh = max(p - i2, 0);                       // rows < p: the run starts at column 0, entry o sits at o - osh
     const int c0i = jhi0[i0] - jlo0[i0];
     const long long S12 = A.S1 * A.S2;
 
@@ -418,7 +417,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     // q = (rr * W + m) * W + o, lane-consecutive -> consecutive lanes write consecutive doubles.  What does not depend on the
     // step is worked out once per lane.
             constexpr int NSL = (RMAX * W * W + 64 * NCW - 1) / (64 * NCW);
-            int pl_rp[NSL], pl_src[NSL], pl_mo[NSL];          // rp2[row] | rr * W + o | m, o, c2, flags
+            int pl_rp[NSL], pl_mo[NSL];                       // rp2[row] | m, o, c2, flags, rr * W + o (bits 16..)
     #pragma unroll
             for (int k = 0; k < NSL; ++k) {
                 const int q = (k * NCW + cw) * 64 + lane;
@@ -428,8 +427,9 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
                 const int i2r = row_lo + rr;
                 const bool ok = q < nrows * W * W && o < rt.y;
                 const bool dg = o <= i2r - max(i2r - p, 0);   // entry of the diagonal line of a diagonal block that is stored (j2 <= i2)
-                pl_rp[k] = rt.x; pl_src[k] = rr * W + o;
-                pl_mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0);   // (rows past the axis have a negative run length)
+                pl_rp[k] = rt.x;
+                pl_mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0)   // (rows past the axis have a negative run length)
+                           | ((rr * W + o) << 16);
             }
     for (int t = s_begin; t < rhi + 2; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
         #pragma unroll
                         for (int k = 0; k < NSL; ++k) {
                             const int kx = min((pl_mo[k] & 15) + koff, 2 * p);
-                            val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl_src[k]];     // always inside the rings
+                            val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl_mo[k] >> 16];     // always inside the rings
                         }
         #pragma unroll
                         for (int k = 0; k < NSL; ++k) {
@@ -485,7 +485,9 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
             BF_SEG_BEGIN();
             {
                 int row1, col1;
-                const int k9 = cw * LW + ln3;
+                int ln3v = ln3;                           // (opaque: the per-lane values derived from it are recomputed per step
+                asm volatile("" : "+v"(ln3v));            //  instead of living in registers the kernel does not have)
+                const int k9 = cw * LW + ln3v;
                 if (v3 && line_ok(k9, row1, col1)) {
                     double accv[W];
 #pragma unroll
@@ -500,11 +502,16 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
                         }
                     }
                     const int la = row1 - col1;
+                    // (recomputed per step from r3: one more long-lived per-lane value would be spilled to scratch, and a scratch
+                    // reload waits for vmcnt(0), i.e. for this wave's CSR stores)
+                    int r3v = r3;
+                    asm volatile("" : "+v"(r3v));
+                    const int oshv = max(p - (row_lo + r3v), 0);
                     double *dste = ((la > 0) ? ring + (size_t)((((row1 % (P + 1)) * p + (p - la)) * RMAX + r3)) * W
-                                             : cur + (size_t)((((dd & 1) * P - la) * RMAX + r3)) * W) - osh;
+                                             : cur + (size_t)((((dd & 1) * P - la) * RMAX + r3)) * W) - oshv;
 #pragma unroll
                     for (int o = 0; o < W; ++o)
-                        if (o >= osh) dste[o] = accv[o];
+                        if (o >= oshv) dste[o] = accv[o];
                 }
             }
             BF_SEG_END(2);
