@@ -283,9 +283,12 @@ def main():
     b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total, kind)
     chain_ms = float(np.median(steps_ms))
     achieved = b_el * nel_rank / (chain_ms * 1e-3) / 1e9
-    fused = stage_ms.get('stage1_ms', 0) > 0 and os.environ.get('IGX_PATH', 'fused' if dim == 3 else 'unfused') != 'unfused' and not os.environ.get('IGX_FINAL')
-    names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_stageA', 'stage1_ms': 'k_bf' if fused else 'k_stageB',
-             'final_ms': 'k_mirror' if fused else 'k_final', 'entry_ms': 'k_entries_csr'}
+    path = patch.last_path()
+    fused = 'fused' in path
+    names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_geoA' if 'geoA' in path else 'k_stageA', 'stage1_ms': 'k_bf' if fused else 'k_stageB',
+             'final_ms': 'k_mirror' if 'mirror' in path else 'k_final', 'entry_ms': 'k_entries_csr'}
+    if 'geoA' in path:
+        stage_ms.pop('fields_ms', None)         # no field kernel: the geometry is evaluated inside k_geoA
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
     flops = algorithmic_flops(dim, p, kvs, kind) if algo_used == 2 else None
@@ -309,7 +312,7 @@ def main():
                                   'cylinder' if dim == 3 else gname),
                    'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
-                   'path': 'fused sweep+final (k_bf) + mirror' if fused else 'stage kernels',
+                   'path': ' + '.join(parts),
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
         'step_ms': {'median': chain_ms, 'min': float(np.min(steps_ms)), 'max': float(np.max(steps_ms))},
         'slab_ms': [round(x, 3) for x in slab_ms],
@@ -365,7 +368,7 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': '%dD p=%d load vector (inner_products), %s spans' % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
-                      'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total,
+                      'config': args.config, **({'emulated_slab': args.emulate} if args.emulate else {}), 'elements': nel_total,
                       'note': 'value = device time of the contractions, function values resident (igx_load_vector_d); whole resident call '
                               '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms' % (wall_ms, host_call_ms)},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -113,6 +113,11 @@ typedef struct {                       /* device time of the last igx_assemble, 
     int32_t n_launches;
 } igx_timing;
 
+/* kernels the last igx_assemble(.., IGX_ALGO_SUMFACT) of a patch ran (igx_patch_last_path) */
+#define IGX_PATH_GEOA    1   /* geometry + axis-0 sweep fused (k_geoA): timing.fields_ms ~ 0, stage0_ms = k_geoA */
+#define IGX_PATH_FUSED   2   /* sweep + final stage fused (k_bf): timing.stage1_ms = k_bf */
+#define IGX_PATH_MIRROR  4   /* upper triangle by the transposing mirror pass: timing.final_ms = k_mirror */
+
 int         igx_version(void);
 const char *igx_last_error(void);
 
@@ -157,6 +162,9 @@ int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *wei
 /* Resident Gauss planes of axis 0: a row slab keeps only the planes its rows touch, [*g0_lo, *g0_lo + *g0_n).
    Device-side inputs (igx_load_vector_d) are laid out on this slab. */
 int igx_patch_gauss_slab(const igx_patch *patch, int64_t *g0_lo, int64_t *g0_n);
+
+/* IGX_PATH_* bits of the last sum-factorised assembly of this patch (0: none yet / entry-wise) */
+int igx_patch_last_path(const igx_patch *patch);
 
 /* Canonical CSR pattern of the owned rows.  indptr has (row_hi-row_lo+1) entries, LOCAL
    (indptr[0] = 0); indices has nnz entries (global column ids).  Either may be NULL.

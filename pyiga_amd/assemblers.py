@@ -208,6 +208,11 @@ class DevicePatch:
                                             _lib.dptr(out) if to_host else None), 'igx_assemble')
         return out
 
+    def last_path(self):
+        """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'mirror' (include/igx.h IGX_PATH_*)."""
+        bits = _lib.load().igx_patch_last_path(self.handle)
+        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror')) if bits & bit}
+
     def timing(self):
         t = _lib.Timing()
         _lib.check(_lib.load().igx_last_timing(self.handle, C.byref(t)), 'igx_last_timing')

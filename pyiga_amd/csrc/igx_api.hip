@@ -563,6 +563,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     hipEvent_t *ev = pt->ctx->ev;
     IGX_HIP(hipEventRecord(ev[0], st));
     pt->fields_kind = -1;                           // the timed path always recomputes the fields
+    pt->last_path = 0;
     int rc = IGX_OK;
     if (algo != IGX_ALGO_SUMFACT || sumfact_needs_fields(pt, kind)) rc = ensure_fields(pt, kind);
     if (rc) return rc;
@@ -698,6 +699,8 @@ int igx_load_vector_d(igx_patch *pt, const double *d_fvals, double *d_out)
     pt->timing.n_launches = pt->dim;
     return IGX_OK;
 }
+
+int igx_patch_last_path(const igx_patch *pt) { return pt ? pt->last_path : 0; }
 
 int igx_patch_gauss_slab(const igx_patch *pt, int64_t *g0_lo, int64_t *g0_n)
 {

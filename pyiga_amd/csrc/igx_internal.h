@@ -152,6 +152,7 @@ struct igx_patch {
     int *d_triv = nullptr;                    // one-dof outer axis of the 2D case: pl0 {0,0} | rp0 {0,1} | jlo0 {0} | jhi0 {1}
     int *d_tpairs = nullptr;                  // [ntp][2] mirror targets: outer pairs (i0 owned, j0 >= i0)
     int ntp = 0;
+    int last_path = 0;                        // kernels of the last sum-factorised assembly: IGX_PATH_* bits
     igx_timing timing{};
 };
 

@@ -1478,6 +1478,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
     }
     if (int rc = launch_bf(st, pt, in, d_data)) return rc;
+    pt->last_path |= IGX_PATH_FUSED;
     pt->timing.n_launches++;
     (void)hipEventRecord(pt->ctx->ev[3], st);
     if (sym && !getenv("IGX_NO_MIRROR")) {
@@ -1485,6 +1486,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
         mi.tpairs = pt->d_tpairs; mi.ntp = pt->ntp; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
         if (int rc = launch_mirror(st, pt, mi, d_data)) return rc;
+        pt->last_path |= IGX_PATH_MIRROR;
         pt->timing.n_launches++;
     }
     (void)hipEventRecord(pt->ctx->ev[4], st);
@@ -1552,6 +1554,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P);
         int rc = launch_geoA(st, pt, kind, nX, sf, stp, so, NPLs, ch.len, ch.nchunks);
         if (rc) return rc;
+        pt->last_path |= IGX_PATH_GEOA;
         pt->timing.n_launches++;
     } else
     // one launch for all fields (blockIdx.y); the types of a field share the field load

@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+for d in 0 16; do
+  echo "== IGX_BF_DBG=$d"
+  IGX_BF_DBG=$d timeout 300 python bench.py --config c4 --no-cpu-baseline --steps 10 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['ms_per_step'], d['roofline']['kernel_ms'])
+    else: print(l.rstrip()[-300:])
+"
+done
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_equals or fullsize_vs_reference_3d or row_slabs or tiny or fixtures" 2>&1 | tail -3
