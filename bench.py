@@ -82,16 +82,21 @@ def algorithmic_flops(dim, p, kvs, kind):
 
 
 def measured_traffic(config, world):
-    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/<round>_traffic.json) with the git
-    commit they were taken at -- or None when the kernels have changed since (stale numbers are not reported)."""
+    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, tools/make_traffic.py)
+    -- or None when the kernel sources have changed since they were taken (stale numbers are not reported)."""
     try:
+        import glob
+        import hashlib
         t = json.load(open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')))[config]
         if world != 1:
             return None
-        head = subprocess.run(['git', '-C', ROOT, 'log', '-1', '--format=%H', '--', 'pyiga_amd/csrc'], capture_output=True, text=True).stdout.strip()
-        if head and t.get('kernels_commit') and not head.startswith(t['kernels_commit']):
+        h = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.h'))):
+            h.update(open(f, 'rb').read())
+        if h.hexdigest()[:16] != t.get('kernels_sha'):
             return None
-        return {'bytes': t['chain_bytes'], 'profile_commit': t.get('kernels_commit'), 'source': 'profiles/r02_traffic.json'}
+        return {'bytes': t['chain_bytes'], 'bytes_low': t.get('chain_bytes_low'), 'kernels_sha': t['kernels_sha'],
+                'source': 'profiles/r02_traffic.json'}
     except Exception:
         return None
 
