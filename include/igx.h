@@ -155,6 +155,10 @@ int igx_patch_set_coeff(igx_patch *patch, const double *coeff);
    pointer) or NULL for an absent (zero) coefficient; r = jet index of the test function v, s = of the trial
    function u.  Copied.  Replaces the previous form of the patch. */
 int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
+/* The same with coefficient arrays that already live on the device, each over the RESIDENT Gauss slab
+   (igx_patch_gauss_slab planes x G1 [x G2], C order): no host staging of full-grid arrays.  A failed call of either
+   variant leaves the previously set form untouched. */
+int igx_patch_set_form_d(igx_patch *patch, const double *const d_coef[16]);
 
 /* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
 int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);

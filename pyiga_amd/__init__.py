@@ -10,6 +10,25 @@ Python host code calls hand-written gfx950 HIP kernels through the C ABI in ``in
 """
 __version__ = '0.1.0'
 
+_max_threads = None
+
+
+def get_max_threads():
+    """pyiga/__init__.py:10-15.  The reference's thread pool has no counterpart here (the launch geometry of the
+    kernels replaces it); the value is kept so that code written for pyiga keeps working."""
+    global _max_threads
+    if not _max_threads:
+        import multiprocessing
+        _max_threads = multiprocessing.cpu_count()
+    return _max_threads
+
+
+def set_max_threads(num):
+    """pyiga/__init__.py:17-19 (no effect on the device path)."""
+    global _max_threads
+    _max_threads = num
+
+
 from . import _lib            # noqa: F401
 from . import bspline         # noqa: F401
 from . import geometry        # noqa: F401

@@ -148,19 +148,26 @@ def _ml_nonzero(kvs0, kvs1, lower_tri):
     return I, J
 
 
-def assemble_entries(asm, symmetric=False, format='csr', algo='auto'):
+def assemble_entries(asm, symmetric=False, format='csr', layout='blocked', algo='auto'):
     """Assemble all entries of the assembler object `asm` into a sparse matrix.
 
     Device assemblers (``pyiga_amd.assemblers``) form the whole matrix on the GPU; any other
     object with the reference's assembler interface (``arity``, ``kvs``, ``multi_entries``) is
     driven exactly like the reference does (pattern -> multi_entries -> COO -> CSR [+ mirror]).
     """
+    if layout != 'blocked':
+        raise ValueError("layout %r: only scalar spaces ('blocked') are assembled on the device" % (layout,))
     if asm.arity == 1:
         return asm.assemble_vector()
     if isinstance(asm, assemblers._DeviceAssembler):
         # mass and stiffness are symmetric forms; the kernels always compute the lower
         # triangle and mirror it, which is what symmetric=True means in the reference
-        return asm.assemble_csr(algo=algo).asformat(format)
+        A = asm.assemble_csr(algo=algo)
+        if symmetric and not getattr(asm, '_symmetric_form', True):
+            # the reference with symmetric=True computes the lower triangle only and mirrors it, whatever the form
+            L = scipy.sparse.tril(A, format='csr')
+            A = (L + scipy.sparse.tril(A, k=-1, format='csr').T).tocsr()
+        return A.asformat(format)
     kvs0, kvs1 = asm.kvs
     I, J = _ml_nonzero(kvs0, kvs1, lower_tri=symmetric)
     entries = asm.multi_entries(np.column_stack((I, J)))
@@ -298,8 +305,12 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
     return problem          # already an assembler object
 
 
-def assemble(problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False, format='csr', **kwargs):
-    """Assemble the matrix of a variational form (string, assembler class or assembler object)."""
+def assemble(problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False, format='csr', layout='blocked', **kwargs):
+    """Assemble the matrix of a variational form (string, assembler class or assembler object); signature of
+    pyiga/assemble.py:837.  `layout` only concerns vector-valued spaces, which are outside the device path:
+    'blocked' (the reference's default) is accepted, anything else is refused."""
+    if layout != 'blocked':
+        raise ValueError("layout %r: only scalar spaces ('blocked') are assembled on the device" % (layout,))
     args = dict(args or {})
     args.update(kwargs)
     asm = instantiate_assembler(problem, kvs, args, bfuns, boundary)

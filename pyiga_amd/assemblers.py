@@ -376,6 +376,7 @@ class StiffnessAssembler3D(_DeviceAssembler):
 
 
 class ConvDiffAssembler3D(_DeviceAssembler):
+    _symmetric_form = False
     """Assembler for the variational form
 
         (inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx
@@ -401,6 +402,7 @@ class ConvDiffAssembler3D(_DeviceAssembler):
 
 
 class _GeneralFormAssembler(_DeviceAssembler):
+    _symmetric_form = False
     """Scalar bilinear form in the first-order jets of u and v,
 
         a(u, v) = integral of  sum_{r,s=0..d} P_rs(x) D_r v D_s u  dx,   D_0 = id, D_1..d = d/dx, d/dy[, d/dz],
@@ -517,8 +519,12 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
 
     def assemble_vector(self):
         if self._vector is None:
-            if all(e is None for e in self._jet[1:]):
-                self._vector = self.patch.load_vector(self._jet[0] if self._jet[0] is not None else np.zeros(1))
+            if all(e is None for e in self._jet):
+                lo, hi = self.patch.row_range                # the zero functional ('0 * v * dx')
+                nd = self.patch.ndofs
+                self._vector = np.zeros(((hi - lo) // int(np.prod(nd[1:])),) + tuple(nd[1:]))
+            elif all(e is None for e in self._jet[1:]):
+                self._vector = self.patch.load_vector(self._jet[0])
             else:
                 self._vector = self.patch.load_vector_jet(self._jet)
         return self._vector.copy()

@@ -61,7 +61,7 @@ __device__ unsigned long long g_ga_stamp[2048 * 8 * 6];
 // while the same arithmetic without them overlaps the stores completely.  The block stages the table rows of a batch in
 // LDS with vector loads issued a whole batch ahead.
 template <int P, int NS, int P0G, int NC>
-__global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 4 : 1, 4)))
 k_geoA(const GeoAArgs A)
 {
     constexpr int NL = P * (P + 1) / 2;                   // lower triangle of the pair window
@@ -403,10 +403,11 @@ bool geoA_supported(const igx_patch *pt, int kind, int nslots)
     if (P < 2 || P > 6) return false;
     const int p0g = pt->gax[0].P;
     if (p0g < 2 || p0g > 3) return false;
-    // the column coefficients are recomputed at every span change of the geometry's axis 0: keep that rare
+    // the column coefficients are recomputed (by the whole block, with barriers) at every span boundary of the geometry's
+    // axis 0: worth it while the geometry is coarser than the quadrature grid.  Decided on the whole axis, not on the
+    // resident slab: every slab of a patch takes the same path (bit-identical row blocks).
     const long long gspans = pt->gax[0].N - pt->gax[0].P + 1;
-    const long long redo = gspans * p0g * pt->gax[1].P * pt->gax[2].P * pt->ncomp * 3;
-    return redo <= 24LL * pt->dev.G0_loc;
+    return 2 * gspans <= (long long)pt->ax[0].G;
 }
 
 int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,

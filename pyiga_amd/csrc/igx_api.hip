@@ -259,16 +259,17 @@ int igx_active_deriv(igx_ctx *ctx, const double *kv, int kv_len, int p, const do
     IGX_HIP(hipSetDevice(ctx->device));
     double *d_kv = nullptr, *d_u = nullptr, *d_out = nullptr;
     const size_t nout = (size_t)(numderiv + 1) * (p + 1) * nu;
-    int rc;
-    if ((rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream))) return rc;
-    if ((rc = dev_alloc_copy(&d_u, u, nu, ctx->stream))) return rc;
-    IGX_HIP(hipMalloc((void **)&d_out, nout * sizeof(double)));
-    rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, numderiv, d_out, nullptr, nullptr, nullptr);
-    if (!rc) {
-        IGX_HIP(hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        IGX_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    // single exit: the temporaries are freed (after the stream has drained) on every path
+    int rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream);
+    if (!rc) rc = dev_alloc_copy(&d_u, u, nu, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMalloc((void **)&d_out, nout * sizeof(double));
+    if (!rc && e == hipSuccess) rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, numderiv, d_out, nullptr, nullptr, nullptr);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
     (void)hipFree(d_kv); (void)hipFree(d_u); (void)hipFree(d_out);
+    if (!rc && e != hipSuccess) { set_error("igx_active_deriv: %s", hipGetErrorString(e)); rc = IGX_ERR_HIP; }
     return rc;
 }
 
@@ -280,16 +281,16 @@ int igx_find_spans(igx_ctx *ctx, const double *kv, int kv_len, int p, const doub
     IGX_HIP(hipSetDevice(ctx->device));
     double *d_kv = nullptr, *d_u = nullptr;
     long long *d_sp = nullptr;
-    int rc;
-    if ((rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream))) return rc;
-    if ((rc = dev_alloc_copy(&d_u, u, nu, ctx->stream))) return rc;
-    IGX_HIP(hipMalloc((void **)&d_sp, nu * sizeof(long long)));
-    rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, 0, nullptr, nullptr, nullptr, d_sp);
-    if (!rc) {
-        IGX_HIP(hipMemcpyAsync(spans, d_sp, nu * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-        IGX_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    int rc = dev_alloc_copy(&d_kv, kv, (size_t)kv_len, ctx->stream);
+    if (!rc) rc = dev_alloc_copy(&d_u, u, nu, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMalloc((void **)&d_sp, nu * sizeof(long long));
+    if (!rc && e == hipSuccess) rc = launch_basis_tables(ctx->stream, d_kv, kv_len, p, d_u, nu, 0, nullptr, nullptr, nullptr, d_sp);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(spans, d_sp, nu * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
     (void)hipFree(d_kv); (void)hipFree(d_u); (void)hipFree(d_sp);
+    if (!rc && e != hipSuccess) { set_error("igx_find_spans: %s", hipGetErrorString(e)); rc = IGX_ERR_HIP; }
     return rc;
 }
 
@@ -477,40 +478,52 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     return IGX_OK;
 }
 
-int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
+// coefficient table of IGX_FORM: validated into locals, committed to the patch only when everything (allocation, copies)
+// has succeeded -- a failed call leaves the previous form in place.  `on_device`: the arrays are device pointers over the
+// RESIDENT Gauss slab (igx_patch_gauss_slab), else host pointers over the full grid.
+static int set_form_impl(igx_patch *pt, const double *const coef[16], bool on_device, const char *who)
 {
-    if (!pt || !coef) { set_error("igx_patch_set_form: null argument"); return IGX_ERR_ARG; }
+    if (!pt || !coef) { set_error("%s: null argument", who); return IGX_ERR_ARG; }
     const int nj = pt->dim + 1;                   // jet size: value + dim derivatives
     for (int r = 0; r < 4; ++r)
         for (int s = 0; s < 4; ++s)
-            if (coef[4 * r + s] && (r >= nj || s >= nj)) { set_error("igx_patch_set_form: coefficient (%d,%d) does not exist in %dD", r, s, pt->dim); return IGX_ERR_ARG; }
-    IGX_HIP(hipSetDevice(pt->ctx->device));
-    int n = 0;
-    for (int k = 0; k < 16; ++k) pt->form_slot[k] = coef[k] ? n++ : -1;
-    if (n == 0) { set_error("igx_patch_set_form: all coefficients are absent"); return IGX_ERR_ARG; }
+            if (coef[4 * r + s] && (r >= nj || s >= nj)) { set_error("%s: coefficient (%d,%d) does not exist in %dD", who, r, s, pt->dim); return IGX_ERR_ARG; }
+    int slot[16], n = 0;
+    for (int k = 0; k < 16; ++k) slot[k] = coef[k] ? n++ : -1;
+    if (n == 0) { set_error("%s: all coefficients are absent", who); return IGX_ERR_ARG; }
     // parametric terms: the Jacobian mixes the three derivative directions of each jet block
     bool blk[2][2] = {{false, false}, {false, false}};      // [test is a derivative][trial is a derivative]
     for (int r = 0; r < 4; ++r)
         for (int s = 0; s < 4; ++s)
             if (coef[4 * r + s]) blk[r > 0][s > 0] = true;
-    int nt = 0;
+    int form_ab[16], nt = 0;
     for (int a = 0; a < nj; ++a)
         for (int b = 0; b < nj; ++b)
-            if (blk[a > 0][b > 0]) pt->dev.form_ab[nt++] = 4 * a + b;
-    pt->dev.form_n = nt;
+            if (blk[a > 0][b > 0]) form_ab[nt++] = 4 * a + b;
+    IGX_HIP(hipSetDevice(pt->ctx->device));
     const size_t npts = (size_t)pt->dev.npts_loc, per_plane = npts / (size_t)pt->dev.G0_loc;
-    (void)hipFree(pt->d_formc);
-    pt->d_formc = nullptr;
-    hipError_t e = hipMalloc((void **)&pt->d_formc, std::max<size_t>(1, (size_t)n * npts) * sizeof(double));
+    double *d_new = nullptr;
+    hipError_t e = hipMalloc((void **)&d_new, std::max<size_t>(1, (size_t)n * npts) * sizeof(double));
     if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for the form coefficients failed", n * npts * 8.0 / 1e9); return IGX_ERR_NOMEM; }
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < 16 && e == hipSuccess; ++k)
         if (coef[k])
-            IGX_HIP(hipMemcpyAsync(pt->d_formc + (size_t)pt->form_slot[k] * npts, coef[k] + (size_t)pt->dev.g0_lo * per_plane,
-                                   npts * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
-    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+            e = on_device ? hipMemcpyAsync(d_new + (size_t)slot[k] * npts, coef[k], npts * sizeof(double), hipMemcpyDeviceToDevice, pt->ctx->stream)
+                          : hipMemcpyAsync(d_new + (size_t)slot[k] * npts, coef[k] + (size_t)pt->dev.g0_lo * per_plane, npts * sizeof(double),
+                                           hipMemcpyHostToDevice, pt->ctx->stream);
+    const hipError_t es = hipStreamSynchronize(pt->ctx->stream);      // also on failure: no copy is in flight when d_new is freed
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) { (void)hipFree(d_new); set_error("%s: %s", who, hipGetErrorString(e)); return IGX_ERR_HIP; }
+    (void)hipFree(pt->d_formc);
+    pt->d_formc = d_new;
+    for (int k = 0; k < 16; ++k) { pt->form_slot[k] = slot[k]; pt->dev.form_ab[k] = k < nt ? form_ab[k] : 0; }
+    pt->dev.form_n = nt;
     pt->fields_kind = -1;
     return IGX_OK;
 }
+
+int igx_patch_set_form(igx_patch *pt, const double *const coef[16]) { return set_form_impl(pt, coef, false, "igx_patch_set_form"); }
+
+int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16]) { return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d"); }
 
 int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)
 {

@@ -974,3 +974,108 @@ def test_entries_wave_vs_thread_and_resident(iga, d, p, n, monkeypatch):
         assert patch.entries_resident(kind) is None
         assert np.array_equal(patch.entries_resident(kind, to_host=True), e_wave)
     patch.close()
+
+
+# ------------------------------------------------------------------------------------------
+def _wavy_box(iga, deg0, spans0, nurbs):
+    """3D spline geometry with several knot spans (and degree deg0) along axis 0: a perturbed box."""
+    kv0 = iga.bspline.make_knots(deg0, 0., 1., spans0)
+    kv1 = iga.bspline.make_knots(2, 0., 1., 2)
+    kv2 = iga.bspline.make_knots(1, 0., 1., 3)
+    n = (kv0.numdofs, kv1.numdofs, kv2.numdofs)
+    z, y, x = np.meshgrid(*(np.linspace(0., 1., k) for k in n), indexing='ij')
+    rng = np.random.default_rng(11)
+    C = np.stack([x * (1.5 + 0.3 * y), y + 0.2 * np.sin(2. * z), z * (1. + 0.25 * x)], axis=-1)
+    C = C + 0.02 * rng.standard_normal(C.shape)
+    if nurbs:
+        return iga.geometry.NurbsFunc((kv0, kv1, kv2), C, 1.0 + 0.3 * rng.random(n))
+    return iga.bspline.BSplineFunc((kv0, kv1, kv2), C)
+
+
+@pytest.mark.parametrize('deg0,spans0,nurbs', [(1, 3, False), (2, 4, True), (2, 9, False), (1, 1, True)])
+@pytest.mark.parametrize('p,n', [(3, 7), (4, 5), (2, 11)])
+def test_geometry_in_sweep_multi_span(iga, deg0, spans0, nurbs, p, n, monkeypatch):
+    """k_geoA (geometry evaluated inside the axis-0 sweep; batches of planes that straddle span boundaries of the
+    geometry's axis 0) against the separate field + sweep kernels, full patch and row slabs, mass and stiffness."""
+    geo = _wavy_box(iga, deg0, spans0, nurbs)
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv,) * 3
+    for kind in ('stiffness', 'mass'):
+        patch = iga.assemblers.DevicePatch(kvs, geo)
+        A = patch.csr(kind, algo='sumfact')
+        assert 'geoA' in patch.last_path()
+        monkeypatch.setenv('IGX_GEOA', '0')
+        B = patch.csr(kind, algo='sumfact')
+        assert 'geoA' not in patch.last_path()
+        E = patch.csr(kind, algo='entrywise')
+        monkeypatch.delenv('IGX_GEOA')
+        patch.close()
+        assert rel_maxdiff(A, B) <= RTOL and rel_maxdiff(A, E) <= RTOL
+        assert abs(A - A.T).max() == 0.0
+        N0 = kv.numdofs
+        parts = []
+        for lo, hi in ((0, N0 // 3), (N0 // 3, N0 - 2), (N0 - 2, N0)):
+            sl = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+            parts.append(sl.csr(kind, algo='sumfact'))
+            sl.close()
+        S = scipy.sparse.vstack(parts).tocsr()
+        assert np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
+
+
+def test_set_form_device_and_failed_call(iga):
+    """igx_patch_set_form_d (coefficients already on the device, resident slab) == the host entry point; a call that fails
+    validation leaves the previous form in place."""
+    import ctypes as C
+    lib = iga._lib.load()
+    kv = iga.bspline.make_knots(2, 0., 1., 6)
+    kvs = (kv,) * 3
+    geo = _geo(iga, 'cylinder')
+    for row0 in (None, (2, 5)):
+        patch = iga.assemblers.DevicePatch(kvs, geo, row0=row0)
+        G = tuple(patch.info.ngauss[k] for k in range(3))
+        rng = np.random.default_rng(5)
+        c00, c12 = 1.0 + rng.random(G), rng.standard_normal(G)
+        table = [[None] * 4 for _ in range(4)]
+        table[0][0], table[1][2] = c00, c12
+        patch.set_form(table)
+        ref = patch.assemble('form', algo='sumfact')
+        lo, cnt = patch.gauss_slab()
+        bufs, ptrs = [], (C.c_void_p * 16)()
+        for k, arr in ((0, c00), (4 * 1 + 2, c12)):
+            part = np.ascontiguousarray(arr[lo:lo + cnt])
+            d = lib.igx_dev_alloc(patch.ctx.handle, part.nbytes)
+            assert d
+            iga._lib.check(lib.igx_dev_upload(patch.ctx.handle, d, part.ctypes.data, part.nbytes), 'upload')
+            bufs.append(d)
+            ptrs[k] = d
+        # a failing call first: a coefficient of the 4th jet slot row and column is fine in 3D, so break it with an empty table
+        empty = (C.c_void_p * 16)()
+        assert lib.igx_patch_set_form_d(patch.handle, empty) != 0
+        assert np.array_equal(patch.assemble('form', algo='sumfact'), ref)         # previous form still in place
+        iga._lib.check(lib.igx_patch_set_form_d(patch.handle, ptrs), 'igx_patch_set_form_d')
+        for d in bufs:
+            lib.igx_dev_free(patch.ctx.handle, d)                                   # the patch keeps its own copy
+        assert np.array_equal(patch.assemble('form', algo='sumfact'), ref)
+        patch.close()
+
+
+def test_reference_signature_kwargs(iga):
+    """assemble(..., layout=, symmetric=) as in pyiga/assemble.py:837; get/set_max_threads; the zero functional."""
+    kv = iga.bspline.make_knots(2, 0., 1., 5)
+    kvs = (kv,) * 3
+    geo = _geo(iga, 'cylinder')
+    A = iga.assemble.assemble('inner(grad(u), grad(v)) * dx', kvs, geo=geo, layout='blocked')
+    assert rel_maxdiff(A, iga.assemble.stiffness(kvs, geo)) <= RTOL
+    with pytest.raises(ValueError):
+        iga.assemble.assemble('u * v * dx', kvs, geo=geo, layout='packed')
+    # symmetric=True on a non-symmetric form: lower triangle mirrored, as the reference does
+    form = 'inner((x[2], 0.0, -x[0]), grad(u)) * v * dx'
+    N = iga.assemble.assemble(form, kvs, geo=geo)
+    S = iga.assemble.assemble(form, kvs, geo=geo, symmetric=True)
+    assert abs(N - N.T).max() > 0.0
+    L = scipy.sparse.tril(N)
+    assert abs(S - (L + scipy.sparse.tril(N, k=-1).T)).max() == 0.0
+    z = iga.assemble.assemble('0 * v * dx', kvs, geo=geo)
+    assert z.shape == (kv.numdofs,) * 3 and not z.any()
+    iga.set_max_threads(3)
+    assert iga.get_max_threads() == 3
