@@ -270,10 +270,10 @@ struct BFSweepDispatch<P, MASK, NA, RI, true> {
 //     loc[a][b] = sum_l sum_tu V[l][b][tu] * (sum_tv V[l][a][tv] * K[tu + 2 tv][l])        (a: test function, b: trial function)
 // -- every K and V value is read from LDS once per (line, span), not once per row.  The values of point l+1 are requested
 // before the arithmetic of point l.  One role per type: role index = position of the type among those that occur.
-template <int P, int NY, int MASK>
-__device__ __forceinline__ void bf_element(double (&loc)[P][P], const double *kl, const double *vl)
+template <int P, int NY, int MASK, int A0 = 0, int A1 = P>
+__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl)
 {
-    constexpr int TL = BF_TL;
+    constexpr int TL = BF_TL, NA_ = A1 - A0;             // rows A0 .. A1-1 of the element matrix (test functions)
     // LDS row of type y inside the line image (roles are ordered by type)
     constexpr int ry0 = 0;
     constexpr int ry1 = bf_roles_of_y(MASK & 15);
@@ -281,7 +281,7 @@ __device__ __forceinline__ void bf_element(double (&loc)[P][P], const double *kl
     constexpr int ry3 = ry2 + bf_roles_of_y((MASK >> 8) & 15);
     constexpr bool h0 = (MASK & 15) != 0, h1 = ((MASK >> 4) & 15) != 0, h2 = ((MASK >> 8) & 15) != 0, h3 = ((MASK >> 12) & 15) != 0;
 #pragma unroll
-    for (int a = 0; a < P; ++a)
+    for (int a = 0; a < NA_; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
     double K[4], V[P][2];
@@ -296,38 +296,38 @@ __device__ __forceinline__ void bf_element(double (&loc)[P][P], const double *kl
 #pragma unroll
     for (int l = 0; l < P; ++l) {
         // every value is replaced by the one of the next point right after its last use (one register set)
-        double c0[P], c1[P];
+        double c0[NA_], c1[NA_];
 #pragma unroll
-        for (int a = 0; a < P; ++a) {
-            if (NY == 1) { c0[a] = V[a][0] * K[0]; c1[a] = 0.0; }
+        for (int a = 0; a < NA_; ++a) {
+            if (NY == 1) { c0[a] = V[A0 + a][0] * K[0]; c1[a] = 0.0; }
             else {
-                c0[a] = fma(V[a][1], K[2], V[a][0] * K[0]);      // types 0, 2
-                c1[a] = fma(V[a][1], K[3], V[a][0] * K[1]);      // types 1, 3
+                c0[a] = fma(V[A0 + a][1], K[2], V[A0 + a][0] * K[0]);      // types 0, 2
+                c1[a] = fma(V[A0 + a][1], K[3], V[A0 + a][0] * K[1]);      // types 1, 3
             }
         }
         if (l + 1 < P) {
 #pragma unroll
-            for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c0[a]), "+v"(c1[a]));     // K is dead from here
+            for (int a = 0; a < NA_; ++a) asm volatile("" : "+v"(c0[a]), "+v"(c1[a]));     // K is dead from here
             load_K(l + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < P; ++b) {
 #pragma unroll
-            for (int a = 0; a < P; ++a) {
+            for (int a = 0; a < NA_; ++a) {
                 if (NY == 1) loc[a][b] = fma(V[b][0], c0[a], loc[a][b]);
                 else loc[a][b] = fma(V[b][0], c0[a], fma(V[b][1], c1[a], loc[a][b]));
             }
             if (l + 1 < P) {
 #pragma unroll
-                for (int a = 0; a < P; ++a) asm volatile("" : "+v"(loc[a][b]));          // V[b] is dead from here
+                for (int a = 0; a < NA_; ++a) asm volatile("" : "+v"(loc[a][b]));          // V[b] is dead from here
                 load_V(l + 1, b);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the reads of point l+2 may not be hoisted above this point (register blow-up)
 #pragma unroll
-        for (int a = 0; a < P; ++a)
+        for (int a = 0; a < NA_; ++a)
 #pragma unroll
             for (int b = 0; b < P; ++b) asm volatile("" : "+v"(loc[a][b]));
         asm volatile("" ::: "memory");
@@ -471,13 +471,23 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
                 int row1, col1;
                 const int k9 = cw * LW + ln1;
                 if (v1 && line_ok(k9, row1, col1)) {
+                    double *xo = xb + (ln1 * SPW + s1) * PP;
+                    if (A.dbg & 32) {                     // (timing experiment: half of the element matrix)
+                        constexpr int AH = (P + 1) / 2;
+                        double loc[AH][P];
+                        bf_element<P, NY, MASK, 0, AH>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
+#pragma unroll
+                        for (int a = 0; a < AH; ++a)
+#pragma unroll
+                            for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
+                    } else {
                     double loc[P][P];
                     bf_element<P, NY, MASK>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
-                    double *xo = xb + (ln1 * SPW + s1) * PP;
 #pragma unroll
                     for (int a = 0; a < P; ++a)
 #pragma unroll
                         for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
+                    }
                 }
             }
             BF_SEG_END(1);

@@ -35,7 +35,7 @@ struct GeoAArgs {
     int nurbs, kind;
     int G1, G2;
     long long NPL, stride;      // points of a plane; doubles between the K1 slices of consecutive pairs
-    const double *PI0;          // [G0][4][P][P]
+    const double *V0;           // [G0][P][2] basis values and derivatives of the swept axis at its Gauss points
     const int *step_ptr;        // [n0+1]
     const int *steps;           // [nsteps][8]
     int s_lo, s_hi, q, chunk_len;
@@ -64,14 +64,13 @@ template <int P, int NS, int P0G, int NC>
 __global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 4 : 1, 4)))
 k_geoA(const GeoAArgs A)
 {
-    constexpr int NL = P * (P + 1) / 2;                   // lower triangle of the pair window
-    constexpr int NLP = (NL + 1) & ~1;                    // 16-byte rows
+    constexpr int PV = (P + 1) & ~1;                      // basis row padded to 16 bytes
     constexpr int NT = NS * 64;                           // threads
-    constexpr int NPI = NS * 4 * NL;                      // coefficient values of a batch
+    constexpr int NPI = NS * 2 * P;                       // basis values of a batch (value and derivative of the P active functions)
     constexpr int KPI = (NPI + NT - 1) / NT;              // ... per thread
     __shared__ double fld[2][NS][6][64];                  // fields of two batches of planes
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
-    __shared__ __attribute__((aligned(16))) double pis[2][NS][4][NLP];   // sweep coefficients PI0[g][t][a][b], b <= a
+    __shared__ __attribute__((aligned(16))) double vs[2][NS][2][PV];     // axis-0 basis at the planes: [value | derivative][active function]
     __shared__ double gts[2][NS][8];                      // axis-0 geometry basis at the plane: (N, N') x P0G | w0 | first active index
     __shared__ int fts[2][NS][12];                        // plane ends a span: number of flush steps | first step | 8 slots of the first step
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,29 +91,23 @@ k_geoA(const GeoAArgs A)
 
     // ---- table staging (vector loads; the values wait in registers until the end of the iteration)
     const GeoView &gv = A.gv;
-    int pi_src[KPI], pi_dst[KPI];                         // per-thread element of the coefficient rows: source offset (plane j in the
-                                                          // top byte), LDS slot
-#pragma unroll
-    for (int k = 0; k < KPI; ++k) {
-        const int i = tid + k * NT;
-        const int j = i / (4 * NL), r = i - j * (4 * NL), t = r / NL, e = r - t * NL;
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= e) ++a;
-        const int bb = e - a * (a + 1) / 2;
-        pi_src[k] = i < NPI ? (j << 24) | (t * (P * P) + a * P + bb) : -1;
-        pi_dst[k] = (j * 4 + t) * NLP + e;
-    }
+    // the sweep coefficient of pair (a, b) and type t = tu + 2 tv is V[b][tu] * V[a][tv]: the 2 P basis values of a plane are
+    // staged instead of the 4 P^2 products (LDS read bandwidth bounds this kernel: every broadcast read delivers 64 lanes)
     double pi_reg[KPI], gt_reg = 0.0;
     int ft_reg[2 + P];
-    auto stage_pi_load = [&](const int gb) {              // coefficient rows of the batch that starts at plane gb
+    auto stage_pi_load = [&](const int gb) {              // basis rows of the batch that starts at plane gb
 #pragma unroll
-        for (int k = 0; k < KPI; ++k)
-            if (pi_src[k] >= 0) pi_reg[k] = A.PI0[(size_t)min(gb + (pi_src[k] >> 24), g_last) * (4 * P * P) + (pi_src[k] & 0xffffff)];
+        for (int k = 0; k < KPI; ++k) {
+            const int i = tid + k * NT, j = i / (2 * P), r = i - j * (2 * P), d = r / P, a_ = r - d * P;
+            if (i < NPI) pi_reg[k] = A.V0[((size_t)min(gb + j, g_last) * P + a_) * 2 + d];
+        }
     };
     auto stage_pi_store = [&](const int buf) {
 #pragma unroll
-        for (int k = 0; k < KPI; ++k)
-            if (pi_src[k] >= 0) (&pis[buf][0][0][0])[pi_dst[k]] = pi_reg[k];
+        for (int k = 0; k < KPI; ++k) {
+            const int i = tid + k * NT, j = i / (2 * P), r = i - j * (2 * P), d = r / P, a_ = r - d * P;
+            if (i < NPI) vs[buf][j][d][a_] = pi_reg[k];
+        }
     };
     auto stage_gt_load = [&](const int gb) {
         if (tid < NS * 8) {
@@ -244,11 +237,12 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
         for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
     typedef double d2 __attribute__((ext_vector_type(2)));
-    constexpr int NH = (NLP / 2 + 1) / 2 * 2;             // first half of the coefficient row (doubles, even)
-    auto coefficients = [&](double (&cf)[NLP], const int buf, const int j, const int k0, const int k1) {
-        const d2 *row = (const d2 *)&pis[buf][j][t][0];
+    const int tu = t & 1, tv = t >> 1;
+    auto basis_row = [&](double (&v)[PV], const int buf, const int j, const int d) {
+        const d2 *row = (const d2 *)&vs[buf][j][d][0];
 #pragma unroll
-        for (int k = k0 / 2; k < k1 / 2; ++k) { const d2 v = row[k]; cf[2 * k] = v.x; cf[2 * k + 1] = v.y; }
+        for (int k = 0; k < P / 2; ++k) { const d2 x = row[k]; v[2 * k] = x.x; v[2 * k + 1] = x.y; }
+        if (P & 1) v[P - 1] = vs[buf][j][d][P - 1];
     };
 
 #ifdef IGX_GA_STAMP
@@ -273,53 +267,42 @@ k_geoA(const GeoAArgs A)
         stage_ft_load(gb + NS);
         stage_gt_load(gb + 2 * NS);
         double bv = fld[buf][0][fi][lane];
-        double cf[NLP];
-        coefficients(cf, buf, 0, 0, NLP);
+        double va[PV], vb[PV];                            // V[.][tv] (test functions, rows a), V[.][tu] (trial functions, columns b)
+        basis_row(va, buf, 0, tv);
+        if (tu != tv) basis_row(vb, buf, 0, tu);
+        else {
+#pragma unroll
+            for (int k = 0; k < PV; ++k) vb[k] = va[k];
+        }
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             if (gb + j >= g_end) break;
-            // the row of the next plane replaces this one half by half, each half right after its last use: the LDS reads
-            // are in flight under the other half's FMAs and one register set serves
+            // the rows of the next plane replace these right after their last use: the LDS reads are in flight under the FMAs
             const int jn = j + 1 < NS ? j + 1 : j;
             const double bvn = fld[buf][jn][fi][lane];
-            double *af = &acc[0][0];
-            (void)af;
-            if (!(A.dbg & 4)) {
-                int k = 0;
+            double c[P];
 #pragma unroll
-                for (int a = 0; a < P; ++a)
+            for (int a = 0; a < P; ++a) c[a] = va[a] * bv;
 #pragma unroll
-                    for (int b = 0; b <= a; ++b, ++k)
-                        if (k < NH) acc[a][b] = fma(cf[k], bv, acc[a][b]);
-            } else acc[0][0] += cf[0] + bv;
-            {
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < P; ++a)
-#pragma unroll
-                    for (int b = 0; b <= a; ++b, ++k)
-                        if (k < NH) asm volatile("" : "+v"(acc[a][b]));
-            }
+            for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c[a]));
             asm volatile("" ::: "memory");
-            coefficients(cf, buf, jn, 0, NH);
+            basis_row(va, buf, jn, tv);
             if (!(A.dbg & 4)) {
-                int k = 0;
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b, ++k)
-                        if (k >= NH) acc[a][b] = fma(cf[k], bv, acc[a][b]);
-            }
-            {
-                int k = 0;
+                    for (int b = 0; b <= a; ++b) acc[a][b] = fma(vb[b], c[a], acc[a][b]);
+            } else acc[0][0] += c[0] + vb[0];
 #pragma unroll
-                for (int a = 0; a < P; ++a)
+            for (int a = 0; a < P; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b, ++k)
-                        if (k >= NH) asm volatile("" : "+v"(acc[a][b]));
-            }
+                for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[a][b]));
             asm volatile("" ::: "memory");
-            coefficients(cf, buf, jn, NH, NLP);
+            if (tu != tv) basis_row(vb, buf, jn, tu);
+            else {                                        // same row: no second broadcast read
+#pragma unroll
+                for (int k = 0; k < PV; ++k) vb[k] = va[k];
+            }
             bv = bvn;
             GA_T(1);                                      // sweep arithmetic (+ parked stores)
             if (++l < q) continue;
@@ -421,7 +404,7 @@ int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
     A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
-    A.PI0 = A0.d_PI; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
+    A.V0 = A0.d_V; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
     A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.q = A0.q; A.chunk_len = chunk_len;
     { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
     for (int x = 0; x < nslots; ++x) { A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x]; }
