@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
         }
     }
     // direct stores: entry f = (row r_, offset o) of the chunk; element offset = B_d*rp + C_d*c + o
-    int d_rp[NIT_D], d_ci[NIT_D], d_o[NIT_D], d_src[NIT_D], d_dst[NIT_D];
+    int d_rp[NIT_D], d_src[NIT_D], d_dst[NIT_D];        // d_src: source index | row length << 12 | offset << 16
     bool d_ok[NIT_D], d_up[NIT_D];
 #pragma unroll
     for (int it = 0; it < NIT_D; ++it) {
@@ -814,14 +814,14 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
         const int jli = F.jlo[ii], ci = F.jhi[ii] - jli;
         d_ok[it] = v && o < ci;
         d_up[it] = jli + o > ii;
-        d_rp[it] = F.rp[ii]; d_ci[it] = ci; d_o[it] = o;
-        d_src[it] = v ? (r_ * P) * W + o : 0;
+        d_rp[it] = F.rp[ii];
+        d_src[it] = (v ? (r_ * P) * W + o : 0) | (ci << 12) | (o << 16);
         d_dst[it] = v ? (ii - blk_lo) * W + o : FINALQ_WAVES * R * W;    // junk slot for lanes past the chunk
     }
     // mirrored stores: row j, column i, value from the sums of row i.  This wave writes (j, i) when it owns
     // row j and row i is in the block, or when row j lies outside the block and it owns row i.
     const int jmin = F.jlo[row_lo], nj = F.jhi[row_hi - 1] - jmin;
-    int m_rp[NIT_M], m_cj[NIT_M], m_o[NIT_M], m_src[NIT_M];
+    int m_rp[NIT_M], m_src[NIT_M];                      // m_src: source index | row length << 12 | offset << 16
     bool m_ok[NIT_M], m_ge[NIT_M];
 #pragma unroll
     for (int it = 0; it < NIT_M; ++it) {
@@ -837,8 +837,8 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
         const int iic = in ? ii : row_lo;
         m_ok[it] = in;
         m_ge[it] = j >= ii;
-        m_src[it] = (iic - blk_lo) * W + (in ? j - F.jlo[iic] : 0);
-        m_rp[it] = F.rp[j]; m_cj[it] = cj; m_o[it] = o;
+        m_src[it] = ((iic - blk_lo) * W + (in ? j - F.jlo[iic] : 0)) | (cj << 12) | (o << 16);
+        m_rp[it] = F.rp[j];
     }
 
     // ---- K lines: HBM -> LDS by DMA (no registers), FINALQ_DEPTH lines ahead of the arithmetic.
@@ -856,14 +856,38 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
     };
     auto do_line = [&](const LineDesc &D_, const int slot, double *out_s) {
         const double *ks = kslot + slot * (NY * KWIN) + koff;
+        double acc[W];
+#pragma unroll
+        for (int o = 0; o < W; ++o) acc[o] = 0.0;
+        if constexpr (P >= 6 && NY == 4) {
+            // p = 5: the basis registers (Vr, va: 168 VGPRs) leave no room for all NY * P window values at once; with them
+            // the kernel spilled, and a scratch reload waits for vmcnt(0) -- for every K window in flight and every store
+            // of the line -- inside this loop.  The values are read span by span, one span ahead of their use.
+            double kc[NY], kn[NY];
+#pragma unroll
+            for (int y = 0; y < NY; ++y) kc[y] = ks[y * KWIN];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                if (k + 1 < P) {
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) kn[y] = ks[y * KWIN + (k + 1) * P];
+                }
+                const double cu0 = fma(va[k][1], kc[2], va[k][0] * kc[0]);     // types 0, 2
+                const double cu1 = fma(va[k][1], kc[3], va[k][0] * kc[1]);     // types 1, 3
+#pragma unroll
+                for (int b = 0; b < P; ++b) acc[k + b] = fma(Vr[k][b][0], cu0, fma(Vr[k][b][1], cu1, acc[k + b]));
+#pragma unroll
+                for (int o = 0; o < W; ++o) asm volatile("" : "+v"(acc[o]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int y = 0; y < NY; ++y) kc[y] = kn[y];
+            }
+        } else {
         double kv[NY][P];
 #pragma unroll
         for (int y = 0; y < NY; ++y)
 #pragma unroll
             for (int k = 0; k < P; ++k) kv[y][k] = ks[y * KWIN + k * P];
-        double acc[W];
-#pragma unroll
-        for (int o = 0; o < W; ++o) acc[o] = 0.0;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             double cu0, cu1 = 0.0;
@@ -878,6 +902,7 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
                 else acc[k + b] = fma(Vr[k][b][0], cu0, fma(Vr[k][b][1], cu1, acc[k + b]));
             }
         }
+        }
 #pragma unroll
         for (int o = 0; o < W; ++o) out_q[lane * W + o] = acc[o];
         __builtin_amdgcn_wave_barrier();
@@ -890,13 +915,13 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
         // which the counted waits on the K windows below rely on.
 #pragma unroll
         for (int it = 0; it < NIT_D; ++it) {
-            const double *q = out_q + d_src[it];            // entries past the chunk: d_src = 0, masked below
+            const double *q = out_q + (d_src[it] & 4095);   // entries past the chunk: source 0, masked below
             double v = q[0];
 #pragma unroll
             for (int p_ = 1; p_ < P; ++p_) v += q[p_ * W];
             out_s[d_dst[it]] = v;
             const bool st = own_row && d_ok[it] && !(diag_lead && d_up[it]);
-            double *p = st ? dst_d + (B_d * d_rp[it] + C_d * d_ci[it] + d_o[it]) : dump;
+            double *p = st ? dst_d + (B_d * d_rp[it] + C_d * ((d_src[it] >> 12) & 15) + (d_src[it] >> 16)) : dump;
             if (!(IGX_Q_DBG & 1)) *p = v;
         }
         // every wave's sums of this line are in LDS before any of them is read; the DMA queue stays untouched
@@ -905,8 +930,8 @@ __global__ void __launch_bounds__(64 * FINALQ_WAVES) __attribute__((amdgpu_waves
 #pragma unroll
             for (int it = 0; it < NIT_M; ++it) {
                 const bool st = own_col && m_ok[it] && !(diag_lead && m_ge[it]);
-                double *p = st ? dst_m + (B_m * m_rp[it] + C_m * m_cj[it] + m_o[it]) : dump;
-                if (!(IGX_Q_DBG & 1)) *p = out_s[m_src[it]];
+                double *p = st ? dst_m + (B_m * m_rp[it] + C_m * ((m_src[it] >> 12) & 15) + (m_src[it] >> 16)) : dump;
+                if (!(IGX_Q_DBG & 1)) *p = out_s[m_src[it] & 4095];
             }
         }
         __builtin_amdgcn_wave_barrier();                // out_q reads above precede the next line's writes
