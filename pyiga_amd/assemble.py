@@ -235,11 +235,15 @@ def inner_products(kvs, f, f_physical=False, geo=None):
         assert geo is not None, 'inner_products in physical domain requires geometry'
     if dim == 1:
         # same steps as the reference: weights, transposed collocation matrix (host; 1D is outside the device path)
-        if geo is not None:
-            raise NotImplementedError('1D inner products with a geometry map are not supported')
         grid, gw = make_tensor_quadrature([kvs[0].mesh], kvs[0].p + 1)
-        fvals = np.array(utils.grid_eval(f, grid), dtype=float)
-        w = gw[0].reshape((-1,) + (1,) * (fvals.ndim - 1))
+        fvals = np.array(utils.grid_eval_transformed(f, grid, geo) if f_physical else utils.grid_eval(f, grid), dtype=float)
+        w = gw[0].copy()
+        if geo is not None:
+            # a curve: |det J| of the reference's `determinants` is |x'(t)| for a scalar map (pyiga/assemble.py:326-333)
+            jac = np.asarray(geo.grid_jacobian(grid), dtype=float).reshape(len(grid[0]), -1)
+            assert jac.shape[1] == 1, '1D inner products need a scalar-valued geometry map'
+            w = w * np.abs(jac[:, 0])
+        w = w.reshape((-1,) + (1,) * (fvals.ndim - 1))
         return bspline.collocation(kvs[0], grid[0]).T @ (fvals * w)
     assert dim in (2, 3), 'Dimensions higher than 3 are currently not implemented.'
     g = geo if geo is not None else geometry.unit_cube(dim)     # parameter domain: |det J| = 1

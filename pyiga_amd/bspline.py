@@ -201,8 +201,25 @@ def _geo_desc(kvs, coeffs, nurbs):
 
 def _device_grid_eval(kvs, coeffs, nurbs, ncomp, gridaxes, want_jac):
     sdim = len(kvs)
+    if sdim == 1:
+        # curves: basis values and derivatives from the device (k_basis_tables), the contraction with the control
+        # points is a few numpy lines (1D is outside the device path, like the reference's 1D assembling)
+        kv = kvs[0]
+        nodes = _lib.f64(np.squeeze(gridaxes[0]) if np.ndim(gridaxes[0]) != 1 else gridaxes[0])
+        first, val = collocation_derivs_info(kv, nodes, derivs=1)
+        idx = first[:, None] + np.arange(kv.p + 1)[None, :]
+        Cn = np.asarray(coeffs, dtype=float).reshape(kv.numdofs, -1)[idx]          # (m, P, ncomp [+ weight])
+        hv = np.einsum('mp,mpc->mc', val[0], Cn)
+        hd = np.einsum('mp,mpc->mc', val[1], Cn)
+        if nurbs:
+            W, dW = hv[:, -1:], hd[:, -1:]
+            ev = hv[:, :-1] / W
+            jac = (hd[:, :-1] * W - hv[:, :-1] * dW) / (W * W)                       # quotient rule, pyiga/geometry.py:17-25
+        else:
+            ev, jac = hv, hd
+        return jac[..., None] if want_jac else ev
     if sdim not in (2, 3):
-        raise NotImplementedError('device spline evaluation supports 2D and 3D parameter domains')
+        raise NotImplementedError('device spline evaluation supports 1D, 2D and 3D parameter domains')
     d, keep = _geo_desc(kvs, coeffs, nurbs)
     axes = [_lib.f64(np.squeeze(ax) if np.ndim(ax) != 1 else ax) for ax in gridaxes]
     assert all(ax.ndim == 1 for ax in axes), 'Grid axes should be one-dimensional'

@@ -1079,3 +1079,15 @@ def test_reference_signature_kwargs(iga):
     assert z.shape == (kv.numdofs,) * 3 and not z.any()
     iga.set_max_threads(3)
     assert iga.get_max_threads() == 3
+
+
+def test_inner_products_1d_with_geometry(iga):
+    """1D load vector over a curve parametrisation: weights times |x'(t)| (pyiga/assemble.py:326-333)."""
+    kv = iga.bspline.make_knots(3, 0., 1., 7)
+    geo = iga.geometry.line_segment(1.0, 3.0, intervals=2)         # x(t) = 1 + 2 t
+    ref0 = iga.assemble.inner_products(kv, lambda x: np.ones_like(x))
+    out = iga.assemble.inner_products(kv, lambda x: np.ones_like(x), geo=geo)
+    assert np.abs(out - 2.0 * ref0).max() <= 1e-14
+    assert abs(out.sum() - 2.0) <= 1e-14                          # length of the segment
+    phys = iga.assemble.inner_products(kv, lambda x: x, f_physical=True, geo=geo)
+    assert abs(phys.sum() - 4.0) <= 1e-13                         # int_1^3 x dx
