@@ -134,6 +134,8 @@ struct igx_patch {
     // 32-byte line descriptors of the quadrature-lane final kernel (symmetric / non-symmetric pair list)
     int *d_qdesc = nullptr, *d_qdescn = nullptr;
     long long n_qdesc = 0, n_qdescn = 0;
+    std::vector<int> h_pl0;                   // host copy of d_pl0 (the line descriptors are built lazily from it)
+    bool desc_built = false;
     int *d_ldesc = nullptr;                   // [n_ldesc][4] line descriptors of the final stage
     int n_ldesc = 0;
     bool ldesc_ok = false;

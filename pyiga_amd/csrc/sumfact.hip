@@ -1207,6 +1207,58 @@ static int build_qdesc(igx_patch *pt, const std::vector<int> &pl, bool sym, int 
     return IGX_OK;
 }
 
+// Line descriptors of the stage-kernel final (k_final_q / k_final_mfma): ~0.8 M descriptors (25 MB) at C4, built on
+// the host.  The default 3D chain (k_geoA, k_bf, k_mirror) never reads them, so they are made on first use.
+static int ensure_line_descriptors(igx_patch *pt)
+{
+    if (pt->desc_built) return IGX_OK;
+    const std::vector<int> &pl = pt->h_pl0;
+    const Axis &A0 = pt->ax[0];
+    // MFMA kernel: one descriptor per K line that is actually contracted
+    {
+        const Axis &A1 = pt->ax[1], &A2 = pt->ax[2];
+        const int dim = pt->dim;
+        std::vector<int> ld;
+        const long long S1 = A1.S, S2 = A2.S;
+        for (int r0 = 0; r0 < pt->npairs0; ++r0) {
+            const int i0 = pl[2 * r0], j0 = pl[2 * r0 + 1];
+            const int c0i = A0.jhi[i0] - A0.jlo[i0], c0j = A0.jhi[j0] - A0.jlo[j0];
+            int flags = 0;
+            if (i0 >= pt->r0_lo && i0 < pt->r0_hi) flags |= 1;
+            if (j0 >= pt->r0_lo && j0 < pt->r0_hi) flags |= 2;
+            if (dim == 2) {
+                const long long Ad = (long long)A0.rp[i0] * S1 - pt->nnz_off, Am = (long long)A0.rp[j0] * S1 - pt->nnz_off;
+                const int fl = flags | ((i0 == j0) ? 4 : 0);
+                ld.push_back((int)Ad); ld.push_back((int)Am);
+                ld.push_back(c0i | ((j0 - A0.jlo[i0]) << 8) | (c0j << 16) | ((i0 - A0.jlo[j0]) << 24));
+                ld.push_back(r0 | (fl << 28));
+            } else {
+                for (int r1 = 0; r1 < A1.S; ++r1) {
+                    const int i1 = A1.pair_i[r1], j1 = A1.pair_j[r1];
+                    if (i0 == j0 && j1 > i1) continue;          // mirrored, not computed
+                    const int c1i = A1.jhi[i1] - A1.jlo[i1], c1j = A1.jhi[j1] - A1.jlo[j1];
+                    const long long Ad = (long long)A0.rp[i0] * S1 * S2 + (long long)c0i * A1.rp[i1] * S2 - pt->nnz_off;
+                    const long long Am = (long long)A0.rp[j0] * S1 * S2 + (long long)c0j * A1.rp[j1] * S2 - pt->nnz_off;
+                    const int Bd = c0i * c1i, Cd = (j0 - A0.jlo[i0]) * c1i + (j1 - A1.jlo[i1]);
+                    const int Bm = c0j * c1j, Cm = (i0 - A0.jlo[j0]) * c1j + (i1 - A1.jlo[j1]);
+                    const int fl = flags | ((i0 == j0 && i1 == j1) ? 4 : 0);
+                    ld.push_back((int)Ad); ld.push_back((int)Am);
+                    ld.push_back(Bd | (Cd << 8) | (Bm << 16) | (Cm << 24));
+                    ld.push_back((int)((long long)r0 * A1.S + r1) | (fl << 28));
+                }
+            }
+        }
+        pt->n_ldesc = (int)(ld.size() / 4);
+        pt->ldesc_ok = (long long)pt->npairs0 * (dim == 3 ? A1.S : 1) < (1LL << 28);
+        IGX_HIP(hipMalloc(&pt->d_ldesc, std::max<size_t>(1, ld.size()) * sizeof(int)));
+        IGX_HIP(hipMemcpyAsync(pt->d_ldesc, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    }
+    if (int rc = build_qdesc(pt, pl, true, &pt->d_qdesc, &pt->n_qdesc)) return rc;
+    pt->desc_built = true;
+    return IGX_OK;
+}
+
 int sumfact_prepare(igx_patch *pt)
 {
     // processed lower pairs of axis 0: j0 <= i0 with the row or the column owned
@@ -1260,47 +1312,7 @@ int sumfact_prepare(igx_patch *pt)
     IGX_HIP(hipMemcpyAsync(pt->d_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
     pt->stepA_ptr = pt->d_steps + oA0; pt->stepA_rec = pt->d_steps + oA1;
     pt->stepB_ptr = pt->d_steps + oB0; pt->stepB_rec = pt->d_steps + oB1;
-    // line descriptors of the final stage (MFMA kernel): one per K line that is actually contracted
-    {
-        const Axis &A1 = pt->ax[1], &A2 = pt->ax[2];
-        const int dim = pt->dim;
-        std::vector<int> ld;
-        const long long S1 = A1.S, S2 = A2.S;
-        for (int r0 = 0; r0 < pt->npairs0; ++r0) {
-            const int i0 = pl[2 * r0], j0 = pl[2 * r0 + 1];
-            const int c0i = A0.jhi[i0] - A0.jlo[i0], c0j = A0.jhi[j0] - A0.jlo[j0];
-            int flags = 0;
-            if (i0 >= pt->r0_lo && i0 < pt->r0_hi) flags |= 1;
-            if (j0 >= pt->r0_lo && j0 < pt->r0_hi) flags |= 2;
-            if (dim == 2) {
-                const long long Ad = (long long)A0.rp[i0] * S1 - pt->nnz_off, Am = (long long)A0.rp[j0] * S1 - pt->nnz_off;
-                const int fl = flags | ((i0 == j0) ? 4 : 0);
-                ld.push_back((int)Ad); ld.push_back((int)Am);
-                ld.push_back(c0i | ((j0 - A0.jlo[i0]) << 8) | (c0j << 16) | ((i0 - A0.jlo[j0]) << 24));
-                ld.push_back(r0 | (fl << 28));
-            } else {
-                for (int r1 = 0; r1 < A1.S; ++r1) {
-                    const int i1 = A1.pair_i[r1], j1 = A1.pair_j[r1];
-                    if (i0 == j0 && j1 > i1) continue;          // mirrored, not computed
-                    const int c1i = A1.jhi[i1] - A1.jlo[i1], c1j = A1.jhi[j1] - A1.jlo[j1];
-                    const long long Ad = (long long)A0.rp[i0] * S1 * S2 + (long long)c0i * A1.rp[i1] * S2 - pt->nnz_off;
-                    const long long Am = (long long)A0.rp[j0] * S1 * S2 + (long long)c0j * A1.rp[j1] * S2 - pt->nnz_off;
-                    const int Bd = c0i * c1i, Cd = (j0 - A0.jlo[i0]) * c1i + (j1 - A1.jlo[i1]);
-                    const int Bm = c0j * c1j, Cm = (i0 - A0.jlo[j0]) * c1j + (i1 - A1.jlo[j1]);
-                    const int fl = flags | ((i0 == j0 && i1 == j1) ? 4 : 0);
-                    ld.push_back((int)Ad); ld.push_back((int)Am);
-                    ld.push_back(Bd | (Cd << 8) | (Bm << 16) | (Cm << 24));
-                    ld.push_back((int)((long long)r0 * A1.S + r1) | (fl << 28));
-                }
-            }
-        }
-        pt->n_ldesc = (int)(ld.size() / 4);
-        pt->ldesc_ok = (long long)pt->npairs0 * (dim == 3 ? A1.S : 1) < (1LL << 28);
-        IGX_HIP(hipMalloc(&pt->d_ldesc, std::max<size_t>(1, ld.size()) * sizeof(int)));
-        IGX_HIP(hipMemcpyAsync(pt->d_ldesc, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
-        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
-    }
-    if (int rc = build_qdesc(pt, pl, true, &pt->d_qdesc, &pt->n_qdesc)) return rc;
+    pt->h_pl0 = pl;                                  // the line descriptors of the stage-kernel final are built on first use
     // fused stage (fused.hip): a row of zeros, the one-dof outer axis of the 2D case, the mirror targets
     {
         const Axis &AL = pt->ax[pt->dim - 1];
@@ -1628,6 +1640,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         }
     }
 
+    if (int rc = ensure_line_descriptors(pt)) return rc;
     // ---- final-stage input
     FinalArgs F{};
     const Axis &AL = (dim == 3) ? A2 : A1;
