@@ -124,12 +124,94 @@ __device__ unsigned long long g_bf_stamp[64 * 1024];
 __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// Split contraction (four roles, four contractor waves, the last one without lines): the element matrices of line group g
+// are computed by TWO waves of the same SIMD between the barriers B1 and B2 -- rows 0..AH-1 by contractor g, rows AH..p by
+// the first sweeper wave of role g+1 (which sweeps afterwards) -- and gathered by the contractor after B2.  A wave that is
+// alone on its SIMD issues one FP64 instruction per 11 cycles, two interleaved waves one per 6 (tools/ubench/mix_f64.hip):
+// the contractor alone was the critical path of a step, the sweepers next to it waited at the barrier.
+template <int P> struct BFSplit {
+    static constexpr int W = 2 * P - 1, LW = (W + BF_NCW - 1) / BF_NCW;
+    static constexpr int AH = (P + 1) / 2;                       // rows of the contractor's part
+};
+template <int P, int MASK> constexpr bool bf_split() { return bf_nroles(MASK) == 4 && BF_NCW == 4 && 3 * BFSplit<P>::LW >= BFSplit<P>::W && P >= 3; }
+struct BFBlk {                // block constants of the stores
+    int i0, j0, diag0, c0i, rlo, rhi, row_lo, nrows;
+    long long S12;
+    const double *ring, *cur;
+};
+struct BFHelp {
+    int group;                // line group whose rows AH..p this sweeper wave computes (-1: none)
+    double *xb;               // exchange buffer of that group
+    const double *V2s;        // last-axis basis values of the tile window
+    int rlo, diag0, nsw;      // first mid-axis row of the block, diagonal outer pair, spans of the window
+    int store_sw;             // this sweeper wave is store wave store_sw of the block (-1: none)
+    BFBlk blk;
+};
+template <int P, int NY, int MASK, int A0, int A1>
+__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl);
+
+// ---- segment stores: whole CSR segments of the mid-axis row completed two steps ago, from the entry rings.  NCW "store
+// waves" share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
+// q = (rr * W + m) * W + o, lane-consecutive -> consecutive lanes write consecutive doubles.  What does not depend on the
+// step is worked out once per lane (the plan).  Without the split contraction the store waves are the contractor waves;
+// with it they are the SECOND sweeper wave of roles 1..3 (idle most of a step) and the last contractor wave.
+template <int P> struct BFStorePlan {
+    static constexpr int W = 2 * P - 1, RMAX = BFGeom<P>::RMAX;
+    static constexpr int NSL = (RMAX * W * W + 64 * BF_NCW - 1) / (64 * BF_NCW);
+    int rp[NSL], mo[NSL];     // rp2[row] | m, o, c2, flags, rr * W + o (bits 16..)
+};
+template <int P>
+__device__ __forceinline__ void bf_store_plan(BFStorePlan<P> &pl, const BFArgs &A, const BFBlk &B, const int sw, const int lane)
+{
+    constexpr int p = P - 1, W = 2 * P - 1, RMAX = BFGeom<P>::RMAX, NCW = BF_NCW;
+    cip rp2 = (cip)A.rp2;
+#pragma unroll
+    for (int k = 0; k < BFStorePlan<P>::NSL; ++k) {
+        const int q = (k * NCW + sw) * 64 + lane;
+        const int rr = min(q / (W * W), RMAX - 1), e2 = q - (q / (W * W)) * (W * W);
+        const int m = e2 / W, o = e2 - m * W;
+        const int2 rt = make_int2(rp2[min(B.row_lo + rr, A.N2 - 1)], min(B.row_lo + rr + p, A.N2 - 1) + 1 - max(B.row_lo + rr - p, 0));
+        const int i2r = B.row_lo + rr;
+        const bool ok = q < B.nrows * W * W && o < rt.y;
+        const bool dg = o <= i2r - max(i2r - p, 0);   // entry of the diagonal line of a diagonal block that is stored (j2 <= i2)
+        pl.rp[k] = rt.x;
+        pl.mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0)   // (rows past the axis have a negative run length)
+                   | ((rr * W + o) << 16);
+    }
+}
+template <int P>
+__device__ __forceinline__ void bf_store_row(const BFArgs &A, const BFBlk &B, const BFStorePlan<P> &pl, const int dd2)
+{
+    constexpr int p = P - 1, W = 2 * P - 1, RMAX = BFGeom<P>::RMAX, NSL = BFStorePlan<P>::NSL;
+    if (!(dd2 >= B.rlo && dd2 < B.rhi) || (A.dbg & 2)) return;
+    cip rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, rp1 = (cip)A.rp1;
+    const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
+    const int nm = B.diag0 ? dd2 - jl1 + 1 : c1;    // lines of the segment
+    const int koff = p - (dd2 - jl1);               // line m of the segment is pair index m + koff: < p ring, >= p cur
+    const double *rg = B.ring + (size_t)((dd2 % (P + 1)) * p) * RMAX * W;
+    const double *cu = B.cur + (size_t)((dd2 & 1) * P) * RMAX * W;
+    double *rowp = A.data + ((long long)rp0[B.i0] * B.S12 + (long long)B.c0i * (long long)rp1[dd2] * A.S2 - A.nnz_off);
+    const int colb = (B.j0 - jlo0[B.i0]) * c1, rsc = B.c0i * c1;
+    double val[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int kx = min((pl.mo[k] & 15) + koff, 2 * p);
+        val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl.mo[k] >> 16];     // always inside the rings
+    }
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int m = pl.mo[k] & 15, o = (pl.mo[k] >> 4) & 15, c2r = (pl.mo[k] >> 8) & 15;
+        const bool ok = ((pl.mo[k] >> 12) & 1) && m < nm && !(B.diag0 && m == nm - 1 && !((pl.mo[k] >> 13) & 1));
+        if (ok) rowp[(long long)rsc * pl.rp[k] + (colb + m) * c2r + o] = val[k];
+    }
+}
+
 // ---- sweeper: role R of MASK, lane = Gauss point g2 of the tile window.  The values of one span live in registers; each
 // is reloaded for the next span right after its use, so a load has a whole step to land and the waits are counted
 // (no branch around a load inside the loops: hipcc answers those with vmcnt(0)).
-template <int P, int MASK, int RI, int NA>
+template <int P, int MASK, int RI, int NA, bool LG0>
 __device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
-                                           const int rhi, double *lines, const int LS)
+                                           const int rhi, double *lines, const int LS, const BFHelp &H)
 {
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = BF_TL;
@@ -179,9 +261,45 @@ __device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const 
 #pragma unroll
         for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
     };
+    // this wave's share of the segment stores (split contraction): row t - 2, any time between the barriers of step t
+    // (role 0, the heaviest sweeper, takes no share: the code is not even instantiated for it -- registers)
+    // (the first wave of a role computes element rows, the second one stores: two instantiations, or each would carry the
+    //  registers of both)
+    constexpr bool SHARE = bf_split<P, MASK>() && RI >= 1;
+    BFStorePlan<P> spl;
+    if constexpr (SHARE && !LG0) {
+        if (H.store_sw >= 0) bf_store_plan<P>(spl, A, H.blk, H.store_sw, g2l & 63);
+    }
+    auto stores = [&](const int t_) {
+        if constexpr (SHARE && !LG0) {
+            if (H.store_sw >= 0) bf_store_row<P>(A, H.blk, spl, t_ - 2);
+        }
+    };
+    // the sweeper's share of the element matrices of flush t - 1 (split contraction)
+    auto help = [&](const int t_) {
+        if constexpr (SHARE && LG0) {
+            using Gm_ = BFGeom<P>;
+            constexpr int NY_ = (MASK & ~15) ? 4 : 1, AH = BFSplit<P>::AH, W_ = 2 * P - 1;
+            const int dd = t_ - 1;
+            if (H.group < 0 || dd < s_begin || dd >= rhi || (A.dbg & 33)) return;
+            const int lane_ = g2l & 63, ln1 = lane_ / Gm_::SPW, s1 = lane_ - ln1 * Gm_::SPW;
+            const int k9 = H.group * Gm_::LW + ln1, la = k9 <= p ? k9 : k9 - p;
+            const int row1 = k9 <= p ? dd + la : dd, col1 = k9 <= p ? dd : dd + la;
+            if (ln1 < Gm_::LW && s1 < H.nsw && k9 < W_ && row1 >= H.rlo && row1 < rhi && col1 < A.N1 && !(H.diag0 && col1 > row1)) {
+                double loc[P - AH][P];
+                bf_element<P, NY_, MASK, AH, P>(loc, lines + k9 * LS + s1 * P, H.V2s + s1 * P * P * 2);
+                double *xo = H.xb + (ln1 * Gm_::SPW + s1) * (P * P) + AH * P;
+#pragma unroll
+                for (int a = 0; a < P - AH; ++a)
+#pragma unroll
+                    for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
+            }
+        }
+    };
     int t = s_begin;
     for (; t < t_sw; ++t) {
         bar_lds();                                       // B1
+        help(t);
         const int tn = min(t + 1, t_sw - 1);
         cdp cf = V1 + (size_t)t * P * P * 2;
         double v[P][2];
@@ -240,29 +358,36 @@ __device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const 
 #pragma unroll
             for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
         }
+        stores(t);
         bar_lds();                                       // B2: the contractors have read the previous lines
         flush();
     }
     for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
         bar_lds();
+        help(t);
+        stores(t);
         bar_lds();
         flush();
     }
-    for (; t < rhi + 2; ++t) { bar_lds(); bar_lds(); }   // the contractors finish the last two rows
+    for (; t < rhi + 2; ++t) { bar_lds(); help(t); stores(t); bar_lds(); }   // the contractors finish the last two rows
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
 template <int P, int MASK, int NA, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BFSweepDispatch {
-    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS,
+                                               const BFHelp &H)
     {
-        if (role == RI) bf_sweeper<P, MASK, RI, NA>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
-        else BFSweepDispatch<P, MASK, NA, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        if (role == RI) {
+            if (__builtin_amdgcn_readfirstlane(g2l) < 64) bf_sweeper<P, MASK, RI, NA, true>(A, r0, g2l, g2, s_begin, rhi, lines, LS, H);
+            else bf_sweeper<P, MASK, RI, NA, false>(A, r0, g2l, g2, s_begin, rhi, lines, LS, H);
+        }
+        else BFSweepDispatch<P, MASK, NA, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, H);
     }
 };
 template <int P, int MASK, int NA, int RI>
 struct BFSweepDispatch<P, MASK, NA, RI, true> {
-    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BFHelp &) {}
 };
 
 // Element matrices of one K2 line on one span of the last axis (the contractors' first half): with K[y][l] the line's values
@@ -352,7 +477,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     double *V2s = lds + OFF_V2;          // [TL][P][2]: last-axis basis values on the tile window
     double *xbuf = lds + OFF_XB;         // [NCW][LW][SPW][P][P]: element matrices of the lines a contractor wave is working on
 
-    cip pl0 = (cip)A.pl0, rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0, rp1 = (cip)A.rp1, rp2 = (cip)A.rp2;
+    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // XCD-aware order: the tiles of one (pair, chunk) share K1 halo lines -> consecutive logical ids on one XCD
     unsigned bid = blockIdx.x;
@@ -385,12 +510,21 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
         if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
         else task = k < 2 ? k : NSW + 3;
     }
+    BFBlk blk;
+    blk.i0 = i0; blk.j0 = j0; blk.diag0 = diag0; blk.c0i = jhi0[i0] - jlo0[i0]; blk.rlo = rlo; blk.rhi = rhi;
+    blk.row_lo = row_lo; blk.nrows = nrows; blk.S12 = A.S1 * A.S2; blk.ring = ring; blk.cur = cur;
     if (task < NSW) {
         // ---------------- sweepers: role, lane group lg
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(win0 + min(g2l, nwin - 1), A.G2 - 1);     // lanes past the window re-read its last point
-        BFSweepDispatch<P, MASK, NA, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        BFHelp H;
+        H.group = (bf_split<P, MASK>() && lg == 0 && role >= 1) ? role - 1 : -1;     // same SIMD as contractor role - 1 (mapping above)
+        H.xb = xbuf + (H.group < 0 ? 0 : H.group) * Gm::XB;
+        H.V2s = V2s; H.rlo = rlo; H.diag0 = diag0; H.nsw = sp_hi - sp_lo;
+        H.store_sw = (bf_split<P, MASK>() && lg == 1 && role >= 1) ? role - 1 : -1;
+        H.blk = blk;
+        BFSweepDispatch<P, MASK, NA, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, H);
         return;
     }
 
@@ -409,53 +543,15 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     const int ln3 = lane / RMAX, r3 = lane - ln3 * RMAX;  // step 2: line slot, row
     const bool v3 = ln3 < LW && r3 < nrows;
     const int i2 = row_lo + r3;
-    const int c0i = jhi0[i0] - jlo0[i0];
-    const long long S12 = A.S1 * A.S2;
 
-    // ---- segment stores: whole CSR segments of the row completed two steps ago, from the entry rings.  The contractor
-    // waves share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
-    // q = (rr * W + m) * W + o, lane-consecutive -> consecutive lanes write consecutive doubles.  What does not depend on the
-    // step is worked out once per lane.
-            constexpr int NSL = (RMAX * W * W + 64 * NCW - 1) / (64 * NCW);
-            int pl_rp[NSL], pl_mo[NSL];                       // rp2[row] | m, o, c2, flags, rr * W + o (bits 16..)
-    #pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                const int q = (k * NCW + cw) * 64 + lane;
-                const int rr = min(q / (W * W), RMAX - 1), e2 = q - (q / (W * W)) * (W * W);
-                const int m = e2 / W, o = e2 - m * W;
-                const int2 rt = make_int2(rp2[min(row_lo + rr, A.N2 - 1)], min(row_lo + rr + p, A.N2 - 1) + 1 - max(row_lo + rr - p, 0));
-                const int i2r = row_lo + rr;
-                const bool ok = q < nrows * W * W && o < rt.y;
-                const bool dg = o <= i2r - max(i2r - p, 0);   // entry of the diagonal line of a diagonal block that is stored (j2 <= i2)
-                pl_rp[k] = rt.x;
-                pl_mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0)   // (rows past the axis have a negative run length)
-                           | ((rr * W + o) << 16);
-            }
+    // store wave index of this contractor (-1: the stores are with the sweepers' second waves, see bf_store_row)
+    const int store_sw = !bf_split<P, MASK>() ? cw : (cw == NCW - 1 ? cw : -1);
+    BFStorePlan<P> spl;
+    if (store_sw >= 0) bf_store_plan<P>(spl, A, blk, store_sw, lane);
     for (int t = s_begin; t < rhi + 2; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
         BF_SEG_BEGIN();
-                    const int dd2 = t - 2;
-                    if (dd2 >= rlo && dd2 < rhi && !(A.dbg & 2)) {
-                        const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
-                        const int nm = diag0 ? dd2 - jl1 + 1 : c1;    // lines of the segment
-                        const int koff = p - (dd2 - jl1);             // line m of the segment is pair index m + koff: < p ring, >= p cur
-                        const double *rg = ring + (size_t)((dd2 % (P + 1)) * p) * RMAX * W;
-                        const double *cu = cur + (size_t)((dd2 & 1) * P) * RMAX * W;
-                        double *rowp = A.data + ((long long)rp0[i0] * S12 + (long long)c0i * (long long)rp1[dd2] * A.S2 - A.nnz_off);
-                        const int colb = (j0 - jlo0[i0]) * c1, rsc = c0i * c1;
-                        double val[NSL];
-        #pragma unroll
-                        for (int k = 0; k < NSL; ++k) {
-                            const int kx = min((pl_mo[k] & 15) + koff, 2 * p);
-                            val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl_mo[k] >> 16];     // always inside the rings
-                        }
-        #pragma unroll
-                        for (int k = 0; k < NSL; ++k) {
-                            const int m = pl_mo[k] & 15, o = (pl_mo[k] >> 4) & 15, c2r = (pl_mo[k] >> 8) & 15;
-                            const bool ok = ((pl_mo[k] >> 12) & 1) && m < nm && !(diag0 && m == nm - 1 && !((pl_mo[k] >> 13) & 1));
-                            if (ok) rowp[(long long)rsc * pl_rp[k] + (colb + m) * c2r + o] = val[k];
-                        }
-                    }
+        if (store_sw >= 0) bf_store_row<P>(A, blk, spl, t - 2);
         BF_SEG_END(0);
         // ---- contract the lines of flush dd = t - 1 with the last axis
         const int dd = t - 1;
@@ -472,7 +568,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
                 const int k9 = cw * LW + ln1;
                 if (v1 && line_ok(k9, row1, col1)) {
                     double *xo = xb + (ln1 * SPW + s1) * PP;
-                    if (A.dbg & 32) {                     // (timing experiment: half of the element matrix)
+                    if (bf_split<P, MASK>() || (A.dbg & 32)) {   // split contraction: rows 0..AH-1 here, the others by a sweeper wave
                         constexpr int AH = (P + 1) / 2;
                         double loc[AH][P];
                         bf_element<P, NY, MASK, 0, AH>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
@@ -492,6 +588,14 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
             }
             BF_SEG_END(1);
             __builtin_amdgcn_wave_barrier();              // LDS operations of one wave execute in order
+        }
+        if constexpr (bf_split<P, MASK>()) bar_lds();     // B2 (split contraction): all parts of the element matrices are in LDS; the sweepers flush after it
+        if (dd >= s_begin && dd < rhi && !(A.dbg & 1)) {
+            auto line_ok = [&](const int k9, int &row1, int &col1) {
+                const int la = k9 <= p ? k9 : k9 - p;
+                row1 = k9 <= p ? dd + la : dd; col1 = k9 <= p ? dd : dd + la;
+                return k9 < W && row1 >= rlo && row1 < rhi && col1 < A.N1 && !(diag0 && col1 > row1);
+            };
             BF_SEG_BEGIN();
             {
                 int row1, col1;
@@ -527,7 +631,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
             BF_SEG_END(2);
             __builtin_amdgcn_wave_barrier();              // the gather precedes the next step's element matrices
         }
-        bar_lds();                                        // B2: lines may be overwritten, entries are visible
+        if constexpr (!bf_split<P, MASK>()) bar_lds();    // B2: lines may be overwritten, entries are visible
     }
     BF_SEG_DUMP(cw);
     BF_STAMP_END(wave);
