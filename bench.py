@@ -148,6 +148,11 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
+def _tdev():
+    """device of the tensors that go through collectives (gloo in the one-GPU test mode)"""
+    return 'cpu' if os.environ.get('BENCH_SHARE_GPU') else 'cuda'
+
+
 def self_launch(args):
     """--gpus N without a launcher: start the N ranks as children (nothing here has touched the GPU), relay rank 0."""
     import socket
@@ -206,8 +211,14 @@ def main():
     if world > 1 or os.environ.get('BENCH_FORCE_DIST'):      # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        # BENCH_SHARE_GPU=1 (testing on a one-GPU box): every rank uses device 0 and the rendezvous runs over gloo --
+        # RCCL refuses two ranks on one device; the slab logic, the reductions and the result line are the same
+        if os.environ.get('BENCH_SHARE_GPU'):
+            local_rank = 0
+            dist.init_process_group(backend='gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit('RCCL world size %d != --gpus %d' % (dist.get_world_size(), args.gpus))
 
@@ -264,14 +275,14 @@ def main():
     slab_ms = [float(np.median(steps_ms))]
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=_tdev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        z = torch.tensor([float(nnz_local)], dtype=torch.float64, device='cuda')
+        z = torch.tensor([float(nnz_local)], dtype=torch.float64, device=_tdev())
         dist.all_reduce(z, op=dist.ReduceOp.SUM)
         nnz_total = int(z.item())
-        sl = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(world)]
-        dist.all_gather(sl, torch.tensor([slab_ms[0]], dtype=torch.float64, device='cuda'))
+        sl = [torch.zeros(1, dtype=torch.float64, device=_tdev()) for _ in range(world)]
+        dist.all_gather(sl, torch.tensor([slab_ms[0]], dtype=torch.float64, device=_tdev()))
         slab_ms = [float(x.item()) for x in sl]
     else:
         nnz_total = nnz_local
@@ -360,7 +371,7 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
     dev_ms = float(np.median(dev))
     if dist is not None:
         import torch
-        t = torch.tensor([dev_ms, wall_ms], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dev_ms, wall_ms], dtype=torch.float64, device=_tdev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dev_ms, wall_ms = float(t[0].item()), float(t[1].item())
     if rank != 0:

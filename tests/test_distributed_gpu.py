@@ -32,3 +32,18 @@ def test_two_ranks_one_gpu(tmp_path):
     assert full.shape == ref.shape and full.nnz == ref.nnz
     assert np.array_equal(full.indptr, ref.indptr) and np.array_equal(full.indices, ref.indices)
     assert np.array_equal(full.data, ref.data)
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py --gpus 2 launches its own ranks; BENCH_SHARE_GPU=1 puts both on device 0 with a gloo rendezvous (RCCL refuses
+    two ranks on one device): the slab split, the max/sum reductions and the result line of the N > 1 path."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'tiny', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and len(d['slab_ms']) == 2
+    assert d['config']['elements'] == 12 ** 3 and d['value'] > 0
