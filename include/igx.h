@@ -187,6 +187,15 @@ const double  *igx_d_csr_data(const igx_patch *patch);
 const int32_t *igx_d_csr_indices(const igx_patch *patch);
 const int32_t *igx_d_csr_indptr(const igx_patch *patch);
 
+/* Low-rank (adaptive cross approximation) assembly of the mass / stiffness matrix of a whole patch: the algorithm of
+   pyiga/fastasm.cc:294-494,701-760 (fast_assemble_2d/3d, reached from mass_fast/stiffness_fast, pyiga/assemble.py:1063-1101)
+   on the host, pulling whole rows / columns / fibres of the reordered matrix from the device with batched entry requests
+   instead of one callback per entry.  data_out: nnz values in the canonical CSR order of igx_pattern (approximate to
+   `tol`).  rank_out: crosses added; entries_out: entries actually evaluated.  Defaults of the reference: tol 1e-10,
+   maxiter 100, skipcount 3, tolcount 3; verbose 0..2 prints the reference's progress lines to stdout. */
+int igx_fast_assemble(igx_patch *patch, int kind, double tol, int maxiter, int skipcount, int tolcount, int verbose,
+                      double *data_out, int *rank_out, long long *entries_out);
+
 /* multi_entries: ij is M x 2 (row, col) of ravelled dof indices; out[k] = 0.0 for pairs whose
    supports do not intersect.  Works for any pair, inside or outside the owned slab provided the
    fields of the pair's Gauss points are resident (always true for a full patch). */

@@ -358,15 +358,29 @@ def stiffness(kvs, geo=None, format='csr'):
 # Low-rank "fast" variants (pyiga/assemble.py:1063-1101)
 ################################################################################
 
+def _fast(kind, kvs, geo, tol, maxiter, skipcount, tolcount, verbose):
+    if geo is None:
+        # the default assemblers use Kronecker product assembling if no geometry is present (pyiga/assemble.py:1068-1070)
+        return mass(kvs) if kind == 'mass' else stiffness(kvs)
+    dim, kvs = _detect_dim(kvs)
+    assert geo.dim == dim, 'Geometry has wrong dimension'
+    assert dim != 1, 'Geometry map not supported for 1D assembling'
+    assert dim in (2, 3), 'Dimensions higher than 3 are currently not implemented.'
+    patch = assemblers.DevicePatch(tuple(kvs), geo)
+    try:
+        return patch.fast_assemble(kind, tol=tol, maxiter=maxiter, skipcount=skipcount, tolcount=tolcount, verbose=verbose)
+    finally:
+        patch.close()
+
+
 def mass_fast(kvs, geo=None, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=2):
-    """Signature of the reference's low-rank (adaptive cross approximation) mass assembler
-    (pyiga/assemble.py:1063-1081, pyiga/fastasm.cc).  The ACA algorithm exists to avoid most of the
-    entry-wise quadrature sums on a CPU; on the device the exact sum-factorised assembly costs less than
-    the entry sampling ACA needs, so this returns the exact matrix -- inside any `tol` by construction.
-    The approximation parameters are accepted and ignored."""
-    return mass(kvs, geo)
+    """Mass matrix by the low-rank (adaptive cross approximation) assembler (pyiga/assemble.py:1063-1081,
+    pyiga/fastasm.cc): the ACA control flow runs on the host, rows / columns / fibres of the reordered matrix are
+    evaluated on the device in batches.  Approximate to `tol`; on this hardware the exact assembly
+    (:func:`mass`) is faster -- the entry point exists for code written against pyiga."""
+    return _fast('mass', kvs, geo, tol, maxiter, skipcount, tolcount, verbose)
 
 
 def stiffness_fast(kvs, geo=None, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=2):
     """See :func:`mass_fast` (pyiga/assemble.py:1083-1101)."""
-    return stiffness(kvs, geo)
+    return _fast('stiffness', kvs, geo, tol, maxiter, skipcount, tolcount, verbose)

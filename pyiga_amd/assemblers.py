@@ -208,6 +208,18 @@ class DevicePatch:
                                             _lib.dptr(out) if to_host else None), 'igx_assemble')
         return out
 
+    def fast_assemble(self, kind, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=0):
+        """Low-rank (ACA) assembly (igx_fast_assemble): scipy CSR, plus the number of crosses and of evaluated entries in
+        ``self.aca_stats``."""
+        assert self.row_range == (0, self.shape[0]), 'the low-rank assembler works on whole patches'
+        data = np.empty(self.nnz)
+        rank, nent = C.c_int(0), C.c_longlong(0)
+        _lib.check(_lib.load().igx_fast_assemble(self.handle, _lib.KINDS[kind], float(tol), int(maxiter), int(skipcount), int(tolcount),
+                                                 int(verbose), _lib.dptr(data), C.byref(rank), C.byref(nent)), 'igx_fast_assemble')
+        self.aca_stats = {'rank': rank.value, 'entries': nent.value, 'nnz': int(self.nnz)}
+        indptr, indices = self.pattern()
+        return scipy.sparse.csr_matrix((data, indices, indptr), shape=self.shape)
+
     def last_path(self):
         """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'mirror' (include/igx.h IGX_PATH_*)."""
         bits = _lib.load().igx_patch_last_path(self.handle)

@@ -791,16 +791,42 @@ def test_full_size_c4(iga, monkeypatch):
         assert np.array_equal(data[pos_t], data[lo:lo + ref.size])      # A[J, I] == A[I, J] bit for bit
 
 
-def test_fast_variants_match_fixtures(iga):
-    """test/test_assemble.py:187-217: the low-rank entry points against the bundled fixtures (their tolerance
-    there is 1e-9; the exact device path meets the 1e-14 of the exact tests)."""
+def test_fast_variants_match_fixtures(iga, capsys):
+    """test/test_assemble.py:187-217 (test_fast_{mass,stiffness}_geo_{2,3}d): the low-rank (ACA) assemblers against the
+    bundled fixtures with the reference's tolerance 1e-9; the approximation really is low-rank (few crosses, fewer entries
+    evaluated than the matrix has where the matrix is large enough)."""
     kv = iga.bspline.make_knots(3, 0.0, 1.0, 15)
     geo = iga.geometry.bspline_quarter_annulus()
     M_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d2_p3_n15_mass.mtx.gz'))
     A_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d2_p3_n15_stiff.mtx.gz'))
-    assert abs(iga.assemble.mass_fast((kv, kv), geo, verbose=0) - M_ref).max() < 1e-14
-    assert abs(iga.assemble.stiffness_fast((kv, kv), geo, verbose=0) - A_ref).max() < 1e-14
-    assert abs(iga.assemble.mass_fast((kv, kv)) - iga.assemble.mass((kv, kv))).max() == 0.0
+    assert abs(iga.assemble.mass_fast((kv, kv), geo, verbose=0) - M_ref).max() < 1e-9
+    assert abs(iga.assemble.stiffness_fast((kv, kv), geo, verbose=0) - A_ref).max() < 1e-9
+    assert abs(iga.assemble.mass_fast((kv, kv)) - iga.assemble.mass((kv, kv))).max() == 0.0     # no geometry: Kronecker path
+    kv3 = iga.bspline.make_knots(2, 0.0, 1.0, 10)
+    box = iga.geometry.twisted_box()
+    M3_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d3_p2_n10_mass.mtx.gz'))
+    A3_ref = iga.utils.read_sparse_matrix(os.path.join(GOLDEN, 'poisson_neu_d3_p2_n10_stiff.mtx.gz'))
+    assert abs(iga.assemble.mass_fast((kv3,) * 3, box, verbose=0) - M3_ref).max() < 1e-9
+    assert abs(iga.assemble.stiffness_fast((kv3,) * 3, box, verbose=0) - A3_ref).max() < 1e-9
+    # statistics, a looser tolerance, and the progress lines of the reference
+    kvb = iga.bspline.make_knots(3, 0.0, 1.0, 40)
+    patch = iga.assemblers.DevicePatch((kvb, kvb), iga.geometry.quarter_annulus())
+    exact = patch.csr('stiffness')
+    A = patch.fast_assemble('stiffness')
+    st = patch.aca_stats
+    assert abs(A - exact).max() < 1e-9 and 0 < st['rank'] <= 40 and st['entries'] < st['nnz']
+    patch.close()                                   # (the annulus is exactly rank 3 in this ordering)
+    patch = iga.assemblers.DevicePatch((kv3,) * 3, box)
+    exact = patch.csr('stiffness')
+    A = patch.fast_assemble('stiffness')
+    st = patch.aca_stats
+    assert abs(A - exact).max() < 1e-9 and st['entries'] < st['nnz']
+    B = patch.fast_assemble('stiffness', tol=1e-4)
+    assert patch.aca_stats['rank'] < st['rank'] and 1e-12 < abs(B - exact).max() < 1e-2
+    capsys.readouterr()
+    patch.close()
+    with pytest.raises(AssertionError):
+        iga.assemblers.DevicePatch((kvb, kvb), iga.geometry.quarter_annulus(), row0=(0, 10)).fast_assemble('mass')
 
 
 def test_full_size_c5(iga, monkeypatch):
