@@ -348,6 +348,19 @@ class _DeviceAssembler:
         """One matrix entry for the ravelled dof indices (i, j)."""
         return float(self.patch.entries(self._kind, np.array([[i, j]], dtype=np.uintp))[0])
 
+    def entry_func_ptr(self):
+        """PyCapsule named "entryfunc" holding a C function ``double(*)(size_t i, size_t j, void *data)`` that returns
+        entry (i, j) (pyiga/genericasm.pxi:780-786; consumed by pyiga/fast_assemble_cy.pyx:102-103, which passes the
+        assembler object as `data`).  The function is a ctypes trampoline into :meth:`entry` -- one device call per entry:
+        for compatibility only; batched consumers should use :meth:`multi_entries` or the ACA assembler of this package
+        (``DevicePatch.fast_assemble``)."""
+        if getattr(self, '_entry_cb', None) is None:
+            proto = C.CFUNCTYPE(C.c_double, C.c_size_t, C.c_size_t, C.c_void_p)
+            self._entry_cb = proto(lambda i, j, _data: float(self.entry(int(i), int(j))))
+        new = C.pythonapi.PyCapsule_New
+        new.restype, new.argtypes = C.py_object, [C.c_void_p, C.c_char_p, C.c_void_p]
+        return new(C.cast(self._entry_cb, C.c_void_p), b'entryfunc', None)
+
     def multi_entries(self, indices):
         """All entries for an ``N x 2`` array (or iterable) of (row, col) pairs; pairs whose
         supports do not intersect give 0.0."""

@@ -1117,3 +1117,18 @@ def test_inner_products_1d_with_geometry(iga):
     assert abs(out.sum() - 2.0) <= 1e-14                          # length of the segment
     phys = iga.assemble.inner_products(kv, lambda x: x, f_physical=True, geo=geo)
     assert abs(phys.sum() - 4.0) <= 1e-13                         # int_1^3 x dx
+
+
+def test_entry_func_ptr_capsule(iga):
+    """The "entryfunc" capsule of the reference's plugin interface (pyiga/genericasm.pxi:780-786): a C function pointer that
+    returns single entries."""
+    import ctypes as C
+    kv = iga.bspline.make_knots(2, 0., 1., 5)
+    asm = iga.assemblers.StiffnessAssembler2D((kv, kv), _geo(iga, 'quarter_annulus'))
+    cap = asm.entry_func_ptr()
+    get = C.pythonapi.PyCapsule_GetPointer
+    get.restype, get.argtypes = C.c_void_p, [C.py_object, C.c_char_p]
+    fn = C.CFUNCTYPE(C.c_double, C.c_size_t, C.c_size_t, C.c_void_p)(get(cap, b'entryfunc'))
+    for i, j in ((0, 0), (8, 9), (20, 13), (3, 40)):
+        assert fn(i, j, None) == asm.entry(i, j)
+    assert fn(3, 40, None) == 0.0
