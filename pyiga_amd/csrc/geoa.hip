@@ -260,9 +260,11 @@ k_geoA(const GeoAArgs A)
     int it = 0, l = 0, sp = s_begin;                      // plane gb + j = point l of span sp
     for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
         const int buf = it & 1;
-        next_batch(gb + NS, buf ^ 1, buf ^ 1);
-        GA_T(0);                                          // geometry
-        // table rows of the next iteration: requested now, stored to LDS after the sweep
+        // Order of an iteration: table loads for the coming batches -> sweep of this batch (K1 stores) -> geometry of the
+        // next batch -> table values to LDS -> barrier.  The compiler cannot count the stores of the flush (they sit behind
+        // branches), so the wait for the table loads is a vmcnt(0): with the geometry evaluation between the last store and
+        // that wait the stores are half an iteration old by then, instead of draining at full HBM latency once per batch
+        // in front of the barrier.
         stage_pi_load(gb + NS);
         stage_ft_load(gb + NS);
         stage_gt_load(gb + 2 * NS);
@@ -333,6 +335,8 @@ k_geoA(const GeoAArgs A)
             GA_T(2);                                      // flush
         }
         GA_T(1);
+        next_batch(gb + NS, buf ^ 1, buf ^ 1);
+        GA_T(0);                                          // geometry
         stage_pi_store(buf ^ 1);
         stage_ft_store(buf ^ 1);
         stage_gt_store(buf);                              // batch it + 2
