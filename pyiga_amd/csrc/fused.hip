@@ -202,7 +202,7 @@ __device__ __forceinline__ void bf_store_row(const BFArgs &A, const BFBlk &B, co
     for (int k = 0; k < NSL; ++k) {
         const int m = pl.mo[k] & 15, o = (pl.mo[k] >> 4) & 15, c2r = (pl.mo[k] >> 8) & 15;
         const bool ok = ((pl.mo[k] >> 12) & 1) && m < nm && !(B.diag0 && m == nm - 1 && !((pl.mo[k] >> 13) & 1));
-        if (ok) rowp[(long long)rsc * pl.rp[k] + (colb + m) * c2r + o] = val[k];
+        if (ok) rowp[rsc * pl.rp[k] + (colb + m) * c2r + o] = val[k];      // (offset inside the row block: < 2^31)
     }
 }
 
