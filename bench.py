@@ -236,7 +236,7 @@ def main():
     kvs = (kv0,) + (kv,) * (dim - 1)
     row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world)
     if kind == 'convdiff':
-        patch = assemblers.ConvDiffAssembler3D(kvs, geo, COEFF, device=local_rank, row0=row0 if part_world > 1 else None).patch
+        patch = assemblers.ConvDiffAssembler3D(kvs, geo, assemblers.AffineCoefficient(1.0, 1.0), device=local_rank, row0=row0 if part_world > 1 else None).patch
     else:
         patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
     patch.ctx.sync()

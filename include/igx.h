@@ -150,6 +150,9 @@ int        igx_patch_get_info(const igx_patch *patch, igx_patch_info *info);
 /* Scalar coefficient field of IGX_CONVDIFF on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
    pointer; what pyiga.utils.grid_eval_transformed(diff_coeff, gaussgrid, geo) returns).  Copied. */
 int igx_patch_set_coeff(igx_patch *patch, const double *coeff);
+/* The same coefficient given as an affine function of the PHYSICAL coordinates, c(x) = c[0] + c[1] x + c[2] y + c[3] z:
+   evaluated on the device through the geometry map, nothing is sampled or shipped by the host. */
+int igx_patch_set_coeff_affine(igx_patch *patch, const double c[4]);
 
 /* Coefficients of IGX_FORM: coef[4*r + s] is P_rs on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
    pointer) or NULL for an absent (zero) coefficient; r = jet index of the test function v, s = of the trial

@@ -83,6 +83,7 @@ SYMBOLS = [
     ('igx_entries_d', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('igx_load_vector_d', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('igx_fast_assemble', C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    ('igx_patch_set_coeff_affine', C.c_int, [C.c_void_p, C.c_double * 4]),
     ('igx_patch_set_form_d', C.c_int, [C.c_void_p, C.c_void_p * 16]),
     ('igx_patch_last_path', C.c_int, [C.c_void_p]),
     ('igx_patch_gauss_slab', C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -253,6 +253,11 @@ class DevicePatch:
         c = _lib.f64(np.broadcast_to(values, G))
         _lib.check(_lib.load().igx_patch_set_coeff(self.handle, _lib.dptr(c)), 'igx_patch_set_coeff')
 
+    def set_coeff_affine(self, c):
+        """Coefficient c[0] + c[1] x + c[2] y + c[3] z of the physical point, evaluated on the device."""
+        arr = (C.c_double * 4)(*[float(v) for v in c])
+        _lib.check(_lib.load().igx_patch_set_coeff_affine(self.handle, arr), 'igx_patch_set_coeff_affine')
+
     def load_vector(self, fvals):
         """Inner products of the owned basis functions with a function given by its values on the full
         tensor Gauss grid (scalar: shape G; vector-valued: G + trailing component axes)."""
@@ -400,6 +405,18 @@ class StiffnessAssembler3D(_DeviceAssembler):
     _kind, _dim = 'stiffness', 3
 
 
+class AffineCoefficient:
+    """c(x, y, z) = c0 + c1 x + c2 y + c3 z in physical coordinates.  Callable like any coefficient function (so it also
+    works with the reference); the device assemblers recognise it and evaluate it on the GPU instead of sampling it on
+    the host and shipping one double per Gauss point."""
+
+    def __init__(self, c0, c1=0.0, c2=0.0, c3=0.0):
+        self.c = (float(c0), float(c1), float(c2), float(c3))
+
+    def __call__(self, x, y, z):
+        return self.c[0] + self.c[1] * x + self.c[2] * y + self.c[3] * z
+
+
 class ConvDiffAssembler3D(_DeviceAssembler):
     _symmetric_form = False
     """Assembler for the variational form
@@ -420,6 +437,9 @@ class ConvDiffAssembler3D(_DeviceAssembler):
 
     def __init__(self, kvs0, geo, diff_coeff, device=None, row0=None):
         super().__init__(kvs0, geo, device=device, row0=row0)
+        if isinstance(diff_coeff, AffineCoefficient):
+            self.patch.set_coeff_affine(diff_coeff.c)             # evaluated on the device: nothing sampled on the host
+            return
         grid = [self.patch.gauss(k)[0] for k in range(3)]
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
         vals = diff_coeff(X[..., 0], X[..., 1], X[..., 2]) if callable(diff_coeff) else diff_coeff

@@ -478,6 +478,19 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     return IGX_OK;
 }
 
+int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
+{
+    if (!pt || !c) { set_error("igx_patch_set_coeff_affine: null argument"); return IGX_ERR_ARG; }
+    if (pt->dim != 3) { set_error("igx_patch_set_coeff_affine: the coefficient belongs to the 3D convection-diffusion form"); return IGX_ERR_UNSUPPORTED; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    const size_t n = (size_t)pt->dev.npts_loc;
+    if (!pt->d_coeff) IGX_HIP(hipMalloc((void **)&pt->d_coeff, std::max<size_t>(1, n) * sizeof(double)));
+    if (int rc = launch_coeff_affine(pt->ctx->stream, pt, c, pt->d_coeff)) return rc;
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    pt->fields_kind = -1;
+    return IGX_OK;
+}
+
 // coefficient table of IGX_FORM: validated into locals, committed to the patch only when everything (allocation, copies)
 // has succeeded -- a failed call leaves the previous form in place.  `on_device`: the arrays are device pointers over the
 // RESIDENT Gauss slab (igx_patch_gauss_slab), else host pointers over the full grid.

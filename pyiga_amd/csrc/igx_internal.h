@@ -170,6 +170,7 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
 int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3],
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);
 int launch_fields_dump(hipStream_t st, const igx_patch *pt);
+int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], double *d_coeff);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);

@@ -240,6 +240,41 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
     return IGX_OK;
 }
 
+// Affine coefficient  c(x) = c[0] + c[1] x + c[2] y + c[3] z  at the resident Gauss points, from the geometry map on the
+// device (the host path samples a Python callable on the whole grid and ships one double per Gauss point).
+template <int DIM>
+__global__ void k_coeff_affine(GeoView gv, bool nurbs, int g0_lo, int G0loc, int G1, int G2, double c0, double c1, double c2, double c3, double *coeff)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)G0loc * G1 * (DIM == 3 ? G2 : 1);
+    if (idx >= total) return;
+    int g[3];
+    if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
+    else { g[1] = idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
+    double Jm[MAX_COMP][3], ev[MAX_COMP];
+    physical_jacobian<DIM>(gv, nurbs, g, DIM, Jm, ev);
+    double v = c0 + c1 * ev[0] + c2 * ev[1];
+    if (DIM == 3) v += c3 * ev[2];
+    coeff[idx] = v;
+}
+
+int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], double *d_coeff)
+{
+    const int dim = pt->dim;
+    if (pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("an affine coefficient needs a spline geometry (physical coordinates)"); return IGX_ERR_UNSUPPORTED; }
+    GeoView gv = make_view(dim, pt->gax, pt->d_ctrl, pt->ncomp);
+    const PatchDev &pd = pt->dev;
+    const long long total = pd.npts_loc;
+    if (total == 0) return IGX_OK;
+    const int G1 = pd.ax[1].G, G2 = dim == 3 ? pd.ax[2].G : 1;
+    dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
+    if (dim == 2) k_coeff_affine<2><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, c[0], c[1], c[2], c[3], d_coeff);
+    else k_coeff_affine<3><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, c[0], c[1], c[2], c[3], d_coeff);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // geo_kind BSPLINE/NURBS: evaluate from the control net; JACOBIAN: read the user array slab.
 template <int DIM, bool FORM>

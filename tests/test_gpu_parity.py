@@ -1132,3 +1132,17 @@ def test_entry_func_ptr_capsule(iga):
     for i, j in ((0, 0), (8, 9), (20, 13), (3, 40)):
         assert fn(i, j, None) == asm.entry(i, j)
     assert fn(3, 40, None) == 0.0
+
+
+def test_affine_coefficient_on_device(iga):
+    """igx_patch_set_coeff_affine: the coefficient of the convection-diffusion form evaluated on the device through the
+    geometry map == the host-sampled callable (full patch and a row slab), to rounding."""
+    kv = iga.bspline.make_knots(2, 0., 1., 6)
+    kvs = (kv,) * 3
+    geo = _geo(iga, 'cylinder')
+    aff = iga.assemblers.AffineCoefficient(1.0, 0.5, -0.25, 2.0)
+    for row0 in (None, (2, 6)):
+        A = iga.assemblers.ConvDiffAssembler3D(kvs, geo, aff, row0=row0).assemble_csr()
+        B = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + 0.5 * x - 0.25 * y + 2.0 * z, row0=row0).assemble_csr()
+        assert rel_maxdiff(A, B) <= RTOL
+    assert aff(1.0, 2.0, 3.0) == 1.0 + 0.5 - 0.5 + 6.0
