@@ -1310,6 +1310,7 @@ int sumfact_prepare(igx_patch *pt)
     tab.insert(tab.end(), recB.begin(), recB.end());
     IGX_HIP(hipMalloc(&pt->d_steps, std::max<size_t>(1, tab.size()) * sizeof(int)));
     IGX_HIP(hipMemcpyAsync(pt->d_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));    // `tab` is a local: no copy in flight when an early return below destroys it
     pt->stepA_ptr = pt->d_steps + oA0; pt->stepA_rec = pt->d_steps + oA1;
     pt->stepB_ptr = pt->d_steps + oB0; pt->stepB_rec = pt->d_steps + oB1;
     pt->h_pl0 = pl;                                  // the line descriptors of the stage-kernel final are built on first use
