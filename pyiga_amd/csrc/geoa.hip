@@ -35,8 +35,7 @@ struct GeoAArgs {
     int nurbs, kind;
     int G1, G2;
     long long NPL, stride;      // points of a plane; doubles between the K1 slices of consecutive pairs
-    const double *V0;           // [G0][P][2] basis values and derivatives of the swept axis at its Gauss points
-    const int *step_ptr;        // [n0+1]
+    const double *tab;          // [G0][GA_REC] per-plane records (k_geoa_table): everything uniform a plane needs
     const int *steps;           // [nsteps][8]
     int s_lo, s_hi, q, chunk_len;
     int ntiles;                 // 64-point tiles of the plane
@@ -55,6 +54,36 @@ __device__ unsigned long long g_ga_stamp[2048 * 8 * 6];
 #define GA_T(i)
 #endif
 
+// Per-plane record of axis 0 (doubles): everything wave-uniform that a Gauss plane g needs, built once per patch so that
+// the staging inside the sweep is one coalesced copy without dependent loads or branches:
+//   [0, 12)   basis of the SPACE at the plane: [value | derivative][active function a < P <= 6]
+//   [12, 18)  basis of the GEOMETRY: (N, N') of its <= 3 active functions;  [18] quadrature weight;  [19] first active
+//             control index (as a double)
+//   [20, 24)  eight ints: number of flush steps after this plane (0 unless it ends a span) | first step | K1 slots of the
+//             first step's P pairs
+constexpr int GA_REC = 24;
+
+__global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const int *fa0g, int P0G, const double *w0, int q,
+                             const int *step_ptr, const int *steps, int G0, double *tab)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G0) return;
+    double *r = tab + (size_t)g * GA_REC;
+    for (int k = 0; k < GA_REC; ++k) r[k] = 0.0;
+    for (int a = 0; a < P; ++a) { r[a] = V0s[((size_t)g * P + a) * 2]; r[6 + a] = V0s[((size_t)g * P + a) * 2 + 1]; }
+    for (int e = 0; e < 2 * P0G; ++e) r[12 + e] = V0g[(size_t)g * P0G * 2 + e];
+    r[18] = w0[g];
+    r[19] = (double)fa0g[g];
+    int *ri = (int *)(r + 20);
+    const int s = g / q;
+    if (g - s * q == q - 1) {
+        const int st0 = step_ptr[s], st1 = step_ptr[s + 1];
+        ri[0] = st1 - st0; ri[1] = st0;
+        if (st1 > st0)
+            for (int a = 0; a < P; ++a) ri[2 + a] = steps[(size_t)st0 * 8 + a];
+    }
+}
+
 // Uniform tables (sweep coefficients, axis-0 geometry basis, flush records) are NOT read with scalar loads inside the loop:
 // the scalar cache holds 16 KB, the tables are larger, and a scalar load that misses it queues in the L2 behind the K1
 // store stream -- tools/ubench/k1_store.hip: 3.1 ms of arithmetic with such loads become 9.4 ms when the stores are on,
@@ -64,15 +93,13 @@ template <int P, int NS, int P0G, int NC>
 __global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 4 : 1, 4)))
 k_geoA(const GeoAArgs A)
 {
-    constexpr int PV = (P + 1) & ~1;                      // basis row padded to 16 bytes
+    constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = NS * 64;                           // threads
-    constexpr int NPI = NS * 2 * P;                       // basis values of a batch (value and derivative of the P active functions)
-    constexpr int KPI = (NPI + NT - 1) / NT;              // ... per thread
+    constexpr int NRC = NS * GA_REC;                      // doubles of a batch of plane records
+    constexpr int KRC = (NRC + NT - 1) / NT;              // ... per thread
     __shared__ double fld[2][NS][6][64];                  // fields of two batches of planes
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
-    __shared__ __attribute__((aligned(16))) double vs[2][NS][2][PV];     // axis-0 basis at the planes: [value | derivative][active function]
-    __shared__ double gts[2][NS][8];                      // axis-0 geometry basis at the plane: (N, N') x P0G | w0 | first active index
-    __shared__ int fts[2][NS][12];                        // plane ends a span: number of flush steps | first step | 8 slots of the first step
+    __shared__ __attribute__((aligned(16))) double rec[3][NS][GA_REC];   // plane records of three batches: swept | evaluated | arriving
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // consecutive block ids go to different XCDs: give each XCD a contiguous range of point tiles
@@ -89,55 +116,22 @@ k_geoA(const GeoAArgs A)
     const int s_begin = max(A.s_lo, own_lo - (P - 1));
     const int g_begin = s_begin * q, g_end = own_hi * q, g_last = g_end - 1;
 
-    // ---- table staging (vector loads; the values wait in registers until the end of the iteration)
+    // ---- table staging: a straight copy of the batch's plane records, requested at the top of an iteration and written to
+    // LDS at its end
     const GeoView &gv = A.gv;
-    // the sweep coefficient of pair (a, b) and type t = tu + 2 tv is V[b][tu] * V[a][tv]: the 2 P basis values of a plane are
-    // staged instead of the 4 P^2 products (LDS read bandwidth bounds this kernel: every broadcast read delivers 64 lanes)
-    double pi_reg[KPI], gt_reg = 0.0;
-    int ft_reg[2 + P];
-    auto stage_pi_load = [&](const int gb) {              // basis rows of the batch that starts at plane gb
+    double rc_reg[KRC];
+    auto stage_load = [&](const int gb) {
 #pragma unroll
-        for (int k = 0; k < KPI; ++k) {
-            const int i = tid + k * NT, j = i / (2 * P), r = i - j * (2 * P), d = r / P, a_ = r - d * P;
-            if (i < NPI) pi_reg[k] = A.V0[((size_t)min(gb + j, g_last) * P + a_) * 2 + d];
+        for (int k = 0; k < KRC; ++k) {
+            const int i = tid + k * NT, j = i / GA_REC;
+            if (i < NRC) rc_reg[k] = A.tab[(size_t)min(gb + j, g_last) * GA_REC + (i - j * GA_REC)];
         }
     };
-    auto stage_pi_store = [&](const int buf) {
+    auto stage_store = [&](const int slot) {
 #pragma unroll
-        for (int k = 0; k < KPI; ++k) {
-            const int i = tid + k * NT, j = i / (2 * P), r = i - j * (2 * P), d = r / P, a_ = r - d * P;
-            if (i < NPI) vs[buf][j][d][a_] = pi_reg[k];
-        }
-    };
-    auto stage_gt_load = [&](const int gb) {
-        if (tid < NS * 8) {
-            const int j = tid >> 3, e = tid & 7, g = min(gb + j, g_last);
-            if (e < 2 * P0G) gt_reg = gv.V[0][(size_t)g * P0G * 2 + e];
-            else if (e == 6) gt_reg = A.w0[g];
-            else if (e == 7) gt_reg = (double)gv.fa[0][g];
-        }
-    };
-    auto stage_gt_store = [&](const int buf) {
-        if (tid < NS * 8) (&gts[buf][0][0])[tid] = gt_reg;
-    };
-    auto stage_ft_load = [&](const int gb) {              // one thread per plane of the batch
-        if (tid < NS) {
-            const int g = gb + tid, sp_ = g / q;
-            ft_reg[0] = 0; ft_reg[1] = 0;
-            if (g < g_end && g - sp_ * q == q - 1) {
-                const int st0 = A.step_ptr[sp_], st1 = A.step_ptr[sp_ + 1];
-                ft_reg[0] = st1 - st0; ft_reg[1] = st0;
-                if (st1 > st0) {
-#pragma unroll
-                    for (int a = 0; a < P; ++a) ft_reg[2 + a] = A.steps[(size_t)st0 * 8 + a];
-                }
-            }
-        }
-    };
-    auto stage_ft_store = [&](const int buf) {
-        if (tid < NS) {
-#pragma unroll
-            for (int k = 0; k < 2 + P; ++k) fts[buf][tid][k] = ft_reg[k];
+        for (int k = 0; k < KRC; ++k) {
+            const int i = tid + k * NT;
+            if (i < NRC) (&rec[slot][0][0])[i] = rc_reg[k];
         }
     };
 
@@ -165,7 +159,7 @@ k_geoA(const GeoAArgs A)
     };
     // fields of plane j of the batch in buffer gbuf at this lane's point -> fld[buf][j]
     auto evaluate = [&](const int gbuf, const int buf) {
-        const double *gt = gts[gbuf][w];
+        const double *gt = &rec[gbuf][w][12];
         double V0[2 * P0G];
 #pragma unroll
         for (int e = 0; e < 2 * P0G; ++e) V0[e] = gt[e];
@@ -207,9 +201,9 @@ k_geoA(const GeoAArgs A)
     auto next_batch = [&](const int gn, const int gbuf, const int buf) {
         if (gn >= g_end) return;
         const int jl = min(NS - 1, g_last - gn);
-        const int mine = w <= jl ? __builtin_amdgcn_readfirstlane((int)gts[gbuf][w][7]) : -1;
-        const int last = __builtin_amdgcn_readfirstlane((int)gts[gbuf][jl][7]);
-        int cur = __builtin_amdgcn_readfirstlane((int)gts[gbuf][0][7]);
+        const int mine = w <= jl ? __builtin_amdgcn_readfirstlane((int)rec[gbuf][w][19]) : -1;
+        const int last = __builtin_amdgcn_readfirstlane((int)rec[gbuf][jl][19]);
+        int cur = __builtin_amdgcn_readfirstlane((int)rec[gbuf][0][19]);
         for (;;) {
             if (cur != f0_blk) {
                 columns(cur);
@@ -220,7 +214,7 @@ k_geoA(const GeoAArgs A)
             if (cur == last) break;
             int nxt = last;
             for (int j = jl; j >= 0; --j) {
-                const int v = __builtin_amdgcn_readfirstlane((int)gts[gbuf][j][7]);
+                const int v = __builtin_amdgcn_readfirstlane((int)rec[gbuf][j][19]);
                 if (v > cur) nxt = v;
             }
             cur = nxt;
@@ -239,39 +233,37 @@ k_geoA(const GeoAArgs A)
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tu = t & 1, tv = t >> 1;
     auto basis_row = [&](double (&v)[PV], const int buf, const int j, const int d) {
-        const d2 *row = (const d2 *)&vs[buf][j][d][0];
+        const d2 *row = (const d2 *)&rec[buf][j][6 * d];
 #pragma unroll
         for (int k = 0; k < P / 2; ++k) { const d2 x = row[k]; v[2 * k] = x.x; v[2 * k + 1] = x.y; }
-        if (P & 1) v[P - 1] = vs[buf][j][d][P - 1];
+        if (P & 1) v[P - 1] = rec[buf][j][6 * d + P - 1];
     };
 
 #ifdef IGX_GA_STAMP
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
 #endif
-    // prologue: tables of batches 0 (all) and 1 (geometry), fields of batch 0
-    stage_gt_load(g_begin); stage_gt_store(0);
-    stage_gt_load(g_begin + NS); stage_gt_store(1);
-    stage_pi_load(g_begin); stage_pi_store(0);
-    stage_ft_load(g_begin); stage_ft_store(0);
+    // prologue: plane records of batches 0 and 1, fields of batch 0
+    stage_load(g_begin); stage_store(0);
+    stage_load(g_begin + NS); stage_store(1);
     __syncthreads();
     next_batch(g_begin, 0, 0);
     __syncthreads();
     GA_T(0);
     int it = 0, l = 0, sp = s_begin;                      // plane gb + j = point l of span sp
+    int rs = 0;                                           // record slot of the batch being swept = it % 3
     for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
         const int buf = it & 1;
-        // Order of an iteration: table loads for the coming batches -> sweep of this batch (K1 stores) -> geometry of the
-        // next batch -> table values to LDS -> barrier.  The compiler cannot count the stores of the flush (they sit behind
-        // branches), so the wait for the table loads is a vmcnt(0): with the geometry evaluation between the last store and
+        const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;     // slots of batches it + 1 (evaluated), it + 2 (arriving)
+        // Order of an iteration: request the records of batch it + 2 -> sweep of this batch (K1 stores) -> geometry of the
+        // next batch -> records to LDS -> barrier.  The compiler cannot count the stores of the flush (they sit behind
+        // branches), so the wait for the record loads is a vmcnt(0): with the geometry evaluation between the last store and
         // that wait the stores are half an iteration old by then, instead of draining at full HBM latency once per batch
         // in front of the barrier.
-        stage_pi_load(gb + NS);
-        stage_ft_load(gb + NS);
-        stage_gt_load(gb + 2 * NS);
+        stage_load(gb + 2 * NS);
         double bv = fld[buf][0][fi][lane];
         double va[PV], vb[PV];                            // V[.][tv] (test functions, rows a), V[.][tu] (trial functions, columns b)
-        basis_row(va, buf, 0, tv);
-        if (tu != tv) basis_row(vb, buf, 0, tu);
+        basis_row(va, rs, 0, tv);
+        if (tu != tv) basis_row(vb, rs, 0, tu);
         else {
 #pragma unroll
             for (int k = 0; k < PV; ++k) vb[k] = va[k];
@@ -288,7 +280,7 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
             for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c[a]));
             asm volatile("" ::: "memory");
-            basis_row(va, buf, jn, tv);
+            basis_row(va, rs, jn, tv);
             if (!(A.dbg & 4)) {
 #pragma unroll
                 for (int a = 0; a < P; ++a)
@@ -300,7 +292,7 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
                 for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[a][b]));
             asm volatile("" ::: "memory");
-            if (tu != tv) basis_row(vb, buf, jn, tu);
+            if (tu != tv) basis_row(vb, rs, jn, tu);
             else {                                        // same row: no second broadcast read
 #pragma unroll
                 for (int k = 0; k < PV; ++k) vb[k] = va[k];
@@ -310,12 +302,13 @@ k_geoA(const GeoAArgs A)
             if (++l < q) continue;
             // dofs that leave the active set after span sp: their pairs are complete
             const bool write = sp >= own_lo && !(A.dbg & 2);
-            const int nst = __builtin_amdgcn_readfirstlane(fts[buf][j][0]), st0 = __builtin_amdgcn_readfirstlane(fts[buf][j][1]);
+            const int *fr = (const int *)&rec[rs][j][20];
+            const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
             for (int st = st0; st < st0 + nst; ++st) {
                 int pr[P];
                 if (st == st0) {
 #pragma unroll
-                    for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(fts[buf][j][2 + a]);
+                    for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(fr[2 + a]);
                 } else {                                  // (several dofs leave at the end of the axis)
                     const int8v rec = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 8);
 #pragma unroll
@@ -335,11 +328,10 @@ k_geoA(const GeoAArgs A)
             GA_T(2);                                      // flush
         }
         GA_T(1);
-        next_batch(gb + NS, buf ^ 1, buf ^ 1);
+        next_batch(gb + NS, rn, buf ^ 1);
         GA_T(0);                                          // geometry
-        stage_pi_store(buf ^ 1);
-        stage_ft_store(buf ^ 1);
-        stage_gt_store(buf);                              // batch it + 2
+        stage_store(ra);
+        rs = rn;
         __syncthreads();
         GA_T(3);                                          // barrier
     }
@@ -402,13 +394,20 @@ int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const
 {
     const PatchDev &pd = pt->dev;
     const Axis &A0 = pt->ax[0];
+    if (!pt->d_geoa_tab) {                               // per-plane records of axis 0: once per patch
+        igx_patch *mpt = const_cast<igx_patch *>(pt);
+        IGX_HIP(hipMalloc((void **)&mpt->d_geoa_tab, (size_t)A0.G * GA_REC * sizeof(double)));
+        k_geoa_table<<<dim3((A0.G + 127) / 128), dim3(128), 0, st>>>(A0.d_V, A0.P, pt->gax[0].d_V, pt->gax[0].d_fa, pt->gax[0].P, pd.ax[0].w, A0.q,
+                                                                     pt->stepA_ptr, pt->stepA_rec, A0.G, mpt->d_geoa_tab);
+        IGX_HIP(hipGetLastError());
+    }
     GeoAArgs A{};
     A.gv = make_view(3, pt->gax, pt->d_ctrl, pt->ncomp);
     A.w0 = pd.ax[0].w; A.w1 = pd.ax[1].w; A.w2 = pd.ax[2].w;
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
     A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
-    A.V0 = A0.d_V; A.step_ptr = pt->stepA_ptr; A.steps = pt->stepA_rec;
+    A.tab = pt->d_geoa_tab; A.steps = pt->stepA_rec;
     A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.q = A0.q; A.chunk_len = chunk_len;
     { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
     for (int x = 0; x < nslots; ++x) { A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x]; }

@@ -342,7 +342,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
-    (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
+    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
     (void)hipFree(pt->d_ws_ij); (void)hipFree(pt->d_ws_out);
     (void)hipFree(pt->d_lv_f); (void)hipFree(pt->d_lv_t1); (void)hipFree(pt->d_lv_t2); (void)hipFree(pt->d_lv_o);
     delete pt;

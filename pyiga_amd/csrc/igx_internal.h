@@ -141,6 +141,7 @@ struct igx_patch {
     bool ldesc_ok = false;
     int *d_steps = nullptr;                   // flush-step tables of the sweeps (one allocation)
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
+    double *d_geoa_tab = nullptr;             // per-plane records of axis 0 for k_geoA (geoa.hip), built on first use
     double *d_K1 = nullptr, *d_K2 = nullptr;
     size_t K1_cap = 0, K2_cap = 0;
     // persistent workspaces of the batched-entry and load-vector entry points (grow-only, freed with the patch)
