@@ -99,6 +99,7 @@ struct BFArgs {
     int mid_lo, mid_hi;           // rows of the mid axis to produce
     int span_hi;                  // spans of the mid axis below this one are resident (2D row slabs; else n1)
     int npairs;
+    int pair_off;                 // first pair of this launch (index into pl0 = K1 slice)
     int dbg;                      // ablation mask (IGX_BF_DBG; timing experiments only): 1 no contraction, 2 no segment stores,
                                   //   4 no sweep arithmetic
 };
@@ -148,7 +149,7 @@ struct BFHelp {
     BFBlk blk;
 };
 template <int P, int NY, int MASK, int A0, int A1>
-__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl);
+__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl, const int TL = BF_TL);
 
 // ---- segment stores: whole CSR segments of the mid-axis row completed two steps ago, from the entry rings.  NCW "store
 // waves" share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
@@ -396,9 +397,9 @@ struct BFSweepDispatch<P, MASK, NA, RI, true> {
 // -- every K and V value is read from LDS once per (line, span), not once per row.  The values of point l+1 are requested
 // before the arithmetic of point l.  One role per type: role index = position of the type among those that occur.
 template <int P, int NY, int MASK, int A0 = 0, int A1 = P>
-__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl)
+__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl, const int TL)
 {
-    constexpr int TL = BF_TL, NA_ = A1 - A0;             // rows A0 .. A1-1 of the element matrix (test functions)
+    constexpr int NA_ = A1 - A0;             // rows A0 .. A1-1 of the element matrix (test functions)
     // LDS row of type y inside the line image (roles are ordered by type)
     constexpr int ry0 = 0;
     constexpr int ry1 = bf_roles_of_y(MASK & 15);
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     }
     const int tile = (int)(bid % A.ntiles);
     const int mch = (int)((bid / A.ntiles) % A.nmchunks);
-    const int r0 = (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
+    const int r0 = A.pair_off + (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
     const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
     const bool diag0 = A.sym && i0 == j0;
     const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
@@ -637,6 +638,440 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
     BF_STAMP_END(wave);
 }
 
+// =============================================================================================
+// k_bf2: the fused stage for 16 waves per CU (P <= 5).  Same data flow as k_bf -- sweepers flush the completed K2 lines to
+// LDS, contractors turn them into CSR row segments -- re-tiled around what bounds the stage, the vector ALU (an FP64
+// instruction occupies it for 5 cycles, any other vector instruction for 4; scalar, LDS-read and memory instructions of
+// other waves issue under it: tools/ubench/valu_f64.hip):
+//   * tile = 64 * NLG Gauss points of the last axis (NLG = 3: 38 spans, 34 rows at p = 4; k_bf: 21 spans, 17 rows on 128
+//     lanes), NLG waves per role + 4 contractor waves = 16 waves, four per SIMD (<= 128 VGPRs each);
+//   * contractor items are (line, span) as before, but lanes hold PIECES of a line (PL consecutive spans, pieces overlap by
+//     p spans, 64 / PL pieces per pass): the entries of row i2 are the sum over the p + 1 spans of its support, i.e. over the
+//     element matrices of the p + 1 lanes below its own -- fetched with ds_bpermute, no exchange buffer in LDS, no barrier;
+//   * entry rings are row-major ([row][line][entry]): a store slot is one LDS read at a compile-time offset and one store at
+//     (scalar row base of the step) + (per-lane offset worked out once): no address arithmetic per element on interior rows
+//     of the mid axis; the first and last p rows take a general path;
+//   * K1 loads are (scalar base) + (per-lane offset): the row advance is scalar arithmetic.
+template <int P, int NLG, int NRO> struct BF2Geom {
+    static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
+    static constexpr int ROWR = p * W, ROWC = P * W;        // doubles per row in the ring / cur parts
+    static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
+    static constexpr int nslots(int R, int per) { return (R * per * W + 64 * BF_NCW - 1) / (64 * BF_NCW); }
+    // LDS image (doubles): lines [W][LS] | ring [P+1][R][p][W] | cur [2][R][P][W] | basis values [TL][P][2] | store plan
+    // (ints) [NSR + NSC][NCW * 64];  R = rows of the last axis per tile: as many as the window and 160 KB allow
+    static constexpr int off_ring() { return (W * LS + 1) & ~1; }
+    static constexpr int off_cur(int R) { return (off_ring() + (P + 1) * R * ROWR + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_cur(R) + 2 * R * ROWC + 1) & ~1; }
+    static constexpr int off_plan(int R) { return off_v2(R) + TL * P * 2; }
+    static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * BF_NCW * 32; }
+    static constexpr int rmax()
+    {
+        int R = TL / P - p;
+        while (R > 1 && lds_doubles(R) * 8 > 160 * 1024) --R;
+        return R;
+    }
+    static constexpr int RMAX = rmax();
+    static constexpr int WS = RMAX + p;                     // spans of the tile window
+    static constexpr int OFF_RING = off_ring(), OFF_CUR = off_cur(RMAX), OFF_V2 = off_v2(RMAX), OFF_PLAN = off_plan(RMAX);
+    static constexpr int LDS_BYTES = lds_doubles(RMAX) * 8;
+    static constexpr int NSR = nslots(RMAX, p), NSC = nslots(RMAX, P);     // store slots per contractor wave: ring / cur part
+    // contractor passes: pieces of PL consecutive spans of a line, 64 / PL pieces per pass, consecutive pieces overlap by p spans
+    static constexpr int npc(int pl) { return (RMAX + pl - p - 1) / (pl - p); }              // pieces per line
+    static constexpr int npass(int pl) { return (W * npc(pl) + 64 / pl - 1) / (64 / pl); }   // passes per step
+    static constexpr int pick()
+    {
+        int best = 64;
+        const int cand[4] = {64, 32, 21, 16};
+        for (int i = 1; i < 4; ++i)
+            if (cand[i] > 2 * p && npass(cand[i]) < npass(best)) best = cand[i];
+        return best;
+    }
+    static constexpr int PL = pick();                       // spans (lanes) of a piece
+    static constexpr int PPP = 64 / PL;                     // pieces per pass
+    static constexpr int NPC = npc(PL);                     // pieces per line
+    static constexpr int RP = PL - p;                       // rows a piece completes
+};
+
+__device__ __forceinline__ double bf2_from_lane(const int src4, const double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+typedef int bf2_v2i __attribute__((ext_vector_type(2)));
+#ifndef BF2_AH
+#define BF2_AH 0                                         // 1: element matrices in two halves (fewer registers, LDS values read twice)
+#endif
+constexpr int BF2_NUMREC = 0x7ffffff0;                     // bytes a descriptor covers; per-lane offsets at or above it are out of range
+constexpr int BF2_OOB = 0x7ffffff8;                        // per-lane offset of a lane that must not store (dropped by the range check)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf2_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, BF2_NUMREC, 0x00020000);
+}
+__device__ __forceinline__ double bf2_buffer_load(__amdgpu_buffer_rsrc_t r, const int voff, const int soff)
+{
+    const bf2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ void bf2_buffer_store(__amdgpu_buffer_rsrc_t r, const int voff, const int soff, const double x)
+{
+    bf2_v2i v;
+    v.x = __double2loint(x); v.y = __double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+struct BF2Blk {
+    int i0, j0, diag0, c0i, cj0, rlo, rhi, row_lo, nrows;
+    long long S12;
+};
+
+// offset (doubles, relative to the row block of mid-axis row dd2) of store element q of a part, or -1.
+//   ring part: q = (rr * p + kx) * W + o      entries of the pairs (dd2, j1 < dd2), kx = p - (dd2 - j1)
+//   cur part:  q = (rr * P + a) * W + o       entries of the pairs (dd2, dd2 + a)
+// o counts the existing columns of row i2 from its first one (packed run, as the rings hold it).
+template <int P>
+__device__ __forceinline__ int bf2_goff(const BFArgs &A, const BF2Blk &B, const bool cur_part, const int q, const int dd2)
+{
+    constexpr int p = P - 1, W = 2 * P - 1;
+    const int per = cur_part ? P : p;
+    const int rr = q / (per * W), e2 = q - rr * (per * W);
+    const int k = e2 / W, o = e2 - k * W;
+    if (rr >= B.nrows) return -1;
+    const int i2 = B.row_lo + rr;
+    const int jl2 = max(i2 - p, 0), c2 = min(i2 + p, A.N2 - 1) + 1 - jl2;
+    if (o >= c2) return -1;
+    const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
+    int m;                                                  // line of the segment: j1 = jl1 + m
+    if (cur_part) {
+        if (dd2 + k >= A.N1) return -1;
+        if (B.diag0 && (k > 0 || jl2 + o > i2)) return -1;  // diagonal block: only j1 <= i1, and on the diagonal line j2 <= i2
+        m = dd2 - jl1 + k;
+    } else {
+        const int koff = p - (dd2 - jl1);
+        if (k < koff) return -1;
+        m = k - koff;
+    }
+    return B.c0i * c1 * ((cip)A.rp2)[i2] + (B.cj0 * c1 + m) * c2 + o;
+}
+
+template <int P, int MASK, int RI, int NA, int NLG>
+__device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
+                                            const int rhi, double *lines, const int LS)
+{
+    constexpr BFRole R = bf_role(MASK, RI);
+    constexpr int p = P - 1, TL = 64 * NLG;
+    __builtin_amdgcn_s_setprio(3);
+    cdp V1 = (cdp)A.V1;
+    double acc[P][P];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+    // input rows through buffer descriptors: (descriptor of the slot's slice: scalar) + (scalar row offset) + (this lane's
+    // point): a load costs no vector instruction and no address registers
+    __amdgpu_buffer_rsrc_t rsrc[4][NA];
+    int urs[4][NA];
+    const int voff = g2 * 8;
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            urs[t1][i] = A.rs[R.y][t1][i] * 8;               // bytes between rows of the mid axis (a slice is < 2^31 bytes: checked on the host)
+            rsrc[t1][i] = bf2_rsrc(A.sp[R.y][t1][i] + (long long)r0 * A.ss[R.y][t1][i] - (long long)A.gmid_lo * A.rs[R.y][t1][i]);
+        }
+    auto ld = [&](const int t1, const int i, const int row) {
+        return bf2_buffer_load(rsrc[t1][i], voff, row * urs[t1][i]);
+    };
+    const int n_sw = min(A.n1, A.span_hi);
+    const int t_sw = min(n_sw, rhi);
+    double kv[P][4][NA];
+    {
+        const int s = min(s_begin, t_sw - 1);
+#pragma unroll
+        for (int l = 0; l < P; ++l)
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1)
+                if (R.has[t1])
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * P + l);
+    }
+    auto flush = [&]() {
+        double *ln = lines + RI * TL + g2l;
+#pragma unroll
+        for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
+#pragma unroll
+        for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
+#pragma unroll
+        for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+        for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
+    };
+    int t = s_begin;
+    for (; t < t_sw; ++t) {
+        bar_lds();                                       // B1
+        const int tn = min(t + 1, t_sw - 1);
+        cdp cf = V1 + (size_t)t * P * P * 2;
+        double v[P][2];
+#pragma unroll
+        for (int b = 0; b < P; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
+#pragma unroll
+        for (int l = 0; l < P; ++l) {
+            double vn[P][2];
+            const int ln_ = l + 1 < P ? l + 1 : l;
+#pragma unroll
+            for (int b = 0; b < P; ++b) { vn[b][0] = cf[(ln_ * P + b) * 2]; vn[b][1] = cf[(ln_ * P + b) * 2 + 1]; }
+            double kt[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1)
+                if (R.has[t1]) {
+                    kt[t1] = kv[l][t1][0];
+                    if (NA == 2) kt[t1] += kv[l][t1][1];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, tn * P + l);
+                }
+            if (R.shape == 1) {
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    double w;
+                    if (R.has[2 * R.f] && R.has[2 * R.f + 1]) w = fma(v[b][1], kt[2 * R.f + 1], v[b][0] * kt[2 * R.f]);
+                    else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
+                    else w = v[b][1] * kt[2 * R.f + 1];
+#pragma unroll
+                    for (int a = 0; a < P; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
+                }
+            } else {
+#pragma unroll
+                for (int tu = 0; tu < 2; ++tu) {
+                    if (!(R.has[tu] || R.has[tu + 2])) continue;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        double c;
+                        if (R.has[tu] && R.has[tu + 2]) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
+                        else if (R.has[tu]) c = v[a][0] * kt[tu];
+                        else c = v[a][1] * kt[tu + 2];
+#pragma unroll
+                        for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+#pragma unroll
+            for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
+        }
+        bar_lds();                                       // B2: the contractors have read the previous lines
+        flush();
+    }
+    for (; t < rhi; ++t) { bar_lds(); bar_lds(); flush(); }          // spans past the end of the axis: the window only drains
+    for (; t < rhi + 2; ++t) { bar_lds(); bar_lds(); }                // the contractors finish the last two rows
+}
+
+template <int P, int MASK, int NA, int NLG, int RI, bool END = (RI >= bf_nroles(MASK))>
+struct BF2SweepDispatch {
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    {
+        if (role == RI) bf2_sweeper<P, MASK, RI, NA, NLG>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
+        else BF2SweepDispatch<P, MASK, NA, NLG, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+    }
+};
+template <int P, int MASK, int NA, int NLG, int RI>
+struct BF2SweepDispatch<P, MASK, NA, NLG, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+};
+
+template <int P, int NY, int MASK, int NA, int NLG>
+__global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(const BFArgs A)
+{
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK)>;
+    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG, NCW = BF_NCW;
+    constexpr int RMAX = Gm::RMAX, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
+    constexpr int LS = Gm::LS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *lines = lds;                 // [W][LS]
+    double *ring = lds + Gm::OFF_RING;   // [P+1][RMAX][p][W]: entries of the pairs (i1, j1 < i1), slot i1 mod (P+1), line kx = p - (i1 - j1)
+    double *cur = lds + Gm::OFF_CUR;     // [2][RMAX][P][W]:   entries of the pairs (d, d + a), slot d & 1
+    double *V2s = lds + Gm::OFF_V2;      // [TL][P][2]: last-axis basis values on the tile window
+    int *plan = (int *)(lds + Gm::OFF_PLAN);   // [NSR + NSC][NCW][64]: byte offsets of the store elements (interior mid-axis rows)
+
+    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned per = gridDim.x / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    const int tile = (int)(bid % A.ntiles);
+    const int mch = (int)((bid / A.ntiles) % A.nmchunks);
+    const int r0 = A.pair_off + (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
+    const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
+    const bool diag0 = A.sym && i0 == j0;
+    const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
+    const int sp_lo = row_lo - p;                                      // first span of the window (virtual: may lie before the axis)
+    const int win0 = sp_lo * P;
+    const int rlo = A.mid_lo + mch * A.mrows, rhi = min(rlo + A.mrows, A.mid_hi);
+    const int s_begin = max(rlo - p, 0);
+
+    for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) {
+        const int gpt = win0 + idx / (2 * P);
+        V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P * 2 + idx] : 0.0;
+    }
+    // (the barrier B1 of the first iteration orders these writes before their first use)
+
+    // wave -> task: a workgroup's waves go to the four SIMDs cyclically; FP64 instructions per step and wave at p = 4:
+    // sweepers of role 0: 370, roles 1, 2: 200, role 3: 165; a contractor pass: 400 (six passes: contractors 0, 1 take two)
+    int task = wave;
+    if (NR == 4 && NLG == 3 && NCW == 4) {
+        constexpr int tmap[16] = {12, 13, 14, 15, 9, 3, 0, 2, 10, 4, 1, 7, 11, 6, 5, 8};
+        task = tmap[wave & 15];
+    } else if (NR == 4 && NLG == 2 && NCW == 4) {
+        const int sd = wave & 3, k = wave >> 2;
+        if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
+        else task = k < 2 ? k : NSW + 3;
+    }
+    if (task < NSW) {
+        const int role = task / NLG, lg = task % NLG;
+        const int g2l = lg * 64 + lane;
+        const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);              // points outside the axis: any finite value (their spans are skipped)
+        BF2SweepDispatch<P, MASK, NA, NLG, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        return;
+    }
+
+    // ---------------- contractors
+    const int cw = task - NSW;
+    BF2Blk B;
+    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.cj0 = j0 - jlo0[i0]; B.rlo = rlo; B.rhi = rhi;
+    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2;
+    // store plan of the interior rows of the mid axis (p <= i1 < N1 - p: the segment has 2p + 1 lines, the first one is
+    // j1 = i1 - p): offset of element q inside the row block, or -1.  Element q of slot k: q = (k * NCW + cw) * 64 + lane.
+    // (kept in LDS, one int per element, written and read by the same wave: the registers belong to the element matrices)
+    int *myplan = plan + cw * 64 + lane;
+    {
+        const int ddi = min(p, max(A.N1 - P, 0));                      // any interior row gives the same offsets
+#pragma unroll
+        for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, (k * NCW + cw) * 64 + lane, ddi); myplan[k * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
+#pragma unroll
+        for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, (k * NCW + cw) * 64 + lane, ddi); myplan[(Gm::NSR + k) * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
+    }
+    const int ps = lane / PL, x = lane - ps * PL;                      // piece slot of the pass, span of the piece
+    const int nlines = diag0 ? P : W;
+    const int npieces = nlines * NPC;
+    cip rp0 = (cip)A.rp0, rp1 = (cip)A.rp1;
+    // the row blocks of outer row i0 through one descriptor: (scalar) offset of mid-axis row i1 = 8 c0i rp1[i1] S2 bytes
+    const __amdgpu_buffer_rsrc_t drs = bf2_rsrc(A.data + ((long long)rp0[i0] * B.S12 - A.nnz_off));
+    const long long rstep = (long long)B.c0i * A.S2 * 8;               // (a block of c0i * S1 * S2 values is < 2^31 bytes: checked on the host)
+    // the last read of a part may not leave it (the slots are padded to whole waves)
+    constexpr int RCLAMP = RMAX * Gm::ROWR - 1, CCLAMP = RMAX * Gm::ROWC - 1;
+    for (int t = s_begin; t < rhi + 2; ++t) {
+        bar_lds();                                        // B1: the lines of flush t-1 are in LDS
+        // ---- whole row segments of mid-axis row t - 2
+        const int dd2 = t - 2;
+        if (dd2 >= rlo && dd2 < rhi) {
+            const int soff = (int)(rstep * rp1[dd2]);
+            const double *rg = ring + (size_t)(dd2 % (P + 1)) * RMAX * Gm::ROWR;
+            const double *cu = cur + (size_t)(dd2 & 1) * RMAX * Gm::ROWC;
+            const int q0 = cw * 64 + lane;
+            if (dd2 >= p && dd2 < A.N1 - p) {
+                double vr[Gm::NSR], vc[Gm::NSC];
+                int gr[Gm::NSR], gc[Gm::NSC];
+#pragma unroll
+                for (int k = 0; k < Gm::NSR; ++k) {
+                    gr[k] = myplan[k * NCW * 64];
+                    vr[k] = rg[(k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP)];
+                }
+#pragma unroll
+                for (int k = 0; k < Gm::NSC; ++k) {
+                    gc[k] = myplan[(Gm::NSR + k) * NCW * 64];
+                    vc[k] = cu[(k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP)];
+                }
+#pragma unroll
+                for (int k = 0; k < Gm::NSR; ++k) bf2_buffer_store(drs, gr[k], soff, vr[k]);
+#pragma unroll
+                for (int k = 0; k < Gm::NSC; ++k) bf2_buffer_store(drs, gc[k], soff, vc[k]);
+            } else {
+                for (int k = 0; k < Gm::NSR; ++k) {
+                    const int q = q0 + k * NCW * 64;
+                    const int g = bf2_goff<P>(A, B, false, q, dd2);
+                    bf2_buffer_store(drs, g < 0 ? BF2_OOB : g * 8, soff, rg[min(q, RCLAMP)]);
+                }
+                for (int k = 0; k < Gm::NSC; ++k) {
+                    const int q = q0 + k * NCW * 64;
+                    const int g = bf2_goff<P>(A, B, true, q, dd2);
+                    bf2_buffer_store(drs, g < 0 ? BF2_OOB : g * 8, soff, cu[min(q, CCLAMP)]);
+                }
+            }
+        }
+        // ---- contract the lines of flush dd = t - 1 with the last axis
+        const int dd = t - 1;
+        if (dd >= s_begin && dd < rhi) {
+            for (int pass = cw; pass * PPP < npieces; pass += NCW) {
+                const int pid = pass * PPP + ps;
+                const int k9 = pid / NPC, pj = pid - k9 * NPC;
+                const int s1 = pj * RP + x;                            // span of the window
+                const int la = k9 <= p ? k9 : k9 - p;
+                const int row1 = k9 <= p ? dd + la : dd, col1 = k9 <= p ? dd : dd + la;
+                const bool lok = ps < PPP && pid < npieces && row1 >= rlo && row1 < rhi && col1 < A.N1;
+                const int sp = sp_lo + s1;
+                const bool eok = lok && s1 < Gm::WS && sp >= 0 && sp < A.n2;
+                const double *kl = lines + k9 * LS + s1 * P, *vl = V2s + s1 * P * P * 2;
+                // entries of row i2 = sp (the row whose function index a = 0 sits on this lane's span): entry o = b - a + p comes
+                // from the element matrix of span i2 - a, i.e. of the lane a places below.  Two halves of the element matrix
+                // (registers): rows 0 .. AH-1, then AH .. p.
+                constexpr int AH = BF2_AH > 0 ? (P + 1) / 2 : P;
+                double out[W];
+#pragma unroll
+                for (int o = 0; o < p; ++o) out[o] = 0.0;
+                {
+                    double loc[AH][P];
+                    if (eok) bf_element<P, NY, MASK, 0, AH>(loc, kl, vl, TL);
+                    else {
+#pragma unroll
+                        for (int a = 0; a < AH; ++a)
+#pragma unroll
+                            for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
+                    }
+#pragma unroll
+                    for (int b = 0; b < P; ++b) out[b + p] = loc[0][b];
+#pragma unroll
+                    for (int a = 1; a < AH; ++a)
+#pragma unroll
+                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a][b]);
+                }
+                if constexpr (AH < P) {
+                    double loc[P - AH][P];
+                    if (eok) bf_element<P, NY, MASK, AH, P>(loc, kl, vl, TL);
+                    else {
+#pragma unroll
+                        for (int a = 0; a < P - AH; ++a)
+#pragma unroll
+                            for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
+                    }
+#pragma unroll
+                    for (int a = AH; a < P; ++a)
+#pragma unroll
+                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - AH][b]);
+                }
+                const int r3 = s1 - p;                                 // row of the tile
+                if (lok && x >= p && r3 < nrows) {
+                    const int i2 = row_lo + r3;
+                    const int oshv = max(p - i2, 0);
+                    double *dste = (k9 <= p && la > 0) ? ring + ((size_t)((row1 % (P + 1)) * RMAX + r3) * p + (p - la)) * W
+                                                       : cur + ((size_t)((dd & 1) * RMAX + r3) * P + (k9 <= p ? 0 : la)) * W;
+                    dste -= oshv;
+#pragma unroll
+                    for (int o = 0; o < W; ++o)
+                        if (o >= oshv) dste[o] = out[o];
+                }
+            }
+        }
+        bar_lds();                                        // B2: lines may be overwritten, entries are visible
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Mirror pass: upper-triangle entries from the lower triangle.  Block = (target outer pair (i0, j0 >= i0), chunk of
 // rows i2 of the last axis, range of rows i1 of the mid axis); it walks its rows i1.  Per step the source runs
@@ -657,17 +1092,20 @@ struct MirrorArgs {
     int ntp, RC, nchunks;
 };
 
-template <int WW> struct MirrorGeom {
-    static constexpr int RCM = WW == 3 ? 128 : WW == 5 ? 128 : WW == 7 ? 112 : WW == 9 ? 66 : 40;   // rows i2 per block (tile <= 48 KB)
+template <int WW, bool LEAN = false> struct MirrorGeom {
+    // rows i2 per block (tile <= 48 KB); LEAN: tile <= 20 KB and few registers, so that a block fits on a CU NEXT TO a block of
+    // k_bf (which leaves ~21 KB of LDS and 80 VGPRs per SIMD): the pass then runs under the fused stage of the next range
+    static constexpr int RCM = LEAN ? (WW == 3 ? 128 : WW == 5 ? 64 : WW == 7 ? 32 : WW == 9 ? 16 : 10)
+                                    : (WW == 3 ? 128 : WW == 5 ? 128 : WW == 7 ? 112 : WW == 9 ? 66 : 40);
     static constexpr int NJ2 = RCM + WW - 1;                           // source rows j2 around a chunk
     static constexpr int SG = (NJ2 * WW + 255) / 256;                  // gather elements (j2, offset) per thread and j1
     static constexpr int SS = (RCM * WW * WW + 255) / 256;             // target elements per thread
 };
 
-template <int WW>
+template <int WW, bool LEAN>
 __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 {
-    using Gm = MirrorGeom<WW>;
+    using Gm = MirrorGeom<WW, LEAN>;
     constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS;
     extern __shared__ __attribute__((aligned(16))) double T[];           // [WW][NJ2][WW]
     cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1;
@@ -785,7 +1223,51 @@ static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
     return IGX_OK;
 }
 
+template <int P, int NY, int MASK, int NA, int NLG>
+static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
+{
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK)>;
+    constexpr size_t lds = (size_t)Gm::LDS_BYTES;
+    static_assert(lds <= 160 * 1024, "k_bf2: LDS");
+    static_assert((bf_nroles(MASK) * NLG + BF_NCW) * 64 <= 1024, "k_bf2: block size");
+    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_bf2<P, NY, MASK, NA, NLG><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + BF_NCW) * 64), lds, st>>>(A);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
+
+// lane groups per role of k_bf2: three where the register budget of 16 waves per CU (128 VGPRs) holds the sweeper
+constexpr int bf2_nlg(int P, int na) { return na == 1 ? 3 : 2; }
+template <int P>
+static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
+{
+    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_k<P, 1, BF_MASK_MASS, 1, 3>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 1, 3>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 2, 2>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF2, 1, 3>(st, A, nblocks);
+    set_error("fused stage: no kernel for this set of types");
+    return IGX_ERR_UNSUPPORTED;
+}
+template <int P> static int bf2_rows_p(int nroles, int nlg)
+{
+    if (nroles == 1) return BF2Geom<P, 3, 1>::RMAX;
+    return nlg == 3 ? BF2Geom<P, 3, 4>::RMAX : BF2Geom<P, 2, 4>::RMAX;
+}
+int fused2_rows_per_tile(int P, int nroles, int na)
+{
+    const int nlg = bf2_nlg(P, na);
+    switch (P) {
+    case 2: return bf2_rows_p<2>(nroles, nlg);
+    case 3: return bf2_rows_p<3>(nroles, nlg);
+    case 4: return bf2_rows_p<4>(nroles, nlg);
+    case 5: return bf2_rows_p<5>(nroles, nlg);
+    }
+    return 1;
+}
+static bool bf2_wanted() { const char *e = getenv("IGX_BF"); return !(e && atoi(e) == 1); }
+
 
 template <int P>
 static int launch_bf_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
@@ -847,24 +1329,33 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     A.S1 = AM.S; A.S2 = AL.S; A.nnz_off = pt->nnz_off;
     A.data = d_data; A.sym = in.sym;
     const int P = AL.P;
-    const int rmax = fused_rows_per_tile(P);
+    const bool v2 = bf2_wanted();
+    const int rmax = v2 ? fused2_rows_per_tile(P, ny == 1 ? 1 : 4, na) : fused_rows_per_tile(P);
     A.ntiles = (AL.N + rmax - 1) / rmax;
     A.R2 = (AL.N + A.ntiles - 1) / A.ntiles;
     A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
     // chunks of the mid axis: enough blocks to fill the chip (each chunk re-sweeps p warm-up spans)
     const int mid_rows = in.mid_hi - in.mid_lo;
-    long long blocks = (long long)in.npairs * A.ntiles;
+    long long blocks = (long long)(in.npairs_all > 0 ? in.npairs_all : in.npairs) * A.ntiles;
     int nmch = 1;
     if (blocks < 1024) nmch = (int)std::min<long long>((1024 + blocks - 1) / blocks, std::max(1, mid_rows / (2 * P)));
     if (const char *e = getenv("IGX_BF_MCHUNKS")) nmch = std::max(1, std::min(mid_rows, atoi(e)));
     A.mrows = (mid_rows + nmch - 1) / nmch;
     A.nmchunks = (mid_rows + A.mrows - 1) / A.mrows;
-    A.npairs = in.npairs;
+    A.npairs = in.npairs; A.pair_off = in.pair_off;
     A.dbg = getenv("IGX_BF_DBG") ? atoi(getenv("IGX_BF_DBG")) : 0;
     blocks = (long long)in.npairs * A.ntiles * A.nmchunks;
     if (blocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (blocks == 0) return IGX_OK;
     const unsigned nb = (unsigned)blocks;
+    if (v2)
+        switch (P) {
+        case 2: return launch_bf2_p<2>(st, A, nb, ny, mask, na);
+        case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na);
+        case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na);
+        case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na);
+        default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
+        }
     switch (P) {
     case 2: return launch_bf_p<2>(st, A, nb, ny, mask, na);
     case 3: return launch_bf_p<3>(st, A, nb, ny, mask, na);
@@ -874,10 +1365,10 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     }
 }
 
-template <int WW>
+template <int WW, bool LEAN>
 static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
 {
-    using Gm = MirrorGeom<WW>;
+    using Gm = MirrorGeom<WW, LEAN>;
     M.nchunks = (N2 + Gm::RCM - 1) / Gm::RCM;
     M.RC = (N2 + M.nchunks - 1) / M.nchunks;
     // a launch wants >= ~1536 blocks: split the rows i1 of a (pair, chunk)
@@ -889,9 +1380,10 @@ static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
     const long long blocks = base * M.ni1;
     if (blocks > 0x7fffffffLL) { set_error("mirror pass: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (blocks == 0) return IGX_OK;
-    constexpr size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
-    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mirror<WW><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
+    size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
+    if (LEAN) { const char *e = getenv("IGX_OVERLAP_MLDS"); if (e) lds = std::max<size_t>(lds, (size_t)atoi(e)); }   // (experiment: at most one block next to k_bf)
+    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror<WW, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mirror<WW, LEAN><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }
@@ -908,11 +1400,11 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
     M.N1 = AM.N; M.N2 = AL.N; M.p = AL.p; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
     M.tpairs = in.tpairs; M.ntp = in.ntp;
     switch (2 * AL.p + 1) {
-    case 3: return launch_mirror_k<3>(st, M, AL.N);
-    case 5: return launch_mirror_k<5>(st, M, AL.N);
-    case 7: return launch_mirror_k<7>(st, M, AL.N);
-    case 9: return launch_mirror_k<9>(st, M, AL.N);
-    case 11: return launch_mirror_k<11>(st, M, AL.N);
+    case 3: return launch_mirror_k<3, false>(st, M, AL.N);
+    case 5: return in.lean ? launch_mirror_k<5, true>(st, M, AL.N) : launch_mirror_k<5, false>(st, M, AL.N);
+    case 7: return in.lean ? launch_mirror_k<7, true>(st, M, AL.N) : launch_mirror_k<7, false>(st, M, AL.N);
+    case 9: return in.lean ? launch_mirror_k<9, true>(st, M, AL.N) : launch_mirror_k<9, false>(st, M, AL.N);
+    case 11: return launch_mirror_k<11, false>(st, M, AL.N);
     default: set_error("mirror pass: degree %d unsupported", AL.p); return IGX_ERR_UNSUPPORTED;
     }
 }

@@ -237,6 +237,10 @@ void igx_destroy(igx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->ev) (void)hipEventDestroy(ev);
+    if (ctx->side_ok) {
+        for (auto &s : ctx->side) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        for (auto &ev : ctx->evx) (void)hipEventDestroy(ev);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -342,7 +346,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
-    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
+    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs); (void)hipFree(pt->d_tpairs_src);
     (void)hipFree(pt->d_ws_ij); (void)hipFree(pt->d_ws_out);
     (void)hipFree(pt->d_lv_f); (void)hipFree(pt->d_lv_t1); (void)hipFree(pt->d_lv_t2); (void)hipFree(pt->d_lv_o);
     delete pt;

@@ -97,6 +97,11 @@ struct igx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    // side streams of the assembly chain (created on first use): the mirror pass of one range of outer pairs runs next
+    // to the fused stage of the following ranges; evx: ordering events without timing
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evx[40] = {};
+    bool side_ok = false;
 };
 
 struct igx_patch {
@@ -155,6 +160,8 @@ struct igx_patch {
     int *d_triv = nullptr;                    // one-dof outer axis of the 2D case: pl0 {0,0} | rp0 {0,1} | jlo0 {0} | jhi0 {1}
     int *d_tpairs = nullptr;                  // [ntp][2] mirror targets: outer pairs (i0 owned, j0 >= i0)
     int ntp = 0;
+    int *d_tpairs_src = nullptr;              // the same targets ordered by their SOURCE row j0 (ranges of the overlapped chain)
+    std::vector<int> h_tp_src;                // host copy
     int last_path = 0;                        // kernels of the last sum-factorised assembly: IGX_PATH_* bits
     igx_timing timing{};
 };
@@ -196,6 +203,8 @@ struct BFInputs {
     const int *rp0, *jlo0, *jhi0;             // outer axis tables (device)
     int sym, mid_lo, mid_hi;
     int span_hi;                              // resident spans of the mid axis end here
+    int pair_off = 0;                         // this launch covers the pairs [pair_off, pair_off + npairs) of pl0
+    int npairs_all = 0;                       // pairs of the whole stage (launch geometry is decided on it; 0: npairs)
 };
 struct MirrorInputs {
     const Axis *mid, *last;
@@ -203,6 +212,7 @@ struct MirrorInputs {
     const int *tpairs;
     int ntp;
     int i1_lo, i1_hi;                         // target rows of the mid axis
+    int lean = 0;                             // small tile / few registers: the pass runs NEXT TO the fused stage on the same CUs
 };
 int fused_rows_per_tile(int P);
 int fused_supported(const BFInputs &in);

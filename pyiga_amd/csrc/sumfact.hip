@@ -1330,6 +1330,16 @@ int sumfact_prepare(igx_patch *pt)
         pt->ntp = (int)(tp.size() / 2);
         IGX_HIP(hipMalloc(&pt->d_tpairs, std::max<size_t>(1, tp.size()) * sizeof(int)));
         IGX_HIP(hipMemcpyAsync(pt->d_tpairs, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
+        // the same targets ordered by their source row j0 (the lower pair (j0, i0) a target is copied from): the overlapped
+        // chain mirrors the targets of a range of source rows as soon as the fused stage has produced that range
+        std::vector<int> &ts = pt->h_tp_src;
+        ts.clear();
+        if (pt->dim == 3) {
+            for (int j0 = pt->r0_lo; j0 < A0.N; ++j0)
+                for (int i0 = std::max(pt->r0_lo, A0.jlo[j0]); i0 <= j0 && i0 < pt->r0_hi; ++i0) { ts.push_back(i0); ts.push_back(j0); }
+        }
+        IGX_HIP(hipMalloc(&pt->d_tpairs_src, std::max<size_t>(1, ts.size()) * sizeof(int)));
+        IGX_HIP(hipMemcpyAsync(pt->d_tpairs_src, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     }
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
@@ -1498,6 +1508,30 @@ static bool bf_add_slot(BFInputs &in, int y, int t1, const double *ptr)
     return true;
 }
 
+// ---- overlapped chain: knobs (experiment phase: environment; read per assembly)
+static int overlap_ranges(const igx_patch *pt, const BFInputs &in, bool sym)
+{
+    if (pt->dim != 3 || !sym || in.npairs < 64) return 1;
+    const char *e = getenv("IGX_OVERLAP");
+    const int n = e ? atoi(e) : 1;
+    return std::max(1, std::min(n, 32));
+}
+static int overlap_bf_streams() { const char *e = getenv("IGX_OVERLAP_BFS"); return e ? std::max(1, std::min(3, atoi(e))) : 2; }
+static int overlap_lean() { const char *e = getenv("IGX_OVERLAP_LEAN"); return e ? atoi(e) : 1; }
+static int ensure_side_streams(igx_ctx *cx)
+{
+    if (cx->side_ok) return IGX_OK;
+    // side[0] carries the mirror pass at the LOWEST priority, side[1..] ranges of the fused stage at the HIGHEST: when a CU
+    // frees up, the dispatcher places a block of the fused stage first and the mirror takes what is left next to it
+    int least = 0, greatest = 0;
+    IGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const bool prio = !getenv("IGX_OVERLAP_NOPRIO");
+    for (int k = 0; k < 4; ++k) IGX_HIP(hipStreamCreateWithPriority(&cx->side[k], hipStreamNonBlocking, prio ? (k == 0 ? least : greatest) : 0));
+    for (auto &ev : cx->evx) IGX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    cx->side_ok = true;
+    return IGX_OK;
+}
+
 static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
 {
     hipStream_t st = pt->ctx->stream;
@@ -1514,6 +1548,54 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         // above it (mirror sources), as far as the resident spans reach
         i1_lo = pt->r0_lo; i1_hi = pt->r0_hi;
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
+    }
+    // ---- overlapped chain (3D, symmetric): the outer pairs are cut into ranges of source rows; the mirror pass of a range
+    // (HBM-bound, a few waves per CU in its lean form) runs on a side stream next to the fused stage (vector-issue-bound)
+    // of the following ranges
+    const int nr = overlap_ranges(pt, in, sym);
+    if (nr > 1) {
+        if (int rc = ensure_side_streams(pt->ctx)) return rc;
+        igx_ctx *cx = pt->ctx;
+        const std::vector<int> &pl = pt->h_pl0, &ts = pt->h_tp_src;
+        const int np = in.npairs, nt = (int)(ts.size() / 2);
+        const int nbs = overlap_bf_streams();               // 1: every range of the fused stage on the main stream; 2: alternating
+        IGX_HIP(hipEventRecord(cx->evx[0], st));
+        for (int k = 0; k < 4; ++k) IGX_HIP(hipStreamWaitEvent(cx->side[k], cx->evx[0], 0));
+        int pa = 0, ta = 0;
+        for (int k = 0; k < nr; ++k) {
+            // pairs [pa, pb): whole source rows, about np / nr pairs
+            int pb = (int)((long long)np * (k + 1) / nr);
+            while (pb < np && pb > 0 && pl[2 * pb] == pl[2 * (pb - 1)]) ++pb;
+            if (k == nr - 1) pb = np;
+            if (pb <= pa) continue;
+            const int row_hi = pb < np ? pl[2 * pb] : 0x7fffffff;
+            int tb = ta;
+            while (tb < nt && ts[2 * tb + 1] < row_hi) ++tb;
+            BFInputs ik = in;
+            ik.pair_off = pa; ik.npairs = pb - pa; ik.npairs_all = np;
+            hipStream_t sb = cx->side[1 + k % nbs];
+            if (int rc = launch_bf(sb, pt, ik, d_data)) return rc;
+            pt->timing.n_launches++;
+            IGX_HIP(hipEventRecord(cx->evx[1 + k], sb));
+            if (tb > ta && !getenv("IGX_NO_MIRROR")) {
+                IGX_HIP(hipStreamWaitEvent(cx->side[0], cx->evx[1 + k], 0));
+                MirrorInputs mi{};
+                mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
+                mi.tpairs = pt->d_tpairs_src + 2 * ta; mi.ntp = tb - ta; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
+                mi.lean = overlap_lean();
+                if (int rc = launch_mirror(cx->side[0], pt, mi, d_data)) return rc;
+                pt->timing.n_launches++;
+            }
+            pa = pb; ta = tb;
+        }
+        pt->last_path |= IGX_PATH_FUSED | IGX_PATH_MIRROR;
+        // join: the main stream continues when the fused stage (ev[3]) and then the mirror (ev[4]) are complete
+        for (int k = 0; k < nbs; ++k) { IGX_HIP(hipEventRecord(cx->evx[38 - k], cx->side[1 + k])); IGX_HIP(hipStreamWaitEvent(st, cx->evx[38 - k], 0)); }
+        (void)hipEventRecord(cx->ev[3], st);
+        IGX_HIP(hipEventRecord(cx->evx[39], cx->side[0]));
+        IGX_HIP(hipStreamWaitEvent(st, cx->evx[39], 0));
+        (void)hipEventRecord(cx->ev[4], st);
+        return IGX_OK;
     }
     if (int rc = launch_bf(st, pt, in, d_data)) return rc;
     pt->last_path |= IGX_PATH_FUSED;
