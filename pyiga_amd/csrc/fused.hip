@@ -652,18 +652,18 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
 //     (scalar row base of the step) + (per-lane offset worked out once): no address arithmetic per element on interior rows
 //     of the mid axis; the first and last p rows take a general path;
 //   * K1 loads are (scalar base) + (per-lane offset): the row advance is scalar arithmetic.
-template <int P, int NLG, int NRO> struct BF2Geom {
+template <int P, int NLG, int NRO, int NCW> struct BF2Geom {
     static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
     static constexpr int ROWR = p * W, ROWC = P * W;        // doubles per row in the ring / cur parts
     static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
-    static constexpr int nslots(int R, int per) { return (R * per * W + 64 * BF_NCW - 1) / (64 * BF_NCW); }
+    static constexpr int nslots(int R, int per) { return (R * per * W + 64 * NCW - 1) / (64 * NCW); }
     // LDS image (doubles): lines [W][LS] | ring [P+1][R][p][W] | cur [2][R][P][W] | basis values [TL][P][2] | store plan
     // (ints) [NSR + NSC][NCW * 64];  R = rows of the last axis per tile: as many as the window and 160 KB allow
     static constexpr int off_ring() { return (W * LS + 1) & ~1; }
     static constexpr int off_cur(int R) { return (off_ring() + (P + 1) * R * ROWR + 1) & ~1; }
     static constexpr int off_v2(int R) { return (off_cur(R) + 2 * R * ROWC + 1) & ~1; }
     static constexpr int off_plan(int R) { return off_v2(R) + TL * P * 2; }
-    static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * BF_NCW * 32; }
+    static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * NCW * 32; }
     static constexpr int rmax()
     {
         int R = TL / P - p;
@@ -700,6 +700,12 @@ __device__ __forceinline__ double bf2_from_lane(const int src4, const double v)
 }
 
 typedef int bf2_v2i __attribute__((ext_vector_type(2)));
+#ifndef BF2_PRIO_S
+#define BF2_PRIO_S 0                                     // s_setprio of the sweepers / contractors (experiments)
+#endif
+#ifndef BF2_PRIO_C
+#define BF2_PRIO_C 3
+#endif
 #ifndef BF2_AH
 #define BF2_AH 0                                         // 1: element matrices in two halves (fewer registers, LDS values read twice)
 #endif
@@ -761,7 +767,8 @@ __device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const
 {
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = 64 * NLG;
-    __builtin_amdgcn_s_setprio(3);
+    BF_STAMP_DECL
+    __builtin_amdgcn_s_setprio(BF2_PRIO_S);
     cdp V1 = (cdp)A.V1;
     double acc[P][P];
 #pragma unroll
@@ -868,7 +875,8 @@ __device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const
         flush();
     }
     for (; t < rhi; ++t) { bar_lds(); bar_lds(); flush(); }          // spans past the end of the axis: the window only drains
-    for (; t < rhi + 2; ++t) { bar_lds(); bar_lds(); }                // the contractors finish the last two rows
+    for (; t < rhi + 1; ++t) { bar_lds(); bar_lds(); }                // the contractors finish the last row
+    BF_STAMP_END(threadIdx.x >> 6);
 }
 
 template <int P, int MASK, int NA, int NLG, int RI, bool END = (RI >= bf_nroles(MASK))>
@@ -884,11 +892,11 @@ struct BF2SweepDispatch<P, MASK, NA, NLG, RI, true> {
     __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
 };
 
-template <int P, int NY, int MASK, int NA, int NLG>
-__global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(const BFArgs A)
+template <int P, int NY, int MASK, int NA, int NLG, int NCW>
+__global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(const BFArgs A)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK)>;
-    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG, NCW = BF_NCW;
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW>;
+    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
     constexpr int RMAX = Gm::RMAX, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
     constexpr int LS = Gm::LS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -925,7 +933,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
     // wave -> task: a workgroup's waves go to the four SIMDs cyclically; FP64 instructions per step and wave at p = 4:
     // sweepers of role 0: 370, roles 1, 2: 200, role 3: 165; a contractor pass: 400 (six passes: contractors 0, 1 take two)
     int task = wave;
-    if (NR == 4 && NLG == 3 && NCW == 4) {
+    if (NR == 4 && NLG == 2 && NCW == 8) {
+        // per SIMD: a heavy and a light sweeper (roles 0 + 3, or 1 + 2) and two contractors
+        constexpr int tmap[16] = {0, 1, 2, 3, 6, 7, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15};
+        task = tmap[wave & 15];
+    } else if (NR == 4 && NLG == 3 && NCW == 4) {
         constexpr int tmap[16] = {12, 13, 14, 15, 9, 3, 0, 2, 10, 4, 1, 7, 11, 6, 5, 8};
         task = tmap[wave & 15];
     } else if (NR == 4 && NLG == 2 && NCW == 4) {
@@ -943,21 +955,22 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
 
     // ---------------- contractors
     const int cw = task - NSW;
+    BF_STAMP_DECL
+    __builtin_amdgcn_s_setprio(BF2_PRIO_C);
     BF2Blk B;
     B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.cj0 = j0 - jlo0[i0]; B.rlo = rlo; B.rhi = rhi;
     B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2;
     // store plan of the interior rows of the mid axis (p <= i1 < N1 - p: the segment has 2p + 1 lines, the first one is
     // j1 = i1 - p): offset of element q inside the row block, or -1.  Element q of slot k: q = (k * NCW + cw) * 64 + lane.
     // (kept in LDS, one int per element, written and read by the same wave: the registers belong to the element matrices)
-    int *myplan = plan + cw * 64 + lane;
     {
+        int *myplan = plan + cw * 64 + lane;
         const int ddi = min(p, max(A.N1 - P, 0));                      // any interior row gives the same offsets
 #pragma unroll
         for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, (k * NCW + cw) * 64 + lane, ddi); myplan[k * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
 #pragma unroll
         for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, (k * NCW + cw) * 64 + lane, ddi); myplan[(Gm::NSR + k) * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
     }
-    const int ps = lane / PL, x = lane - ps * PL;                      // piece slot of the pass, span of the piece
     const int nlines = diag0 ? P : W;
     const int npieces = nlines * NPC;
     cip rp0 = (cip)A.rp0, rp1 = (cip)A.rp1;
@@ -966,49 +979,45 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
     const long long rstep = (long long)B.c0i * A.S2 * 8;               // (a block of c0i * S1 * S2 values is < 2^31 bytes: checked on the host)
     // the last read of a part may not leave it (the slots are padded to whole waves)
     constexpr int RCLAMP = RMAX * Gm::ROWR - 1, CCLAMP = RMAX * Gm::ROWC - 1;
-    for (int t = s_begin; t < rhi + 2; ++t) {
+    // Stores: the entries of mid-axis row t - 1 are complete behind the barrier B2 of step t.  They (and their offsets) are
+    // read from LDS there -- while the sweepers flush -- and stored right behind the next B1, from registers: the LDS latency
+    // lies in the barrier wait, not in front of the pass.  A row that is not stored goes through a descriptor of length 0
+    // (every lane out of range): no branch around the stores.
+    const __amdgpu_buffer_rsrc_t drs0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.data, (short)0, 0, 0x00020000);
+    constexpr int NSL = Gm::NSR + Gm::NSC;
+    double sv[NSL];
+    int sg[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) { sv[k] = 0.0; sg[k] = BF2_OOB; }
+    int s_soff = 0;
+    bool s_on = false;
+    for (int t = s_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
-        // ---- whole row segments of mid-axis row t - 2
-        const int dd2 = t - 2;
-        if (dd2 >= rlo && dd2 < rhi) {
-            const int soff = (int)(rstep * rp1[dd2]);
-            const double *rg = ring + (size_t)(dd2 % (P + 1)) * RMAX * Gm::ROWR;
-            const double *cu = cur + (size_t)(dd2 & 1) * RMAX * Gm::ROWC;
-            const int q0 = cw * 64 + lane;
-            if (dd2 >= p && dd2 < A.N1 - p) {
-                double vr[Gm::NSR], vc[Gm::NSC];
-                int gr[Gm::NSR], gc[Gm::NSC];
+        BF_SEG_BEGIN();
+#ifndef BF2_NOSTORE
+        {
+            const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
 #pragma unroll
-                for (int k = 0; k < Gm::NSR; ++k) {
-                    gr[k] = myplan[k * NCW * 64];
-                    vr[k] = rg[(k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP)];
-                }
-#pragma unroll
-                for (int k = 0; k < Gm::NSC; ++k) {
-                    gc[k] = myplan[(Gm::NSR + k) * NCW * 64];
-                    vc[k] = cu[(k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP)];
-                }
-#pragma unroll
-                for (int k = 0; k < Gm::NSR; ++k) bf2_buffer_store(drs, gr[k], soff, vr[k]);
-#pragma unroll
-                for (int k = 0; k < Gm::NSC; ++k) bf2_buffer_store(drs, gc[k], soff, vc[k]);
-            } else {
-                for (int k = 0; k < Gm::NSR; ++k) {
-                    const int q = q0 + k * NCW * 64;
-                    const int g = bf2_goff<P>(A, B, false, q, dd2);
-                    bf2_buffer_store(drs, g < 0 ? BF2_OOB : g * 8, soff, rg[min(q, RCLAMP)]);
-                }
-                for (int k = 0; k < Gm::NSC; ++k) {
-                    const int q = q0 + k * NCW * 64;
-                    const int g = bf2_goff<P>(A, B, true, q, dd2);
-                    bf2_buffer_store(drs, g < 0 ? BF2_OOB : g * 8, soff, cu[min(q, CCLAMP)]);
-                }
-            }
+            for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
         }
+#endif
+        BF_SEG_END(0);
         // ---- contract the lines of flush dd = t - 1 with the last axis
         const int dd = t - 1;
+        BF_SEG_BEGIN();
+#ifndef BF2_NOPASS
         if (dd >= s_begin && dd < rhi) {
-            for (int pass = cw; pass * PPP < npieces; pass += NCW) {
+            // a wave issues one vector instruction per 8 cycles at best: with NCW >= passes per step every wave takes at most one
+            // pass per step, and the passes rotate over the contractor waves from step to step
+            const int npass = (npieces + PPP - 1) / PPP;
+            const int rot = NCW >= Gm::npass(PL) ? (int)((unsigned)(t * npass) % (unsigned)NCW) : 0;
+            for (int pass = (cw - rot + NCW) % NCW; pass < npass; pass += NCW) {
+                // (per-lane constants are worked out again where they are used, from an opaque copy of the lane number: held in
+                // registers across the element matrices they would be spilled, and a scratch reload waits for vmcnt(0), i.e. for
+                // this wave's stores)
+                int ln_ = lane;
+                asm volatile("" : "+v"(ln_));
+                const int ps = ln_ / PL, x = ln_ - ps * PL;              // piece slot of the pass, span of the piece
                 const int pid = pass * PPP + ps;
                 const int k9 = pid / NPC, pj = pid - k9 * NPC;
                 const int s1 = pj * RP + x;                            // span of the window
@@ -1039,7 +1048,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
 #pragma unroll
                     for (int a = 1; a < AH; ++a)
 #pragma unroll
-                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a][b]);
+                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a][b]);
                 }
                 if constexpr (AH < P) {
                     double loc[P - AH][P];
@@ -1053,14 +1062,22 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
 #pragma unroll
                     for (int a = AH; a < P; ++a)
 #pragma unroll
-                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - AH][b]);
+                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a - AH][b]);
                 }
-                const int r3 = s1 - p;                                 // row of the tile
-                if (lok && x >= p && r3 < nrows) {
+                int lw_ = lane;
+                asm volatile("" : "+v"(lw_));
+                const int ps2 = lw_ / PL, x2 = lw_ - ps2 * PL;
+                const int pid2 = pass * PPP + ps2;
+                const int k9w = pid2 / NPC, s1w = (pid2 - k9w * NPC) * RP + x2;
+                const int law = k9w <= p ? k9w : k9w - p;
+                const int row1w = k9w <= p ? dd + law : dd, col1w = k9w <= p ? dd : dd + law;
+                const bool lokw = ps2 < PPP && pid2 < npieces && row1w >= rlo && row1w < rhi && col1w < A.N1;
+                const int r3 = s1w - p;                                // row of the tile
+                if (lokw && x2 >= p && r3 < nrows) {
                     const int i2 = row_lo + r3;
                     const int oshv = max(p - i2, 0);
-                    double *dste = (k9 <= p && la > 0) ? ring + ((size_t)((row1 % (P + 1)) * RMAX + r3) * p + (p - la)) * W
-                                                       : cur + ((size_t)((dd & 1) * RMAX + r3) * P + (k9 <= p ? 0 : la)) * W;
+                    double *dste = (k9w <= p && law > 0) ? ring + ((size_t)((row1w % (P + 1)) * RMAX + r3) * p + (p - law)) * W
+                                                         : cur + ((size_t)((dd & 1) * RMAX + r3) * P + (k9w <= p ? 0 : law)) * W;
                     dste -= oshv;
 #pragma unroll
                     for (int o = 0; o < W; ++o)
@@ -1068,8 +1085,44 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + BF_NCW) * 64) k_bf2(c
                 }
             }
         }
+#endif
+        BF_SEG_END(1);
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
+#ifndef BF2_NOSTORE
+        {
+            const int dd2 = t - 1;
+            s_on = dd2 >= rlo && dd2 < rhi;
+            const int ddc = min(max(dd2, 0), A.N1 - 1);
+            s_soff = (int)(rstep * rp1[ddc]);
+            const double *rg = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR;
+            const double *cu = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
+            int lq_ = lane;
+            asm volatile("" : "+v"(lq_));
+            const int q0 = cw * 64 + lq_;
+            const int *myplan = plan + q0;
+#pragma unroll
+            for (int k = 0; k < Gm::NSR; ++k) sv[k] = rg[(k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP)];
+#pragma unroll
+            for (int k = 0; k < Gm::NSC; ++k) sv[Gm::NSR + k] = cu[(k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP)];
+            if (ddc >= p && ddc < A.N1 - p) {
+#pragma unroll
+                for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NCW * 64];
+            } else if (s_on) {                              // first and last p rows of the mid axis: offsets worked out here
+                for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, q0 + k * NCW * 64, ddc); sg[k] = g < 0 ? BF2_OOB : g * 8; }
+                for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, q0 + k * NCW * 64, ddc); sg[Gm::NSR + k] = g < 0 ? BF2_OOB : g * 8; }
+            }
+        }
+#endif
     }
+#ifndef BF2_NOSTORE
+    {                                                     // the last row
+        const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
+    }
+#endif
+    BF_SEG_DUMP(cw & 3);
+    BF_STAMP_END(wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1223,46 +1276,65 @@ static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
     return IGX_OK;
 }
 
-template <int P, int NY, int MASK, int NA, int NLG>
+template <int P, int NY, int MASK, int NA, int NLG, int NCW>
 static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK)>;
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "k_bf2: LDS");
-    static_assert((bf_nroles(MASK) * NLG + BF_NCW) * 64 <= 1024, "k_bf2: block size");
-    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_bf2<P, NY, MASK, NA, NLG><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + BF_NCW) * 64), lds, st>>>(A);
+    static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf2: block size");
+    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_bf2<P, NY, MASK, NA, NLG, NCW><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + NCW) * 64), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
+#ifdef IGX_BF_STAMP
+    {
+        static std::vector<unsigned long long> h(64 * 1024);
+        IGX_HIP(hipStreamSynchronize(st));
+        IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bf_stamp), h.size() * sizeof(unsigned long long)));
+        const int nw = bf_nroles(MASK) * NLG + NCW, nb = std::min<unsigned>(nblocks, 2048);
+        for (int w = 0; w < nw; ++w) {
+            double wt = 0, tot = 0;
+            for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
+            fprintf(stderr, "k_bf2 stamp: wave %2d  wait %.0f  total %.0f x100ns/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
+        }
+        for (int w = 0; w < 4; ++w) {
+            double sg[3] = {0, 0, 0};
+            for (int b = 0; b < nb; ++b) for (int i = 0; i < 3; ++i) sg[i] += h[32768 + (b * 4 + w) * 3 + i];
+            fprintf(stderr, "k_bf2 stamp: contractor %d (+4)  stores %.0f  passes %.0f x100ns/block\n", w, sg[0] / nb, sg[1] / nb);
+        }
+    }
+#endif
     return IGX_OK;
 }
 
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
-// lane groups per role of k_bf2: three where the register budget of 16 waves per CU (128 VGPRs) holds the sweeper
-constexpr int bf2_nlg(int P, int na) { return na == 1 ? 3 : 2; }
+// Shapes of k_bf2: lane groups per role (tile = 64 NLG points) and contractor waves.  A wave issues at most one vector
+// instruction per 8 cycles (tools/ubench/valu_f64.hip: one wave per SIMD), so the work of a step has to be spread evenly
+// over ALL waves, not only over the SIMDs: 8 sweepers + 8 contractors (one pass per contractor and step) at the four-role
+// forms; three lane groups would need 12 + 6 waves.
 template <int P>
 static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
 {
-    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_k<P, 1, BF_MASK_MASS, 1, 3>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 1, 3>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 2, 2>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF2, 1, 3>(st, A, nblocks);
+    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_k<P, 1, BF_MASK_MASS, 1, 3, 8>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 1, 2, 8>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 2, 2, 4>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF2, 1, 2, 8>(st, A, nblocks);
     set_error("fused stage: no kernel for this set of types");
     return IGX_ERR_UNSUPPORTED;
 }
-template <int P> static int bf2_rows_p(int nroles, int nlg)
+template <int P> static int bf2_rows_p(int nroles, int na)
 {
-    if (nroles == 1) return BF2Geom<P, 3, 1>::RMAX;
-    return nlg == 3 ? BF2Geom<P, 3, 4>::RMAX : BF2Geom<P, 2, 4>::RMAX;
+    if (nroles == 1) return BF2Geom<P, 3, 1, 8>::RMAX;
+    return na == 1 ? BF2Geom<P, 2, 4, 8>::RMAX : BF2Geom<P, 2, 4, 4>::RMAX;
 }
 int fused2_rows_per_tile(int P, int nroles, int na)
 {
-    const int nlg = bf2_nlg(P, na);
     switch (P) {
-    case 2: return bf2_rows_p<2>(nroles, nlg);
-    case 3: return bf2_rows_p<3>(nroles, nlg);
-    case 4: return bf2_rows_p<4>(nroles, nlg);
-    case 5: return bf2_rows_p<5>(nroles, nlg);
+    case 2: return bf2_rows_p<2>(nroles, na);
+    case 3: return bf2_rows_p<3>(nroles, na);
+    case 4: return bf2_rows_p<4>(nroles, na);
+    case 5: return bf2_rows_p<5>(nroles, na);
     }
     return 1;
 }

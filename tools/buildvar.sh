@@ -1,0 +1,9 @@
+#!/bin/bash
+# build a variant library: buildvar.sh <name> <extra flags...>
+name=$1; shift
+R=/root/repo
+mkdir -p $R/pyiga_amd/csrc/build_var
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -Wno-unused-function -Xarch_host -ffp-contract=off "$@" -c $R/pyiga_amd/csrc/fused.hip -o $R/pyiga_amd/csrc/build_var/fused_$name.o || exit 1
+objs=""
+for f in igx_api kern_basis kern_entries kern_vector sumfact geoa aca; do objs="$objs $R/pyiga_amd/csrc/build/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/pyiga_amd/libigx_$name.so $objs $R/pyiga_amd/csrc/build_var/fused_$name.o
