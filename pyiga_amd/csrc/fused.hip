@@ -652,16 +652,16 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_
 //     (scalar row base of the step) + (per-lane offset worked out once): no address arithmetic per element on interior rows
 //     of the mid axis; the first and last p rows take a general path;
 //   * K1 loads are (scalar base) + (per-lane offset): the row advance is scalar arithmetic.
-template <int P, int NLG, int NRO, int NCW> struct BF2Geom {
+template <int P, int NLG, int NRO, int NCW, int NH> struct BF2Geom {
     static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
     static constexpr int ROWR = p * W, ROWC = P * W;        // doubles per row in the ring / cur parts
     static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
     static constexpr int nslots(int R, int per) { return (R * per * W + 64 * NCW - 1) / (64 * NCW); }
-    // LDS image (doubles): lines [W][LS] | ring [P+1][R][p][W] | cur [2][R][P][W] | basis values [TL][P][2] | store plan
+    // LDS image (doubles): lines [W][LS] | ring [NH][P+1][R][p][W] | cur [NH][2][R][P][W] | basis values [TL][P][2] | store plan
     // (ints) [NSR + NSC][NCW * 64];  R = rows of the last axis per tile: as many as the window and 160 KB allow
     static constexpr int off_ring() { return (W * LS + 1) & ~1; }
-    static constexpr int off_cur(int R) { return (off_ring() + (P + 1) * R * ROWR + 1) & ~1; }
-    static constexpr int off_v2(int R) { return (off_cur(R) + 2 * R * ROWC + 1) & ~1; }
+    static constexpr int off_cur(int R) { return (off_ring() + NH * (P + 1) * R * ROWR + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_cur(R) + NH * 2 * R * ROWC + 1) & ~1; }
     static constexpr int off_plan(int R) { return off_v2(R) + TL * P * 2; }
     static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * NCW * 32; }
     static constexpr int rmax()
@@ -690,6 +690,7 @@ template <int P, int NLG, int NRO, int NCW> struct BF2Geom {
     static constexpr int PPP = 64 / PL;                     // pieces per pass
     static constexpr int NPC = npc(PL);                     // pieces per line
     static constexpr int RP = PL - p;                       // rows a piece completes
+    static constexpr int RING1 = (P + 1) * RMAX * ROWR, CUR1 = 2 * RMAX * ROWC;   // doubles of one copy of the rings
 };
 
 __device__ __forceinline__ double bf2_from_lane(const int src4, const double v)
@@ -706,8 +707,14 @@ typedef int bf2_v2i __attribute__((ext_vector_type(2)));
 #ifndef BF2_PRIO_C
 #define BF2_PRIO_C 3
 #endif
-#ifndef BF2_AH
-#define BF2_AH 0                                         // 1: element matrices in two halves (fewer registers, LDS values read twice)
+#ifndef BF2_NLG
+#define BF2_NLG 3
+#endif
+#ifndef BF2_NCW
+#define BF2_NCW 4
+#endif
+#ifndef BF2_NH
+#define BF2_NH 1                                         // units of the contraction per pass at the four-role forms (1: whole passes)
 #endif
 constexpr int BF2_NUMREC = 0x7ffffff0;                     // bytes a descriptor covers; per-lane offsets at or above it are out of range
 constexpr int BF2_OOB = 0x7ffffff8;                        // per-lane offset of a lane that must not store (dropped by the range check)
@@ -892,17 +899,17 @@ struct BF2SweepDispatch<P, MASK, NA, NLG, RI, true> {
     __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
 };
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW>
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
 __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(const BFArgs A)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW>;
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
     constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
     constexpr int RMAX = Gm::RMAX, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
     constexpr int LS = Gm::LS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lines = lds;                 // [W][LS]
-    double *ring = lds + Gm::OFF_RING;   // [P+1][RMAX][p][W]: entries of the pairs (i1, j1 < i1), slot i1 mod (P+1), line kx = p - (i1 - j1)
-    double *cur = lds + Gm::OFF_CUR;     // [2][RMAX][P][W]:   entries of the pairs (d, d + a), slot d & 1
+    double *ring = lds + Gm::OFF_RING;   // [NH][P+1][RMAX][p][W]: entries of the pairs (i1, j1 < i1), slot i1 mod (P+1), line kx = p - (i1 - j1)
+    double *cur = lds + Gm::OFF_CUR;     // [NH][2][RMAX][P][W]:   entries of the pairs (d, d + a), slot d & 1   (NH = 2: partial sums of the two halves of a pass)
     double *V2s = lds + Gm::OFF_V2;      // [TL][P][2]: last-axis basis values on the tile window
     int *plan = (int *)(lds + Gm::OFF_PLAN);   // [NSR + NSC][NCW][64]: byte offsets of the store elements (interior mid-axis rows)
 
@@ -1007,11 +1014,15 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         BF_SEG_BEGIN();
 #ifndef BF2_NOPASS
         if (dd >= s_begin && dd < rhi) {
-            // a wave issues one vector instruction per 8 cycles at best: with NCW >= passes per step every wave takes at most one
-            // pass per step, and the passes rotate over the contractor waves from step to step
+            // A wave issues one vector instruction per 8 cycles at best (tools/ubench/valu_f64.hip), so the contraction of a step is
+            // cut into units that fit one wave each: a pass (64 lanes of (line, span) items), or -- NH = 2 -- half a pass: rows
+            // 0 .. AH-1 resp. AH .. p of the element matrices; the two halves add up in separate copies of the entry rings, which the
+            // stores sum.  The units rotate over the contractor waves from step to step.
             const int npass = (npieces + PPP - 1) / PPP;
-            const int rot = NCW >= Gm::npass(PL) ? (int)((unsigned)(t * npass) % (unsigned)NCW) : 0;
-            for (int pass = (cw - rot + NCW) % NCW; pass < npass; pass += NCW) {
+            constexpr int AH = NH == 2 ? (P + 1) / 2 : P;
+            auto unit = [&](auto h_, const int pass) {
+                constexpr int H = decltype(h_)::value;                 // 0: rows 0 .. AH-1 (all rows when NH = 1), 1: rows AH .. p
+                constexpr int A0 = H == 0 ? 0 : AH, A1 = H == 0 ? AH : P;
                 // (per-lane constants are worked out again where they are used, from an opaque copy of the lane number: held in
                 // registers across the element matrices they would be spilled, and a scratch reload waits for vmcnt(0), i.e. for
                 // this wave's stores)
@@ -1028,41 +1039,26 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                 const bool eok = lok && s1 < Gm::WS && sp >= 0 && sp < A.n2;
                 const double *kl = lines + k9 * LS + s1 * P, *vl = V2s + s1 * P * P * 2;
                 // entries of row i2 = sp (the row whose function index a = 0 sits on this lane's span): entry o = b - a + p comes
-                // from the element matrix of span i2 - a, i.e. of the lane a places below.  Two halves of the element matrix
-                // (registers): rows 0 .. AH-1, then AH .. p.
-                constexpr int AH = BF2_AH > 0 ? (P + 1) / 2 : P;
+                // from the element matrix of span i2 - a, i.e. of the lane a places below
                 double out[W];
 #pragma unroll
-                for (int o = 0; o < p; ++o) out[o] = 0.0;
+                for (int o = 0; o < W; ++o) out[o] = 0.0;
                 {
-                    double loc[AH][P];
-                    if (eok) bf_element<P, NY, MASK, 0, AH>(loc, kl, vl, TL);
+                    double loc[A1 - A0][P];
+                    if (eok) bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
                     else {
 #pragma unroll
-                        for (int a = 0; a < AH; ++a)
+                        for (int a = 0; a < A1 - A0; ++a)
 #pragma unroll
                             for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
                     }
 #pragma unroll
-                    for (int b = 0; b < P; ++b) out[b + p] = loc[0][b];
+                    for (int a = A0; a < A1; ++a)
 #pragma unroll
-                    for (int a = 1; a < AH; ++a)
-#pragma unroll
-                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a][b]);
-                }
-                if constexpr (AH < P) {
-                    double loc[P - AH][P];
-                    if (eok) bf_element<P, NY, MASK, AH, P>(loc, kl, vl, TL);
-                    else {
-#pragma unroll
-                        for (int a = 0; a < P - AH; ++a)
-#pragma unroll
-                            for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
-                    }
-#pragma unroll
-                    for (int a = AH; a < P; ++a)
-#pragma unroll
-                        for (int b = 0; b < P; ++b) out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a - AH][b]);
+                        for (int b = 0; b < P; ++b) {
+                            if (a == 0) out[b + p] = loc[0][b];
+                            else out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a - A0][b]);
+                        }
                 }
                 int lw_ = lane;
                 asm volatile("" : "+v"(lw_));
@@ -1076,12 +1072,26 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                 if (lokw && x2 >= p && r3 < nrows) {
                     const int i2 = row_lo + r3;
                     const int oshv = max(p - i2, 0);
-                    double *dste = (k9w <= p && law > 0) ? ring + ((size_t)((row1w % (P + 1)) * RMAX + r3) * p + (p - law)) * W
-                                                         : cur + ((size_t)((dd & 1) * RMAX + r3) * P + (k9w <= p ? 0 : law)) * W;
+                    double *dste = (k9w <= p && law > 0) ? ring + H * Gm::RING1 + ((size_t)((row1w % (P + 1)) * RMAX + r3) * p + (p - law)) * W
+                                                         : cur + H * Gm::CUR1 + ((size_t)((dd & 1) * RMAX + r3) * P + (k9w <= p ? 0 : law)) * W;
                     dste -= oshv;
 #pragma unroll
                     for (int o = 0; o < W; ++o)
                         if (o >= oshv) dste[o] = out[o];
+                }
+            };
+            const int wslot = (int)((unsigned)(cw + t) % (unsigned)NCW);
+            if constexpr (NH == 1) {
+                for (int pass = wslot; pass < npass; pass += NCW) unit(std::integral_constant<int, 0>(), pass);
+            } else if (NCW > npass) {
+                // first halves on the wave slots 0 .. npass-1, second halves (lighter) shared by the others
+                if (wslot < npass) unit(std::integral_constant<int, 0>(), wslot);
+                else
+                    for (int pass = wslot - npass; pass < npass; pass += NCW - npass) unit(std::integral_constant<int, 1>(), pass);
+            } else {
+                for (int u = wslot; u < 2 * npass; u += NCW) {
+                    if (u < npass) unit(std::integral_constant<int, 0>(), u);
+                    else unit(std::integral_constant<int, 1>(), u - npass);
                 }
             }
         }
@@ -1101,9 +1111,15 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
             const int q0 = cw * 64 + lq_;
             const int *myplan = plan + q0;
 #pragma unroll
-            for (int k = 0; k < Gm::NSR; ++k) sv[k] = rg[(k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP)];
+            for (int k = 0; k < Gm::NSR; ++k) {
+                const int o_ = (k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP);
+                sv[k] = NH == 2 ? rg[o_] + rg[Gm::RING1 + o_] : rg[o_];
+            }
 #pragma unroll
-            for (int k = 0; k < Gm::NSC; ++k) sv[Gm::NSR + k] = cu[(k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP)];
+            for (int k = 0; k < Gm::NSC; ++k) {
+                const int o_ = (k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP);
+                sv[Gm::NSR + k] = NH == 2 ? cu[o_] + cu[Gm::CUR1 + o_] : cu[o_];
+            }
             if (ddc >= p && ddc < A.N1 - p) {
 #pragma unroll
                 for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NCW * 64];
@@ -1242,6 +1258,8 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 
 // ---------------------------------------------------------------------------------------------
 // host side
+constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
+
 template <int P, int NY, int MASK, int NA>
 static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
@@ -1276,15 +1294,15 @@ static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
     return IGX_OK;
 }
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW>
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
 static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW>;
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "k_bf2: LDS");
     static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf2: block size");
-    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_bf2<P, NY, MASK, NA, NLG, NCW><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + NCW) * 64), lds, st>>>(A);
+    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_bf2<P, NY, MASK, NA, NLG, NCW, NH><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + NCW) * 64), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_BF_STAMP
     {
@@ -1307,34 +1325,49 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
     return IGX_OK;
 }
 
-constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
-// Shapes of k_bf2: lane groups per role (tile = 64 NLG points) and contractor waves.  A wave issues at most one vector
-// instruction per 8 cycles (tools/ubench/valu_f64.hip: one wave per SIMD), so the work of a step has to be spread evenly
-// over ALL waves, not only over the SIMDs: 8 sweepers + 8 contractors (one pass per contractor and step) at the four-role
-// forms; three lane groups would need 12 + 6 waves.
+// Shapes of k_bf2 per set of types: lane groups per role (tile = 64 NLG points), contractor waves, units per pass.  A wave
+// issues at most one vector instruction per 8 cycles (tools/ubench/valu_f64.hip: one wave per SIMD), so a step is bound by
+// its longest wave as much as by the SIMDs: three lane groups + four contractors (two of them take two passes per step) beat
+// two lane groups + eight contractors at the 3D forms because the larger tile needs fewer instructions per row.
+template <int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
+template <> struct BF2Cfg<BF_MASK_MASS, 1> { static constexpr int NLG = 3, NCW = 8, NH = 1; };
+template <> struct BF2Cfg<BF_MASK_STIFF3, 1> { static constexpr int NLG = BF2_NLG, NCW = BF2_NCW, NH = BF2_NH; };
+template <> struct BF2Cfg<BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = 8, NH = 1; };
+template <int P, int NY, int MASK, int NA>
+static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks)
+{
+    using C = BF2Cfg<MASK, NA>;
+    return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH>(st, A, nblocks);
+}
+template <int P, int MASK, int NA> constexpr int bf2_rmax()
+{
+    using C = BF2Cfg<MASK, NA>;
+    return BF2Geom<P, C::NLG, bf_nroles(MASK), C::NCW, C::NH>::RMAX;
+}
 template <int P>
 static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
 {
-    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_k<P, 1, BF_MASK_MASS, 1, 3, 8>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 1, 2, 8>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_k<P, 4, BF_MASK_STIFF3, 2, 2, 4>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_k<P, 4, BF_MASK_STIFF2, 1, 2, 8>(st, A, nblocks);
+    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_c<P, 1, BF_MASK_MASS, 1>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 1>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 2>(st, A, nblocks);
+    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF2, 1>(st, A, nblocks);
     set_error("fused stage: no kernel for this set of types");
     return IGX_ERR_UNSUPPORTED;
 }
-template <int P> static int bf2_rows_p(int nroles, int na)
+template <int P> static int bf2_rows_p(int mask, int na)
 {
-    if (nroles == 1) return BF2Geom<P, 3, 1, 8>::RMAX;
-    return na == 1 ? BF2Geom<P, 2, 4, 8>::RMAX : BF2Geom<P, 2, 4, 4>::RMAX;
+    if (mask == BF_MASK_MASS) return bf2_rmax<P, BF_MASK_MASS, 1>();
+    if (mask == BF_MASK_STIFF2) return bf2_rmax<P, BF_MASK_STIFF2, 1>();
+    return na == 1 ? bf2_rmax<P, BF_MASK_STIFF3, 1>() : bf2_rmax<P, BF_MASK_STIFF3, 2>();
 }
-int fused2_rows_per_tile(int P, int nroles, int na)
+int fused2_rows_per_tile(int P, int mask, int na)
 {
     switch (P) {
-    case 2: return bf2_rows_p<2>(nroles, na);
-    case 3: return bf2_rows_p<3>(nroles, na);
-    case 4: return bf2_rows_p<4>(nroles, na);
-    case 5: return bf2_rows_p<5>(nroles, na);
+    case 2: return bf2_rows_p<2>(mask, na);
+    case 3: return bf2_rows_p<3>(mask, na);
+    case 4: return bf2_rows_p<4>(mask, na);
+    case 5: return bf2_rows_p<5>(mask, na);
     }
     return 1;
 }
@@ -1402,7 +1435,7 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     A.data = d_data; A.sym = in.sym;
     const int P = AL.P;
     const bool v2 = bf2_wanted();
-    const int rmax = v2 ? fused2_rows_per_tile(P, ny == 1 ? 1 : 4, na) : fused_rows_per_tile(P);
+    const int rmax = v2 ? fused2_rows_per_tile(P, mask, na) : fused_rows_per_tile(P);
     A.ntiles = (AL.N + rmax - 1) / rmax;
     A.R2 = (AL.N + A.ntiles - 1) / A.ntiles;
     A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
