@@ -406,10 +406,6 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
     constexpr int ry2 = ry1 + bf_roles_of_y((MASK >> 4) & 15);
     constexpr int ry3 = ry2 + bf_roles_of_y((MASK >> 8) & 15);
     constexpr bool h0 = (MASK & 15) != 0, h1 = ((MASK >> 4) & 15) != 0, h2 = ((MASK >> 8) & 15) != 0, h3 = ((MASK >> 12) & 15) != 0;
-#pragma unroll
-    for (int a = 0; a < NA_; ++a)
-#pragma unroll
-        for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
     double K[4], V[P][2];
     auto load_K = [&](const int l) {
         K[0] = h0 ? kl[ry0 * TL + l] : 0.0;
@@ -441,7 +437,10 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
         for (int b = 0; b < P; ++b) {
 #pragma unroll
             for (int a = 0; a < NA_; ++a) {
-                if (NY == 1) loc[a][b] = fma(V[b][0], c0[a], loc[a][b]);
+                if (l == 0) {                                   // the first point assigns (no zero fill)
+                    if (NY == 1) loc[a][b] = V[b][0] * c0[a];
+                    else loc[a][b] = fma(V[b][0], c0[a], V[b][1] * c1[a]);
+                } else if (NY == 1) loc[a][b] = fma(V[b][0], c0[a], loc[a][b]);
                 else loc[a][b] = fma(V[b][0], c0[a], fma(V[b][1], c1[a], loc[a][b]));
             }
             if (l + 1 < P) {
@@ -657,11 +656,11 @@ template <int P, int NLG, int NRO, int NCW, int NH> struct BF2Geom {
     static constexpr int ROWR = p * W, ROWC = P * W;        // doubles per row in the ring / cur parts
     static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
     static constexpr int nslots(int R, int per) { return (R * per * W + 64 * NCW - 1) / (64 * NCW); }
-    // LDS image (doubles): lines [W][LS] | ring [NH][P+1][R][p][W] | cur [NH][2][R][P][W] | basis values [TL][P][2] | store plan
+    // LDS image (doubles): lines [W][LS] | ring [P+1][R][p][W] | cur [2][R][P][W] | basis values [TL][P][2] | store plan
     // (ints) [NSR + NSC][NCW * 64];  R = rows of the last axis per tile: as many as the window and 160 KB allow
     static constexpr int off_ring() { return (W * LS + 1) & ~1; }
-    static constexpr int off_cur(int R) { return (off_ring() + NH * (P + 1) * R * ROWR + 1) & ~1; }
-    static constexpr int off_v2(int R) { return (off_cur(R) + NH * 2 * R * ROWC + 1) & ~1; }
+    static constexpr int off_cur(int R) { return (off_ring() + (P + 1) * R * ROWR + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_cur(R) + 2 * R * ROWC + 1) & ~1; }
     static constexpr int off_plan(int R) { return off_v2(R) + TL * P * 2; }
     static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * NCW * 32; }
     static constexpr int rmax()
@@ -690,7 +689,6 @@ template <int P, int NLG, int NRO, int NCW, int NH> struct BF2Geom {
     static constexpr int PPP = 64 / PL;                     // pieces per pass
     static constexpr int NPC = npc(PL);                     // pieces per line
     static constexpr int RP = PL - p;                       // rows a piece completes
-    static constexpr int RING1 = (P + 1) * RMAX * ROWR, CUR1 = 2 * RMAX * ROWC;   // doubles of one copy of the rings
 };
 
 __device__ __forceinline__ double bf2_from_lane(const int src4, const double v)
@@ -714,7 +712,7 @@ typedef int bf2_v2i __attribute__((ext_vector_type(2)));
 #define BF2_NCW 4
 #endif
 #ifndef BF2_NH
-#define BF2_NH 1                                         // units of the contraction per pass at the four-role forms (1: whole passes)
+#define BF2_NH 2                                         // 2: the passes beyond one per contractor wave are cut into halves (1: whole passes)
 #endif
 constexpr int BF2_NUMREC = 0x7ffffff0;                     // bytes a descriptor covers; per-lane offsets at or above it are out of range
 constexpr int BF2_OOB = 0x7ffffff8;                        // per-lane offset of a lane that must not store (dropped by the range check)
@@ -908,8 +906,8 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
     constexpr int LS = Gm::LS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lines = lds;                 // [W][LS]
-    double *ring = lds + Gm::OFF_RING;   // [NH][P+1][RMAX][p][W]: entries of the pairs (i1, j1 < i1), slot i1 mod (P+1), line kx = p - (i1 - j1)
-    double *cur = lds + Gm::OFF_CUR;     // [NH][2][RMAX][P][W]:   entries of the pairs (d, d + a), slot d & 1   (NH = 2: partial sums of the two halves of a pass)
+    double *ring = lds + Gm::OFF_RING;   // [P+1][RMAX][p][W]: entries of the pairs (i1, j1 < i1), slot i1 mod (P+1), line kx = p - (i1 - j1)
+    double *cur = lds + Gm::OFF_CUR;     // [2][RMAX][P][W]:   entries of the pairs (d, d + a), slot d & 1
     double *V2s = lds + Gm::OFF_V2;      // [TL][P][2]: last-axis basis values on the tile window
     int *plan = (int *)(lds + Gm::OFF_PLAN);   // [NSR + NSC][NCW][64]: byte offsets of the store elements (interior mid-axis rows)
 
@@ -935,6 +933,8 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         const int gpt = win0 + idx / (2 * P);
         V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P * 2 + idx] : 0.0;
     }
+    if (NH == 2)
+        for (int idx = threadIdx.x; idx < Gm::OFF_V2 - Gm::OFF_RING; idx += blockDim.x) ring[idx] = 0.0;     // the halves of a pass add onto zeros
     // (the barrier B1 of the first iteration orders these writes before their first use)
 
     // wave -> task: a workgroup's waves go to the four SIMDs cyclically; FP64 instructions per step and wave at p = 4:
@@ -1014,19 +1014,20 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         BF_SEG_BEGIN();
 #ifndef BF2_NOPASS
         if (dd >= s_begin && dd < rhi) {
-            // A wave issues one vector instruction per 8 cycles at best (tools/ubench/valu_f64.hip), so the contraction of a step is
-            // cut into units that fit one wave each: a pass (64 lanes of (line, span) items), or -- NH = 2 -- half a pass: rows
-            // 0 .. AH-1 resp. AH .. p of the element matrices; the two halves add up in separate copies of the entry rings, which the
-            // stores sum.  The units rotate over the contractor waves from step to step.
+            // A wave issues one vector instruction per 8 cycles at best (tools/ubench/valu_f64.hip), so a step is bound by its longest
+            // wave: the passes (64 lanes of (line, span) items) go one per contractor wave; NH = 2: the passes beyond that are cut
+            // into two halves -- rows 0 .. AH-1 resp. AH .. p of the element matrices -- for two different waves.  The halves ADD
+            // their entries into the rings (ds_add_f64 onto zeros: the stores clear what they have read; two addends commute, the
+            // sum does not depend on which wave comes first).  The units rotate over the contractor waves from step to step.
             const int npass = (npieces + PPP - 1) / PPP;
-            constexpr int AH = NH == 2 ? (P + 1) / 2 : P;
+            constexpr int AH = (P + 1) / 2;
             auto unit = [&](auto h_, const int pass) {
-                constexpr int H = decltype(h_)::value;                 // 0: rows 0 .. AH-1 (all rows when NH = 1), 1: rows AH .. p
-                constexpr int A0 = H == 0 ? 0 : AH, A1 = H == 0 ? AH : P;
+                constexpr int H = decltype(h_)::value;                 // 0: whole pass, 1: rows 0 .. AH-1, 2: rows AH .. p
+                constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P;
                 // (per-lane constants are worked out again where they are used, from an opaque copy of the lane number: held in
                 // registers across the element matrices they would be spilled, and a scratch reload waits for vmcnt(0), i.e. for
                 // this wave's stores)
-                int ln_ = lane;
+                int ln_ = min(lane, PPP * PL - 1);                     // (lanes past the last piece repeat its last item: nobody reads them)
                 asm volatile("" : "+v"(ln_));
                 const int ps = ln_ / PL, x = ln_ - ps * PL;              // piece slot of the pass, span of the piece
                 const int pid = pass * PPP + ps;
@@ -1057,7 +1058,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
 #pragma unroll
                         for (int b = 0; b < P; ++b) {
                             if (a == 0) out[b + p] = loc[0][b];
-                            else out[b - a + p] += bf2_from_lane(((ln_ - a) & 63) * 4, loc[a - A0][b]);
+                            else out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
                         }
                 }
                 int lw_ = lane;
@@ -1072,26 +1073,37 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                 if (lokw && x2 >= p && r3 < nrows) {
                     const int i2 = row_lo + r3;
                     const int oshv = max(p - i2, 0);
-                    double *dste = (k9w <= p && law > 0) ? ring + H * Gm::RING1 + ((size_t)((row1w % (P + 1)) * RMAX + r3) * p + (p - law)) * W
-                                                         : cur + H * Gm::CUR1 + ((size_t)((dd & 1) * RMAX + r3) * P + (k9w <= p ? 0 : law)) * W;
+                    double *dste = (k9w <= p && law > 0) ? ring + ((size_t)((row1w % (P + 1)) * RMAX + r3) * p + (p - law)) * W
+                                                         : cur + ((size_t)((dd & 1) * RMAX + r3) * P + (k9w <= p ? 0 : law)) * W;
                     dste -= oshv;
+                    if constexpr (H == 0) {
+                        if (row_lo >= p) {                              // (uniform) no row of the tile lacks columns on the left
 #pragma unroll
-                    for (int o = 0; o < W; ++o)
-                        if (o >= oshv) dste[o] = out[o];
+                            for (int o = 0; o < W; ++o) dste[o] = out[o];
+                        } else {
+#pragma unroll
+                            for (int o = 0; o < W; ++o)
+                                if (o >= oshv) dste[o] = out[o];
+                        }
+                    } else {
+                        // entries this half contributes to: rows a in [A0, A1) -> o = b - a + p
+                        constexpr int OLO = p - (A1 - 1), OHI = 2 * p - A0;
+#pragma unroll
+                        for (int o = OLO; o <= OHI; ++o)
+                            if (o >= oshv) (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             };
             const int wslot = (int)((unsigned)(cw + t) % (unsigned)NCW);
-            if constexpr (NH == 1) {
+            if (NH == 1 || npass <= NCW) {
                 for (int pass = wslot; pass < npass; pass += NCW) unit(std::integral_constant<int, 0>(), pass);
-            } else if (NCW > npass) {
-                // first halves on the wave slots 0 .. npass-1, second halves (lighter) shared by the others
-                if (wslot < npass) unit(std::integral_constant<int, 0>(), wslot);
-                else
-                    for (int pass = wslot - npass; pass < npass; pass += NCW - npass) unit(std::integral_constant<int, 1>(), pass);
             } else {
-                for (int u = wslot; u < 2 * npass; u += NCW) {
-                    if (u < npass) unit(std::integral_constant<int, 0>(), u);
-                    else unit(std::integral_constant<int, 1>(), u - npass);
+                unit(std::integral_constant<int, 0>(), wslot);
+                // the halves of the passes NCW .. npass-1: second halves (lighter) first in the rotation
+                const int nsp = npass - NCW;
+                for (int u = wslot; u < 2 * nsp; u += NCW) {
+                    if (u < nsp) unit(std::integral_constant<int, 2>(), NCW + u);
+                    else unit(std::integral_constant<int, 1>(), NCW + u - nsp);
                 }
             }
         }
@@ -1110,15 +1122,18 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
             asm volatile("" : "+v"(lq_));
             const int q0 = cw * 64 + lq_;
             const int *myplan = plan + q0;
+            double *rgw = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR, *cuw = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
 #pragma unroll
             for (int k = 0; k < Gm::NSR; ++k) {
                 const int o_ = (k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP);
-                sv[k] = NH == 2 ? rg[o_] + rg[Gm::RING1 + o_] : rg[o_];
+                sv[k] = rg[o_];
+                if (NH == 2 && s_on) rgw[o_] = 0.0;
             }
 #pragma unroll
             for (int k = 0; k < Gm::NSC; ++k) {
                 const int o_ = (k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP);
-                sv[Gm::NSR + k] = NH == 2 ? cu[o_] + cu[Gm::CUR1 + o_] : cu[o_];
+                sv[Gm::NSR + k] = cu[o_];
+                if (NH == 2 && s_on) cuw[o_] = 0.0;
             }
             if (ddc >= p && ddc < A.N1 - p) {
 #pragma unroll

@@ -12,13 +12,12 @@ for l in sys.stdin:
 "
 }
 {
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=2
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=2 IGX_OVERLAP_NOPRIO=1
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=3
-run IGX_OVERLAP=24 IGX_OVERLAP_BFS=2
+run IGX_OVERLAP=1
+run IGX_OVERLAP=4 IGX_OVERLAP_BFS=2
 run IGX_OVERLAP=8 IGX_OVERLAP_BFS=2
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=2 IGX_OVERLAP_MLDS=24000
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=2 IGX_OVERLAP_LEAN=0
-run IGX_OVERLAP=16 IGX_OVERLAP_BFS=1
-} > gpurun_out/r3b/overlap3.txt 2>&1
-cat gpurun_out/r3b/overlap3.txt
+run IGX_OVERLAP=16 IGX_OVERLAP_BFS=2
+run IGX_OVERLAP=8 IGX_OVERLAP_BFS=2 IGX_OVERLAP_LEAN=0
+run IGX_OVERLAP=8 IGX_OVERLAP_BFS=3
+run IGX_OVERLAP=1
+} > gpurun_out/r3b/overlap4.txt 2>&1
+cat gpurun_out/r3b/overlap4.txt
