@@ -725,11 +725,12 @@ __device__ __forceinline__ double bf2_buffer_load(__amdgpu_buffer_rsrc_t r, cons
     const bf2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double(v.y, v.x);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void bf2_buffer_store(__amdgpu_buffer_rsrc_t r, const int voff, const int soff, const double x)
 {
     bf2_v2i v;
     v.x = __double2loint(x); v.y = __double2hiint(x);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
 }
 
 struct BF2Blk {
@@ -1271,6 +1272,110 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
     }
 }
 
+// k_mirror2: the same pass with 32-bit offsets inside the row blocks of the two outer rows (buffer descriptors: scalar base of
+// the step + per-thread offsets: two multiply-adds per element instead of 64-bit address arithmetic) and with the gather of
+// the NEXT row i1 in flight under the stores of the current one.  Used when a row block (c0 S1 S2 values) is below 2^31
+// bytes; k_mirror otherwise.
+#ifndef MIRROR_ST_AUX
+#define MIRROR_ST_AUX 0                                  // cache policy bits of the mirror's stores (2: nt)
+#endif
+template <int WW, int VAR> struct Mirror2Geom {
+    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : VAR == 2 ? 22 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
+    static constexpr int NJ2 = RCM + WW - 1;
+    static constexpr int SG = (NJ2 * WW + 255) / 256;
+    static constexpr int SS = (RCM * WW * WW + 255) / 256;
+};
+
+template <int WW, int VAR>
+__global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
+{
+    using Gm = Mirror2Geom<WW, VAR>;
+    constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS;
+    extern __shared__ __attribute__((aligned(16))) double T[];           // [WW][NJ2][WW]
+    cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned per = gridDim.x / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    const int ib = (int)(bid % M.ni1), chunk = (int)((bid / M.ni1) % M.nchunks), tp = (int)(bid / ((unsigned)M.ni1 * M.nchunks));
+    const int i0 = ((cip)M.tpairs)[2 * tp], j0 = ((cip)M.tpairs)[2 * tp + 1];
+    const bool diag = i0 == j0;
+    const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
+    const int cl = chunk * M.RC, ch = min(cl + M.RC, M.N2);
+    const int j2lo = max(cl - p, 0), j2hi = min(ch - 1 + p, M.N2 - 1) + 1, nj2 = j2hi - j2lo;
+    const long long S12 = M.S1 * M.S2;
+    auto jlo = [&](const int i) { return max(i - p, 0); };
+    auto cnt = [&](const int i, const int N) { return min(i + p, N - 1) + 1 - max(i - p, 0); };
+    const __amdgpu_buffer_rsrc_t d0 = __builtin_amdgcn_make_buffer_rsrc((void *)M.data, (short)0, 0, 0x00020000);
+    // ---- gather plan: element (j2, op) of a source run = column i2' = jlo2[j2] + op.  Offset inside the row block of (j0, j1):
+    //      8 (A1 rp2[j2] + B1 c2 + op), A1 = c0j c1j, B1 = (i0 - jlo0[j0]) c1j + i1 - jlo1(j1): scalars of the step
+    int g_a[SG], g_c[SG], g_o[SG], g_t[SG];      // 8 rp2[j2] | 8 c2 | 8 op or BF2_OOB | tile offset, bit 30: j2 <= i2'
+#pragma unroll
+    for (int s_ = 0; s_ < SG; ++s_) {
+        const int f = threadIdx.x + 256 * s_;
+        const int j2r = min(f / WW, nj2 - 1), op = f - (f / WW) * WW;
+        const int j2 = j2lo + j2r, c2 = cnt(j2, M.N2), i2p = jlo(j2) + op;
+        const bool ok = f < nj2 * WW && op < c2 && i2p >= cl && i2p < ch;
+        g_a[s_] = M.rp2[j2] * 8; g_c[s_] = c2 * 8; g_o[s_] = ok ? op * 8 : BF2_OOB;
+        g_t[s_] = (j2r * WW + op) | (j2 <= i2p ? 1 << 30 : 0) | (f < nj2 * WW ? 0 : 1 << 29);
+    }
+    // ---- target plan: element (i2, line m, offset o) of a target segment: 8 (A rp2[i2] + (B + m) c2 + o), A = c0i c1i,
+    //      B = (j0 - jlo0[i0]) c1i + a1 - jlo1(i1)
+    int t_a[SS], t_c[SS], t_m[SS], t_off[SS];    // 8 rp2[i2] | 8 c2 | 8 (m c2 + o) or BF2_OOB | tile offset, m in bits 24.., bit 30: j2 <= i2
+#pragma unroll
+    for (int s_ = 0; s_ < SS; ++s_) {
+        const int q = threadIdx.x + 256 * s_;
+        const int rr = q / (WW * WW), e2 = q - rr * (WW * WW);
+        const int m = e2 / WW, o = e2 - m * WW;
+        const int i2 = min(cl + rr, M.N2 - 1), c2 = cnt(i2, M.N2), j2 = min(jlo(i2) + o, M.N2 - 1);
+        const bool ok = cl + rr < ch && o < c2;
+        t_a[s_] = M.rp2[i2] * 8; t_c[s_] = c2 * 8; t_m[s_] = ok ? (m * c2 + o) * 8 : BF2_OOB;
+        t_off[s_] = ((m * NJ2 + (j2 - j2lo)) * WW + (i2 - jlo(j2))) | (m << 24) | (j2 <= i2 ? 1 << 30 : 0);
+    }
+    const int i1b = M.i1_lo + ib * M.i1_rows, i1e = min(i1b + M.i1_rows, M.i1_hi);
+    double v[WW][SG];
+    auto gather = [&](const int i1) {
+        const int jl1i = jlo(i1), c1i = cnt(i1, M.N1);
+        const int a1 = diag ? i1 : jl1i, nj1 = jl1i + c1i - a1;
+#pragma unroll
+        for (int m = 0; m < WW; ++m) {
+            const int j1 = min(a1 + m, M.N1 - 1), c1j = cnt(j1, M.N1);
+            const __amdgpu_buffer_rsrc_t d = m < nj1 ? bf2_rsrc(M.data + ((long long)rp0[j0] * S12 + (long long)c0j * rp1[j1] * M.S2 - M.nnz_off)) : d0;
+            const int A1 = c0j * c1j, B1 = (i0 - jlo0[j0]) * c1j + (i1 - jlo(j1));
+#pragma unroll
+            for (int s_ = 0; s_ < SG; ++s_) {
+                int off = A1 * g_a[s_] + B1 * g_c[s_] + g_o[s_];
+                if (g_o[s_] == BF2_OOB || (m == 0 && diag && (g_t[s_] & (1 << 30)))) off = BF2_OOB;
+                v[m][s_] = bf2_buffer_load(d, off, 0);
+            }
+        }
+    };
+    if (i1b < i1e) gather(i1b);
+    for (int i1 = i1b; i1 < i1e; ++i1) {
+        const int jl1i = jlo(i1), c1i = cnt(i1, M.N1);
+        const int a1 = diag ? i1 : jl1i, nj1 = jl1i + c1i - a1;
+#pragma unroll
+        for (int m = 0; m < WW; ++m)
+#pragma unroll
+            for (int s_ = 0; s_ < SG; ++s_)
+                if (!(g_t[s_] & (1 << 29))) T[m * (NJ2 * WW) + (g_t[s_] & 0xffffff)] = v[m][s_];
+        __syncthreads();
+        gather(min(i1 + 1, i1e - 1));                        // the next row's runs are in flight under the stores (the last row is read twice)
+        // ---- whole target segments
+        const __amdgpu_buffer_rsrc_t dt = bf2_rsrc(M.data + ((long long)rp0[i0] * S12 + (long long)c0i * rp1[i1] * M.S2 - M.nnz_off));
+        const int A = c0i * c1i, B = (j0 - jlo0[i0]) * c1i + (a1 - jl1i);
+#pragma unroll
+        for (int s_ = 0; s_ < SS; ++s_) {
+            const int m = (t_off[s_] >> 24) & 15;
+            int off = A * t_a[s_] + B * t_c[s_] + t_m[s_];
+            if (t_m[s_] == BF2_OOB || m >= nj1 || (diag && m == 0 && (t_off[s_] & (1 << 30)))) off = BF2_OOB;
+            bf2_buffer_store<MIRROR_ST_AUX>(dt, off, 0, T[t_off[s_] & 0xffffff]);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
@@ -1508,6 +1613,27 @@ static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
     return IGX_OK;
 }
 
+template <int WW, int VAR>
+static int launch_mirror2_k(hipStream_t st, MirrorArgs &M, int N2)
+{
+    using Gm = Mirror2Geom<WW, VAR>;
+    M.nchunks = (N2 + Gm::RCM - 1) / Gm::RCM;
+    M.RC = (N2 + M.nchunks - 1) / M.nchunks;
+    const int rows = M.i1_hi - M.i1_lo;
+    long long base = (long long)M.ntp * M.nchunks;
+    M.ni1 = (int)std::max<long long>(1, std::min<long long>((2048 + base - 1) / base, std::max(1, rows / 8)));
+    M.i1_rows = (rows + M.ni1 - 1) / M.ni1;
+    M.ni1 = (rows + M.i1_rows - 1) / M.i1_rows;
+    const long long blocks = base * M.ni1;
+    if (blocks > 0x7fffffffLL) { set_error("mirror pass: too many blocks"); return IGX_ERR_UNSUPPORTED; }
+    if (blocks == 0) return IGX_OK;
+    const size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
+    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror2<WW, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mirror2<WW, VAR><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data)
 {
     if (in.ntp == 0) return IGX_OK;
@@ -1519,6 +1645,18 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
     M.rp1 = AM.dev.rp; M.rp2 = AL.dev.rp;
     M.N1 = AM.N; M.N2 = AL.N; M.p = AL.p; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
     M.tpairs = in.tpairs; M.ntp = in.ntp;
+    // 32-bit offsets inside a row block: c0 S1 S2 values of 8 bytes below 2^31
+    const long long c0max = 2 * pt->ax[0].p + 1;
+    const bool small = pt->dim == 3 && c0max * AM.S * AL.S * 8 < 0x7fff0000LL && !in.lean;
+    int var = 0;
+    if (const char *e = getenv("IGX_MIRROR")) var = atoi(e);
+    if (small && var >= 0) {
+        switch (2 * AL.p + 1) {
+        case 5: return launch_mirror2_k<5, 0>(st, M, AL.N);
+        case 7: return launch_mirror2_k<7, 0>(st, M, AL.N);
+        case 9: return var == 1 ? launch_mirror2_k<9, 1>(st, M, AL.N) : var == 2 ? launch_mirror2_k<9, 2>(st, M, AL.N) : launch_mirror2_k<9, 0>(st, M, AL.N);
+        }
+    }
     switch (2 * AL.p + 1) {
     case 3: return launch_mirror_k<3, false>(st, M, AL.N);
     case 5: return in.lean ? launch_mirror_k<5, true>(st, M, AL.N) : launch_mirror_k<5, false>(st, M, AL.N);
