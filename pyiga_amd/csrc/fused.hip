@@ -36,9 +36,6 @@ namespace igx {
 typedef const double __attribute__((address_space(4))) *cdp;
 typedef const int __attribute__((address_space(4))) *cip;
 
-constexpr int BF_TL = 128;            // Gauss points of the last axis per block = lanes of the sweep (2 waves per role)
-constexpr int BF_NCW = 4;             // contractor waves
-constexpr int BF_NSTW = 0;            // dedicated store waves (0: the contractor waves also store the segments)
 
 // Sweeper roles: one per last-axis type y that occurs.  The arrays entering the sweep are grouped by (y, mid-axis type
 // t1 = tu + 2 tv); MASK has bit 4 y + t1 set for the groups that exist.  Per Gauss point a role accumulates
@@ -70,15 +67,6 @@ constexpr BFRole bf_role(int MASK, int r)
     }
     return BFRole{0, 0, 0, {0, 0, 0, 0}};
 }
-template <int P>
-struct BFGeom {
-    static constexpr int p = P - 1, W = 2 * P - 1;
-    static constexpr int LW = (W + BF_NCW - 1) / BF_NCW;   // K2 lines per contractor wave and step
-    static constexpr int SPW = (BF_TL / P) < (64 / LW) ? (BF_TL / P) : (64 / LW);   // spans of a tile window: one lane per (line, span)
-    static constexpr int RMAX = SPW - p;                   // rows of the last axis per tile (their supports fit the window)
-    static constexpr int XB = LW * SPW * P * P;            // doubles of a contractor wave's exchange buffer
-};
-
 struct BFArgs {
     // input arrays of the sweep: In(y, t1, i)[slice][g_mid][g_last]; absent slots point at a row of zeros (strides 0)
     const double *sp[4][4][2];
@@ -99,9 +87,6 @@ struct BFArgs {
     int mid_lo, mid_hi;           // rows of the mid axis to produce
     int span_hi;                  // spans of the mid axis below this one are resident (2D row slabs; else n1)
     int npairs;
-    int pair_off;                 // first pair of this launch (index into pl0 = K1 slice)
-    int dbg;                      // ablation mask (IGX_BF_DBG; timing experiments only): 1 no contraction, 2 no segment stores,
-                                  //   4 no sweep arithmetic
 };
 
 // Diagnostic build (-DIGX_BF_STAMP, never the shipped library): every wave adds up the shader cycles it spends waiting
@@ -124,272 +109,6 @@ __device__ unsigned long long g_bf_stamp[64 * 1024];
 #define BF_STAMP_END(w)
 __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
-
-// Split contraction (four roles, four contractor waves, the last one without lines): the element matrices of line group g
-// are computed by TWO waves of the same SIMD between the barriers B1 and B2 -- rows 0..AH-1 by contractor g, rows AH..p by
-// the first sweeper wave of role g+1 (which sweeps afterwards) -- and gathered by the contractor after B2.  A wave that is
-// alone on its SIMD issues one FP64 instruction per 11 cycles, two interleaved waves one per 6 (tools/ubench/mix_f64.hip):
-// the contractor alone was the critical path of a step, the sweepers next to it waited at the barrier.
-template <int P> struct BFSplit {
-    static constexpr int W = 2 * P - 1, LW = (W + BF_NCW - 1) / BF_NCW;
-    static constexpr int AH = (P + 1) / 2;                       // rows of the contractor's part
-};
-template <int P, int MASK> constexpr bool bf_split() { return bf_nroles(MASK) == 4 && BF_NCW == 4 && 3 * BFSplit<P>::LW >= BFSplit<P>::W && P >= 3; }
-struct BFBlk {                // block constants of the stores
-    int i0, j0, diag0, c0i, rlo, rhi, row_lo, nrows;
-    long long S12;
-    const double *ring, *cur;
-};
-struct BFHelp {
-    int group;                // line group whose rows AH..p this sweeper wave computes (-1: none)
-    double *xb;               // exchange buffer of that group
-    const double *V2s;        // last-axis basis values of the tile window
-    int rlo, diag0, nsw;      // first mid-axis row of the block, diagonal outer pair, spans of the window
-    int store_sw;             // this sweeper wave is store wave store_sw of the block (-1: none)
-    BFBlk blk;
-};
-template <int P, int NY, int MASK, int A0, int A1>
-__device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl, const int TL = BF_TL);
-
-// ---- segment stores: whole CSR segments of the mid-axis row completed two steps ago, from the entry rings.  NCW "store
-// waves" share the elements of a step: element q = (row rr, line m, offset o) of the largest possible segment shape,
-// q = (rr * W + m) * W + o, lane-consecutive -> consecutive lanes write consecutive doubles.  What does not depend on the
-// step is worked out once per lane (the plan).  Without the split contraction the store waves are the contractor waves;
-// with it they are the SECOND sweeper wave of roles 1..3 (idle most of a step) and the last contractor wave.
-template <int P> struct BFStorePlan {
-    static constexpr int W = 2 * P - 1, RMAX = BFGeom<P>::RMAX;
-    static constexpr int NSL = (RMAX * W * W + 64 * BF_NCW - 1) / (64 * BF_NCW);
-    int rp[NSL], mo[NSL];     // rp2[row] | m, o, c2, flags, rr * W + o (bits 16..)
-};
-template <int P>
-__device__ __forceinline__ void bf_store_plan(BFStorePlan<P> &pl, const BFArgs &A, const BFBlk &B, const int sw, const int lane)
-{
-    constexpr int p = P - 1, W = 2 * P - 1, RMAX = BFGeom<P>::RMAX, NCW = BF_NCW;
-    cip rp2 = (cip)A.rp2;
-#pragma unroll
-    for (int k = 0; k < BFStorePlan<P>::NSL; ++k) {
-        const int q = (k * NCW + sw) * 64 + lane;
-        const int rr = min(q / (W * W), RMAX - 1), e2 = q - (q / (W * W)) * (W * W);
-        const int m = e2 / W, o = e2 - m * W;
-        const int2 rt = make_int2(rp2[min(B.row_lo + rr, A.N2 - 1)], min(B.row_lo + rr + p, A.N2 - 1) + 1 - max(B.row_lo + rr - p, 0));
-        const int i2r = B.row_lo + rr;
-        const bool ok = q < B.nrows * W * W && o < rt.y;
-        const bool dg = o <= i2r - max(i2r - p, 0);   // entry of the diagonal line of a diagonal block that is stored (j2 <= i2)
-        pl.rp[k] = rt.x;
-        pl.mo[k] = (m & 15) | ((o & 15) << 4) | ((max(rt.y, 0) & 15) << 8) | (ok ? 1 << 12 : 0) | (dg ? 1 << 13 : 0)   // (rows past the axis have a negative run length)
-                   | ((rr * W + o) << 16);
-    }
-}
-template <int P>
-__device__ __forceinline__ void bf_store_row(const BFArgs &A, const BFBlk &B, const BFStorePlan<P> &pl, const int dd2)
-{
-    constexpr int p = P - 1, W = 2 * P - 1, RMAX = BFGeom<P>::RMAX, NSL = BFStorePlan<P>::NSL;
-    if (!(dd2 >= B.rlo && dd2 < B.rhi) || (A.dbg & 2)) return;
-    cip rp0 = (cip)A.rp0, jlo0 = (cip)A.jlo0, rp1 = (cip)A.rp1;
-    const int jl1 = max(dd2 - p, 0), c1 = min(dd2 + p, A.N1 - 1) + 1 - jl1;
-    const int nm = B.diag0 ? dd2 - jl1 + 1 : c1;    // lines of the segment
-    const int koff = p - (dd2 - jl1);               // line m of the segment is pair index m + koff: < p ring, >= p cur
-    const double *rg = B.ring + (size_t)((dd2 % (P + 1)) * p) * RMAX * W;
-    const double *cu = B.cur + (size_t)((dd2 & 1) * P) * RMAX * W;
-    double *rowp = A.data + ((long long)rp0[B.i0] * B.S12 + (long long)B.c0i * (long long)rp1[dd2] * A.S2 - A.nnz_off);
-    const int colb = (B.j0 - jlo0[B.i0]) * c1, rsc = B.c0i * c1;
-    double val[NSL];
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) {
-        const int kx = min((pl.mo[k] & 15) + koff, 2 * p);
-        val[k] = (kx < p ? rg + kx * (RMAX * W) : cu + (kx - p) * (RMAX * W))[pl.mo[k] >> 16];     // always inside the rings
-    }
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) {
-        const int m = pl.mo[k] & 15, o = (pl.mo[k] >> 4) & 15, c2r = (pl.mo[k] >> 8) & 15;
-        const bool ok = ((pl.mo[k] >> 12) & 1) && m < nm && !(B.diag0 && m == nm - 1 && !((pl.mo[k] >> 13) & 1));
-        if (ok) rowp[rsc * pl.rp[k] + (colb + m) * c2r + o] = val[k];      // (offset inside the row block: < 2^31)
-    }
-}
-
-// ---- sweeper: role R of MASK, lane = Gauss point g2 of the tile window.  The values of one span live in registers; each
-// is reloaded for the next span right after its use, so a load has a whole step to land and the waits are counted
-// (no branch around a load inside the loops: hipcc answers those with vmcnt(0)).
-template <int P, int MASK, int RI, int NA, bool LG0>
-__device__ __forceinline__ void bf_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
-                                           const int rhi, double *lines, const int LS, const BFHelp &H)
-{
-    constexpr BFRole R = bf_role(MASK, RI);
-    constexpr int p = P - 1, TL = BF_TL;
-    BF_STAMP_DECL
-    // the sweepers feed the memory pipeline: they issue first, the contractors take the remaining slots of the SIMD
-    __builtin_amdgcn_s_setprio(3);
-    cdp V1 = (cdp)A.V1;
-    double acc[P][P];
-#pragma unroll
-    for (int a = 0; a < P; ++a)
-#pragma unroll
-        for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
-    // per-lane row pointers of the slots that exist
-    const double *base[4][NA];
-    long long rs[4][NA];
-#pragma unroll
-    for (int t1 = 0; t1 < 4; ++t1)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            rs[t1][i] = A.rs[R.y][t1][i];
-            base[t1][i] = A.sp[R.y][t1][i] + (long long)r0 * A.ss[R.y][t1][i] - (long long)A.gmid_lo * rs[t1][i] + g2;
-        }
-    const int n_sw = min(A.n1, A.span_hi);               // spans that exist and are resident
-    const int t_sw = min(n_sw, rhi);                     // sweeping steps end here
-    double kv[P][4][NA];
-    {
-        const int s = min(s_begin, t_sw - 1);
-#pragma unroll
-        for (int l = 0; l < P; ++l)
-#pragma unroll
-            for (int t1 = 0; t1 < 4; ++t1)
-                if (R.has[t1])
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = base[t1][i][(long long)(s * P + l) * rs[t1][i]];
-    }
-    auto flush = [&]() {
-        // dof t leaves: column (t+a, t) and row (t, t+a) of the pair window are complete
-        double *ln = lines + RI * TL + g2l;
-#pragma unroll
-        for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
-#pragma unroll
-        for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
-#pragma unroll
-        for (int a = 0; a < P - 1; ++a)
-#pragma unroll
-            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
-#pragma unroll
-        for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
-    };
-    // this wave's share of the segment stores (split contraction): row t - 2, any time between the barriers of step t
-    // (role 0, the heaviest sweeper, takes no share: the code is not even instantiated for it -- registers)
-    // (the first wave of a role computes element rows, the second one stores: two instantiations, or each would carry the
-    //  registers of both)
-    constexpr bool SHARE = bf_split<P, MASK>() && RI >= 1;
-    BFStorePlan<P> spl;
-    if constexpr (SHARE && !LG0) {
-        if (H.store_sw >= 0) bf_store_plan<P>(spl, A, H.blk, H.store_sw, g2l & 63);
-    }
-    auto stores = [&](const int t_) {
-        if constexpr (SHARE && !LG0) {
-            if (H.store_sw >= 0) bf_store_row<P>(A, H.blk, spl, t_ - 2);
-        }
-    };
-    // the sweeper's share of the element matrices of flush t - 1 (split contraction)
-    auto help = [&](const int t_) {
-        if constexpr (SHARE && LG0) {
-            using Gm_ = BFGeom<P>;
-            constexpr int NY_ = (MASK & ~15) ? 4 : 1, AH = BFSplit<P>::AH, W_ = 2 * P - 1;
-            const int dd = t_ - 1;
-            if (H.group < 0 || dd < s_begin || dd >= rhi || (A.dbg & 33)) return;
-            const int lane_ = g2l & 63, ln1 = lane_ / Gm_::SPW, s1 = lane_ - ln1 * Gm_::SPW;
-            const int k9 = H.group * Gm_::LW + ln1, la = k9 <= p ? k9 : k9 - p;
-            const int row1 = k9 <= p ? dd + la : dd, col1 = k9 <= p ? dd : dd + la;
-            if (ln1 < Gm_::LW && s1 < H.nsw && k9 < W_ && row1 >= H.rlo && row1 < rhi && col1 < A.N1 && !(H.diag0 && col1 > row1)) {
-                double loc[P - AH][P];
-                bf_element<P, NY_, MASK, AH, P>(loc, lines + k9 * LS + s1 * P, H.V2s + s1 * P * P * 2);
-                double *xo = H.xb + (ln1 * Gm_::SPW + s1) * (P * P) + AH * P;
-#pragma unroll
-                for (int a = 0; a < P - AH; ++a)
-#pragma unroll
-                    for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
-            }
-        }
-    };
-    int t = s_begin;
-    for (; t < t_sw; ++t) {
-        bar_lds();                                       // B1
-        help(t);
-        const int tn = min(t + 1, t_sw - 1);
-        cdp cf = V1 + (size_t)t * P * P * 2;
-        double v[P][2];
-#pragma unroll
-        for (int b = 0; b < P; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
-#pragma unroll
-        for (int l = 0; l < P; ++l) {
-            // coefficients of the next point are requested before this point's arithmetic
-            double vn[P][2];
-            const int ln_ = l + 1 < P ? l + 1 : l;
-#pragma unroll
-            for (int b = 0; b < P; ++b) { vn[b][0] = cf[(ln_ * P + b) * 2]; vn[b][1] = cf[(ln_ * P + b) * 2 + 1]; }
-            double kt[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t1 = 0; t1 < 4; ++t1)
-                if (R.has[t1]) {
-                    kt[t1] = kv[l][t1][0];
-                    if (NA == 2) kt[t1] += kv[l][t1][1];
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = base[t1][i][(long long)(tn * P + l) * rs[t1][i]];
-                }
-            if (!(A.dbg & 4)) {
-                if (R.shape == 1) {
-                    // one tv = f: w[b] = sum_tu V[b][tu] K[tu + 2 f]
-#pragma unroll
-                    for (int b = 0; b < P; ++b) {
-                        double w;
-                        if (R.has[2 * R.f] && R.has[2 * R.f + 1]) w = fma(v[b][1], kt[2 * R.f + 1], v[b][0] * kt[2 * R.f]);
-                        else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
-                        else w = v[b][1] * kt[2 * R.f + 1];
-#pragma unroll
-                        for (int a = 0; a < P; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
-                    }
-                } else {
-                    // c[a] = sum_tv V[a][tv] K[tu + 2 tv] for the tu that occur
-#pragma unroll
-                    for (int tu = 0; tu < 2; ++tu) {
-                        if (!(R.has[tu] || R.has[tu + 2])) continue;
-#pragma unroll
-                        for (int a = 0; a < P; ++a) {
-                            double c;
-                            if (R.has[tu] && R.has[tu + 2]) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
-                            else if (R.has[tu]) c = v[a][0] * kt[tu];
-                            else c = v[a][1] * kt[tu + 2];
-#pragma unroll
-                            for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
-                        }
-                    }
-                }
-            } else acc[0][0] += kt[0] + kt[1] + kt[2] + kt[3];
-            // keep the points apart (the FMAs of point l precede the coefficient use of point l+1)
-#pragma unroll
-            for (int a = 0; a < P; ++a)
-#pragma unroll
-                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
-#pragma unroll
-            for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
-        }
-        stores(t);
-        bar_lds();                                       // B2: the contractors have read the previous lines
-        flush();
-    }
-    for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
-        bar_lds();
-        help(t);
-        stores(t);
-        bar_lds();
-        flush();
-    }
-    for (; t < rhi + 2; ++t) { bar_lds(); help(t); stores(t); bar_lds(); }   // the contractors finish the last two rows
-    BF_STAMP_END(threadIdx.x >> 6);
-}
-
-template <int P, int MASK, int NA, int RI, bool END = (RI >= bf_nroles(MASK))>
-struct BFSweepDispatch {
-    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS,
-                                               const BFHelp &H)
-    {
-        if (role == RI) {
-            if (__builtin_amdgcn_readfirstlane(g2l) < 64) bf_sweeper<P, MASK, RI, NA, true>(A, r0, g2l, g2, s_begin, rhi, lines, LS, H);
-            else bf_sweeper<P, MASK, RI, NA, false>(A, r0, g2l, g2, s_begin, rhi, lines, LS, H);
-        }
-        else BFSweepDispatch<P, MASK, NA, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, H);
-    }
-};
-template <int P, int MASK, int NA, int RI>
-struct BFSweepDispatch<P, MASK, NA, RI, true> {
-    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BFHelp &) {}
-};
 
 // Element matrices of one K2 line on one span of the last axis (the contractors' first half): with K[y][l] the line's values
 // of type y = tu + 2 tv at the span's Gauss points and V[l][.][.] the basis values there,
@@ -457,184 +176,6 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
             for (int b = 0; b < P; ++b) asm volatile("" : "+v"(loc[a][b]));
         asm volatile("" ::: "memory");
     }
-}
-
-template <int P, int NY, int MASK, int NA>
-__global__ void __launch_bounds__((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW) * 64) k_bf(const BFArgs A)
-{
-    using Gm = BFGeom<P>;
-    constexpr int p = P - 1, W = 2 * P - 1, TL = BF_TL, NLG = TL / 64, NR = bf_nroles(MASK), NSW = NR * NLG, NCW = BF_NCW;
-    constexpr int RMAX = Gm::RMAX;
-    constexpr int LS = NR * TL + 2;                       // doubles per line (all roles), padded against bank conflicts
-    constexpr int OFF_RING = (W * LS + 1) & ~1;
-    constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * RMAX * W + 1) & ~1;
-    constexpr int OFF_V2 = (OFF_CUR + 2 * P * RMAX * W + 1) & ~1;
-    constexpr int OFF_XB = OFF_V2 + TL * P * 2;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lines = lds;                 // [W][LS]: lines 0..p = pairs (d+a, d), lines p+a = pairs (d, d+a) of the last flush
-    double *ring = lds + OFF_RING;       // [P+1][p][RMAX][W]: entries of the pairs (i1, j1 < i1), row slot i1 mod (P+1)
-    double *cur = lds + OFF_CUR;         // [2][P][RMAX][W]:   entries of the pairs (d, d .. d+p), slot d & 1
-    double *V2s = lds + OFF_V2;          // [TL][P][2]: last-axis basis values on the tile window
-    double *xbuf = lds + OFF_XB;         // [NCW][LW][SPW][P][P]: element matrices of the lines a contractor wave is working on
-
-    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // XCD-aware order: the tiles of one (pair, chunk) share K1 halo lines -> consecutive logical ids on one XCD
-    unsigned bid = blockIdx.x;
-    {
-        const unsigned per = gridDim.x / 8;
-        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
-    }
-    const int tile = (int)(bid % A.ntiles);
-    const int mch = (int)((bid / A.ntiles) % A.nmchunks);
-    const int r0 = A.pair_off + (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
-    const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
-    const bool diag0 = A.sym && i0 == j0;
-    const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
-    const int sp_lo = max(row_lo - p, 0), sp_hi = min(row_hi - 1, A.n2 - 1) + 1;
-    const int win0 = sp_lo * P, nwin = (sp_hi - sp_lo) * P;
-    const int rlo = A.mid_lo + mch * A.mrows, rhi = min(rlo + A.mrows, A.mid_hi);
-    const int s_begin = max(rlo - p, 0);
-
-    for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) V2s[idx] = idx < nwin * P * 2 ? A.V2[(size_t)win0 * P * 2 + idx] : 0.0;
-    // the barrier B1 of the first iteration orders these writes before their first use
-
-    // wave -> task.  A workgroup's waves go to the four SIMDs cyclically (wave % 4), and the stage is bound by vector issue:
-    // for four roles the FP64 work per step (role 0: 70 FMAs per point, roles 1..3: 30..35, contractor: ~75 per point) is
-    // spread as  SIMD 0: contractor 0 + both waves of role 1 | 1: contractor 1 + role 2 | 2: contractor 2 + role 3 |
-    // 3: both waves of role 0 + contractor 3 (few lines, stores).  Task ids: sweepers 0..NSW-1 (role = id / 2, lane group = id % 2),
-    // contractors NSW..
-    int task = wave;
-    if (NR == 4 && NCW == 4) {
-        const int sd = wave & 3, k = wave >> 2;           // SIMD residue, position
-        if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
-        else task = k < 2 ? k : NSW + 3;
-    }
-    BFBlk blk;
-    blk.i0 = i0; blk.j0 = j0; blk.diag0 = diag0; blk.c0i = jhi0[i0] - jlo0[i0]; blk.rlo = rlo; blk.rhi = rhi;
-    blk.row_lo = row_lo; blk.nrows = nrows; blk.S12 = A.S1 * A.S2; blk.ring = ring; blk.cur = cur;
-    if (task < NSW) {
-        // ---------------- sweepers: role, lane group lg
-        const int role = task / NLG, lg = task % NLG;
-        const int g2l = lg * 64 + lane;
-        const int g2 = min(win0 + min(g2l, nwin - 1), A.G2 - 1);     // lanes past the window re-read its last point
-        BFHelp H;
-        H.group = (bf_split<P, MASK>() && lg == 0 && role >= 1) ? role - 1 : -1;     // same SIMD as contractor role - 1 (mapping above)
-        H.xb = xbuf + (H.group < 0 ? 0 : H.group) * Gm::XB;
-        H.V2s = V2s; H.rlo = rlo; H.diag0 = diag0; H.nsw = sp_hi - sp_lo;
-        H.store_sw = (bf_split<P, MASK>() && lg == 1 && role >= 1) ? role - 1 : -1;
-        H.blk = blk;
-        BFSweepDispatch<P, MASK, NA, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, H);
-        return;
-    }
-
-    // ---------------- contractors.  Per step and contractor wave LW lines of the last flush:
-    //   1. lane = (line, span of the window): element matrices loc[a][b] of the line on that span (bf_element) -> wave-private
-    //      exchange buffer;
-    //   2. lane = (line, row of the tile): the 2p+1 entries of the row are gathered from the element matrices of the spans
-    //      of its support, entry o = b - a + p from (span i2 - a, a, b), in a fixed order -> entry rings.
-    constexpr int LW = Gm::LW, SPW = Gm::SPW, PP = P * P;
-    BF_STAMP_DECL
-    const int cw = task - NSW;
-    double *xb = xbuf + cw * Gm::XB;
-    const int nsw = sp_hi - sp_lo;                        // spans of the window
-    const int ln1 = lane / SPW, s1 = lane - ln1 * SPW;    // step 1: line slot, span
-    const bool v1 = ln1 < LW && s1 < nsw;
-    const int ln3 = lane / RMAX, r3 = lane - ln3 * RMAX;  // step 2: line slot, row
-    const bool v3 = ln3 < LW && r3 < nrows;
-    const int i2 = row_lo + r3;
-
-    // store wave index of this contractor (-1: the stores are with the sweepers' second waves, see bf_store_row)
-    const int store_sw = !bf_split<P, MASK>() ? cw : (cw == NCW - 1 ? cw : -1);
-    BFStorePlan<P> spl;
-    if (store_sw >= 0) bf_store_plan<P>(spl, A, blk, store_sw, lane);
-    for (int t = s_begin; t < rhi + 2; ++t) {
-        bar_lds();                                        // B1: the lines of flush t-1 are in LDS
-        BF_SEG_BEGIN();
-        if (store_sw >= 0) bf_store_row<P>(A, blk, spl, t - 2);
-        BF_SEG_END(0);
-        // ---- contract the lines of flush dd = t - 1 with the last axis
-        const int dd = t - 1;
-        if (dd >= s_begin && dd < rhi && !(A.dbg & 1)) {
-            // line k9: pair (dd + la, dd) for k9 <= p, else (dd, dd + la)
-            auto line_ok = [&](const int k9, int &row1, int &col1) {
-                const int la = k9 <= p ? k9 : k9 - p;
-                row1 = k9 <= p ? dd + la : dd; col1 = k9 <= p ? dd : dd + la;
-                return k9 < W && row1 >= rlo && row1 < rhi && col1 < A.N1 && !(diag0 && col1 > row1);
-            };
-            BF_SEG_BEGIN();
-            {
-                int row1, col1;
-                const int k9 = cw * LW + ln1;
-                if (v1 && line_ok(k9, row1, col1)) {
-                    double *xo = xb + (ln1 * SPW + s1) * PP;
-                    if (bf_split<P, MASK>() || (A.dbg & 32)) {   // split contraction: rows 0..AH-1 here, the others by a sweeper wave
-                        constexpr int AH = (P + 1) / 2;
-                        double loc[AH][P];
-                        bf_element<P, NY, MASK, 0, AH>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
-#pragma unroll
-                        for (int a = 0; a < AH; ++a)
-#pragma unroll
-                            for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
-                    } else {
-                    double loc[P][P];
-                    bf_element<P, NY, MASK>(loc, lines + k9 * LS + s1 * P, V2s + s1 * P * P * 2);
-#pragma unroll
-                    for (int a = 0; a < P; ++a)
-#pragma unroll
-                        for (int b = 0; b < P; ++b) xo[a * P + b] = loc[a][b];
-                    }
-                }
-            }
-            BF_SEG_END(1);
-            __builtin_amdgcn_wave_barrier();              // LDS operations of one wave execute in order
-        }
-        if constexpr (bf_split<P, MASK>()) bar_lds();     // B2 (split contraction): all parts of the element matrices are in LDS; the sweepers flush after it
-        if (dd >= s_begin && dd < rhi && !(A.dbg & 1)) {
-            auto line_ok = [&](const int k9, int &row1, int &col1) {
-                const int la = k9 <= p ? k9 : k9 - p;
-                row1 = k9 <= p ? dd + la : dd; col1 = k9 <= p ? dd : dd + la;
-                return k9 < W && row1 >= rlo && row1 < rhi && col1 < A.N1 && !(diag0 && col1 > row1);
-            };
-            BF_SEG_BEGIN();
-            {
-                int row1, col1;
-                int ln3v = ln3;                           // (opaque: the per-lane values derived from it are recomputed per step
-                asm volatile("" : "+v"(ln3v));            //  instead of living in registers the kernel does not have)
-                const int k9 = cw * LW + ln3v;
-                if (v3 && line_ok(k9, row1, col1)) {
-                    double accv[W];
-#pragma unroll
-                    for (int o = 0; o < W; ++o) accv[o] = 0.0;
-                    const double *xi = xb + (ln3 * SPW - sp_lo) * PP;
-#pragma unroll
-                    for (int a = 0; a < P; ++a) {
-                        const int sp = i2 - a;            // the span in which row i2 is test function a
-                        if (sp >= 0 && sp < A.n2) {
-#pragma unroll
-                            for (int b = 0; b < P; ++b) accv[b - a + p] += xi[sp * PP + a * P + b];
-                        }
-                    }
-                    const int la = row1 - col1;
-                    // (recomputed per step from r3: one more long-lived per-lane value would be spilled to scratch, and a scratch
-                    // reload waits for vmcnt(0), i.e. for this wave's CSR stores)
-                    int r3v = r3;
-                    asm volatile("" : "+v"(r3v));
-                    const int oshv = max(p - (row_lo + r3v), 0);
-                    double *dste = ((la > 0) ? ring + (size_t)((((row1 % (P + 1)) * p + (p - la)) * RMAX + r3)) * W
-                                             : cur + (size_t)((((dd & 1) * P - la) * RMAX + r3)) * W) - oshv;
-#pragma unroll
-                    for (int o = 0; o < W; ++o)
-                        if (o >= oshv) dste[o] = accv[o];
-                }
-            }
-            BF_SEG_END(2);
-            __builtin_amdgcn_wave_barrier();              // the gather precedes the next step's element matrices
-        }
-        if constexpr (!bf_split<P, MASK>()) bar_lds();    // B2: lines may be overwritten, entries are visible
-    }
-    BF_SEG_DUMP(cw);
-    BF_STAMP_END(wave);
 }
 
 // =============================================================================================
@@ -921,7 +462,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
     }
     const int tile = (int)(bid % A.ntiles);
     const int mch = (int)((bid / A.ntiles) % A.nmchunks);
-    const int r0 = A.pair_off + (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
+    const int r0 = (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
     const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
     const bool diag0 = A.sym && i0 == j0;
     const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
@@ -1128,13 +669,13 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
             for (int k = 0; k < Gm::NSR; ++k) {
                 const int o_ = (k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP);
                 sv[k] = rg[o_];
-                if (NH == 2 && s_on) rgw[o_] = 0.0;
+                if (NH == 2 && s_on && q0 + k * NCW * 64 <= RCLAMP) rgw[o_] = 0.0;      // (only the element's owner clears it)
             }
 #pragma unroll
             for (int k = 0; k < Gm::NSC; ++k) {
                 const int o_ = (k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP);
                 sv[Gm::NSR + k] = cu[o_];
-                if (NH == 2 && s_on) cuw[o_] = 0.0;
+                if (NH == 2 && s_on && q0 + k * NCW * 64 <= CCLAMP) cuw[o_] = 0.0;
             }
             if (ddc >= p && ddc < A.N1 - p) {
 #pragma unroll
@@ -1177,20 +718,17 @@ struct MirrorArgs {
     int ntp, RC, nchunks;
 };
 
-template <int WW, bool LEAN = false> struct MirrorGeom {
-    // rows i2 per block (tile <= 48 KB); LEAN: tile <= 20 KB and few registers, so that a block fits on a CU NEXT TO a block of
-    // k_bf (which leaves ~21 KB of LDS and 80 VGPRs per SIMD): the pass then runs under the fused stage of the next range
-    static constexpr int RCM = LEAN ? (WW == 3 ? 128 : WW == 5 ? 64 : WW == 7 ? 32 : WW == 9 ? 16 : 10)
-                                    : (WW == 3 ? 128 : WW == 5 ? 128 : WW == 7 ? 112 : WW == 9 ? 66 : 40);
+template <int WW> struct MirrorGeom {
+    static constexpr int RCM = WW == 3 ? 128 : WW == 5 ? 128 : WW == 7 ? 112 : WW == 9 ? 66 : 40;   // rows i2 per block (tile <= 48 KB)
     static constexpr int NJ2 = RCM + WW - 1;                           // source rows j2 around a chunk
     static constexpr int SG = (NJ2 * WW + 255) / 256;                  // gather elements (j2, offset) per thread and j1
     static constexpr int SS = (RCM * WW * WW + 255) / 256;             // target elements per thread
 };
 
-template <int WW, bool LEAN>
+template <int WW>
 __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 {
-    using Gm = MirrorGeom<WW, LEAN>;
+    using Gm = MirrorGeom<WW>;
     constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS;
     extern __shared__ __attribute__((aligned(16))) double T[];           // [WW][NJ2][WW]
     cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1;
@@ -1280,7 +818,7 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 #define MIRROR_ST_AUX 0                                  // cache policy bits of the mirror's stores (2: nt)
 #endif
 template <int WW, int VAR> struct Mirror2Geom {
-    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : VAR == 2 ? 22 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
+    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
     static constexpr int NJ2 = RCM + WW - 1;
     static constexpr int SG = (NJ2 * WW + 255) / 256;
     static constexpr int SS = (RCM * WW * WW + 255) / 256;
@@ -1380,40 +918,6 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
 // host side
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
-template <int P, int NY, int MASK, int NA>
-static int launch_bf_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
-{
-    using Gm = BFGeom<P>;
-    constexpr int W = 2 * P - 1, p = P - 1, LS = bf_nroles(MASK) * BF_TL + 2;
-    constexpr int OFF_RING = (W * LS + 1) & ~1;
-    constexpr int OFF_CUR = (OFF_RING + (P + 1) * p * Gm::RMAX * W + 1) & ~1;
-    constexpr int OFF_V2 = (OFF_CUR + 2 * P * Gm::RMAX * W + 1) & ~1;
-    constexpr size_t lds = (size_t)(OFF_V2 + BF_TL * P * 2 + BF_NCW * Gm::XB) * sizeof(double);
-    static_assert(lds <= 160 * 1024, "k_bf: LDS");
-    IGX_HIP(hipFuncSetAttribute((const void *)k_bf<P, NY, MASK, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_bf<P, NY, MASK, NA><<<dim3(nblocks), dim3((bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW) * 64), lds, st>>>(A);
-    IGX_HIP(hipGetLastError());
-#ifdef IGX_BF_STAMP
-    {
-        static std::vector<unsigned long long> h(64 * 1024);
-        IGX_HIP(hipStreamSynchronize(st));
-        IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bf_stamp), h.size() * sizeof(unsigned long long)));
-        const int nw = bf_nroles(MASK) * (BF_TL / 64) + BF_NCW + BF_NSTW, nb = std::min<unsigned>(nblocks, 2048);
-        for (int w = 0; w < nw; ++w) {
-            double wt = 0, tot = 0;
-            for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
-            fprintf(stderr, "k_bf stamp: wave %2d  wait %.0f  total %.0f cycles/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
-        }
-        for (int w = 0; w < BF_NCW; ++w) {
-            double sg[3] = {0, 0, 0};
-            for (int b = 0; b < nb; ++b) for (int i = 0; i < 3; ++i) sg[i] += h[32768 + (b * 4 + w) * 3 + i];
-            fprintf(stderr, "k_bf stamp: contractor %d  stores %.0f  elements %.0f  gather %.0f cycles/block\n", w, sg[0] / nb, sg[1] / nb, sg[2] / nb);
-        }
-    }
-#endif
-    return IGX_OK;
-}
-
 template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
 static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
@@ -1491,20 +995,6 @@ int fused2_rows_per_tile(int P, int mask, int na)
     }
     return 1;
 }
-static bool bf2_wanted() { const char *e = getenv("IGX_BF"); return !(e && atoi(e) == 1); }
-
-
-template <int P>
-static int launch_bf_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
-{
-    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf_k<P, 1, BF_MASK_MASS, 1>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf_k<P, 4, BF_MASK_STIFF3, 1>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf_k<P, 4, BF_MASK_STIFF3, 2>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf_k<P, 4, BF_MASK_STIFF2, 1>(st, A, nblocks);
-    set_error("fused stage: no kernel for this set of types");
-    return IGX_ERR_UNSUPPORTED;
-}
-
 static void bf_signature(const BFInputs &in, int &ny, int &mask, int &na)
 {
     int ymax = 0;
@@ -1522,12 +1012,6 @@ int fused_supported(const BFInputs &in)
     int ny, mask, na;
     bf_signature(in, ny, mask, na);
     return (ny == 1 && mask == 0x0001 && na == 1) || (ny == 4 && mask == 0x135F && na <= 2) || (ny == 4 && mask == 0x1248 && na == 1);
-}
-
-int fused_rows_per_tile(int P)
-{
-    const int W = 2 * P - 1, lw = (W + BF_NCW - 1) / BF_NCW;
-    return std::min(BF_TL / P, 64 / lw) - (P - 1);
 }
 
 // slots[y][t1]: input arrays (device pointers) of the sweep with their strides; see BFArgs
@@ -1554,46 +1038,38 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     A.S1 = AM.S; A.S2 = AL.S; A.nnz_off = pt->nnz_off;
     A.data = d_data; A.sym = in.sym;
     const int P = AL.P;
-    const bool v2 = bf2_wanted();
-    const int rmax = v2 ? fused2_rows_per_tile(P, mask, na) : fused_rows_per_tile(P);
+    const int rmax = fused2_rows_per_tile(P, mask, na);
     A.ntiles = (AL.N + rmax - 1) / rmax;
     A.R2 = (AL.N + A.ntiles - 1) / A.ntiles;
     A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
     // chunks of the mid axis: enough blocks to fill the chip (each chunk re-sweeps p warm-up spans)
     const int mid_rows = in.mid_hi - in.mid_lo;
-    long long blocks = (long long)(in.npairs_all > 0 ? in.npairs_all : in.npairs) * A.ntiles;
+    long long blocks = (long long)in.npairs * A.ntiles;
     int nmch = 1;
     if (blocks < 1024) nmch = (int)std::min<long long>((1024 + blocks - 1) / blocks, std::max(1, mid_rows / (2 * P)));
+#ifdef IGX_ABLATE
     if (const char *e = getenv("IGX_BF_MCHUNKS")) nmch = std::max(1, std::min(mid_rows, atoi(e)));
+#endif
     A.mrows = (mid_rows + nmch - 1) / nmch;
     A.nmchunks = (mid_rows + A.mrows - 1) / A.mrows;
-    A.npairs = in.npairs; A.pair_off = in.pair_off;
-    A.dbg = getenv("IGX_BF_DBG") ? atoi(getenv("IGX_BF_DBG")) : 0;
+    A.npairs = in.npairs;
     blocks = (long long)in.npairs * A.ntiles * A.nmchunks;
     if (blocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (blocks == 0) return IGX_OK;
     const unsigned nb = (unsigned)blocks;
-    if (v2)
-        switch (P) {
-        case 2: return launch_bf2_p<2>(st, A, nb, ny, mask, na);
-        case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na);
-        case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na);
-        case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na);
-        default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
-        }
     switch (P) {
-    case 2: return launch_bf_p<2>(st, A, nb, ny, mask, na);
-    case 3: return launch_bf_p<3>(st, A, nb, ny, mask, na);
-    case 4: return launch_bf_p<4>(st, A, nb, ny, mask, na);
-    case 5: return launch_bf_p<5>(st, A, nb, ny, mask, na);
+    case 2: return launch_bf2_p<2>(st, A, nb, ny, mask, na);
+    case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na);
+    case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na);
+    case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na);
     default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
     }
 }
 
-template <int WW, bool LEAN>
+template <int WW>
 static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
 {
-    using Gm = MirrorGeom<WW, LEAN>;
+    using Gm = MirrorGeom<WW>;
     M.nchunks = (N2 + Gm::RCM - 1) / Gm::RCM;
     M.RC = (N2 + M.nchunks - 1) / M.nchunks;
     // a launch wants >= ~1536 blocks: split the rows i1 of a (pair, chunk)
@@ -1605,10 +1081,9 @@ static int launch_mirror_k(hipStream_t st, MirrorArgs &M, int N2)
     const long long blocks = base * M.ni1;
     if (blocks > 0x7fffffffLL) { set_error("mirror pass: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (blocks == 0) return IGX_OK;
-    size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
-    if (LEAN) { const char *e = getenv("IGX_OVERLAP_MLDS"); if (e) lds = std::max<size_t>(lds, (size_t)atoi(e)); }   // (experiment: at most one block next to k_bf)
-    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror<WW, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_mirror<WW, LEAN><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
+    const size_t lds = (size_t)WW * Gm::NJ2 * WW * sizeof(double);
+    IGX_HIP(hipFuncSetAttribute((const void *)k_mirror<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_mirror<WW><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(M);
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }
@@ -1645,24 +1120,25 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
     M.rp1 = AM.dev.rp; M.rp2 = AL.dev.rp;
     M.N1 = AM.N; M.N2 = AL.N; M.p = AL.p; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
     M.tpairs = in.tpairs; M.ntp = in.ntp;
-    // 32-bit offsets inside a row block: c0 S1 S2 values of 8 bytes below 2^31
+    // 32-bit offsets inside a row block (k_mirror2): c0 S1 S2 values of 8 bytes below 2^31
     const long long c0max = 2 * pt->ax[0].p + 1;
-    const bool small = pt->dim == 3 && c0max * AM.S * AL.S * 8 < 0x7fff0000LL && !in.lean;
-    int var = 0;
-    if (const char *e = getenv("IGX_MIRROR")) var = atoi(e);
-    if (small && var >= 0) {
+#ifdef MIRROR_OLD
+    if (false) {
+#else
+    if (pt->dim == 3 && c0max * AM.S * AL.S * 8 < 0x7fff0000LL) {
+#endif
         switch (2 * AL.p + 1) {
         case 5: return launch_mirror2_k<5, 0>(st, M, AL.N);
         case 7: return launch_mirror2_k<7, 0>(st, M, AL.N);
-        case 9: return var == 1 ? launch_mirror2_k<9, 1>(st, M, AL.N) : var == 2 ? launch_mirror2_k<9, 2>(st, M, AL.N) : launch_mirror2_k<9, 0>(st, M, AL.N);
+        case 9: return launch_mirror2_k<9, 1>(st, M, AL.N);
         }
     }
     switch (2 * AL.p + 1) {
-    case 3: return launch_mirror_k<3, false>(st, M, AL.N);
-    case 5: return in.lean ? launch_mirror_k<5, true>(st, M, AL.N) : launch_mirror_k<5, false>(st, M, AL.N);
-    case 7: return in.lean ? launch_mirror_k<7, true>(st, M, AL.N) : launch_mirror_k<7, false>(st, M, AL.N);
-    case 9: return in.lean ? launch_mirror_k<9, true>(st, M, AL.N) : launch_mirror_k<9, false>(st, M, AL.N);
-    case 11: return launch_mirror_k<11, false>(st, M, AL.N);
+    case 3: return launch_mirror_k<3>(st, M, AL.N);
+    case 5: return launch_mirror_k<5>(st, M, AL.N);
+    case 7: return launch_mirror_k<7>(st, M, AL.N);
+    case 9: return launch_mirror_k<9>(st, M, AL.N);
+    case 11: return launch_mirror_k<11>(st, M, AL.N);
     default: set_error("mirror pass: degree %d unsupported", AL.p); return IGX_ERR_UNSUPPORTED;
     }
 }

@@ -39,12 +39,21 @@ struct GeoAArgs {
     const int *steps;           // [nsteps][8]
     int s_lo, s_hi, q, chunk_len;
     int ntiles;                 // 64-point tiles of the plane
-    int dbg;                    // ablation (IGX_GEOA_DBG): 1 no geometry, 2 no stores, 4 no sweep arithmetic
+#ifdef IGX_ABLATE
+    int dbg;                    // ablation (IGX_GEOA_DBG, -DIGX_ABLATE builds only): 1 no geometry, 2 no stores, 4 no sweep arithmetic
+#endif
     int field[GA_MAXS], type[GA_MAXS];
     double *out[GA_MAXS];
 };
 
 typedef int int8v __attribute__((ext_vector_type(8)));
+
+// switches of the timing experiments (work left out, wrong results by construction): compiled only into -DIGX_ABLATE builds
+#ifdef IGX_ABLATE
+#define GA_OFF(bit) (A.dbg & (bit))
+#else
+#define GA_OFF(bit) false
+#endif
 
 // Diagnostic build (-DIGX_GA_STAMP, never the shipped library): shader cycles per wave in the sections of the loop
 #ifdef IGX_GA_STAMP
@@ -105,7 +114,9 @@ k_geoA(const GeoAArgs A)
     // consecutive block ids go to different XCDs: give each XCD a contiguous range of point tiles
     const int per_xcd = gridDim.x >> 3;                   // the grid is padded to a multiple of 8 blocks
     int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#ifdef IGX_ABLATE
     if (A.dbg & 8) tile = blockIdx.x;
+#endif
     if (tile >= A.ntiles) tile = A.ntiles - 1;            // surplus blocks redo the last tile (same values again: harmless)
     long long pt = (long long)tile * 64 + lane;
     if (pt >= A.NPL) pt = A.NPL - 1;                      // lanes past the end redo the last point (and store it again: harmless)
@@ -210,7 +221,7 @@ k_geoA(const GeoAArgs A)
                 f0_blk = cur;
                 __syncthreads();
             }
-            if (mine == cur && !(A.dbg & 1)) evaluate(gbuf, buf);
+            if (mine == cur && !GA_OFF(1)) evaluate(gbuf, buf);
             if (cur == last) break;
             int nxt = last;
             for (int j = jl; j >= 0; --j) {
@@ -281,7 +292,7 @@ k_geoA(const GeoAArgs A)
             for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c[a]));
             asm volatile("" ::: "memory");
             basis_row(va, rs, jn, tv);
-            if (!(A.dbg & 4)) {
+            if (!GA_OFF(4)) {
 #pragma unroll
                 for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -301,7 +312,7 @@ k_geoA(const GeoAArgs A)
             GA_T(1);                                      // sweep arithmetic (+ parked stores)
             if (++l < q) continue;
             // dofs that leave the active set after span sp: their pairs are complete
-            const bool write = sp >= own_lo && !(A.dbg & 2);
+            const bool write = sp >= own_lo && !GA_OFF(2);
             const int *fr = (const int *)&rec[rs][j][20];
             const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
             for (int st = st0; st < st0 + nst; ++st) {
@@ -409,7 +420,9 @@ int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
     A.tab = pt->d_geoa_tab; A.steps = pt->stepA_rec;
     A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.q = A0.q; A.chunk_len = chunk_len;
+#ifdef IGX_ABLATE
     { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
+#endif
     for (int x = 0; x < nslots; ++x) { A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x]; }
     A.ntiles = (int)((A.NPL + 63) / 64);
     dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs

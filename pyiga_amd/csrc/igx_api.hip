@@ -237,10 +237,6 @@ void igx_destroy(igx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->ev) (void)hipEventDestroy(ev);
-    if (ctx->side_ok) {
-        for (auto &s : ctx->side) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-        for (auto &ev : ctx->evx) (void)hipEventDestroy(ev);
-    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -346,7 +342,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
-    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs); (void)hipFree(pt->d_tpairs_src);
+    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
     (void)hipFree(pt->d_ws_ij); (void)hipFree(pt->d_ws_out);
     (void)hipFree(pt->d_lv_f); (void)hipFree(pt->d_lv_t1); (void)hipFree(pt->d_lv_t2); (void)hipFree(pt->d_lv_o);
     delete pt;
@@ -359,6 +355,14 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     if (dim != 2 && dim != 3) { set_error("igx_patch_create: dim must be 2 or 3 (got %d)", dim); return nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     igx_patch *pt = new (std::nothrow) igx_patch();
+    if (pt) {                                   // chain choices: read once, here
+        igx_knobs &k = pt->knobs;
+        if (const char *e = getenv("IGX_PATH")) k.path = !strcmp(e, "fused") ? 1 : !strcmp(e, "unfused") ? 2 : 0;
+        if (const char *e = getenv("IGX_GEOA")) k.geoa = strcmp(e, "0") != 0;
+        if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
+        if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");
+        k.poison = getenv("IGX_DEBUG_POISON") != nullptr;
+    }
     if (pt) for (int k = 0; k < 16; ++k) pt->form_slot[k] = -1;
     if (!pt) return nullptr;
     pt->ctx = ctx;
@@ -586,7 +590,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         hipError_t e = hipMalloc((void **)&pt->d_data, ((size_t)std::max(pt->nnz, pt->nnz_ext) + IGX_DUMP_PAD) * sizeof(double));   // + halo rows of the mirror pass / dump slots of masked stores
         if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR values failed", pt->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
     }
-    if (getenv("IGX_DEBUG_POISON"))               // every value must be written exactly once
+    if (pt->knobs.poison)                         // every value must be written exactly once
         IGX_HIP(hipMemsetAsync(pt->d_data, 0xFF, (size_t)pt->nnz * sizeof(double), st));
     memset(&pt->timing, 0, sizeof(pt->timing));
     pt->timing.algo_used = algo;

@@ -97,15 +97,21 @@ struct igx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    // side streams of the assembly chain (created on first use): the mirror pass of one range of outer pairs runs next
-    // to the fused stage of the following ranges; evx: ordering events without timing
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t evx[40] = {};
-    bool side_ok = false;
+};
+
+// Kernel-chain choices of a patch, read from the environment ONCE when the patch is created (igx_patch_create): every
+// assembly of the patch takes the same path, whatever happens to the environment afterwards.  None selects a CPU path.
+struct igx_knobs {
+    int path = 0;                             // IGX_PATH: 0 default (fused in 3D, stage kernels in 2D), 1 fused, 2 unfused
+    int geoa = 1;                             // IGX_GEOA=0: separate field and axis-0 sweep kernels
+    int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
+    int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
+    int poison = 0;                           // IGX_DEBUG_POISON: NaN-fill the CSR values before an assembly (tests)
 };
 
 struct igx_patch {
     igx_ctx *ctx = nullptr;
+    igx_knobs knobs;
     int dim = 0, nqp = 0;
     igx::Axis ax[3];
     // geometry
@@ -160,8 +166,6 @@ struct igx_patch {
     int *d_triv = nullptr;                    // one-dof outer axis of the 2D case: pl0 {0,0} | rp0 {0,1} | jlo0 {0} | jhi0 {1}
     int *d_tpairs = nullptr;                  // [ntp][2] mirror targets: outer pairs (i0 owned, j0 >= i0)
     int ntp = 0;
-    int *d_tpairs_src = nullptr;              // the same targets ordered by their SOURCE row j0 (ranges of the overlapped chain)
-    std::vector<int> h_tp_src;                // host copy
     int last_path = 0;                        // kernels of the last sum-factorised assembly: IGX_PATH_* bits
     igx_timing timing{};
 };
@@ -203,8 +207,6 @@ struct BFInputs {
     const int *rp0, *jlo0, *jhi0;             // outer axis tables (device)
     int sym, mid_lo, mid_hi;
     int span_hi;                              // resident spans of the mid axis end here
-    int pair_off = 0;                         // this launch covers the pairs [pair_off, pair_off + npairs) of pl0
-    int npairs_all = 0;                       // pairs of the whole stage (launch geometry is decided on it; 0: npairs)
 };
 struct MirrorInputs {
     const Axis *mid, *last;
@@ -212,9 +214,7 @@ struct MirrorInputs {
     const int *tpairs;
     int ntp;
     int i1_lo, i1_hi;                         // target rows of the mid axis
-    int lean = 0;                             // small tile / few registers: the pass runs NEXT TO the fused stage on the same CUs
 };
-int fused_rows_per_tile(int P);
 int fused_supported(const BFInputs &in);
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);

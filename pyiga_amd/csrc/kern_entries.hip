@@ -220,8 +220,7 @@ int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const siz
     // wave-per-entry for the fixed forms at p >= 2 (IGX_ENTRIES=thread keeps the one-thread form, the reference's summation order)
     int pmax = 0;
     for (int k = 0; k < pt->dim; ++k) pmax = std::max(pmax, pt->ax[k].p);
-    const char *sel = getenv("IGX_ENTRIES");
-    if (kind != IGX_FORM && pmax >= 2 && !(sel && !strcmp(sel, "thread")) && M < (1ull << 25)) {
+    if (kind != IGX_FORM && pmax >= 2 && !pt->knobs.entries_thread && M < (1ull << 25)) {
         dim3 gridw((unsigned)((M + 3) / 4)), blockw(256);
         if (pt->dim == 2) {
             if (kind == IGX_MASS) k_entries_wave<2, IGX_MASS><<<gridw, blockw, 0, st>>>(pd, pt->d_fields, d_ij, M, d_out);

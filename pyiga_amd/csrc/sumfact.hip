@@ -1162,7 +1162,9 @@ static int build_qdesc(igx_patch *pt, const std::vector<int> &pl, bool sym, int 
     };
     const int np = (int)(pl.size() / 2);
     int T = 1;          // measured at C4: 1, 2, 4, 16 within noise of each other (the final stage is bound by its HBM writes)
+#ifdef IGX_ABLATE
     if (const char *e = getenv("IGX_FINALQ_TILE")) T = std::max(1, atoi(e));
+#endif
     if (dim == 3) {
         // group lines by (r0, i1): rows i1 in order, their columns j1 in order
         for (int r0 = 0; r0 < np; ++r0) {
@@ -1330,16 +1332,6 @@ int sumfact_prepare(igx_patch *pt)
         pt->ntp = (int)(tp.size() / 2);
         IGX_HIP(hipMalloc(&pt->d_tpairs, std::max<size_t>(1, tp.size()) * sizeof(int)));
         IGX_HIP(hipMemcpyAsync(pt->d_tpairs, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
-        // the same targets ordered by their source row j0 (the lower pair (j0, i0) a target is copied from): the overlapped
-        // chain mirrors the targets of a range of source rows as soon as the fused stage has produced that range
-        std::vector<int> &ts = pt->h_tp_src;
-        ts.clear();
-        if (pt->dim == 3) {
-            for (int j0 = pt->r0_lo; j0 < A0.N; ++j0)
-                for (int i0 = std::max(pt->r0_lo, A0.jlo[j0]); i0 <= j0 && i0 < pt->r0_hi; ++i0) { ts.push_back(i0); ts.push_back(j0); }
-        }
-        IGX_HIP(hipMalloc(&pt->d_tpairs_src, std::max<size_t>(1, ts.size()) * sizeof(int)));
-        IGX_HIP(hipMemcpyAsync(pt->d_tpairs_src, ts.data(), ts.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     }
     IGX_HIP(hipMalloc(&pt->d_pl0, std::max<size_t>(1, pl.size()) * sizeof(int)));
@@ -1476,8 +1468,7 @@ static int launch_final(hipStream_t st, const double *K, double *data, const Fin
 // geometry + stage A in one kernel (IGX_GEOA=0: separate field and sweep kernels)
 static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
 {
-    const char *e = getenv("IGX_GEOA");
-    if (e && !strcmp(e, "0")) return false;
+    if (!pt->knobs.geoa) return false;
     return igx_kind_symmetric(kind) && geoA_supported(pt, kind, nslots);
 }
 
@@ -1489,11 +1480,9 @@ bool sumfact_needs_fields(const igx_patch *pt, int kind)
 
 static bool fused_applicable(const igx_patch *pt)
 {
-    const char *e = getenv("IGX_PATH");
-    if (e && !strcmp(e, "unfused")) return false;
-    if (getenv("IGX_FINAL")) return false;
+    if (pt->knobs.path == 2 || pt->knobs.final_sel) return false;
     const int dim = pt->dim;
-    if (dim == 2 && !(e && !strcmp(e, "fused"))) return false;
+    if (dim == 2 && pt->knobs.path != 1) return false;
     const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
     if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 5) return false;      // (p = 5: the exchange buffers of k_bf do not fit LDS yet)
     return true;
@@ -1506,30 +1495,6 @@ static bool bf_add_slot(BFInputs &in, int y, int t1, const double *ptr)
     if (n >= 2) return false;
     in.slot_ptr[y][t1][n++] = ptr;
     return true;
-}
-
-// ---- overlapped chain: knobs (experiment phase: environment; read per assembly)
-static int overlap_ranges(const igx_patch *pt, const BFInputs &in, bool sym)
-{
-    if (pt->dim != 3 || !sym || in.npairs < 64) return 1;
-    const char *e = getenv("IGX_OVERLAP");
-    const int n = e ? atoi(e) : 1;
-    return std::max(1, std::min(n, 32));
-}
-static int overlap_bf_streams() { const char *e = getenv("IGX_OVERLAP_BFS"); return e ? std::max(1, std::min(3, atoi(e))) : 2; }
-static int overlap_lean() { const char *e = getenv("IGX_OVERLAP_LEAN"); return e ? atoi(e) : 1; }
-static int ensure_side_streams(igx_ctx *cx)
-{
-    if (cx->side_ok) return IGX_OK;
-    // side[0] carries the mirror pass at the LOWEST priority, side[1..] ranges of the fused stage at the HIGHEST: when a CU
-    // frees up, the dispatcher places a block of the fused stage first and the mirror takes what is left next to it
-    int least = 0, greatest = 0;
-    IGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    const bool prio = !getenv("IGX_OVERLAP_NOPRIO");
-    for (int k = 0; k < 4; ++k) IGX_HIP(hipStreamCreateWithPriority(&cx->side[k], hipStreamNonBlocking, prio ? (k == 0 ? least : greatest) : 0));
-    for (auto &ev : cx->evx) IGX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    cx->side_ok = true;
-    return IGX_OK;
 }
 
 static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
@@ -1549,59 +1514,15 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         i1_lo = pt->r0_lo; i1_hi = pt->r0_hi;
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
     }
-    // ---- overlapped chain (3D, symmetric): the outer pairs are cut into ranges of source rows; the mirror pass of a range
-    // (HBM-bound, a few waves per CU in its lean form) runs on a side stream next to the fused stage (vector-issue-bound)
-    // of the following ranges
-    const int nr = overlap_ranges(pt, in, sym);
-    if (nr > 1) {
-        if (int rc = ensure_side_streams(pt->ctx)) return rc;
-        igx_ctx *cx = pt->ctx;
-        const std::vector<int> &pl = pt->h_pl0, &ts = pt->h_tp_src;
-        const int np = in.npairs, nt = (int)(ts.size() / 2);
-        const int nbs = overlap_bf_streams();               // 1: every range of the fused stage on the main stream; 2: alternating
-        IGX_HIP(hipEventRecord(cx->evx[0], st));
-        for (int k = 0; k < 4; ++k) IGX_HIP(hipStreamWaitEvent(cx->side[k], cx->evx[0], 0));
-        int pa = 0, ta = 0;
-        for (int k = 0; k < nr; ++k) {
-            // pairs [pa, pb): whole source rows, about np / nr pairs
-            int pb = (int)((long long)np * (k + 1) / nr);
-            while (pb < np && pb > 0 && pl[2 * pb] == pl[2 * (pb - 1)]) ++pb;
-            if (k == nr - 1) pb = np;
-            if (pb <= pa) continue;
-            const int row_hi = pb < np ? pl[2 * pb] : 0x7fffffff;
-            int tb = ta;
-            while (tb < nt && ts[2 * tb + 1] < row_hi) ++tb;
-            BFInputs ik = in;
-            ik.pair_off = pa; ik.npairs = pb - pa; ik.npairs_all = np;
-            hipStream_t sb = cx->side[1 + k % nbs];
-            if (int rc = launch_bf(sb, pt, ik, d_data)) return rc;
-            pt->timing.n_launches++;
-            IGX_HIP(hipEventRecord(cx->evx[1 + k], sb));
-            if (tb > ta && !getenv("IGX_NO_MIRROR")) {
-                IGX_HIP(hipStreamWaitEvent(cx->side[0], cx->evx[1 + k], 0));
-                MirrorInputs mi{};
-                mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
-                mi.tpairs = pt->d_tpairs_src + 2 * ta; mi.ntp = tb - ta; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
-                mi.lean = overlap_lean();
-                if (int rc = launch_mirror(cx->side[0], pt, mi, d_data)) return rc;
-                pt->timing.n_launches++;
-            }
-            pa = pb; ta = tb;
-        }
-        pt->last_path |= IGX_PATH_FUSED | IGX_PATH_MIRROR;
-        // join: the main stream continues when the fused stage (ev[3]) and then the mirror (ev[4]) are complete
-        for (int k = 0; k < nbs; ++k) { IGX_HIP(hipEventRecord(cx->evx[38 - k], cx->side[1 + k])); IGX_HIP(hipStreamWaitEvent(st, cx->evx[38 - k], 0)); }
-        (void)hipEventRecord(cx->ev[3], st);
-        IGX_HIP(hipEventRecord(cx->evx[39], cx->side[0]));
-        IGX_HIP(hipStreamWaitEvent(st, cx->evx[39], 0));
-        (void)hipEventRecord(cx->ev[4], st);
-        return IGX_OK;
-    }
     if (int rc = launch_bf(st, pt, in, d_data)) return rc;
     pt->last_path |= IGX_PATH_FUSED;
     pt->timing.n_launches++;
     (void)hipEventRecord(pt->ctx->ev[3], st);
+#ifdef IGX_ABLATE
     if (sym && !getenv("IGX_NO_MIRROR")) {
+#else
+    if (sym) {
+#endif
         MirrorInputs mi{};
         mi.mid = in.mid; mi.last = in.last; mi.rp0 = in.rp0; mi.jlo0 = in.jlo0; mi.jhi0 = in.jhi0;
         mi.tpairs = pt->d_tpairs; mi.ntp = pt->ntp; mi.i1_lo = i1_lo; mi.i1_hi = i1_hi;
@@ -1661,7 +1582,9 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     // K1 slice stride: padded when both producer (geoA) and consumer (k_bf) take a stride (experiment: IGX_K1PAD doubles)
     const bool use_geoA = geoA_wanted(pt, kind, nX);
     long long NPLs = NPL;
+#ifdef IGX_ABLATE
     if (use_geoA && fused && dim == 3) { const char *e = getenv("IGX_K1PAD"); NPLs = NPL + (e ? atoi(e) : 0); }
+#endif
     if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPLs)) return IGX_ERR_NOMEM;
 
     const int nF = igx_num_fields(dim, kind, pd.form_n);
@@ -1816,8 +1739,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 wmax = std::max(wmax, (AL.mshi[i_last] - AL.mslo[i_first]) * AL.q);
             }
             const int nch = (wmax + 7) / 8;
-            const char *sel = getenv("IGX_FINAL");
-            const bool want_mfma = sel && !strcmp(sel, "mfma");
+            const bool want_mfma = pt->knobs.final_sel == 3;
             if (want_mfma && sym && nch >= 1 && nch <= 6 && pt->ldesc_ok && AL.G >= 2) {
                 FinalMArgs M{};
                 M.desc = (const int4 *)pt->d_ldesc; M.nl = pt->n_ldesc; M.nlines = F.nlines;
@@ -1825,8 +1747,10 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 M.jlo = AL.dev.jlo; M.jhi = AL.dev.jhi; M.rp = AL.dev.rp;
                 M.N = AL.N; M.P = AL.P; M.q = AL.q; M.G = AL.G; M.W = W; M.ntile = ntile;
                 int LC = 256;
+#ifdef IGX_ABLATE
                 if (const char *e = getenv("IGX_FINAL_LC")) LC = std::max(16, (atoi(e) / 16) * 16);
-                M.LC = LC; M.debug = getenv("IGX_DEBUG_M") ? atoi(getenv("IGX_DEBUG_M")) : 0;
+#endif
+                M.LC = LC; M.debug = 0;
                 M.nchunk_blocks = (M.nl + LC - 1) / LC;
                 const long long nblocks = (long long)((ntile + 3) / 4) * M.nchunk_blocks;
                 if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
@@ -1848,8 +1772,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         }
         // ---- quadrature-lane kernel: single interior knots and q == P on the last axis
         {
-            const char *sel = getenv("IGX_FINAL");
-            const bool want_q = !(sel && !strcmp(sel, "valu"));
+            const bool want_q = pt->knobs.final_sel != 2;
             if (want_q && AL.q == AL.P && AL.simple) {
                 FinalQArgs Q{};
                 Q.V = AL.d_V; Q.fa = AL.dev.fa; Q.mslo = AL.dev.mslo; Q.mshi = AL.dev.mshi;
@@ -1862,7 +1785,9 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 Q.nchunks = (AL.N + R - 1) / R;
                 // ~8 waves per CU and a few rounds; at least 16 lines per wave to amortise its set-up
                 long long target_waves = 8192;
+#ifdef IGX_ABLATE
                 if (const char *e = getenv("IGX_FINALQ_WAVES")) target_waves = std::max(1, atoi(e));
+#endif
                 Q.nsuper = (Q.nchunks + FINALQ_WAVES - 1) / FINALQ_WAVES;
                 Q.lpw = (int)std::max<long long>(16, (Q.ndesc * Q.nsuper * FINALQ_WAVES + target_waves - 1) / target_waves);
                 const long long nblocks = ((Q.ndesc + Q.lpw - 1) / Q.lpw) * Q.nsuper;
@@ -1917,13 +1842,17 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         const bool fast = AL.q == AL.P && AL.simple;
         const int max_waves = fast ? 12 : 6;
         int NW = (int)std::min<size_t>(max_waves, (160 * 1024 - vbytes - tbytes) / kslot);
+#ifdef IGX_ABLATE
         if (const char *e = getenv("IGX_FINAL_NW")) NW = std::max(1, std::min(NW, atoi(e)));
+#endif
         int max_lines = 1;
         if (dim == 3)
             for (int i = 0; i < A1.N; ++i) max_lines = std::max(max_lines, A1.jhi[i] - A1.jlo[i]);
         // row groups per block: enough tasks for ~8 rounds per wave
         int GPB = std::max(1, (8 * NW) / std::max(1, max_lines * (tile_rows / CR)));
+#ifdef IGX_ABLATE
         if (const char *e = getenv("IGX_FINAL_GPB")) GPB = std::max(1, atoi(e));
+#endif
         F.NW = NW; F.GPB = GPB;
         const size_t lds = vbytes + (size_t)NW * kslot + tbytes;
         const long long nblocks = ((ngroups + GPB - 1) / GPB) * ntiles;

@@ -111,3 +111,13 @@ def test_geometry_constructors(golden):
         for k, kv in enumerate(geo.kvs):
             assert kv.p == int(g['%s_gp%d' % (name, k)]) and np.array_equal(kv.kv, g['%s_gkv%d' % (name, k)])
         assert geo.dim == geo.sdim == len(geo.kvs)
+
+
+def test_shipped_library_has_no_ablation_switches():
+    """The switches of the timing experiments are compiled only into -DIGX_ABLATE builds."""
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pyiga_amd', 'libigx.so')
+    if not os.path.exists(lib):
+        pytest.skip('libigx.so not built')
+    blob = open(lib, 'rb').read()
+    for name in (b'_DBG', b'IGX_NO_MIRROR', b'IGX_K1PAD', b'IGX_BF_MCHUNKS', b'IGX_FINAL_', b'IGX_FINALQ_', b'IGX_OVERLAP'):
+        assert name not in blob, name

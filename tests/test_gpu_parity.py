@@ -866,6 +866,28 @@ def test_repeatability(iga):
         assert len(hashes) == 1
 
 
+def test_ablation_variables_have_no_effect(iga, monkeypatch):
+    """The switches of the timing experiments (work left out: wrong matrices by construction) exist only in -DIGX_ABLATE
+    builds; in the shipped library the variables change nothing, and the chain of a patch is fixed when it is created."""
+    kvs = (iga.bspline.make_knots(3, 0., 1., 9),) * 3
+    geo = _geo(iga, 'cylinder')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    A = patch.csr('stiffness', algo='sumfact')
+    for var in ('IGX_GEOA_DBG', 'IGX_BF_DBG', 'IGX_NO_MIRROR', 'IGX_K1PAD', 'IGX_BF_MCHUNKS', 'IGX_FINALQ_TILE'):
+        monkeypatch.setenv(var, '7')
+    for var, val in (('IGX_PATH', 'unfused'), ('IGX_GEOA', '0'), ('IGX_FINAL', 'valu')):     # read at creation only
+        monkeypatch.setenv(var, val)
+    B = patch.csr('stiffness', algo='sumfact')
+    assert patch.last_path() == {'geoA', 'fused', 'mirror'}
+    patch.close()
+    for var in ('IGX_PATH', 'IGX_GEOA', 'IGX_FINAL'):
+        monkeypatch.delenv(var)
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    C = patch.csr('stiffness', algo='sumfact')
+    patch.close()
+    assert np.array_equal(A.data, B.data) and np.array_equal(A.data, C.data)
+
+
 # ------------------------------------------------------------------------------------------
 # Full-size parity pinned to the REFERENCE (tests/golden/golden_fullsize.npz, make_golden.py 'fullsize'):
 # multi_entries of the reference at seeded in-pattern pairs of BASELINE configs 2 and 3 at their real sizes and of the
@@ -983,12 +1005,14 @@ def test_entries_wave_vs_thread_and_resident(iga, d, p, n, monkeypatch):
     idx = np.stack([rows[pick], indices[pick]], axis=1)
     idx = np.concatenate([idx, rng.integers(0, N, size=(500, 2))])          # + arbitrary pairs (mostly outside the pattern)
     kinds = ['mass', 'stiffness'] + (['convdiff'] if d == 3 else [])
+    monkeypatch.setenv('IGX_ENTRIES', 'thread')                     # (chain choices are read when a patch is created)
+    patch_t = iga.assemblers.DevicePatch(kvs, geo)
+    monkeypatch.delenv('IGX_ENTRIES')
     if d == 3:
         patch.set_coeff(1.5)
+        patch_t.set_coeff(1.5)
     for kind in kinds:
-        monkeypatch.setenv('IGX_ENTRIES', 'thread')
-        e_thread = patch.entries(kind, idx)
-        monkeypatch.delenv('IGX_ENTRIES')
+        e_thread = patch_t.entries(kind, idx)
         e_wave = patch.entries(kind, idx)
         scale = np.abs(e_thread).max()
         assert np.abs(e_wave - e_thread).max() <= RTOL * scale
@@ -1030,11 +1054,13 @@ def test_geometry_in_sweep_multi_span(iga, deg0, spans0, nurbs, p, n, monkeypatc
         patch = iga.assemblers.DevicePatch(kvs, geo)
         A = patch.csr(kind, algo='sumfact')
         assert 'geoA' in patch.last_path()
-        monkeypatch.setenv('IGX_GEOA', '0')
-        B = patch.csr(kind, algo='sumfact')
-        assert 'geoA' not in patch.last_path()
-        E = patch.csr(kind, algo='entrywise')
+        monkeypatch.setenv('IGX_GEOA', '0')                             # (chain choices are read when a patch is created)
+        patch0 = iga.assemblers.DevicePatch(kvs, geo)
         monkeypatch.delenv('IGX_GEOA')
+        B = patch0.csr(kind, algo='sumfact')
+        assert 'geoA' not in patch0.last_path()
+        patch0.close()
+        E = patch.csr(kind, algo='entrywise')
         patch.close()
         assert rel_maxdiff(A, B) <= RTOL and rel_maxdiff(A, E) <= RTOL
         assert abs(A - A.T).max() == 0.0

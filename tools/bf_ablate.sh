@@ -1,6 +1,7 @@
 #!/bin/bash
-# timing experiments on the fused stage (C4): ablation masks of k_bf
-for d in ${@:-0 1 2 3 4 8 12 7 15}; do
-  echo -n "IGX_BF_DBG=$d  "
-  IGX_PATH=fused IGX_BF_DBG=$d python bench.py --no-cpu-baseline --steps 5 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['roofline']['kernel_ms'])"
-done
+# k_bf2 with parts of its work compiled out (timing experiment, wrong results by construction).  Variant libraries are built
+# on the build host with tools/buildvar.sh, e.g.
+#   tools/buildvar.sh nostore -DBF2_NOSTORE      tools/buildvar.sh nopass -DBF2_NOPASS      tools/buildvar.sh nh1 -DBF2_NH=1
+# and travel to the GPU box with the snapshot; this script times them (tools/var_try.sh does the same for any list).
+cd "$GRAFT_REPO_ROOT"
+bash tools/var_try.sh base nostore nopass nh1

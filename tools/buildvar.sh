@@ -1,7 +1,8 @@
 #!/bin/bash
-# build a variant library: buildvar.sh <name> <extra flags...>
+# build a variant library on the build host: tools/buildvar.sh <name> <extra hipcc flags for fused.hip ...>
+#   -> pyiga_amd/libigx_<name>.so  (the other objects are the ones of the regular build; select with IGX_LIB on the GPU box)
 name=$1; shift
-R=/root/repo
+R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/pyiga_amd/csrc/build_var
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -Wno-unused-function -Xarch_host -ffp-contract=off "$@" -c $R/pyiga_amd/csrc/fused.hip -o $R/pyiga_amd/csrc/build_var/fused_$name.o || exit 1
 objs=""

@@ -8,4 +8,4 @@ for l in sys.stdin:
         d = json.loads(l); print(d['ms_per_step'], d['step_ms'], d['roofline']['kernel_ms'])
     else: print(l.rstrip()[-300:])
 "
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_equals or fullsize_vs_reference_3d or row_slabs or tiny or fixtures" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fused_equals or fullsize_vs_reference or row_slabs or tiny or fixtures or full_size or repeat or ablation" 2>&1 | tail -3
