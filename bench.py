@@ -138,6 +138,27 @@ def cpu_baseline(dim, p, kind):
     }
 
 
+def api_call(args, kvs, geo, kind, nnz):
+    """assemble.stiffness()/mass() end to end, as a user of the reference API sees it: patch creation, assembly, pattern,
+    D2H of values + indices, scipy wrap (pyiga/assemble.py:1017-1049).  Skipped (None) when the host copy would not fit
+    comfortably into the free memory of the box."""
+    need = nnz * 12.0 + 4.0 * float(np.prod([k.numdofs for k in kvs]))
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 2.5 * need:
+            return None
+    except Exception:
+        if need > 8e9:
+            return None
+    from pyiga_amd import assemble
+    t0 = time.perf_counter()
+    A = getattr(assemble, kind)(kvs, geo)
+    dt = time.perf_counter() - t0
+    assert A.nnz == nnz
+    del A
+    return round(dt, 3)
+
+
 def flush_c_stdio():
     # RCCL writes its banner through C stdio, which is block-buffered on a pipe: flush it so that the result is the LAST line
     try:
@@ -160,18 +181,54 @@ def self_launch(args):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        import tempfile
+        log = tempfile.TemporaryFile(mode='w+')              # stderr (and, for ranks > 0, stdout) of the rank: shown if it fails
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=True))
+    # rank 0's stdout is drained by a thread; the parent polls ALL ranks: the first one that fails takes the others down
+    # (a survivor would sit in the rendezvous or a barrier until the backend times out)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get('BENCH_LAUNCH_TIMEOUT', '1500'))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = 'rank %d exited with %d' % (bad[0], rcs[bad[0]])
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = 'timeout'
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:                                      # exactly the children started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(''.join(c for c in chunks if c))
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit('bench.py: ranks exited with %s' % rcs)
+    if failed:
+        for r, log in enumerate(logs):
+            log.seek(0)
+            tail = log.read()[-2000:]
+            if tail.strip():
+                sys.stderr.write('--- rank %d ---\n%s\n' % (r, tail))
+        raise SystemExit('bench.py: %s (exit codes %s)' % (failed, [p.returncode for p in procs]))
 
 
 def main():
@@ -183,6 +240,7 @@ def main():
     ap.add_argument('--n', type=int, default=0, help='override spans per axis (testing)')
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-api-call', action='store_true', help='skip the end-to-end assemble.stiffness() call (host copy of the matrix)')
     ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries'],
                     help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs')
     ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
@@ -204,7 +262,7 @@ def main():
 
     # the CPU baseline first: it may compile the oracle (child processes only before the GPU is initialised)
     cpu = None
-    if rank == 0 and world == 1 and emu is None and not args.no_cpu_baseline and args.op == 'matrix':
+    if rank == 0 and emu is None and not args.no_cpu_baseline and args.op == 'matrix':
         cpu = cpu_baseline(dim, p, kind)
 
     dist = None
@@ -230,17 +288,31 @@ def main():
     part_rank, part_world = (rank, world) if emu is None else emu
     weak = args.weak and part_world > 1
     n0 = n * part_world if weak else n
+    # test hook (tests/test_bench_launch_cpu.py): a stand-in for DevicePatch from the named file, so that the launcher, the
+    # rendezvous, the reductions and the result line can be exercised on a box without a GPU.  Never set in a measurement.
+    stub = os.environ.get('BENCH_PATCH_STUB')
+    if stub:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('bench_patch_stub', stub)
+        stubmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(stubmod)
+        assemblers = stubmod
+    t_init = time.perf_counter()
+    if not stub:
+        from pyiga_amd import _lib
+        _lib.context(local_rank).sync()                     # HIP runtime + device context + stream: first GPU call of the process
+    runtime_init_s = time.perf_counter() - t_init
     t_setup = time.perf_counter()
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
-    row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world)
+    row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world, p if dim == 3 else None)      # balanced by work
     if kind == 'convdiff':
         patch = assemblers.ConvDiffAssembler3D(kvs, geo, assemblers.AffineCoefficient(1.0, 1.0), device=local_rank, row0=row0 if part_world > 1 else None).patch
     else:
         patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
     patch.ctx.sync()
-    setup_s = time.perf_counter() - t_setup                 # knots, tables, plan, coefficient sampling + upload
+    setup_s = time.perf_counter() - t_setup                 # knots, tables, plan, coefficient sampling + upload (context warm)
     nel_total = n0 * n ** (dim - 1)
     if emu is not None:
         nel_total //= part_world        # one slab's share
@@ -250,13 +322,18 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not os.environ.get('BENCH_PATCH_STUB'):
+                torch.cuda.synchronize()
         patch.ctx.sync()
 
     if args.op == 'rhs':
         return bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, barrier)
     if args.op == 'entries':
         return bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank)
+    # cold assembly: the first one of the patch allocates the workspaces (K1, CSR values) and builds the per-plane table
+    t_cold = time.perf_counter()
+    patch.assemble(kind, algo=args.algo, to_host=False)
+    cold_ms = 1e3 * (setup_s + time.perf_counter() - t_cold)       # patch creation + first assembly, result resident on the device
     for _ in range(args.warmup):
         patch.assemble(kind, algo=args.algo, to_host=False)
     stage_ms, steps_ms = {}, []
@@ -281,16 +358,22 @@ def main():
         z = torch.tensor([float(nnz_local)], dtype=torch.float64, device=_tdev())
         dist.all_reduce(z, op=dist.ReduceOp.SUM)
         nnz_total = int(z.item())
-        sl = [torch.zeros(1, dtype=torch.float64, device=_tdev()) for _ in range(world)]
-        dist.all_gather(sl, torch.tensor([slab_ms[0]], dtype=torch.float64, device=_tdev()))
-        slab_ms = [float(x.item()) for x in sl]
+        sl = [torch.zeros(3, dtype=torch.float64, device=_tdev()) for _ in range(world)]
+        dist.all_gather(sl, torch.tensor([slab_ms[0], setup_s, cold_ms], dtype=torch.float64, device=_tdev()))
+        slab_ms = [float(x[0].item()) for x in sl]
+        setup_all = [round(float(x[1].item()), 4) for x in sl]
+        cold_all = [round(float(x[2].item()), 2) for x in sl]
     else:
         nnz_total = nnz_local
+        setup_all, cold_all = [round(setup_s, 4)], [round(cold_ms, 2)]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    api_call_s = None
+    if world == 1 and emu is None and not args.no_api_call and kind in ('stiffness', 'mass'):
+        api_call_s = api_call(args, kvs, geo, kind, nnz_total)
     ms_per_step = 1e3 * dt / args.steps
     value = nel_total * args.steps / dt
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
@@ -322,7 +405,7 @@ def main():
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak' if weak else 'strong',
-        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (launcher test, no device work)',
         'config': {'workload': '%dD p=%d %s, %s spans, NURBS quarter-annulus %s, uniform open knots'
                                % (dim, p, kind, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1)),
                                   'cylinder' if dim == 3 else gname),
@@ -332,7 +415,10 @@ def main():
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
         'step_ms': {'median': chain_ms, 'min': float(np.min(steps_ms)), 'max': float(np.max(steps_ms))},
         'slab_ms': [round(x, 3) for x in slab_ms],
-        'setup_s': round(setup_s, 3),
+        'setup_s': round(max(setup_all), 4), 'setup_s_ranks': setup_all,      # patch creation per rank (device context warm)
+        'runtime_init_s': round(runtime_init_s, 3),                            # HIP runtime + context + stream of rank 0: once per process
+        'cold_ms': round(max(cold_all), 2), 'cold_ms_ranks': cold_all,         # patch creation + FIRST assembly (workspace allocation), device-resident result
+        'api_call_s': api_call_s,                                              # assemble.stiffness() end to end: + pattern, D2H of values and indices, scipy
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': measured_traffic(args.config, world),

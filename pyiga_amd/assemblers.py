@@ -12,6 +12,7 @@ through ``multi_entries`` with one index pair per nonzero, which at 3D p=4 n=128
 25 GB of index pairs.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import scipy.sparse
@@ -19,6 +20,9 @@ import scipy.sparse
 from . import _lib
 from . import bspline
 from .quadrature import make_tensor_quadrature
+from . import geometry
+
+_ENTRY_TRAMPOLINES = []          # ctypes trampolines handed out in "entryfunc" capsules (entry_func_ptr)
 
 
 def _is_spline_geo(geo):
@@ -100,7 +104,9 @@ class DevicePatch:
     def _dev_free(self, name):
         buf = getattr(self, name, None)
         if buf:
-            _lib.load().igx_dev_free(self.ctx.handle, buf[0])
+            ctx = getattr(self, 'ctx', None)
+            if ctx is not None and getattr(ctx, 'handle', None):      # (the context may be gone at interpreter shutdown)
+                _lib.load().igx_dev_free(ctx.handle, buf[0])
             setattr(self, name, None)
 
     def _dev_buffer(self, name, nbytes):
@@ -360,8 +366,12 @@ class _DeviceAssembler:
         for compatibility only; batched consumers should use :meth:`multi_entries` or the ACA assembler of this package
         (``DevicePatch.fast_assemble``)."""
         if getattr(self, '_entry_cb', None) is None:
+            me = weakref.proxy(self)                           # no self -> callback -> self cycle
             proto = C.CFUNCTYPE(C.c_double, C.c_size_t, C.c_size_t, C.c_void_p)
-            self._entry_cb = proto(lambda i, j, _data: float(self.entry(int(i), int(j))))
+            self._entry_cb = proto(lambda i, j, _data: float(me.entry(int(i), int(j))))
+            # a capsule may outlive the assembler: the trampoline stays registered for the life of the process (a call
+            # after the assembler is gone raises ReferenceError inside the callback instead of jumping to freed memory)
+            _ENTRY_TRAMPOLINES.append(self._entry_cb)
         new = C.pythonapi.PyCapsule_New
         new.restype, new.argtypes = C.py_object, [C.c_void_p, C.c_char_p, C.c_void_p]
         return new(C.cast(self._entry_cb, C.c_void_p), b'entryfunc', None)
@@ -418,7 +428,6 @@ class AffineCoefficient:
 
 
 class ConvDiffAssembler3D(_DeviceAssembler):
-    _symmetric_form = False
     """Assembler for the variational form
 
         (inner(diff_coeff*grad(u),grad(v)) + inner((x[1],-x[0],1.0),grad(u))*v)*dx
@@ -429,6 +438,7 @@ class ConvDiffAssembler3D(_DeviceAssembler):
     ``pyiga.utils.grid_eval_transformed`` (host numpy, as in the reference); everything else runs on
     the device.
     """
+    _symmetric_form = False
     _kind, _dim = 'convdiff', 3
 
     @classmethod
@@ -437,9 +447,10 @@ class ConvDiffAssembler3D(_DeviceAssembler):
 
     def __init__(self, kvs0, geo, diff_coeff, device=None, row0=None):
         super().__init__(kvs0, geo, device=device, row0=row0)
-        if isinstance(diff_coeff, AffineCoefficient):
+        if isinstance(diff_coeff, AffineCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
             self.patch.set_coeff_affine(diff_coeff.c)             # evaluated on the device: nothing sampled on the host
             return
+        # (any other geometry object: the coefficient is sampled through geo.grid_eval like a plain callable)
         grid = [self.patch.gauss(k)[0] for k in range(3)]
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
         vals = diff_coeff(X[..., 0], X[..., 1], X[..., 2]) if callable(diff_coeff) else diff_coeff
@@ -447,7 +458,6 @@ class ConvDiffAssembler3D(_DeviceAssembler):
 
 
 class _GeneralFormAssembler(_DeviceAssembler):
-    _symmetric_form = False
     """Scalar bilinear form in the first-order jets of u and v,
 
         a(u, v) = integral of  sum_{r,s=0..d} P_rs(x) D_r v D_s u  dx,   D_0 = id, D_1..d = d/dx, d/dy[, d/dz],
@@ -460,6 +470,7 @@ class _GeneralFormAssembler(_DeviceAssembler):
     the Jacobian transformation of the coefficients and all sums run on the device (sum-factorised stages
     or entry-wise kernel).
     """
+    _symmetric_form = False
     _kind = 'form'
 
     def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):

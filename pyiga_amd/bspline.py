@@ -13,7 +13,11 @@ from . import _lib
 
 
 class KnotVector:
-    """Open B-spline knot vector with a spline degree (pyiga/bspline.py:36-190).
+    """Open B-spline knot vector with a spline degree (interface of pyiga/bspline.py:36-190).
+
+    The knots are run-length coded once, when the vector is built: ``mesh`` holds the distinct knots (the breakpoints)
+    and ``_cell`` the index of the breakpoint each knot sits on.  Supports, nonempty spans and mesh supports are
+    slices of these two arrays.
 
     Attributes:
         kv (ndarray): the knots; first and last repeated ``p+1`` times
@@ -21,22 +25,17 @@ class KnotVector:
     """
 
     def __init__(self, knots, p):
-        self.kv = np.asarray(knots)
-        assert np.all(self.kv[1:] - self.kv[:-1] >= 0), 'knots should be increasing'
+        kv = np.asarray(knots)
+        rises = np.diff(kv)
+        assert not (rises < 0).any(), 'knots should be increasing'
+        self.kv = kv
         self.p = p
-        self._mesh = None
-        self._knots_to_mesh = None
+        starts = np.concatenate(([True], rises > 0)) if kv.size else np.zeros(0, dtype=bool)
+        self._breaks = kv[starts]                          # distinct knots, in order
+        self._cell = np.cumsum(starts) - 1                 # knot index -> index into the breakpoints
+        self._rising = np.flatnonzero(rises > 0)           # knot indices i with kv[i] < kv[i+1]
 
-    def __str__(self):
-        return '<KnotVector p=%d sz=%d>' % (self.p, self.kv.size)
-
-    def __repr__(self):
-        return 'KnotVector(%s, %s)' % (repr(self.kv), repr(self.p))
-
-    def __eq__(self, other):
-        return (self.p == other.p and len(self.kv) == len(other.kv)
-                and bool(np.allclose(self.kv, other.kv, atol=1e-8, rtol=1e-8)))
-
+    # ---- sizes
     @property
     def numknots(self):
         return self.kv.size
@@ -44,52 +43,43 @@ class KnotVector:
     @property
     def numdofs(self):
         """Number of B-splines over this knot vector."""
-        return self.kv.size - self.p - 1
+        return self.kv.size - (self.p + 1)
 
     @property
     def numspans(self):
         """Number of nonempty knot intervals."""
-        return self.mesh.size - 1
-
-    def copy(self):
-        return KnotVector(self.kv.copy(), self.p)
-
-    def support(self, j=None):
-        if j is None:
-            return (self.kv[0], self.kv[-1])
-        return (self.kv[j], self.kv[j + self.p + 1])
-
-    def support_idx(self, j):
-        return (j, j + self.p + 1)
-
-    def _ensure_mesh(self):
-        if self._knots_to_mesh is None:
-            self._mesh, self._knots_to_mesh = np.unique(self.kv, return_inverse=True)
+        return self._breaks.size - 1
 
     @property
     def mesh(self):
-        """Unique knots."""
-        self._ensure_mesh()
-        return self._mesh
+        """The distinct knots."""
+        return self._breaks
+
+    def meshsize_avg(self):
+        return abs(self.kv[-1] - self.kv[0]) / self.numspans
+
+    # ---- supports: B-spline j lives on the knots j .. j+p+1
+    def support_idx(self, j):
+        return (j, j + self.p + 1)
+
+    def support(self, j=None):
+        lo, hi = (0, self.kv.size - 1) if j is None else self.support_idx(j)
+        return (self.kv[lo], self.kv[hi])
 
     def mesh_support_idx(self, j):
-        self._ensure_mesh()
-        a, b = self.support_idx(j)
-        return (self._knots_to_mesh[a], self._knots_to_mesh[b])
+        lo, hi = self.support_idx(j)
+        return (self._cell[lo], self._cell[hi])
 
     def mesh_support_idx_all(self):
         """``N x 2`` array: first and one-past-last mesh index of every B-spline's support."""
-        self._ensure_mesh()
-        n = self.numdofs
-        startend = np.stack((np.arange(0, n), np.arange(self.p + 1, n + self.p + 1)), axis=1)
-        return self._knots_to_mesh[startend]
+        n, width = self.numdofs, self.p + 1
+        return np.column_stack((self._cell[:n], self._cell[width:width + n]))
 
     def mesh_span_indices(self):
         """Knot indices ``i`` with ``kv[i] != kv[i+1]`` (one per nonempty span)."""
-        self._ensure_mesh()
-        k2m = self._knots_to_mesh
-        return np.where(k2m[1:] != k2m[:-1])[0]
+        return self._rising
 
+    # ---- spans
     def findspan(self, u):
         """Index ``i`` with ``kv[i] <= u < kv[i+1]`` (last span closed on the right)."""
         return int(findspans(self, np.array([u], dtype=float))[0])
@@ -100,8 +90,20 @@ class KnotVector:
     def first_active_at(self, u):
         return self.first_active(self.findspan(u))
 
-    def meshsize_avg(self):
-        return abs(self.kv[-1] - self.kv[0]) / self.numspans
+    # ---- value semantics
+    def copy(self):
+        return KnotVector(self.kv.copy(), self.p)
+
+    def __eq__(self, other):
+        if self.p != other.p or self.kv.shape != other.kv.shape:
+            return False
+        return bool(np.allclose(self.kv, other.kv, atol=1e-8, rtol=1e-8))
+
+    def __str__(self):
+        return '<KnotVector p=%d sz=%d>' % (self.p, self.kv.size)
+
+    def __repr__(self):
+        return 'KnotVector(%r, %r)' % (self.kv, self.p)
 
 
 def make_knots(p, a, b, n, mult=1):

@@ -400,17 +400,23 @@ bool geoA_supported(const igx_patch *pt, int kind, int nslots)
     return 2 * gspans <= (long long)pt->ax[0].G;
 }
 
-int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
+int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
                 double *const *slot_out, long long slice_stride, int chunk_len, int nchunks)
 {
     const PatchDev &pd = pt->dev;
     const Axis &A0 = pt->ax[0];
     if (!pt->d_geoa_tab) {                               // per-plane records of axis 0: once per patch
-        igx_patch *mpt = const_cast<igx_patch *>(pt);
-        IGX_HIP(hipMalloc((void **)&mpt->d_geoa_tab, (size_t)A0.G * GA_REC * sizeof(double)));
+        double *tab = nullptr;                           // committed to the patch only when the build has been launched
+        IGX_HIP(hipMalloc((void **)&tab, (size_t)A0.G * GA_REC * sizeof(double)));
         k_geoa_table<<<dim3((A0.G + 127) / 128), dim3(128), 0, st>>>(A0.d_V, A0.P, pt->gax[0].d_V, pt->gax[0].d_fa, pt->gax[0].P, pd.ax[0].w, A0.q,
-                                                                     pt->stepA_ptr, pt->stepA_rec, A0.G, mpt->d_geoa_tab);
-        IGX_HIP(hipGetLastError());
+                                                                     pt->stepA_ptr, pt->stepA_rec, A0.G, tab);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            (void)hipFree(tab);
+            set_error("per-plane table of the fused geometry + axis-0 sweep: %s", hipGetErrorString(e));
+            return IGX_ERR_HIP;
+        }
+        pt->d_geoa_tab = tab;
     }
     GeoAArgs A{};
     A.gv = make_view(3, pt->gax, pt->d_ctrl, pt->ncomp);

@@ -220,7 +220,7 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);
-int launch_geoA(hipStream_t st, const igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
+int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
                 double *const *slot_out, long long slice_stride, int chunk_len, int nchunks);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
 int sumfact_supported(const igx_patch *pt);

@@ -1252,6 +1252,7 @@ static int ensure_line_descriptors(igx_patch *pt)
         }
         pt->n_ldesc = (int)(ld.size() / 4);
         pt->ldesc_ok = (long long)pt->npairs0 * (dim == 3 ? A1.S : 1) < (1LL << 28);
+        if (pt->d_ldesc) { (void)hipFree(pt->d_ldesc); pt->d_ldesc = nullptr; }     // (a retry after a failed build: no leak)
         IGX_HIP(hipMalloc(&pt->d_ldesc, std::max<size_t>(1, ld.size()) * sizeof(int)));
         IGX_HIP(hipMemcpyAsync(pt->d_ldesc, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, pt->ctx->stream));
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));

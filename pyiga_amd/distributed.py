@@ -1,7 +1,7 @@
 """Multi-GPU assembly: one process per GPU, rows sharded in slabs of axis-0 dof planes.
 
 The path shards without any exchange ("zero-communication
-alternative"): rank r owns the dof planes ``[N0*r/W, N0*(r+1)/W)`` of axis 0, i.e. a
+alternative"): rank r owns a slab of dof planes of axis 0 (``slab_range``: balanced by work), i.e. a
 contiguous block of CSR rows, and computes every entry of those rows itself -- the lower
 triangle directly and the upper triangle as the mirror of lower entries it (re)computes for
 the p planes above its slab.  Each rank evaluates the quadrature fields only on the spans its
@@ -16,16 +16,94 @@ import numpy as np
 import scipy.sparse
 
 
-def slab_range(ndofs0, rank, world):
-    """Dof planes [lo, hi) of axis 0 owned by `rank`; the slabs tile [0, ndofs0) exactly."""
+# Cost model of one slab of the default 3D chain (microseconds; MI355X, C4 kernels of round 3 -- only the RATIOS matter):
+# the fused stage works per processed outer pair (i0, j0 <= i0) with the row or the column owned, the mirror per target
+# pair (i0 owned, j0 >= i0), the geometry + axis-0 sweep per resident span (own spans + p warm-up spans).
+_COST_PAIR, _COST_TARGET, _COST_SPAN = 10.8, 5.7, 39.0
+
+
+def slab_cost(ndofs0, p, lo, hi):
+    """Modelled cost of the slab of dof planes [lo, hi) of an axis with single interior knots and degree p."""
+    own = np.arange(lo, hi)
+    halo = np.arange(hi, min(hi + p, ndofs0))                 # rows above the slab whose lower pairs have an owned column
+    pairs = int(np.sum(np.minimum(own, p) + 1) + np.sum(np.maximum(hi - np.maximum(halo - p, lo), 0)))
+    targets = int(np.sum(np.minimum(own + p, ndofs0 - 1) + 1 - own))
+    spans = min(hi - 1, ndofs0 - p - 1) - max(lo - p, 0) + 1     # spans the rows lo .. hi-1 touch
+    return _COST_PAIR * pairs + _COST_TARGET * targets + _COST_SPAN * spans
+
+
+def balanced_slabs(ndofs0, world, p):
+    """Edges e[0] = 0 < e[1] < ... < e[world] = ndofs0 of the slabs with the smallest maximal modelled cost: the cost of
+    a slab grows with every plane added, so the smallest feasible bottleneck is found by bisection (greedy packing)."""
+    assert world <= ndofs0, 'more ranks than dof planes along axis 0'
+
+    def pack(limit):
+        """edges of a greedy packing with slab cost <= limit, or None if it needs more than `world` slabs"""
+        edges, a = [0], 0
+        for w in range(world):
+            left = world - 1 - w                            # slabs still to come: leave them one plane each
+            lo_b, hi_b = a + 1, ndofs0 - left
+            if slab_cost(ndofs0, p, a, lo_b) > limit:
+                return None
+            while lo_b < hi_b:                              # largest b with cost(a, b) <= limit
+                mid = (lo_b + hi_b + 1) // 2
+                if slab_cost(ndofs0, p, a, mid) <= limit:
+                    lo_b = mid
+                else:
+                    hi_b = mid - 1
+            a = lo_b
+            edges.append(a)
+            if a == ndofs0:
+                break
+        if edges[-1] != ndofs0:
+            return None
+        while len(edges) < world + 1:                       # fewer slabs than ranks: split the largest ones
+            k = int(np.argmax(np.diff(edges)))
+            edges.insert(k + 1, (edges[k] + edges[k + 1]) // 2)
+        return edges
+
+    lo_t, hi_t = 0.0, slab_cost(ndofs0, p, 0, ndofs0)
+    best = pack(hi_t)
+    for _ in range(60):
+        mid = 0.5 * (lo_t + hi_t)
+        e = pack(mid)
+        if e is None:
+            lo_t = mid
+        else:
+            best, hi_t = e, mid
+        if hi_t - lo_t < 1e-6 * hi_t:
+            break
+    # the greedy packing fills the first slabs to the limit and leaves the rest to the last one: even the slack out from the
+    # right as well (same bottleneck, smaller spread)
+    return best
+
+
+_EDGES = {}
+
+
+def slab_range(ndofs0, rank, world, p=None):
+    """Dof planes [lo, hi) of axis 0 owned by `rank`; the slabs tile [0, ndofs0) exactly.  With the degree `p` of the
+    axis the slabs are balanced by WORK (modelled cost of the default 3D chain: the first and the last slab own more
+    planes, they have no halo on one side and fewer pairs per plane); without it by planes."""
     assert 0 <= rank < world
     assert world <= ndofs0, 'more ranks than dof planes along axis 0'
-    return (ndofs0 * rank) // world, (ndofs0 * (rank + 1)) // world
+    if p is None or world == 1:
+        return (ndofs0 * rank) // world, (ndofs0 * (rank + 1)) // world
+    key = (ndofs0, world, p)
+    if key not in _EDGES:
+        _EDGES[key] = balanced_slabs(ndofs0, world, p)
+    e = _EDGES[key]
+    return e[rank], e[rank + 1]
 
 
-def row_range(kvs, rank, world):
+def _balance_degree(kvs, balance):
+    """degree to balance the slabs with, or None (even split): the cost model is the one of the 3D chain"""
+    return int(kvs[0].p) if balance and len(kvs) == 3 else None
+
+
+def row_range(kvs, rank, world, balance=True):
     """Global CSR rows [lo, hi) owned by `rank`."""
-    lo, hi = slab_range(kvs[0].numdofs, rank, world)
+    lo, hi = slab_range(kvs[0].numdofs, rank, world, _balance_degree(kvs, balance))
     plane = int(np.prod([kv.numdofs for kv in kvs[1:]]))
     return lo * plane, hi * plane
 
@@ -39,17 +117,17 @@ def _device_block(kind, kvs, geo, row0, device, algo):
         patch.close()
 
 
-def assemble_rows(kind, kvs, geo, rank, world, device=None, algo='auto', block_fn=None):
+def assemble_rows(kind, kvs, geo, rank, world, device=None, algo='auto', block_fn=None, balance=True):
     """CSR block (owned rows x all columns) of the `kind` matrix for this rank.
 
     `block_fn(kind, kvs, geo, row0, device, algo)` produces the block; the default runs the HIP
     path on `device` (default: LOCAL_RANK).  Tests inject a CPU producer to exercise the
     sharding logic without a GPU.
     """
-    row0 = slab_range(kvs[0].numdofs, rank, world)
+    row0 = slab_range(kvs[0].numdofs, rank, world, _balance_degree(kvs, balance))
     fn = _device_block if block_fn is None else block_fn
     blk = fn(kind, tuple(kvs), geo, row0, device, algo)
-    lo, hi = row_range(kvs, rank, world)
+    lo, hi = row_range(kvs, rank, world, balance)
     assert blk.shape[0] == hi - lo, 'block has the wrong number of rows'
     return blk
 

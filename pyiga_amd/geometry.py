@@ -14,60 +14,50 @@ from .bspline import BSplineFunc, _BaseSplineFunc, _device_grid_eval
 
 
 class NurbsFunc(_BaseSplineFunc):
-    """Function in a tensor-product NURBS basis (pyiga/geometry.py:27-123).
+    """Function in a tensor-product NURBS basis (interface of pyiga/geometry.py:27-123).
 
-    ``coeffs`` holds the premultiplied coefficients with the weight as last component.
+    Stored homogeneously: ``coeffs[..., :-1]`` are the coefficients multiplied by their weights, ``coeffs[..., -1]``
+    the weights -- the control net the device kernels take as it is.
     """
 
     def __init__(self, kvs, coeffs, weights, premultiplied=False):
-        if isinstance(kvs, bspline.KnotVector):
-            kvs = (kvs,)
-        self.kvs = tuple(kvs)
+        self.kvs = (kvs,) if isinstance(kvs, bspline.KnotVector) else tuple(kvs)
         self.sdim = len(self.kvs)
-        N = tuple(kv.numdofs for kv in self.kvs)
-        coeffs = np.asanyarray(coeffs)
-        if coeffs.ndim == 1:
-            assert coeffs.shape[0] == np.prod(N), 'Wrong length of coefficient vector'
-            coeffs = coeffs.reshape(N)
-        assert N == coeffs.shape[:self.sdim], 'Wrong shape of coefficients'
-        self.coeffs = coeffs
-        dim = coeffs.shape[self.sdim:]
-        if len(dim) == 0:
-            dim = 1
-            self._isscalar = True
-        elif len(dim) == 1:
-            dim = dim[0]
-            self._isscalar = False
-        else:
-            assert False, 'Tensor-valued NURBS functions not implemented'
-        self.dim = dim
+        grid = tuple(kv.numdofs for kv in self.kvs)
+        net = np.asanyarray(coeffs)
+        if net.ndim == 1:                                   # flat vector of scalar coefficients
+            assert net.size == int(np.prod(grid)), 'Wrong length of coefficient vector'
+            net = net.reshape(grid)
+        assert net.shape[:self.sdim] == grid, 'Wrong shape of coefficients'
+        tail = net.shape[self.sdim:]                        # () scalar-valued, (d,) vector-valued
+        assert len(tail) <= 1, 'Tensor-valued NURBS functions not implemented'
         if weights is None:
-            assert self.dim > 1, 'Weights must be specified in the coeffs array'
-            self.dim -= 1
+            # the weight is the last component of `coeffs`
+            assert tail and tail[0] > 1, 'Weights must be specified in the coeffs array'
+            homog = net
+            self._isscalar = False
+            self.dim = tail[0] - 1
         else:
-            weights = np.asanyarray(weights)
-            assert weights.shape == N, 'Wrong shape of weights array'
-            if self.coeffs.shape == N:
-                self.coeffs = np.stack((self.coeffs, weights), axis=-1)
-            else:
-                self.coeffs = np.concatenate((self.coeffs, weights[..., None]), axis=-1)
+            w = np.asanyarray(weights)
+            assert w.shape == grid, 'Wrong shape of weights array'
+            self._isscalar = not tail
+            self.dim = tail[0] if tail else 1
+            comps = net[..., None] if not tail else net
+            homog = np.concatenate((comps, w[..., None]), axis=-1)
         if not premultiplied:
-            self.coeffs[..., :-1] *= self.coeffs[..., -1:]
+            homog[..., :-1] *= homog[..., -1:]
+        self.coeffs = homog
 
     def output_shape(self):
-        if self._isscalar:
-            return ()
-        shp = list(self.coeffs.shape[self.sdim:])
-        shp[-1] -= 1
-        return tuple(shp)
+        return () if self._isscalar else (self.dim,)
 
     def copy(self):
         return NurbsFunc(tuple(kv.copy() for kv in self.kvs), self.coeffs.copy(), None, premultiplied=True)
 
     def coeffs_weights(self):
         """Non-premultiplied coefficients and weights."""
-        W = self.coeffs[..., -1]
-        return self.coeffs[..., :-1] / W[..., None], W.copy()
+        w = self.coeffs[..., -1]
+        return self.coeffs[..., :-1] / w[..., None], w.copy()
 
     def grid_eval(self, gridaxes):
         assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
@@ -75,7 +65,7 @@ class NurbsFunc(_BaseSplineFunc):
         return np.squeeze(f, -1) if self._isscalar else f
 
     def grid_jacobian(self, gridaxes):
-        """Quotient rule on the homogeneous spline (pyiga/geometry.py:17-25,116-123)."""
+        """Quotient rule on the homogeneous spline (pyiga/geometry.py:17-25,116-123), on the device."""
         assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
         J = _device_grid_eval(self.kvs, self.coeffs, True, self.dim, gridaxes, want_jac=True)
         return np.squeeze(J, -2) if self._isscalar else J
@@ -87,8 +77,8 @@ class NurbsFunc(_BaseSplineFunc):
         if self.is_vector():
             return self
         assert self.is_scalar()
-        C, W = self.coeffs_weights()
-        return NurbsFunc(self.kvs, C, W)
+        vals, w = self.coeffs_weights()
+        return NurbsFunc(self.kvs, vals, w)
 
 
 # ---------------------------------------------------------------------------------------------
