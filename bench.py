@@ -45,10 +45,10 @@ FP64_PEAK_TFLOPS = 78.6        # vector = MFMA FP64 peak on MI355X
 
 
 def algorithmic_bytes_per_element(dim, p, nnz, nelem, kind='stiffness'):
-    """Jacobian in (8 d^2 q^d) + CSR values out (8 nnz / n^d); the
-    convection-diffusion form also reads its coefficient (8 q^d)."""
+    """Jacobian in (8 d^2 q^d) + CSR values out (8 nnz / n^d); the convection-diffusion form adds
+    its coefficient and the d coordinate fields of the convection direction (8 (1 + d) q^d): C5 = 33.9 KB per element."""
     q = p + 1
-    return 8.0 * (dim * dim + (1 if kind == 'convdiff' else 0)) * q ** dim + 8.0 * nnz / nelem
+    return 8.0 * (dim * dim + ((1 + dim) if kind == 'convdiff' else 0)) * q ** dim + 8.0 * nnz / nelem
 
 
 def algorithmic_flops(dim, p, kvs, kind):

@@ -954,19 +954,20 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 // issues at most one vector instruction per 8 cycles (tools/ubench/valu_f64.hip: one wave per SIMD), so a step is bound by
 // its longest wave as much as by the SIMDs: three lane groups + four contractors (two of them take two passes per step) beat
 // two lane groups + eight contractors at the 3D forms because the larger tile needs fewer instructions per row.
-template <int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
-template <> struct BF2Cfg<BF_MASK_MASS, 1> { static constexpr int NLG = 3, NCW = 8, NH = 1; };
-template <> struct BF2Cfg<BF_MASK_STIFF3, 1> { static constexpr int NLG = BF2_NLG, NCW = BF2_NCW, NH = BF2_NH; };
-template <> struct BF2Cfg<BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = 8, NH = 1; };
+// (P = 6: the window of a 192-point tile does not fit LDS next to the rings; two lane groups, 168 registers per wave)
+template <int P, int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
+template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P <= 5 ? 3 : 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
+template <int P> struct BF2Cfg<P, BF_MASK_STIFF3, 1> { static constexpr int NLG = P <= 5 ? BF2_NLG : 2, NCW = P <= 5 ? BF2_NCW : 4, NH = P <= 5 ? BF2_NH : 1; };
+template <int P> struct BF2Cfg<P, BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
 template <int P, int NY, int MASK, int NA>
 static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks)
 {
-    using C = BF2Cfg<MASK, NA>;
+    using C = BF2Cfg<P, MASK, NA>;
     return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH>(st, A, nblocks);
 }
 template <int P, int MASK, int NA> constexpr int bf2_rmax()
 {
-    using C = BF2Cfg<MASK, NA>;
+    using C = BF2Cfg<P, MASK, NA>;
     return BF2Geom<P, C::NLG, bf_nroles(MASK), C::NCW, C::NH>::RMAX;
 }
 template <int P>
@@ -992,6 +993,7 @@ int fused2_rows_per_tile(int P, int mask, int na)
     case 3: return bf2_rows_p<3>(mask, na);
     case 4: return bf2_rows_p<4>(mask, na);
     case 5: return bf2_rows_p<5>(mask, na);
+    case 6: return bf2_rows_p<6>(mask, na);
     }
     return 1;
 }
@@ -1062,6 +1064,7 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na);
     case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na);
     case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na);
+    case 6: return launch_bf2_p<6>(st, A, nb, ny, mask, na);
     default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
     }
 }

@@ -110,6 +110,10 @@ struct StageAGroup {
     const double *field;        // [G0_loc][NPL]
     double *out0, *out1;        // K1 arrays [npairs0][NPL]
     int t0, t1, nt;
+    // optional second source of an output (merged slots of the fused stage: two terms that differ only in their axis-0 type
+    // and field feed the same later stages): out_k = sum_g0 PI0[t_k] field + PI0[xt[k]] xfield[k]
+    const double *xfield[2];
+    int xt[2];
 };
 struct StageAArgs {
     StageAGroup grp[16];
@@ -122,10 +126,11 @@ struct StageAArgs {
     long long NPL;
 };
 
-template <int P, int NT, int Q, bool SYM>
+template <int P, int NT, int Q, bool SYM, bool HASX = false>
 __device__ __forceinline__ void stageA_body(const double *__restrict__ field, double *__restrict__ out0,
                                             double *__restrict__ out1, const int t0, const int t1,
-                                            const StageAArgs &A, const long long pt, const bool live, double *pis)
+                                            const StageAArgs &A, const long long pt, const bool live, double *pis,
+                                            const double *xf0 = nullptr, const double *xf1 = nullptr, const int xt0 = 0, const int xt1 = 0)
 {
     cip step_ptr = (cip)A.step_ptr, steps = (cip)A.steps;
     const int q = Q ? Q : A.q;
@@ -163,6 +168,8 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
     stage_store(0);
 
     const double *fp = field + (long long)(s_begin * q - A.g0_lo) * A.NPL + pt;
+    const double *xp[2] = {HASX && xf0 ? xf0 + (long long)(s_begin * q - A.g0_lo) * A.NPL + pt : nullptr,
+                           HASX && xf1 ? xf1 + (long long)(s_begin * q - A.g0_lo) * A.NPL + pt : nullptr};
     for (int s = s_begin; s < own_hi; ++s) {
         const int buf = (s - s_begin) & 1;
         if (s + 1 < own_hi) stage_load(s + 1);            // in flight during this span
@@ -184,6 +191,19 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
                 asm volatile("" ::: "memory");
             }
         };
+        // second source of output ty (uniform per group): acc[ty] += PI0[xt] * value of the other field
+        auto accumulate_x = [&](const int ty, const int xt, const int l, const double bv) {
+            const double *pt_ = (const double *)__builtin_assume_aligned(pi_s + (l * 4 + xt) * PP, 16);
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b <= (SYM ? a : P - 1); ++b) acc[ty][a][b] = fma(pt_[a * P + b], bv, acc[ty][a][b]);
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b <= (SYM ? a : P - 1); ++b) asm volatile("" : "+v"(acc[ty][a][b]));
+            asm volatile("" ::: "memory");
+        };
         if (Q) {
             double bv[Q ? Q : 1];
 #pragma unroll
@@ -194,6 +214,14 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
         } else {
             __syncthreads();
             for (int l = 0; l < q; ++l) accumulate(l, fp[(long long)l * A.NPL]);
+        }
+        if (HASX) {
+#pragma unroll
+            for (int ty = 0; ty < NT; ++ty)
+                if (xp[ty]) {
+                    for (int l = 0; l < q; ++l) accumulate_x(ty, ty == 0 ? xt0 : xt1, l, xp[ty][(long long)l * A.NPL]);
+                    xp[ty] += (long long)q * A.NPL;
+                }
         }
         fp += (long long)q * A.NPL;
         if (s + 1 < own_hi) stage_store(buf ^ 1);
@@ -239,6 +267,11 @@ __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
     const bool live = pt < A.NPL;
     if (!live) pt = A.NPL - 1;
     const StageAGroup &G = A.grp[blockIdx.y];
+    if (!SYM && (G.xfield[0] || G.xfield[1])) {          // (merged slots occur with the non-symmetric forms only)
+        if (G.nt == 2) stageA_body<P, 2, Q, SYM, true>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis, G.xfield[0], G.xfield[1], G.xt[0], G.xt[1]);
+        else stageA_body<P, 1, Q, SYM, true>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis, G.xfield[0], nullptr, G.xt[0], 0);
+        return;
+    }
     if (G.nt == 2) stageA_body<P, 2, Q, SYM>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
     else stageA_body<P, 1, Q, SYM>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
 }
@@ -1485,7 +1518,7 @@ static bool fused_applicable(const igx_patch *pt)
     const int dim = pt->dim;
     if (dim == 2 && pt->knobs.path != 1) return false;
     const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
-    if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 5) return false;      // (p = 5: the exchange buffers of k_bf do not fit LDS yet)
+    if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 6) return false;
     return true;
 }
 
@@ -1565,21 +1598,64 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 
     // ---- stage-A arrays X = unique (t0, f).  In 2D the final stage wants the arrays ordered by
     // the last-axis type of their (single) consuming term; in 3D any order works.
-    struct XA { int t0, f, slot; };
+    struct XA { int t0, f, slot, key, xt0, xf, alias; };
     std::vector<XA> X;
     std::vector<int> term_x(terms.size());
-    for (size_t i = 0; i < terms.size(); ++i) {
+    // Fused stage with the stage-A kernel (non-symmetric 3D forms): one K1 array per SLOT (last-axis type, mid-axis type) of the
+    // sweep, holding the sum of the (at most two) terms of the slot -- the later stages cannot tell them apart.  Fewer arrays
+    // than unique (t0, field) pairs when terms collide (convection-diffusion: 9 instead of 11), and one input per slot.
+    bool merged = fused && dim == 3 && !sym;
+    if (merged) {                                        // only where the fused stage has a kernel for the set of slots
+        BFInputs probe{};
+        for (const Term &t : terms) probe.slot_n[kind == IGX_MASS ? 0 : t.t[2]][t.t[1]] = 1;
+        merged = fused_supported(probe) != 0;
+    }
+    if (merged) {
+        for (size_t i = 0; i < terms.size() && merged; ++i) {
+            const int key = 4 * (kind == IGX_MASS ? 0 : terms[i].t[2]) + terms[i].t[1];
+            int found = -1;
+            for (size_t x = 0; x < X.size(); ++x)
+                if (X[x].key == key) found = (int)x;
+            if (found < 0) { found = (int)X.size(); X.push_back(XA{terms[i].t[0], terms[i].f, found, key, -1, -1, 0}); }
+            else if (X[found].xf < 0) { X[found].xt0 = terms[i].t[0]; X[found].xf = terms[i].f; }
+            else merged = false;                         // three terms in one slot: the general path
+            term_x[i] = found;
+        }
+        if (merged) {                                    // every field may lead at most two arrays (k_stageA groups)
+            for (int f = 0; f < 16 && merged; ++f) {
+                int n = 0;
+                for (const XA &x : X) n += x.f == f;
+                if (n > 2) merged = false;
+            }
+        }
+        if (!merged) X.clear();
+        else {
+            // slots with identical sources share ONE array (stiffness: B12 with axis-0 type 0 feeds two slots); the arrays
+            // are numbered over the distinct ones, key < 0 marks an alias that stage A does not produce again
+            int na = 0;
+            for (size_t a = 0; a < X.size(); ++a) {
+                int same = -1;
+                for (size_t b = 0; b < a; ++b)
+                    if (X[b].t0 == X[a].t0 && X[b].f == X[a].f && X[b].xt0 == X[a].xt0 && X[b].xf == X[a].xf) { same = (int)b; break; }
+                if (same >= 0) { X[a].slot = X[same].slot; X[a].alias = 1; }
+                else { X[a].slot = na++; X[a].alias = 0; }
+            }
+        }
+    }
+    for (size_t i = 0; i < terms.size() && !merged; ++i) {
         int found = -1;
         if (dim == 3)
             for (size_t x = 0; x < X.size(); ++x)
                 if (X[x].t0 == terms[i].t[0] && X[x].f == terms[i].f) found = (int)x;
         if (found < 0) {
             found = (int)X.size();
-            X.push_back(XA{terms[i].t[0], terms[i].f, (dim == 2 && kind != IGX_FORM) ? (kind == IGX_MASS ? 0 : terms[i].t[1]) : found});
+            X.push_back(XA{terms[i].t[0], terms[i].f, (dim == 2 && kind != IGX_FORM) ? (kind == IGX_MASS ? 0 : terms[i].t[1]) : found, -1, -1, -1, 0});
         }
         term_x[i] = found;
     }
-    const int nX = (int)X.size();
+    int nX = 0;                                          // K1 arrays (aliases of the merged slots do not count)
+    for (const XA &x : X) nX = std::max(nX, x.slot + 1);
+    if (!merged || dim == 2) nX = (int)X.size();
     // K1 slice stride: padded when both producer (geoA) and consumer (k_bf) take a stride (experiment: IGX_K1PAD doubles)
     const bool use_geoA = geoA_wanted(pt, kind, nX);
     long long NPLs = NPL;
@@ -1607,11 +1683,12 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         int ng = 0;
         for (int f = 0; f < nF; ++f) {
             StageAGroup g{};
-            for (int x = 0; x < nX; ++x)
-                if (X[x].f == f) {
+            for (size_t x = 0; x < X.size(); ++x)
+                if (X[x].f == f && !X[x].alias) {
                     if (g.nt == 2) { set_error("internal: more than two stage-A types per field"); return IGX_ERR_UNSUPPORTED; }
                     double *o = pt->d_K1 + (size_t)X[x].slot * np0 * NPL;
                     if (g.nt == 0) { g.t0 = X[x].t0; g.out0 = o; } else { g.t1 = X[x].t0; g.out1 = o; }
+                    if (X[x].xf >= 0) { g.xfield[g.nt] = pt->d_fields + (size_t)X[x].xf * pd.npts_loc; g.xt[g.nt] = X[x].xt0; }
                     g.nt++;
                 }
             if (g.nt == 0) continue;
@@ -1638,6 +1715,9 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     if (fused && dim == 3) {
         BFInputs in{};
         bool ok = true;
+        if (merged) {
+            for (const XA &x : X) ok = ok && bf_add_slot(in, x.key >> 2, x.key & 3, pt->d_K1 + (size_t)x.slot * np0 * NPLs);
+        } else
         for (size_t i = 0; i < terms.size(); ++i)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : terms[i].t[2], terms[i].t[1],
                                    pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPLs);
