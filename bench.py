@@ -82,12 +82,12 @@ def algorithmic_flops(dim, p, kvs, kind):
 
 
 def measured_traffic(config, world):
-    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, tools/make_traffic.py)
+    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/r03_traffic.json, tools/make_traffic.py)
     -- or None when the kernel sources have changed since they were taken (stale numbers are not reported)."""
     try:
         import glob
         import hashlib
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')))[config]
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r03_traffic.json')))[config]
         if world != 1:
             return None
         h = hashlib.sha256()
@@ -95,8 +95,8 @@ def measured_traffic(config, world):
             h.update(open(f, 'rb').read())
         if h.hexdigest()[:16] != t.get('kernels_sha'):
             return None
-        return {'bytes': t['chain_bytes'], 'bytes_low': t.get('chain_bytes_low'), 'kernels_sha': t['kernels_sha'],
-                'source': 'profiles/r02_traffic.json'}
+        return {'bytes': t['chain_bytes'], 'kernels_sha': t['kernels_sha'], 'source': 'profiles/r03_traffic.json',
+                'kernels': {k: round(v['read_bytes'] + v['write_bytes']) for k, v in t['kernels'].items()}}
     except Exception:
         return None
 

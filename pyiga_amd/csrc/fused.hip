@@ -817,18 +817,29 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 #ifndef MIRROR_ST_AUX
 #define MIRROR_ST_AUX 0                                  // cache policy bits of the mirror's stores (2: nt)
 #endif
+#ifndef MIRROR_IB
+#define MIRROR_IB 3                                      // target rows gathered together
+#endif
+#ifndef MIRROR_VAR
+#define MIRROR_VAR 1                                     // tile of the p = 4 case: 1: 33 rows, 0: 44 rows
+#endif
 template <int WW, int VAR> struct Mirror2Geom {
-    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
+    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : VAR == 2 ? 22 : VAR == 3 ? 16 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
+    static constexpr int IB = MIRROR_IB;                // target rows i1 gathered together
     static constexpr int NJ2 = RCM + WW - 1;
     static constexpr int SG = (NJ2 * WW + 255) / 256;
     static constexpr int SS = (RCM * WW * WW + 255) / 256;
 };
 
+// The source runs of CONSECUTIVE target rows i1 are neighbours in memory (72 bytes apart inside the source segment) and a
+// read request is a whole 128-byte line (profiles/r03_fetch_calibration.txt): gathered one row at a time a line is fetched
+// again a step later, when the L2 has long dropped it (2.7x the useful bytes).  IB rows are therefore gathered TOGETHER --
+// the second touch of a line follows within the same burst -- and written out one after the other through the tile.
 template <int WW, int VAR>
 __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
 {
     using Gm = Mirror2Geom<WW, VAR>;
-    constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS;
+    constexpr int p = (WW - 1) / 2, NJ2 = Gm::NJ2, SG = Gm::SG, SS = Gm::SS, IB = Gm::IB;
     extern __shared__ __attribute__((aligned(16))) double T[];           // [WW][NJ2][WW]
     cip rp0 = (cip)M.rp0, jlo0 = (cip)M.jlo0, jhi0 = (cip)M.jhi0, rp1 = (cip)M.rp1;
     unsigned bid = blockIdx.x;
@@ -848,7 +859,7 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
     const __amdgpu_buffer_rsrc_t d0 = __builtin_amdgcn_make_buffer_rsrc((void *)M.data, (short)0, 0, 0x00020000);
     // ---- gather plan: element (j2, op) of a source run = column i2' = jlo2[j2] + op.  Offset inside the row block of (j0, j1):
     //      8 (A1 rp2[j2] + B1 c2 + op), A1 = c0j c1j, B1 = (i0 - jlo0[j0]) c1j + i1 - jlo1(j1): scalars of the step
-    int g_a[SG], g_c[SG], g_o[SG], g_t[SG];      // 8 rp2[j2] | 8 c2 | 8 op or BF2_OOB | tile offset, bit 30: j2 <= i2'
+    int g_a[SG], g_c[SG], g_o[SG], g_t[SG];      // 8 rp2[j2] | 8 c2 | 8 op or BF2_OOB | tile offset, bit 30: j2 <= i2', bit 29: no element
 #pragma unroll
     for (int s_ = 0; s_ < SG; ++s_) {
         const int f = threadIdx.x + 256 * s_;
@@ -872,45 +883,52 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
         t_off[s_] = ((m * NJ2 + (j2 - j2lo)) * WW + (i2 - jlo(j2))) | (m << 24) | (j2 <= i2 ? 1 << 30 : 0);
     }
     const int i1b = M.i1_lo + ib * M.i1_rows, i1e = min(i1b + M.i1_rows, M.i1_hi);
-    double v[WW][SG];
-    auto gather = [&](const int i1) {
+    double v[IB][WW][SG];
+    auto gather = [&](const int d, const int i1r) {
+        const int i1 = min(i1r, i1e - 1);                    // (rows past the end repeat the last one; they are not written)
         const int jl1i = jlo(i1), c1i = cnt(i1, M.N1);
         const int a1 = diag ? i1 : jl1i, nj1 = jl1i + c1i - a1;
 #pragma unroll
         for (int m = 0; m < WW; ++m) {
             const int j1 = min(a1 + m, M.N1 - 1), c1j = cnt(j1, M.N1);
-            const __amdgpu_buffer_rsrc_t d = m < nj1 ? bf2_rsrc(M.data + ((long long)rp0[j0] * S12 + (long long)c0j * rp1[j1] * M.S2 - M.nnz_off)) : d0;
+            const __amdgpu_buffer_rsrc_t dsc = m < nj1 ? bf2_rsrc(M.data + ((long long)rp0[j0] * S12 + (long long)c0j * rp1[j1] * M.S2 - M.nnz_off)) : d0;
             const int A1 = c0j * c1j, B1 = (i0 - jlo0[j0]) * c1j + (i1 - jlo(j1));
 #pragma unroll
             for (int s_ = 0; s_ < SG; ++s_) {
                 int off = A1 * g_a[s_] + B1 * g_c[s_] + g_o[s_];
                 if (g_o[s_] == BF2_OOB || (m == 0 && diag && (g_t[s_] & (1 << 30)))) off = BF2_OOB;
-                v[m][s_] = bf2_buffer_load(d, off, 0);
+                v[d][m][s_] = bf2_buffer_load(dsc, off, 0);
             }
         }
     };
-    if (i1b < i1e) gather(i1b);
-    for (int i1 = i1b; i1 < i1e; ++i1) {
-        const int jl1i = jlo(i1), c1i = cnt(i1, M.N1);
-        const int a1 = diag ? i1 : jl1i, nj1 = jl1i + c1i - a1;
+    for (int i1s = i1b; i1s < i1e; i1s += IB) {
 #pragma unroll
-        for (int m = 0; m < WW; ++m)
+        for (int d = 0; d < IB; ++d) gather(d, i1s + d);     // IB rows in flight: neighbouring runs of a source segment together
 #pragma unroll
-            for (int s_ = 0; s_ < SG; ++s_)
-                if (!(g_t[s_] & (1 << 29))) T[m * (NJ2 * WW) + (g_t[s_] & 0xffffff)] = v[m][s_];
-        __syncthreads();
-        gather(min(i1 + 1, i1e - 1));                        // the next row's runs are in flight under the stores (the last row is read twice)
-        // ---- whole target segments
-        const __amdgpu_buffer_rsrc_t dt = bf2_rsrc(M.data + ((long long)rp0[i0] * S12 + (long long)c0i * rp1[i1] * M.S2 - M.nnz_off));
-        const int A = c0i * c1i, B = (j0 - jlo0[i0]) * c1i + (a1 - jl1i);
+        for (int d = 0; d < IB; ++d) {
+            const int i1 = i1s + d;
+            const bool on = i1 < i1e;
+            const int i1c = min(i1, i1e - 1);
+            const int jl1i = jlo(i1c), c1i = cnt(i1c, M.N1);
+            const int a1 = diag ? i1c : jl1i, nj1 = jl1i + c1i - a1;
 #pragma unroll
-        for (int s_ = 0; s_ < SS; ++s_) {
-            const int m = (t_off[s_] >> 24) & 15;
-            int off = A * t_a[s_] + B * t_c[s_] + t_m[s_];
-            if (t_m[s_] == BF2_OOB || m >= nj1 || (diag && m == 0 && (t_off[s_] & (1 << 30)))) off = BF2_OOB;
-            bf2_buffer_store<MIRROR_ST_AUX>(dt, off, 0, T[t_off[s_] & 0xffffff]);
+            for (int m = 0; m < WW; ++m)
+#pragma unroll
+                for (int s_ = 0; s_ < SG; ++s_)
+                    if (!(g_t[s_] & (1 << 29))) T[m * (NJ2 * WW) + (g_t[s_] & 0xffffff)] = v[d][m][s_];
+            __syncthreads();
+            // ---- whole target segments
+            const __amdgpu_buffer_rsrc_t dt = on ? bf2_rsrc(M.data + ((long long)rp0[i0] * S12 + (long long)c0i * rp1[i1c] * M.S2 - M.nnz_off)) : d0;
+            const int A = c0i * c1i, B = (j0 - jlo0[i0]) * c1i + (a1 - jl1i);
+#pragma unroll
+            for (int s_ = 0; s_ < SS; ++s_) {
+                const int m = (t_off[s_] >> 24) & 15;
+                int off = A * t_a[s_] + B * t_c[s_] + t_m[s_];
+                if (t_m[s_] == BF2_OOB || m >= nj1 || (diag && m == 0 && (t_off[s_] & (1 << 30)))) off = BF2_OOB;
+                bf2_buffer_store<MIRROR_ST_AUX>(dt, off, 0, T[t_off[s_] & 0xffffff]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -1133,7 +1151,7 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
         switch (2 * AL.p + 1) {
         case 5: return launch_mirror2_k<5, 0>(st, M, AL.N);
         case 7: return launch_mirror2_k<7, 0>(st, M, AL.N);
-        case 9: return launch_mirror2_k<9, 1>(st, M, AL.N);
+        case 9: return launch_mirror2_k<9, MIRROR_VAR>(st, M, AL.N);
         }
     }
     switch (2 * AL.p + 1) {

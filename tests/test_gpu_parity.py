@@ -780,8 +780,10 @@ def test_full_size_c4(iga, monkeypatch):
     rowsum = np.add.reduceat(data, indptr)
     assert np.abs(rowsum).max() <= 1e-10 * scale
     rng = np.random.default_rng(7)
-    sample = np.unique(np.concatenate(([0, n - 1, n // 2], rng.integers(0, n, 60))))
-    S = iga.assemble.assemble_partial_rows(asm, sample)          # entry-wise kernel, 60 rows
+    N = kv.numdofs
+    line = np.arange(N) + (71 * N + 40) * N                       # every row of one line of the last axis: all tile positions
+    sample = np.unique(np.concatenate(([0, n - 1, n // 2], line, rng.integers(0, n, 40))))
+    S = iga.assemble.assemble_partial_rows(asm, sample)          # entry-wise kernel, ~175 rows
     for r in sample:
         lo = indptr[r]
         ref = S.data[S.indptr[r]:S.indptr[r + 1]]
@@ -851,10 +853,42 @@ def test_full_size_c5(iga, monkeypatch):
         assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
 
 
+def test_full_size_c5_affine_coefficient(iga, golden, monkeypatch):
+    """The coefficient of BASELINE config 5 as bench.py passes it -- AffineCoefficient(1, 1): 1 + x evaluated ON THE DEVICE
+    through the geometry map -- pinned (i) at p=5 n=24 to the reference's matrix (golden_fullsize p5n24_convdiff, made with
+    the host-sampled lambda) and (ii) at full size to the host-sampled lambda on sampled rows and through the row sums."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    geo = _geo(iga, 'cylinder')
+    g = golden('fullsize')
+    kv = iga.bspline.make_knots(5, 0., 1., 24)
+    A = iga.assemblers.ConvDiffAssembler3D((kv,) * 3, geo, iga.assemblers.AffineCoefficient(1.0, 1.0)).assemble_csr()
+    assert np.abs(_csr_at(A, g['p5n24_idx']) - g['p5n24_convdiff']).max() <= RTOL * abs(A).max()
+    del A
+    kv = iga.bspline.make_knots(5, 0., 1., 96)
+    kvs = (kv, kv, kv)
+    aff = iga.assemblers.ConvDiffAssembler3D(kvs, geo, iga.assemblers.AffineCoefficient(1.0, 1.0))
+    data = aff.patch.assemble('convdiff', algo='sumfact', to_host=True)
+    assert 'fused' in aff.patch.last_path() and not np.isnan(data).any()
+    n = aff.patch.shape[0]
+    _, indptr = _positions(kvs, np.arange(n, dtype=np.int64), np.arange(n, dtype=np.int64))
+    scale = np.abs(data).max()
+    assert np.abs(np.add.reduceat(data, indptr)).max() <= 1e-10 * scale
+    aff.patch.close()
+    lam = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + x)
+    N = kv.numdofs
+    # rows of one line of the last axis (every position inside the tiles of the fused stage) + scattered rows
+    sample = np.unique(np.concatenate((np.arange(N) + (37 * N + 53) * N, np.random.default_rng(3).integers(0, n, 10))))
+    S = iga.assemble.assemble_partial_rows(lam, sample)          # host-sampled coefficient, entry-wise kernel
+    for r in sample:
+        ref = S.data[S.indptr[r]:S.indptr[r + 1]]
+        assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
+
+
 def test_repeatability(iga):
     """Race hunt: the final stage waits on its LDS-DMA queue with counted vmcnt and exchanges sums between waves
-    through LDS; an under-wait would show up as run-to-run differences.  40 repetitions, bit-identical values
-    (tools/scratch/stress.py runs hundreds, up to the full C4 size)."""
+    through LDS; the halves of a pass of the fused stage ADD into the entry rings (ds_add_f64, two addends: the order must
+    not matter); an under-wait or an order dependence would show up as run-to-run differences.  40 repetitions,
+    bit-identical values (tools/rowsum_check.py repeats the full C4 size)."""
     import hashlib
     mk = iga.bspline.make_knots
     for kvs, gname, kind in (((mk(4, 0., 1., 14),) * 3, 'cylinder', 'stiffness'),
