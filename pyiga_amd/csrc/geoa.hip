@@ -26,6 +26,12 @@
 namespace igx {
 
 constexpr int GA_MAXS = 8;
+#ifndef GA_ONEDIV
+#define GA_ONEDIV 1           // stiffness fields from the unscaled quotient-rule matrix: one division per point
+#endif
+#ifndef GA_READBOTH
+#define GA_READBOTH 1         // both basis rows of a plane are read from LDS even when they are the same row (no register copies)
+#endif
 typedef const double __attribute__((address_space(4))) *cdp;      // uniform tables: scalar loads
 typedef const int __attribute__((address_space(4))) *cip;
 
@@ -190,6 +196,38 @@ k_geoA(const GeoAArgs A)
                 jac[c][2] = fma(n, c2, jac[c][2]);
             }
         }
+        double GW = gw0 * GW1;
+        GW = GW * GW2;
+        if (GA_ONEDIV && NS == 8) {
+            // stiffness fields with ONE division (an f64 division is 12 vector instructions).  With the unscaled quotient-rule
+            // matrix M = V'W - V W' (J = M / W^2; M = J for a polynomial geometry):
+            //   GW |det J| J^-1 J^-T = GW adj(J) adj(J)^T / |det J| = GW / (W^2 |det M|) * adj(M) adj(M)^T
+            double t[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    t[r * 3 + c] = NC == 4 ? jac[r][2 - c] * val[3] - val[r] * jac[3][2 - c] : jac[r][2 - c];
+            double a[9];
+            a[0] = t[4] * t[8] - t[5] * t[7];
+            a[1] = -(t[1] * t[8] - t[2] * t[7]);
+            a[2] = t[1] * t[5] - t[2] * t[4];
+            a[3] = -(t[3] * t[8] - t[5] * t[6]);
+            a[4] = t[0] * t[8] - t[2] * t[6];
+            a[5] = -(t[0] * t[5] - t[2] * t[3]);
+            a[6] = t[3] * t[7] - t[4] * t[6];
+            a[7] = -(t[0] * t[7] - t[1] * t[6]);
+            a[8] = t[0] * t[4] - t[1] * t[3];
+            const double det = (t[0] * a[0] + t[1] * a[3]) + t[2] * a[6];
+            const double sc = GW / (NC == 4 ? (val[3] * val[3]) * fabs(det) : fabs(det));
+            fld[buf][w][0][lane] = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+            fld[buf][w][1][lane] = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
+            fld[buf][w][2][lane] = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
+            fld[buf][w][3][lane] = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
+            fld[buf][w][4][lane] = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
+            fld[buf][w][5][lane] = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
+            return;
+        }
         double Jm[MAX_COMP][3], ev[MAX_COMP];
         finish_jacobian<3>(val, jac, NC == 4, 3, NC, Jm, ev);
         double tt[9];
@@ -197,8 +235,6 @@ k_geoA(const GeoAArgs A)
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) tt[r * 3 + c] = Jm[r][c];
-        double GW = gw0 * GW1;
-        GW = GW * GW2;
         double f[6];
         fields_values<3>(tt, GW, A.kind, f);
         const int nf = A.kind == IGX_MASS ? 1 : 6;
@@ -274,7 +310,7 @@ k_geoA(const GeoAArgs A)
         double bv = fld[buf][0][fi][lane];
         double va[PV], vb[PV];                            // V[.][tv] (test functions, rows a), V[.][tu] (trial functions, columns b)
         basis_row(va, rs, 0, tv);
-        if (tu != tv) basis_row(vb, rs, 0, tu);
+        if (GA_READBOTH || tu != tv) basis_row(vb, rs, 0, tu);
         else {
 #pragma unroll
             for (int k = 0; k < PV; ++k) vb[k] = va[k];
@@ -303,7 +339,7 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
                 for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[a][b]));
             asm volatile("" ::: "memory");
-            if (tu != tv) basis_row(vb, rs, jn, tu);
+            if (GA_READBOTH || tu != tv) basis_row(vb, rs, jn, tu);
             else {                                        // same row: no second broadcast read
 #pragma unroll
                 for (int k = 0; k < PV; ++k) vb[k] = va[k];
