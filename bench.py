@@ -241,8 +241,9 @@ def main():
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api-call', action='store_true', help='skip the end-to-end assemble.stiffness() call (host copy of the matrix)')
-    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries'],
-                    help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs')
+    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries', 'fast'],
+                    help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs; '
+                         'fast: the low-rank (ACA) assembler against the exact assembly (use --config c2 / c3: the reordered tensor lives on the host)')
     ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
     ap.add_argument('--strong', action='store_true', help='(default) strong scaling: the patch is fixed, its rows are split')
     ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank run on this one GPU (no collectives)')
@@ -330,6 +331,8 @@ def main():
         return bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, barrier)
     if args.op == 'entries':
         return bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank)
+    if args.op == 'fast':
+        return bench_fast(args, patch, kvs, dim, p, kind, n0, n, nel_total)
     # cold assembly: the first one of the patch allocates the workspaces (K1, CSR values) and builds the per-plane table
     t_cold = time.perf_counter()
     patch.assemble(kind, algo=args.algo, to_host=False)
@@ -507,6 +510,43 @@ def bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank):
                       'config': args.config, 'note': 'device time with resident pairs; host-pointer call (upload pairs, download values) %.1f ms' % host_ms},
            'roofline': {'bound': 'fp64', 'note': 'the entry-wise sum is arithmetic: ~33 flop per Gauss point of the support intersection',
                         'achieved': None, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_fast(args, patch, kvs, dim, p, kind, n0, n, nel_total):
+    """Low-rank (ACA) assembler (pyiga/fastasm.cc, mass_fast / stiffness_fast) as a consumer of batched entries:
+    wall time of a whole call (host control flow + device requests + inflation to CSR) beside the exact assembly."""
+    assert kind in ('mass', 'stiffness'), 'the low-rank assembler knows the mass and stiffness forms'
+    S = [kv.numdofs * (2 * kv.p + 1) - kv.p * (kv.p + 1) for kv in kvs]
+    if 8.0 * float(np.prod(S)) > 16e9:
+        raise SystemExit('bench.py --op fast: the reordered tensor of this config needs %.0f GB of host memory; use --config c2 or c3'
+                         % (8e-9 * float(np.prod(S))))
+    t0 = time.perf_counter()
+    exact = patch.assemble(kind, algo=args.algo, to_host=True)
+    exact_wall = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    exact = patch.assemble(kind, algo=args.algo, to_host=True)
+    exact_wall = min(exact_wall, time.perf_counter() - t0)
+    exact_dev_ms = patch.timing()['total_ms']
+    patch.pattern()
+    walls = []
+    for _ in range(max(1, min(args.steps, 3))):
+        t0 = time.perf_counter()
+        A = patch.fast_assemble(kind, tol=1e-10)
+        walls.append(time.perf_counter() - t0)
+    st = patch.aca_stats
+    err = float(np.abs(A.data - exact).max() / np.abs(exact).max())
+    wall = float(np.median(walls))
+    out = {'metric': 'low-rank (ACA) assembly, elements/sec of a whole call', 'value': nel_total / wall, 'unit': 'elements/s', 'n_gpus': 1,
+           'steps': len(walls), 'warmup': 0, 'ms_per_step': 1e3 * wall, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+           'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%dD p=%d %s, %s spans, tol 1e-10' % (dim, p, kind, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
+                      'config': args.config},
+           'aca': {'crosses': st['rank'], 'requests': st['requests'], 'entries_evaluated': st['entries'], 'nnz': st['nnz'],
+                   'max_rel_error_vs_exact': err},
+           'exact': {'wall_s_with_copy_to_host': round(exact_wall, 4), 'device_ms': round(exact_dev_ms, 3)},
+           'roofline': {'bound': 'host', 'note': 'control flow, rank-1 updates of the reordered tensor and the inflation run on the host; the device '
+                        'serves %d requests' % st['requests'], 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None}}
     print(json.dumps(out), flush=True)
 
 

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define IGX_VERSION 100            /* 0.1.0 */
+#define IGX_VERSION 101            /* 0.1.1: igx_patch_desc.box_lo / box_hi */
 #define IGX_MAX_DIM 3
 #define IGX_MAX_DEGREE 15          /* basis evaluation / entry-wise kernels */
 #define IGX_MAX_SF_DEGREE 5        /* sum-factorised fast path */
@@ -92,6 +92,13 @@ typedef struct {
     /* Row slab for multi-GPU: this patch owns the dof planes row0_lo <= i0 < row0_hi of axis 0
        (row0_hi = 0 means "all").  Only those CSR rows are produced. */
     int32_t row0_lo, row0_hi;
+
+    /* Span box for on-demand assemblers (pyiga/codegen/cython.py:541-559, callers pyiga/_hdiscr.py:37-56,204-209): the
+       geometry-dependent fields are kept only on the spans box_lo[k] <= s < box_hi[k] of every axis (all box_hi zero = whole
+       patch).  A boxed patch serves igx_entries / igx_entries_d for pairs whose common support lies inside the box (others:
+       NaN) and nothing else; IGX_GEO_JACOBIAN arrays and sampled coefficients are then given on the Gauss grid of the BOX.
+       Present since igx_version() >= 101. */
+    int32_t box_lo[IGX_MAX_DIM], box_hi[IGX_MAX_DIM];
 } igx_patch_desc;
 
 typedef struct {
@@ -198,6 +205,14 @@ const int32_t *igx_d_csr_indptr(const igx_patch *patch);
    maxiter 100, skipcount 3, tolcount 3; verbose 0..2 prints the reference's progress lines to stdout. */
 int igx_fast_assemble(igx_patch *patch, int kind, double tol, int maxiter, int skipcount, int tolcount, int verbose,
                       double *data_out, int *rank_out, long long *entries_out);
+/* Request granularity of igx_fast_assemble.  A request is one launch: the index pairs of whole lines / slices of the
+   reordered tensor are generated on the device from resident per-axis tables (nothing is uploaded), only the values come
+   back.  A slice (3D) or the whole matrix (2D) with at most `max_entries` entries is fetched exactly in ONE request instead
+   of being approximated line by line (on this hardware a launch costs as much as ~2000 entries); 0 = always line by line (the
+   reference's access pattern).  Default 65536. */
+int igx_patch_set_aca_batch(igx_patch *patch, long long max_entries);
+/* Counters of the last igx_fast_assemble of the patch: batched requests (launches), entries evaluated, crosses. */
+int igx_fast_assemble_stats(const igx_patch *patch, long long *requests, long long *entries, int *rank);
 
 /* multi_entries: ij is M x 2 (row, col) of ravelled dof indices; out[k] = 0.0 for pairs whose
    supports do not intersect.  Works for any pair, inside or outside the owned slab provided the

@@ -29,6 +29,7 @@ class PatchDesc(C.Structure):
         ('ctrl', _dp), ('jac', _dp),
         ('nqp', C.c_int32), ('gauss_x', _dp), ('gauss_w', _dp),
         ('row0_lo', C.c_int32), ('row0_hi', C.c_int32),
+        ('box_lo', C.c_int32 * 3), ('box_hi', C.c_int32 * 3),
     ]
 
 
@@ -83,6 +84,8 @@ SYMBOLS = [
     ('igx_entries_d', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('igx_load_vector_d', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('igx_fast_assemble', C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    ('igx_patch_set_aca_batch', C.c_int, [C.c_void_p, C.c_longlong]),
+    ('igx_fast_assemble_stats', C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     ('igx_patch_set_coeff_affine', C.c_int, [C.c_void_p, C.c_double * 4]),
     ('igx_patch_set_form_d', C.c_int, [C.c_void_p, C.c_void_p * 16]),
     ('igx_patch_last_path', C.c_int, [C.c_void_p]),

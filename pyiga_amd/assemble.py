@@ -202,6 +202,21 @@ def _nonzeros_for_rows(kvs0, kvs1, row_indices):
     return np.concatenate(I), np.concatenate(J)
 
 
+def bbox_for_rows(kvs, row_indices):
+    """Cell ranges ((lo, hi) per axis, upper limit exclusive) that contain the supports of the given basis functions
+    (ravelled dof indices) -- the bounding box the hierarchical discretisation passes to an on-demand assembler
+    (pyiga/_hdiscr.py:225-233)."""
+    nd = tuple(kv.numdofs for kv in kvs)
+    mi = np.unravel_index(np.asarray(row_indices, dtype=np.int64).ravel(), nd)
+    if mi[0].size == 0:
+        return tuple((0, 0) for _ in kvs)
+    box = []
+    for kv, ik in zip(kvs, mi):
+        supp = kv.mesh_support_idx_all()
+        box.append((int(supp[ik, 0].min()), int(supp[ik, 1].max())))
+    return tuple(box)
+
+
 def assemble_partial_rows(asm, row_indices):
     """Submatrix (full shape, CSR) that contains only the given rows -- what the hierarchical
     discretisation asks of an assembler (pyiga/_hdiscr.py:5-11): the pattern entries of those rows go

@@ -37,7 +37,7 @@ def _is_nurbs(geo):
 class DevicePatch:
     """RAII wrapper of ``igx_patch``: discretisation + geometry resident on one GPU."""
 
-    def __init__(self, kvs, geo, device=None, row0=None, jacobian=None):
+    def __init__(self, kvs, geo, device=None, row0=None, jacobian=None, bbox=None):
         lib = _lib.load()
         self.ctx = _lib.context(device)
         self.kvs = tuple(kvs)
@@ -58,6 +58,16 @@ class DevicePatch:
         gx, gw = _lib.f64(gx), _lib.f64(gw)
         keep += [gx, gw]
         d.gauss_x, d.gauss_w = _lib.dptr(gx), _lib.dptr(gw)
+        # on-demand assembler (pyiga/codegen/cython.py:541-559): geometry-dependent fields only on the cells
+        # bbox[k][0] <= cell < bbox[k][1] of every axis; such a patch serves multi_entries inside the box and nothing else
+        self.bbox = None
+        if bbox is not None:
+            assert row0 is None, 'a bounding box and a row slab exclude each other'
+            self.bbox = tuple((int(lo), int(hi)) for lo, hi in bbox)
+            assert len(self.bbox) == self.dim, 'bounding box needs one cell range per axis'
+            for k, (lo, hi) in enumerate(self.bbox):
+                assert 0 <= lo < hi <= self.kvs[k].numspans, 'bounding box outside the mesh (or empty)'
+                d.box_lo[k], d.box_hi[k] = lo, hi
         if jacobian is None and _is_spline_geo(geo) and len(geo.kvs) == self.dim:
             d.geo_kind = _lib.IGX_GEO_NURBS if _is_nurbs(geo) else _lib.IGX_GEO_BSPLINE
             for k, gkv in enumerate(geo.kvs):
@@ -75,10 +85,15 @@ class DevicePatch:
             # arbitrary geometry object: take its Jacobians on the Gauss grid as an array
             # (the reference does this for every geometry, assemblers.pyx:1376)
             if jacobian is None:
-                grid, _ = make_tensor_quadrature([kv.mesh for kv in self.kvs], self.nqp)
+                meshes = [kv.mesh for kv in self.kvs]
+                if self.bbox is not None:                       # (upper cell index exclusive: include its end point)
+                    meshes = [m[lo:hi + 1] for m, (lo, hi) in zip(meshes, self.bbox)]
+                grid, _ = make_tensor_quadrature(meshes, self.nqp)
                 jacobian = geo.grid_jacobian(grid)
             jac = _lib.f64(jacobian)
             G = tuple(kv.numspans * self.nqp for kv in self.kvs)
+            if self.bbox is not None:
+                G = tuple((hi - lo) * self.nqp for lo, hi in self.bbox)
             assert jac.shape == G + (self.dim, self.dim), 'Jacobian array has wrong shape'
             keep.append(jac)
             d.geo_kind = _lib.IGX_GEO_JACOBIAN
@@ -119,6 +134,13 @@ class DevicePatch:
             raise _lib.IgxError('igx_dev_alloc failed: ' + _lib.last_error())
         setattr(self, name, (ptr, nbytes))
         return ptr
+
+    def resident_grid(self):
+        """Shape of the Gauss grid the coefficient arrays of this patch are given on: the whole tensor grid, or the grid of the
+        bounding box for an on-demand patch."""
+        if self.bbox is not None:
+            return tuple((hi - lo) * self.nqp for lo, hi in self.bbox)
+        return tuple(self.info.ngauss[k] for k in range(self.dim))
 
     def gauss_slab(self):
         """(first plane, number of planes) of the Gauss planes of axis 0 that are resident for this row slab."""
@@ -214,15 +236,20 @@ class DevicePatch:
                                             _lib.dptr(out) if to_host else None), 'igx_assemble')
         return out
 
-    def fast_assemble(self, kind, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=0):
-        """Low-rank (ACA) assembly (igx_fast_assemble): scipy CSR, plus the number of crosses and of evaluated entries in
-        ``self.aca_stats``."""
+    def fast_assemble(self, kind, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=0, batch=None):
+        """Low-rank (ACA) assembly (igx_fast_assemble): scipy CSR, plus the number of crosses, of evaluated entries and of
+        batched device requests in ``self.aca_stats``.  `batch`: slices (3D) / matrices (2D) of the reordered tensor with at
+        most that many entries are fetched exactly in one request (default 65536; 0 = line by line like the reference)."""
         assert self.row_range == (0, self.shape[0]), 'the low-rank assembler works on whole patches'
+        lib = _lib.load()
+        if batch is not None:
+            _lib.check(lib.igx_patch_set_aca_batch(self.handle, int(batch)), 'igx_patch_set_aca_batch')
         data = np.empty(self.nnz)
-        rank, nent = C.c_int(0), C.c_longlong(0)
-        _lib.check(_lib.load().igx_fast_assemble(self.handle, _lib.KINDS[kind], float(tol), int(maxiter), int(skipcount), int(tolcount),
-                                                 int(verbose), _lib.dptr(data), C.byref(rank), C.byref(nent)), 'igx_fast_assemble')
-        self.aca_stats = {'rank': rank.value, 'entries': nent.value, 'nnz': int(self.nnz)}
+        rank, nent, nreq = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+        _lib.check(lib.igx_fast_assemble(self.handle, _lib.KINDS[kind], float(tol), int(maxiter), int(skipcount), int(tolcount),
+                                         int(verbose), _lib.dptr(data), C.byref(rank), C.byref(nent)), 'igx_fast_assemble')
+        _lib.check(lib.igx_fast_assemble_stats(self.handle, C.byref(nreq), None, None), 'igx_fast_assemble_stats')
+        self.aca_stats = {'rank': rank.value, 'entries': nent.value, 'requests': nreq.value, 'nnz': int(self.nnz)}
         indptr, indices = self.pattern()
         return scipy.sparse.csr_matrix((data, indices, indptr), shape=self.shape)
 
@@ -254,8 +281,8 @@ class DevicePatch:
         return out
 
     def set_coeff(self, values):
-        """Scalar coefficient on the full tensor Gauss grid (for the convection-diffusion form)."""
-        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        """Scalar coefficient on the tensor Gauss grid (of the bounding box, for an on-demand patch) for the convection-diffusion form."""
+        G = self.resident_grid()
         c = _lib.f64(np.broadcast_to(values, G))
         _lib.check(_lib.load().igx_patch_set_coeff(self.handle, _lib.dptr(c)), 'igx_patch_set_coeff')
 
@@ -286,8 +313,8 @@ class DevicePatch:
         return out.reshape((n0,) + nd[1:] + comp_shape)
 
     def set_form(self, table):
-        """Physical coefficient table of IGX_FORM: 4x4 nested list of arrays on the full Gauss grid or None."""
-        G = tuple(self.info.ngauss[k] for k in range(self.dim))
+        """Physical coefficient table of IGX_FORM: 4x4 nested list of arrays on the Gauss grid (see resident_grid) or None."""
+        G = self.resident_grid()
         keep, ptrs = [], (_lib._dp * 16)()
         for r in range(4):
             for s in range(4):
@@ -317,9 +344,13 @@ class DevicePatch:
         return out
 
     def gauss(self, axis):
+        """Gauss nodes and weights of an axis (of its part inside the bounding box, for an on-demand patch)."""
         n = self.info.ngauss[axis]
         nodes, weights = np.empty(n), np.empty(n)
         _lib.check(_lib.load().igx_patch_gauss(self.handle, axis, _lib.dptr(nodes), _lib.dptr(weights)), 'igx_patch_gauss')
+        if self.bbox is not None:
+            lo, hi = self.bbox[axis]
+            return nodes[lo * self.nqp:hi * self.nqp], weights[lo * self.nqp:hi * self.nqp]
         return nodes, weights
 
     def csr(self, kind, algo='auto'):
@@ -344,7 +375,7 @@ class _DeviceAssembler:
     def parameters(cls):
         return {}
 
-    def __init__(self, kvs0, geo, device=None, row0=None):
+    def __init__(self, kvs0, geo, device=None, row0=None, bbox=None):
         assert len(kvs0) == self._dim, 'Assembler requires %d knot vectors' % self._dim
         assert geo.sdim == self._dim, 'Geometry has wrong source dimension'
         assert geo.dim == self._dim, 'Geometry has wrong dimension'
@@ -352,7 +383,9 @@ class _DeviceAssembler:
         self.nqp = max(kv.p for kv in kvs0) + 1
         kvs0 = tuple(kvs0)
         self.kvs = (kvs0, kvs0)
-        self.patch = DevicePatch(kvs0, geo, device=device, row0=row0)
+        # bbox: the reference's on-demand assemblers (compile_vform(..., on_demand=True), pyiga/_hdiscr.py:37-56) -- cell
+        # ranges per axis outside of which nothing is precomputed; multi_entries then serves pairs inside the box
+        self.patch = DevicePatch(kvs0, geo, device=device, row0=row0, bbox=bbox)
 
     # --- the reference's per-entry interface (genericasm.pxi:677-758)
     def entry(self, i, j):
@@ -445,8 +478,8 @@ class ConvDiffAssembler3D(_DeviceAssembler):
     def inputs(cls):
         return {'geo': (3,), 'diff_coeff': ()}
 
-    def __init__(self, kvs0, geo, diff_coeff, device=None, row0=None):
-        super().__init__(kvs0, geo, device=device, row0=row0)
+    def __init__(self, kvs0, geo, diff_coeff, device=None, row0=None, bbox=None):
+        super().__init__(kvs0, geo, device=device, row0=row0, bbox=bbox)
         if isinstance(diff_coeff, AffineCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
             self.patch.set_coeff_affine(diff_coeff.c)             # evaluated on the device: nothing sampled on the host
             return
@@ -473,9 +506,9 @@ class _GeneralFormAssembler(_DeviceAssembler):
     _symmetric_form = False
     _kind = 'form'
 
-    def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
+    def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None, bbox=None):
         from . import forms
-        super().__init__(kvs0, geo, device=device, row0=row0)
+        super().__init__(kvs0, geo, device=device, row0=row0, bbox=bbox)
         d = self._dim
         grid = [self.patch.gauss(k)[0] for k in range(d)]
         G = tuple(len(g) for g in grid)

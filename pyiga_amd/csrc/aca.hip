@@ -2,8 +2,9 @@
 //
 // The reference's one native component (pyiga/fastasm.cc:294-494 `aca`, `aca_3d`; :505-760 reordering and inflation;
 // driver pyiga/fast_assemble_cy.pyx:101-113) pulls single entries A(i, j) through a C callback.  Here the same algorithm
-// runs on the host and asks the device for whole rows, columns and fibres of the REORDERED matrix at a time
-// (igx_entries: one kernel launch per request):
+// runs on the host and asks the device for whole rows, columns, fibres -- and, where they are small, whole slices -- of the
+// REORDERED matrix at a time (entries_pair_boxes: the index pairs of a request are generated on the device from the
+// resident per-axis pair tables, one launch per request, only the values come back):
 //
 //   2D:  X[r0][r1]     = A[(i0,i1),(j0,j1)],      r_k = index of the 1D pair (i_k, j_k) with overlapping supports
 //   3D:  X[r0][r1][r2] = A[(i0,i1,i2),(j0,j1,j2)]
@@ -27,33 +28,31 @@ namespace {
 struct Requests {
     igx_patch *pt;
     int kind, dim;
-    std::vector<size_t> ij;
     long long nreq = 0, nent = 0;
     unsigned lcg = 12345u;
 
     size_t S(int k) const { return (size_t)pt->ax[k].S; }
     unsigned next_random() { lcg = lcg * 1664525u + 1013904223u; return lcg >> 8; }
 
-    // entries along axis `free_ax` of the reordered tensor, the other pair indices fixed: out[r] for r < S(free_ax)
-    int line(int free_ax, const size_t r[3], double *out)
+    // one box of the reordered tensor: axes in `full` (bit k) run over all their pairs, the others are fixed at r[k]; the index
+    // pairs are generated on the device (launch_box_pairs), only the values travel
+    int box(unsigned full, const size_t r[3], double *out)
     {
-        const int d = dim;
-        const size_t n = S(free_ax);
-        ij.resize(2 * n);
-        size_t N[3] = {1, 1, 1};
-        for (int k = 0; k < d; ++k) N[k] = (size_t)pt->ax[k].N;
-        for (size_t l = 0; l < n; ++l) {
-            size_t I = 0, J = 0;
-            for (int k = 0; k < d; ++k) {
-                const size_t rk = k == free_ax ? l : r[k];
-                I = I * N[k] + (size_t)pt->ax[k].pair_i[rk];
-                J = J * N[k] + (size_t)pt->ax[k].pair_j[rk];
-            }
-            ij[2 * l] = I; ij[2 * l + 1] = J;
+        PairBoxes B{};
+        B.n = 1;
+        long long n = 1;
+        for (int k = 0; k < 3; ++k) {
+            const bool f = k < dim && ((full >> k) & 1u);
+            B.lo[0][k] = f || k >= dim ? 0 : (int)r[k];
+            B.len[0][k] = f ? (int)S(k) : 1;
+            n *= B.len[0][k];
         }
-        ++nreq; nent += (long long)n;
-        return igx_entries(pt, kind, ij.data(), n, out);
+        B.off[0] = 0; B.off[1] = n;
+        ++nreq; nent += n;
+        return entries_pair_boxes(pt, kind, B, out);
     }
+    // entries along axis `free_ax`, the other pair indices fixed: out[r] for r < S(free_ax)
+    int line(int free_ax, const size_t r[3], double *out) { return box(1u << free_ax, r, out); }
 };
 
 size_t argmax_abs(const double *v, size_t n)
@@ -113,6 +112,7 @@ extern "C" int igx_fast_assemble(igx_patch *pt, int kind, double tol, int maxite
                                  double *data_out, int *rank_out, long long *entries_out)
 {
     if (!pt || !data_out) { set_error("igx_fast_assemble: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_fast_assemble: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_fast_assemble: mass and stiffness forms only"); return IGX_ERR_UNSUPPORTED; }
     if (pt->row_lo != 0 || pt->row_hi != pt->nrows_total) { set_error("igx_fast_assemble: needs the whole patch, not a row slab"); return IGX_ERR_UNSUPPORTED; }
     if (maxiter < 1 || skipcount < 1 || tolcount < 1) { set_error("igx_fast_assemble: bad iteration parameters"); return IGX_ERR_ARG; }
@@ -123,7 +123,13 @@ extern "C" int igx_fast_assemble(igx_patch *pt, int kind, double tol, int maxite
     std::vector<double> X;
     try { X.assign(n0 * n1 * n2, 0.0); } catch (...) { set_error("igx_fast_assemble: %.2f GB of host memory for the reordered tensor", n0 * n1 * n2 * 8.0 / 1e9); return IGX_ERR_NOMEM; }
     int rank = 0;
-    if (dim == 2) {
+    const bool batch_all = dim == 2 && (long long)(n0 * n1) <= pt->aca_batch;        // 2D: the whole matrix in one request
+    const bool batch_slice = dim == 3 && (long long)(n1 * n2) <= pt->aca_batch;     // 3D: a slice in one request
+    if (batch_all) {
+        const size_t r[3] = {0, 0, 0};
+        if (rq.box(3u, r, X.data())) return IGX_ERR_HIP;
+        if (verbose >= 1) printf("%zu x %zu pairs fetched in one request (exact)\n", n0, n1);
+    } else if (dim == 2) {
         auto row = [&](size_t i, double *out) { const size_t r[3] = {i, 0, 0}; return rq.line(1, r, out); };
         auto col = [&](size_t j, double *out) { const size_t r[3] = {0, j, 0}; return rq.line(0, r, out); };
         rank = aca_matrix(n0, n1, row, col, X.data(), tol, maxiter, skipcount, tolcount, verbose, rq);
@@ -150,10 +156,15 @@ extern "C" int igx_fast_assemble(igx_patch *pt, int kind, double tol, int maxite
             I[0] = i0;
             if (verbose >= 2) printf("%zu\t%zu\t%zu\t%g\n", I[0], I[1], I[2], e);
             // the slice A[i0, :, :] by 2D ACA, starting from the current approximation
-            std::copy(X.begin() + i0 * n1 * n2, X.begin() + (i0 + 1) * n1 * n2, mat.begin());
-            auto srow = [&](size_t i, double *out) { const size_t r[3] = {i0, i, 0}; return rq.line(2, r, out); };
-            auto scol = [&](size_t j, double *out) { const size_t r[3] = {i0, 0, j}; return rq.line(1, r, out); };
-            if (aca_matrix(n1, n2, srow, scol, mat.data(), tol, maxiter, skipcount, tolcount, std::min(verbose, 1), rq) < 0) return IGX_ERR_HIP;
+            if (batch_slice) {                                                  // exact slice, one request
+                const size_t r[3] = {i0, 0, 0};
+                if (rq.box(6u, r, mat.data())) return IGX_ERR_HIP;
+            } else {
+                std::copy(X.begin() + i0 * n1 * n2, X.begin() + (i0 + 1) * n1 * n2, mat.begin());
+                auto srow = [&](size_t i, double *out) { const size_t r[3] = {i0, i, 0}; return rq.line(2, r, out); };
+                auto scol = [&](size_t j, double *out) { const size_t r[3] = {i0, 0, j}; return rq.line(1, r, out); };
+                if (aca_matrix(n1, n2, srow, scol, mat.data(), tol, maxiter, skipcount, tolcount, std::min(verbose, 1), rq) < 0) return IGX_ERR_HIP;
+            }
             for (size_t a = 0; a < n1 * n2; ++a) mat[a] -= X[i0 * n1 * n2 + a];     // error slice
             const double pivot = col[i0];
             for (size_t l = 0; l < n0; ++l) col[l] /= pivot;
@@ -188,6 +199,7 @@ extern "C" int igx_fast_assemble(igx_patch *pt, int kind, double tol, int maxite
     }
     if (rank_out) *rank_out = rank;
     if (entries_out) *entries_out = rq.nent;
+    pt->aca_requests = rq.nreq; pt->aca_entries = rq.nent; pt->aca_rank = rank;
     if (verbose >= 1) {
         printf("ACA: %d crosses, %lld entries in %lld batched requests (matrix has %lld)\n", rank, rq.nent, rq.nreq, (long long)pos);
         fflush(stdout);

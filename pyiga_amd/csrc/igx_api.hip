@@ -387,6 +387,16 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         pt->ax[2].N = 1; pt->ax[2].n = 1; pt->ax[2].G = 1; pt->ax[2].S = 1; pt->ax[2].q = q;
         pt->ax[2].dev.N = 1; pt->ax[2].dev.n = 1; pt->ax[2].dev.G = 1; pt->ax[2].dev.S = 1; pt->ax[2].dev.q = q;
     }
+    // span box (on-demand assemblers): fields on a window of every axis, batched entries only
+    for (int k = 0; k < dim && !rc; ++k) pt->boxed = pt->boxed || d->box_hi[k] != 0 || d->box_lo[k] != 0;
+    if (!rc && pt->boxed) {
+        for (int k = 0; k < dim && !rc; ++k)
+            if (d->box_lo[k] < 0 || d->box_lo[k] >= d->box_hi[k] || d->box_hi[k] > pt->ax[k].n) {
+                set_error("igx_patch_create: bad span box [%d,%d) on axis %d (%d spans)", d->box_lo[k], d->box_hi[k], k, pt->ax[k].n);
+                rc = IGX_ERR_ARG;
+            }
+        if (!rc && (d->row0_lo != 0 || d->row0_hi != 0)) { set_error("igx_patch_create: a span box and a row slab exclude each other"); rc = IGX_ERR_ARG; }
+    }
     // slab
     if (!rc) {
         const Axis &A0 = pt->ax[0];
@@ -401,6 +411,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
         pt->s0_lo = A0.mslo[pt->r0_lo];
         pt->s0_hi = A0.mshi[pt->r0_hi - 1];
+        if (pt->boxed) { pt->s0_lo = d->box_lo[0]; pt->s0_hi = d->box_hi[0]; }
         const long long plane = (long long)A1.N * A2.N;
         const long long Srest = (long long)A1.S * A2.S;
         pt->nrows_total = (long long)A0.N * plane;
@@ -414,7 +425,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         // elements attributed to this slab: spans of axis 0 split proportionally to the owned dofs
         const long long sp_lo = (long long)A0.n * pt->r0_lo / A0.N, sp_hi = (long long)A0.n * pt->r0_hi / A0.N;
         pt->nelem_owned = (sp_hi - sp_lo) * A1.n * A2.n;
-        if (pt->nnz > 0x7fffffffLL) {
+        if (pt->nnz > 0x7fffffffLL && !pt->boxed) {
             set_error("slab has %lld nonzeros; int32 CSR indices need < 2^31 (use more slabs)", pt->nnz);
             rc = IGX_ERR_UNSUPPORTED;
         }
@@ -423,7 +434,12 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         for (int k = 0; k < 3; ++k) pd.ax[k] = pt->ax[k].dev;
         pd.r0_lo = pt->r0_lo; pd.r0_hi = pt->r0_hi; pd.s0_lo = pt->s0_lo; pd.s0_hi = pt->s0_hi;
         pd.g0_lo = pt->s0_lo * q; pd.G0_loc = (pt->s0_hi - pt->s0_lo) * q;
-        pd.npts_loc = (long long)pd.G0_loc * A1.G * A2.G;
+        pd.b1 = pd.b2 = 0; pd.L1 = A1.G; pd.L2 = A2.G;
+        if (pt->boxed) {
+            pd.b1 = d->box_lo[1] * q; pd.L1 = (d->box_hi[1] - d->box_lo[1]) * q;
+            if (dim == 3) { pd.b2 = d->box_lo[2] * q; pd.L2 = (d->box_hi[2] - d->box_lo[2]) * q; }
+        }
+        pd.npts_loc = (long long)pd.G0_loc * pd.L1 * pd.L2;
         pd.nnz_off = pt->nnz_off;
     }
     // geometry
@@ -447,13 +463,14 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         } else if (d->geo_kind == IGX_GEO_JACOBIAN) {
             if (!d->jac) { set_error("igx_patch_create: jac is null"); rc = IGX_ERR_ARG; }
             else {
-                const size_t per_plane = (size_t)pt->ax[1].G * pt->ax[2].G * dim * dim;
-                rc = dev_alloc_copy(&pt->d_jac, d->jac + (size_t)pt->dev.g0_lo * per_plane, (size_t)pt->dev.G0_loc * per_plane, st);
+                // whole-grid array: the resident planes of axis 0; boxed patch: the array IS the box
+                const size_t per_plane = (size_t)pt->dev.L1 * pt->dev.L2 * dim * dim;
+                rc = dev_alloc_copy(&pt->d_jac, d->jac + (pt->boxed ? 0 : (size_t)pt->dev.g0_lo * per_plane), (size_t)pt->dev.G0_loc * per_plane, st);
             }
         } else { set_error("igx_patch_create: unknown geo_kind %d", d->geo_kind); rc = IGX_ERR_ARG; }
     }
     if (!rc) {
-        pt->sumfact_ok = sumfact_supported(pt) != 0;
+        pt->sumfact_ok = !pt->boxed && sumfact_supported(pt) != 0;
         if (pt->sumfact_ok) rc = sumfact_prepare(pt);
     }
     if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("igx_patch_create: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = IGX_ERR_HIP; }
@@ -477,10 +494,10 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
 {
     if (!pt || !coeff) { set_error("igx_patch_set_coeff: null argument"); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
-    const size_t per_plane = (size_t)pt->ax[1].G * pt->ax[2].G;
+    const size_t per_plane = (size_t)pt->dev.L1 * pt->dev.L2;
     const size_t n = (size_t)pt->dev.G0_loc * per_plane;
     if (!pt->d_coeff) IGX_HIP(hipMalloc((void **)&pt->d_coeff, std::max<size_t>(1, n) * sizeof(double)));
-    IGX_HIP(hipMemcpyAsync(pt->d_coeff, coeff + (size_t)pt->dev.g0_lo * per_plane, n * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
+    IGX_HIP(hipMemcpyAsync(pt->d_coeff, coeff + (pt->boxed ? 0 : (size_t)pt->dev.g0_lo * per_plane), n * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
     IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     pt->fields_kind = -1;
     return IGX_OK;
@@ -529,7 +546,7 @@ static int set_form_impl(igx_patch *pt, const double *const coef[16], bool on_de
     for (int k = 0; k < 16 && e == hipSuccess; ++k)
         if (coef[k])
             e = on_device ? hipMemcpyAsync(d_new + (size_t)slot[k] * npts, coef[k], npts * sizeof(double), hipMemcpyDeviceToDevice, pt->ctx->stream)
-                          : hipMemcpyAsync(d_new + (size_t)slot[k] * npts, coef[k] + (size_t)pt->dev.g0_lo * per_plane, npts * sizeof(double),
+                          : hipMemcpyAsync(d_new + (size_t)slot[k] * npts, coef[k] + (pt->boxed ? 0 : (size_t)pt->dev.g0_lo * per_plane), npts * sizeof(double),
                                            hipMemcpyHostToDevice, pt->ctx->stream);
     const hipError_t es = hipStreamSynchronize(pt->ctx->stream);      // also on failure: no copy is in flight when d_new is freed
     if (e == hipSuccess) e = es;
@@ -557,6 +574,7 @@ int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weight
 int igx_pattern(igx_patch *pt, int32_t *indptr, int32_t *indices)
 {
     if (!pt) { set_error("igx_pattern: null patch"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_pattern: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     const long long nrows = pt->row_hi - pt->row_lo;
@@ -580,6 +598,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
 {
     if (!pt) { set_error("igx_assemble: null patch"); return IGX_ERR_ARG; }
     if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_assemble: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     if (algo == IGX_ALGO_AUTO) algo = (pt->sumfact_ok && sumfact_supports_kind(pt, kind)) ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
@@ -684,6 +703,41 @@ int igx_entries(igx_patch *pt, int kind, const size_t *ij, size_t M, double *out
     return IGX_OK;
 }
 
+} // extern "C"
+// values of boxes of the reordered tensor (ACA consumer): no index upload, one launch pair, one copy back
+int igx::entries_pair_boxes(igx_patch *pt, int kind, const PairBoxes &B, double *out)
+{
+    const size_t M = (size_t)B.off[B.n];
+    if (M == 0) return IGX_OK;
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc;
+    if ((rc = ws_reserve(&pt->d_ws_ij, &pt->ws_ij_cap, 2 * M, "index pairs"))) return rc;
+    if ((rc = ws_reserve(&pt->d_ws_out, &pt->ws_out_cap, M, "entry values"))) return rc;
+    if ((rc = launch_box_pairs(st, pt, B, pt->d_ws_ij))) return rc;
+    if ((rc = igx_entries_d(pt, kind, pt->d_ws_ij, M, pt->d_ws_out))) return rc;
+    IGX_HIP(hipMemcpyAsync(out, pt->d_ws_out, M * sizeof(double), hipMemcpyDeviceToHost, st));
+    IGX_HIP(hipStreamSynchronize(st));
+    return IGX_OK;
+}
+
+extern "C" {
+int igx_patch_set_aca_batch(igx_patch *pt, long long max_entries)
+{
+    if (!pt || max_entries < 0) { set_error("igx_patch_set_aca_batch: bad argument"); return IGX_ERR_ARG; }
+    pt->aca_batch = max_entries;
+    return IGX_OK;
+}
+
+int igx_fast_assemble_stats(const igx_patch *pt, long long *requests, long long *entries, int *rank)
+{
+    if (!pt) { set_error("igx_fast_assemble_stats: null patch"); return IGX_ERR_ARG; }
+    if (requests) *requests = pt->aca_requests;
+    if (entries) *entries = pt->aca_entries;
+    if (rank) *rank = pt->aca_rank;
+    return IGX_OK;
+}
+
 int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
 {
     if (!pt) { set_error("igx_fields: null patch"); return IGX_ERR_ARG; }
@@ -691,7 +745,7 @@ int igx_fields(igx_patch *pt, int kind, double *out, int64_t *shape4)
     int rc = ensure_fields(pt, kind);
     if (rc) return rc;
     const int nF = igx_num_fields(pt->dim, kind, pt->dev.form_n);
-    if (shape4) { shape4[0] = nF; shape4[1] = pt->dev.G0_loc; shape4[2] = pt->ax[1].G; shape4[3] = pt->dim == 3 ? pt->ax[2].G : 1; }
+    if (shape4) { shape4[0] = nF; shape4[1] = pt->dev.G0_loc; shape4[2] = pt->dev.L1; shape4[3] = pt->dim == 3 ? pt->dev.L2 : 1; }
     if (out) {
         IGX_HIP(hipMemcpyAsync(out, pt->d_fields, (size_t)nF * pt->dev.npts_loc * sizeof(double), hipMemcpyDeviceToHost, pt->ctx->stream));
         IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
@@ -716,6 +770,7 @@ static int lv_workspace(igx_patch *pt, size_t *n_out)
 int igx_load_vector_d(igx_patch *pt, const double *d_fvals, double *d_out)
 {
     if (!pt || !d_fvals || !d_out) { set_error("igx_load_vector_d: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_load_vector_d: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab
@@ -747,6 +802,7 @@ int igx_patch_gauss_slab(const igx_patch *pt, int64_t *g0_lo, int64_t *g0_n)
 int igx_load_vector(igx_patch *pt, const double *fvals, double *out)
 {
     if (!pt || !fvals || !out) { set_error("igx_load_vector: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_load_vector: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     const PatchDev &pd = pt->dev;
@@ -802,6 +858,7 @@ int igx_dev_download(igx_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
 {
     if (!pt || !coef || !out) { set_error("igx_load_vector_jet: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_load_vector_jet: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     const int dim = pt->dim;
     for (int r = dim + 1; r < 4; ++r)
         if (coef[r]) { set_error("igx_load_vector_jet: coefficient %d does not exist in %dD", r, dim); return IGX_ERR_ARG; }

@@ -46,13 +46,21 @@ struct PatchDev {
     int s0_lo, s0_hi;         // resident span range of axis 0
     int g0_lo;                // first resident Gauss index of axis 0 (= s0_lo * q)
     int G0_loc;               // number of resident Gauss planes
-    long long npts_loc;       // resident Gauss points = G0_loc * G1 [* G2]
+    long long npts_loc;       // resident Gauss points = G0_loc * L1 [* L2]
+    int b1, b2, L1, L2;       // resident Gauss window of axes 1, 2: first index and extent (whole axes unless the patch is boxed)
     long long nnz_off;        // global indptr[row_lo]
     // IGX_FORM: the terms that are present, in field order; ab = 4 * (jet index of v) + (jet index of u),
     // jet index 0 = value, 1..3 = PARAMETRIC derivative in (x, y, z) order (x = last grid axis)
     int form_n;
     int form_ab[16];
 };
+
+// index of Gauss point (g0, g1, g2) in the resident field arrays
+__host__ __device__ inline long long field_index(const PatchDev &pd, int g0, int g1, int g2)
+{
+    const long long l = (long long)(g0 - pd.g0_lo) * pd.L1 + (g1 - pd.b1);
+    return pd.dim == 3 ? l * pd.L2 + (g2 - pd.b2) : l;
+}
 
 // IGX_FORM coefficients on the resident Gauss slab
 struct FormView {
@@ -112,6 +120,7 @@ struct igx_knobs {
 struct igx_patch {
     igx_ctx *ctx = nullptr;
     igx_knobs knobs;
+    bool boxed = false;                       // fields only on a span box (igx_patch_desc.box_*): batched entries only
     int dim = 0, nqp = 0;
     igx::Axis ax[3];
     // geometry
@@ -158,6 +167,8 @@ struct igx_patch {
     // persistent workspaces of the batched-entry and load-vector entry points (grow-only, freed with the patch)
     size_t *d_ws_ij = nullptr; double *d_ws_out = nullptr;
     size_t ws_ij_cap = 0, ws_out_cap = 0;
+    long long aca_batch = 65536;              // igx_patch_set_aca_batch
+    long long aca_requests = 0, aca_entries = 0; int aca_rank = 0;      // igx_fast_assemble_stats
     double *d_lv_f = nullptr, *d_lv_t1 = nullptr, *d_lv_t2 = nullptr, *d_lv_o = nullptr;
     size_t lv_f_cap = 0, lv_t1_cap = 0, lv_t2_cap = 0, lv_o_cap = 0;
     // fused sweep + final stage (fused.hip)
@@ -185,6 +196,11 @@ int launch_fields_dump(hipStream_t st, const igx_patch *pt);
 int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], double *d_coeff);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
+// boxes of the reordered tensor X[r0][r1][r2] (r_k = index of a 1D pair (i_k, j_k) with overlapping supports): the entries
+// lo[b][k] <= r_k < lo[b][k] + len[b][k] of every box, box after box, lexicographic inside a box
+struct PairBoxes { int n; int lo[8][3], len[8][3]; long long off[9]; };
+int launch_box_pairs(hipStream_t st, const igx_patch *pt, const PairBoxes &B, size_t *d_ij);
+int entries_pair_boxes(igx_patch *pt, int kind, const PairBoxes &B, double *out_host);   // (igx_api.hip: index pairs built on the device)
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
                        double *d_t1, double *d_t2, int deriv_axis = -1, int accumulate = 0);

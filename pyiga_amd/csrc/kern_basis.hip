@@ -243,14 +243,14 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
 // Affine coefficient  c(x) = c[0] + c[1] x + c[2] y + c[3] z  at the resident Gauss points, from the geometry map on the
 // device (the host path samples a Python callable on the whole grid and ships one double per Gauss point).
 template <int DIM>
-__global__ void k_coeff_affine(GeoView gv, bool nurbs, int g0_lo, int G0loc, int G1, int G2, double c0, double c1, double c2, double c3, double *coeff)
+__global__ void k_coeff_affine(GeoView gv, bool nurbs, int g0_lo, int G0loc, int G1, int G2, int b1, int b2, double c0, double c1, double c2, double c3, double *coeff)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)G0loc * G1 * (DIM == 3 ? G2 : 1);
     if (idx >= total) return;
-    int g[3];
-    if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
-    else { g[1] = idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
+    int g[3];                 // (G1, G2: extents of the resident window of axes 1, 2; b1, b2: its first Gauss indices)
+    if (DIM == 3) { g[2] = b2 + idx % G2; g[1] = b1 + (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
+    else { g[1] = b1 + idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
     double Jm[MAX_COMP][3], ev[MAX_COMP];
     physical_jacobian<DIM>(gv, nurbs, g, DIM, Jm, ev);
     double v = c0 + c1 * ev[0] + c2 * ev[1];
@@ -266,11 +266,11 @@ int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], 
     const PatchDev &pd = pt->dev;
     const long long total = pd.npts_loc;
     if (total == 0) return IGX_OK;
-    const int G1 = pd.ax[1].G, G2 = dim == 3 ? pd.ax[2].G : 1;
+    const int G1 = pd.L1, G2 = dim == 3 ? pd.L2 : 1;
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     const bool nurbs = pt->geo_kind == IGX_GEO_NURBS;
-    if (dim == 2) k_coeff_affine<2><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, c[0], c[1], c[2], c[3], d_coeff);
-    else k_coeff_affine<3><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, c[0], c[1], c[2], c[3], d_coeff);
+    if (dim == 2) k_coeff_affine<2><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, pd.b1, pd.b2, c[0], c[1], c[2], c[3], d_coeff);
+    else k_coeff_affine<3><<<grid, block, 0, st>>>(gv, nurbs, pd.g0_lo, pd.G0_loc, G1, G2, pd.b1, pd.b2, c[0], c[1], c[2], c[3], d_coeff);
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }
@@ -285,9 +285,9 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
     const long long total = (long long)G0loc * G1 * (DIM == 3 ? G2 : 1);
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    int g[3];
-    if (DIM == 3) { g[2] = idx % G2; g[1] = (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
-    else { g[1] = idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
+    int g[3];                 // (G1, G2: extents of the resident window of axes 1, 2 -- the whole axes unless the patch is boxed)
+    if (DIM == 3) { g[2] = pd.b2 + idx % G2; g[1] = pd.b1 + (idx / G2) % G1; g[0] = g0_lo + (int)(idx / ((long long)G2 * G1)); }
+    else { g[1] = pd.b1 + idx % G1; g[0] = g0_lo + (int)(idx / G1); g[2] = 0; }
     double t[9];
     double ev[MAX_COMP] = {0.0, 0.0, 0.0, 0.0};
     if (geo_kind == IGX_GEO_JACOBIAN) {
@@ -416,8 +416,8 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     FormView fv{};
     fv.c = pt->d_formc;
     for (int k = 0; k < 16; ++k) fv.slot[k] = pt->form_slot[k];
-    const int G1 = pd.ax[1].G, G2 = (dim == 3) ? pd.ax[2].G : 1;
-    if (pt->geo_kind != IGX_GEO_JACOBIAN) {
+    const int G1 = pd.L1, G2 = (dim == 3) ? pd.L2 : 1;
+    if (pt->geo_kind != IGX_GEO_JACOBIAN && !pt->boxed) {      // (a boxed patch is small: the point-wise kernel)
         const int LN = (dim == 3) ? G2 : G1;
         const int LPB = std::max(1, 256 / LN);
         const size_t lds = (size_t)LPB * pt->gax[dim - 1].N * pt->ncomp * dim * sizeof(double);

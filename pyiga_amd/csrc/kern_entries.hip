@@ -49,6 +49,8 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
     }
     // Gauss points outside the resident slab cannot be evaluated here
     if (glo[0] < pd.g0_lo || ghi[0] > pd.g0_lo + pd.G0_loc) return __builtin_nan("");
+    if (glo[1] < pd.b1 || ghi[1] > pd.b1 + pd.L1) return __builtin_nan("");          // (boxed patches: every axis)
+    if (DIM == 3 && (glo[2] < pd.b2 || ghi[2] > pd.b2 + pd.L2)) return __builtin_nan("");
     const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1], &A2 = pd.ax[2];
     const long long stride = pd.npts_loc;
     double r = 0.0;
@@ -61,7 +63,7 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
             const double *u1 = A1.V + ((size_t)g1 * A1.P + (j[1] - f1)) * 2;
             const double *v1 = A1.V + ((size_t)g1 * A1.P + (i[1] - f1)) * 2;
             if (DIM == 2) {
-                const long long pt = (long long)(g0 - pd.g0_lo) * A1.G + g1;
+                const long long pt = (long long)(g0 - pd.g0_lo) * pd.L1 + (g1 - pd.b1);
                 if (KIND == IGX_MASS) {
                     r += (((u0[0] * u1[0]) * (v0[0] * v1[0])) * fields[pt]);
                 } else if (KIND == IGX_FORM) {
@@ -88,7 +90,7 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                     const int f2 = A2.fa[g2 / A2.q];
                     const double *u2 = A2.V + ((size_t)g2 * A2.P + (j[2] - f2)) * 2;
                     const double *v2 = A2.V + ((size_t)g2 * A2.P + (i[2] - f2)) * 2;
-                    const long long pt = ((long long)(g0 - pd.g0_lo) * A1.G + g1) * A2.G + g2;
+                    const long long pt = ((long long)(g0 - pd.g0_lo) * pd.L1 + (g1 - pd.b1)) * pd.L2 + (g2 - pd.b2);
                     if (KIND == IGX_MASS) {
                         r += (((u0[0] * u1[0] * u2[0]) * (v0[0] * v1[0] * v2[0])) * fields[pt]);
                     } else if (KIND == IGX_FORM) {
@@ -163,7 +165,8 @@ __global__ void __launch_bounds__(256) k_entries_wave(PatchDev pd, const double 
             glo[a] = lo * A.q; ng[a] = (hi - lo) * A.q;
         }
     if (empty) { if (lane == 0) out[k] = 0.0; return; }
-    if (glo[0] < pd.g0_lo || glo[0] + ng[0] > pd.g0_lo + pd.G0_loc) { if (lane == 0) out[k] = __builtin_nan(""); return; }
+    if (glo[0] < pd.g0_lo || glo[0] + ng[0] > pd.g0_lo + pd.G0_loc || glo[1] < pd.b1 || glo[1] + ng[1] > pd.b1 + pd.L1 ||
+        (DIM == 3 && (glo[2] < pd.b2 || glo[2] + ng[2] > pd.b2 + pd.L2))) { if (lane == 0) out[k] = __builtin_nan(""); return; }
     const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1], &A2 = pd.ax[2];
     const long long stride = pd.npts_loc;
     const int nbox = ng[1] * (DIM == 3 ? ng[2] : 1);
@@ -181,7 +184,8 @@ __global__ void __launch_bounds__(256) k_entries_wave(PatchDev pd, const double 
         for (int g0 = glo[0]; g0 < glo[0] + ng[0]; ++g0) {
             const int f0 = A0.fa[g0 / A0.q];
             const double *u0 = A0.V + ((size_t)g0 * A0.P + (j[0] - f0)) * 2, *v0 = A0.V + ((size_t)g0 * A0.P + (i[0] - f0)) * 2;
-            const long long pt = DIM == 3 ? ((long long)(g0 - pd.g0_lo) * A1.G + g1) * A2.G + g2 : (long long)(g0 - pd.g0_lo) * A1.G + g1;
+            const long long pt = DIM == 3 ? ((long long)(g0 - pd.g0_lo) * pd.L1 + (g1 - pd.b1)) * pd.L2 + (g2 - pd.b2)
+                                          : (long long)(g0 - pd.g0_lo) * pd.L1 + (g1 - pd.b1);
             if (DIM == 2) {
                 if (KIND == IGX_MASS) r += (((u0[0] * u1[0]) * (v0[0] * v1[0])) * fields[pt]);
                 else {
@@ -211,6 +215,35 @@ __global__ void __launch_bounds__(256) k_entries_wave(PatchDev pd, const double 
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) r += __shfl_xor(r, sft);
     if (lane == 0) out[k] = r;
+}
+
+// index pairs (ravelled row, column) of boxes of the reordered tensor, from the resident per-axis pair tables
+__global__ void k_box_pairs(PatchDev pd, PairBoxes B, size_t *ij)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B.off[B.n]) return;
+    int b = 0;
+    while (b + 1 < B.n && idx >= B.off[b + 1]) ++b;
+    long long l = idx - B.off[b];
+    int r[3];
+    r[2] = B.lo[b][2] + (int)(l % B.len[b][2]); l /= B.len[b][2];
+    r[1] = B.lo[b][1] + (int)(l % B.len[b][1]); l /= B.len[b][1];
+    r[0] = B.lo[b][0] + (int)l;
+    size_t I = 0, J = 0;
+    for (int k = 0; k < pd.dim; ++k) {
+        I = I * (size_t)pd.ax[k].N + (size_t)pd.ax[k].pair_i[r[k]];
+        J = J * (size_t)pd.ax[k].N + (size_t)pd.ax[k].pair_j[r[k]];
+    }
+    ij[2 * idx] = I; ij[2 * idx + 1] = J;
+}
+
+int launch_box_pairs(hipStream_t st, const igx_patch *pt, const PairBoxes &B, size_t *d_ij)
+{
+    const long long M = B.off[B.n];
+    if (M == 0) return IGX_OK;
+    k_box_pairs<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st>>>(pt->dev, B, d_ij);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
 }
 
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out)

@@ -490,3 +490,55 @@ def golden_fullsize():
 
 if __name__ == '__main__' and 'fullsize' in sys.argv[1:]:
     golden_fullsize()
+
+
+# ---------------------------------------------------------------------------
+# (11) on-demand assemblers with a bounding box, SURVEY section 8 f2 (pyiga/codegen/cython.py:541-559, callers
+#      pyiga/_hdiscr.py:5-11,37-56): compile_vform(vf, on_demand=True)(kvs, geo, bbox) and _assemble_partial_rows
+def golden_ondemand():
+    from pyiga import vform, _hdiscr
+    from pyiga import compile as pcompile
+    out = {}
+    cyl = cylinder()
+    ann = geometry.quarter_annulus()
+
+    def diff_coeff(x, y, z):
+        return 1.0 + x
+
+    def bbox_of(kvs, rows):
+        mi = np.unravel_index(rows, [kv.numdofs for kv in kvs])
+        box = []
+        for kv, ik in zip(kvs, mi):
+            s = kv.mesh_support_idx_all()
+            box.append((int(s[ik, 0].min()), int(s[ik, 1].max())))
+        return tuple(box)
+
+    kvs3 = (bspline.make_knots(2, 0.0, 1.0, 6), bspline.make_knots(3, 0.0, 1.0, 5), bspline.make_knots(2, 0.0, 1.0, 7, mult=2))
+    nd3 = [kv.numdofs for kv in kvs3]
+    rows3 = np.ravel_multi_index(np.array([(3, 2, 5), (3, 3, 5), (4, 2, 6), (3, 3, 7), (4, 4, 4)]).T, nd3)
+    kvs2 = (bspline.make_knots(3, 0.0, 1.0, 9), bspline.make_knots(2, 0.0, 1.0, 12))
+    nd2 = [kv.numdofs for kv in kvs2]
+    rows2 = np.ravel_multi_index(np.array([(5, 6), (5, 7), (6, 6), (4, 9)]).T, nd2)
+    cases = (('stiff3d', vform.stiffness_vf(3), kvs3, {'geo': cyl}, rows3),
+             ('mass3d', vform.mass_vf(3), kvs3, {'geo': cyl}, rows3),
+             ('convdiff3d', vform.parse_vf(CONVDIFF, kvs3, {'geo': cyl, 'diff_coeff': diff_coeff}), kvs3,
+              {'geo': cyl, 'diff_coeff': diff_coeff}, rows3),
+             ('stiff2d', vform.stiffness_vf(2), kvs2, {'geo': ann}, rows2),
+             ('mass2d', vform.mass_vf(2), kvs2, {'geo': ann}, rows2))
+    for name, vf, kvs, args, rows in cases:
+        cls = pcompile.compile_vform(vf, on_demand=True)
+        bbox = bbox_of(kvs, rows)
+        asm = cls(kvs, bbox=bbox, **args)
+        A = _hdiscr._assemble_partial_rows(asm, rows).tocsr()
+        out[name + '_rows'] = rows.astype(np.int64)
+        out[name + '_bbox'] = np.array(bbox, dtype=np.int64)
+        sub = A[rows]
+        out[name + '_indptr'] = sub.indptr.astype(np.int64)
+        out[name + '_indices'] = sub.indices.astype(np.int64)
+        out[name + '_data'] = sub.data
+        print(name, 'bbox', bbox, 'nnz', sub.nnz)
+    save('ondemand', **out)
+
+
+if __name__ == '__main__' and 'ondemand' in sys.argv[1:]:
+    golden_ondemand()

@@ -31,7 +31,7 @@ def test_header_symbols_exported(lib):
     cdll = lib.load()
     for name in declared:
         assert hasattr(cdll, name)
-    assert cdll.igx_version() == 100
+    assert cdll.igx_version() == 101
     nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in declared:
         assert re.search(r'\bT %s\b' % name, nm), name
@@ -41,14 +41,14 @@ def test_struct_layout_matches_header(lib, tmp_path):
     """sizeof/offsetof of the ctypes structures equal the C compiler's."""
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "igx.h"\nint main(){'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(igx_patch_desc), offsetof(igx_patch_desc, kv),'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(igx_patch_desc), offsetof(igx_patch_desc, kv),'
                    'offsetof(igx_patch_desc, geo_kind), offsetof(igx_patch_desc, ctrl), offsetof(igx_patch_desc, gauss_x),'
-                   'offsetof(igx_patch_desc, row0_lo), sizeof(igx_patch_info)); printf("%zu\\n", sizeof(igx_timing)); return 0;}')
+                   'offsetof(igx_patch_desc, row0_lo), offsetof(igx_patch_desc, box_lo), sizeof(igx_patch_info)); printf("%zu\\n", sizeof(igx_timing)); return 0;}')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)], text=True).split()
     D = lib.PatchDesc
-    mine = [ctypes.sizeof(D), D.kv.offset, D.geo_kind.offset, D.ctrl.offset, D.gauss_x.offset, D.row0_lo.offset,
+    mine = [ctypes.sizeof(D), D.kv.offset, D.geo_kind.offset, D.ctrl.offset, D.gauss_x.offset, D.row0_lo.offset, D.box_lo.offset,
             ctypes.sizeof(lib.PatchInfo), ctypes.sizeof(lib.Timing)]
     assert [int(x) for x in out] == mine
 
@@ -121,3 +121,19 @@ def test_shipped_library_has_no_ablation_switches():
     blob = open(lib, 'rb').read()
     for name in (b'_DBG', b'IGX_NO_MIRROR', b'IGX_K1PAD', b'IGX_BF_MCHUNKS', b'IGX_FINAL_', b'IGX_FINALQ_', b'IGX_OVERLAP'):
         assert name not in blob, name
+
+
+def test_bbox_for_rows_matches_reference():
+    """Host logic of the on-demand assemblers: the cell box of a set of basis functions equals the one the reference's
+    hierarchical discretisation computes (golden_ondemand.npz, made by tests/golden/make_golden.py from the reference)."""
+    import numpy as np
+    from pyiga_amd import bspline, assemble
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_ondemand.npz'))
+    mk = bspline.make_knots
+    kvs3 = (mk(2, 0., 1., 6), mk(3, 0., 1., 5), mk(2, 0., 1., 7, mult=2))
+    kvs2 = (mk(3, 0., 1., 9), mk(2, 0., 1., 12))
+    for name, kvs in (('stiff3d', kvs3), ('convdiff3d', kvs3), ('mass2d', kvs2)):
+        assert np.array_equal(np.array(assemble.bbox_for_rows(kvs, g[name + '_rows'])), g[name + '_bbox'])
+        I, J = assemble._nonzeros_for_rows(kvs, kvs, g[name + '_rows'])
+        assert np.array_equal(J, g[name + '_indices']) and I.size == g[name + '_indptr'][-1]
+    assert assemble.bbox_for_rows(kvs2, []) == ((0, 0), (0, 0))

@@ -823,9 +823,21 @@ def test_fast_variants_match_fixtures(iga, capsys):
     A = patch.fast_assemble('stiffness')
     st = patch.aca_stats
     assert abs(A - exact).max() < 1e-9 and st['entries'] < st['nnz']
-    B = patch.fast_assemble('stiffness', tol=1e-4)
+    # request granularity: by default a small slice is ONE request (index pairs generated on the device); batch=0 is the
+    # reference's access pattern (slices approximated line by line) -- same tolerance, many more launches
+    assert st['requests'] < 150, st
+    A0 = patch.fast_assemble('stiffness', batch=0)
+    st0 = patch.aca_stats
+    assert abs(A0 - exact).max() < 1e-9 and st0['requests'] > 2 * st['requests'] and st0['entries'] < st['nnz']
+    assert abs(A0 - A3_ref).max() < 1e-9
+    B = patch.fast_assemble('stiffness', tol=1e-4, batch=65536)
     assert patch.aca_stats['rank'] < st['rank'] and 1e-12 < abs(B - exact).max() < 1e-2
     capsys.readouterr()
+    patch.close()
+    # 2D fixture through the line-by-line pattern as well (the default fetches this small matrix in one request, exactly)
+    patch = iga.assemblers.DevicePatch((kv, kv), geo)
+    assert abs(patch.fast_assemble('stiffness', batch=0) - A_ref).max() < 1e-9 and patch.aca_stats['rank'] > 0
+    assert abs(patch.fast_assemble('mass', batch=65536) - M_ref).max() < 1e-14 and patch.aca_stats['requests'] == 1
     patch.close()
     with pytest.raises(AssertionError):
         iga.assemblers.DevicePatch((kvb, kvb), iga.geometry.quarter_annulus(), row0=(0, 10)).fast_assemble('mass')
@@ -1206,3 +1218,109 @@ def test_affine_coefficient_on_device(iga):
         B = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + 0.5 * x - 0.25 * y + 2.0 * z, row0=row0).assemble_csr()
         assert rel_maxdiff(A, B) <= RTOL
     assert aff(1.0, 2.0, 3.0) == 1.0 + 0.5 - 0.5 + 6.0
+
+
+# ------------------------------------------------------------------------------------------
+# On-demand assemblers with a bounding box (pyiga/codegen/cython.py:541-559, pyiga/_hdiscr.py:5-11,37-56)
+def _ondemand_cases(iga):
+    mk = iga.bspline.make_knots
+    kvs3 = (mk(2, 0., 1., 6), mk(3, 0., 1., 5), mk(2, 0., 1., 7, mult=2))
+    kvs2 = (mk(3, 0., 1., 9), mk(2, 0., 1., 12))
+    A = iga.assemblers
+    cyl, ann = _geo(iga, 'cylinder'), _geo(iga, 'quarter_annulus')
+    return [('stiff3d', kvs3, lambda **kw: A.StiffnessAssembler3D(kvs3, cyl, **kw)),
+            ('mass3d', kvs3, lambda **kw: A.MassAssembler3D(kvs3, cyl, **kw)),
+            ('convdiff3d', kvs3, lambda **kw: A.ConvDiffAssembler3D(kvs3, cyl, lambda x, y, z: 1.0 + x, **kw)),
+            ('stiff2d', kvs2, lambda **kw: A.StiffnessAssembler2D(kvs2, ann, **kw)),
+            ('mass2d', kvs2, lambda **kw: A.MassAssembler2D(kvs2, ann, **kw))]
+
+
+def test_ondemand_bbox_vs_reference(iga, golden):
+    """Rows assembled by an assembler that only holds the bounding box of their supports = what the reference's
+    compile_vform(..., on_demand=True) class with the same bbox gives through _assemble_partial_rows."""
+    g = golden('ondemand')
+    for name, kvs, make in _ondemand_cases(iga):
+        rows = g[name + '_rows']
+        bbox = iga.assemble.bbox_for_rows(kvs, rows)
+        assert np.array_equal(np.array(bbox), g[name + '_bbox'])
+        asm = make(bbox=bbox)
+        S = iga.assemble.assemble_partial_rows(asm, rows)
+        sub = S[rows]
+        assert np.array_equal(sub.indptr, g[name + '_indptr']) and np.array_equal(sub.indices, g[name + '_indices'])
+        ref = g[name + '_data']
+        assert np.abs(sub.data - ref).max() <= RTOL * np.abs(ref).max(), name
+        # the whole-patch assembler agrees; a pair whose common support leaves the box is refused (NaN), not wrong
+        full = make()
+        I, J = iga.assemble._nonzeros_for_rows(kvs, kvs, rows)
+        pairs = np.column_stack((I, J)).astype(np.uintp)
+        assert np.abs(asm.multi_entries(pairs) - full.multi_entries(pairs)).max() <= RTOL * np.abs(ref).max()
+        n = int(np.prod([kv.numdofs for kv in kvs]))
+        far = np.array([[n - 1, n - 1], [0, 0]], dtype=np.uintp)
+        out = asm.multi_entries(far)
+        assert np.isnan(out).all(), (name, out)
+        assert asm.multi_entries(np.array([[0, n - 1]], dtype=np.uintp))[0] == 0.0      # disjoint supports: still exact 0
+        with pytest.raises(iga._lib.IgxError):
+            asm.patch.assemble(asm._kind)                     # a boxed patch serves batched entries only
+
+
+def test_ondemand_bbox_other_geometries_and_forms(iga):
+    """Bounding boxes with a Jacobian-array geometry (sampled on the box only), a general form string with sampled
+    coefficients and the device-evaluated affine coefficient: equal to the whole-patch assemblers on the rows of the box."""
+    mk = iga.bspline.make_knots
+    kvs = (mk(3, 0., 1., 6), mk(2, 0., 1., 8), mk(2, 0., 1., 7))
+    nd = [kv.numdofs for kv in kvs]
+    rows = np.ravel_multi_index(np.array([(4, 5, 3), (5, 5, 4), (4, 6, 4)]).T, nd)
+    bbox = iga.assemble.bbox_for_rows(kvs, rows)
+    I, J = iga.assemble._nonzeros_for_rows(kvs, kvs, rows)
+    pairs = np.column_stack((I, J)).astype(np.uintp)
+    cyl = _geo(iga, 'cylinder')
+    A = iga.assemblers
+    form = '(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v + c * u * v) * dx'
+    inputs = {'K': lambda x, y, z: np.stack([np.stack([2.0 + x, 0.1 * y, 0 * x], -1), np.stack([0.1 * y, 1.0 + z, 0 * x], -1),
+                                             np.stack([0 * x, 0 * x, 1.5 + 0 * x], -1)], -2),
+              'b': lambda x, y, z: np.stack([y, -x, 1.0 + 0 * x], -1), 'c': lambda x, y, z: 1.0 + x * y}
+    makers = [lambda **kw: A.StiffnessAssembler3D(kvs, _OpaqueGeo(cyl), **kw),
+              lambda **kw: A.ConvDiffAssembler3D(kvs, cyl, A.AffineCoefficient(1.0, 1.0, 0.5, -0.25), **kw),
+              lambda **kw: A.GeneralFormAssembler3D(kvs, cyl, form, inputs=inputs, **kw)]
+    for make in makers:
+        full, boxed = make(), make(bbox=bbox)
+        ref = full.multi_entries(pairs)
+        out = boxed.multi_entries(pairs)
+        assert np.isfinite(out).all()
+        assert np.abs(out - ref).max() <= RTOL * np.abs(ref).max()
+    # the opaque geometry was asked for its Jacobians on the box only
+    boxed = makers[0](bbox=bbox)
+    assert boxed.patch.fields('stiffness').shape[1:] == tuple((hi - lo) * boxed.nqp for lo, hi in bbox)
+
+
+def _device_free_bytes():
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_ondemand_bbox_at_c4_size(iga):
+    """A 60-row request on the 3D p=4 128^3 patch through a boxed assembler: < 100 MB of device memory (the whole patch keeps
+    12.6 GB of fields for the same request), same values as the whole-patch assembler."""
+    kv = iga.bspline.make_knots(4, 0., 1., 128)
+    kvs = (kv, kv, kv)
+    cyl = _geo(iga, 'cylinder')
+    N = kv.numdofs
+    rows = np.ravel_multi_index((np.full(60, 70), np.full(60, 41), 30 + np.arange(60)), (N, N, N))
+    bbox = iga.assemble.bbox_for_rows(kvs, rows)
+    iga._lib.context().sync()
+    before = _device_free_bytes()
+    asm = iga.assemblers.StiffnessAssembler3D(kvs, cyl, bbox=bbox)
+    S = iga.assemble.assemble_partial_rows(asm, rows)
+    used = before - _device_free_bytes()
+    assert used < 100e6, used
+    assert S.nnz == S[rows].nnz and S.nnz > 60 * 5 ** 3
+    full = iga.assemblers.StiffnessAssembler3D(kvs, cyl)
+    I, J = iga.assemble._nonzeros_for_rows(kvs, kvs, rows[::7])
+    pairs = np.column_stack((I, J)).astype(np.uintp)
+    ref = full.multi_entries(pairs)
+    got = np.asarray(S[I, J]).ravel()
+    assert np.abs(got - ref).max() <= RTOL * np.abs(ref).max()
+    full.patch.close()
