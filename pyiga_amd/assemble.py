@@ -155,8 +155,15 @@ def assemble_entries(asm, symmetric=False, format='csr', layout='blocked', algo=
     object with the reference's assembler interface (``arity``, ``kvs``, ``multi_entries``) is
     driven exactly like the reference does (pattern -> multi_entries -> COO -> CSR [+ mirror]).
     """
+    from .form_assemblers import FormAssembler
+    if isinstance(asm, FormAssembler):
+        # vector-valued functions and boundary integrals: one scalar jet form per pair of components on the device
+        # (symmetric=True is the reference's request to compute half of the entries; the result is the same matrix)
+        if layout not in ('blocked', 'packed'):
+            raise ValueError("layout %r: 'blocked' or 'packed'" % (layout,))
+        return asm.assemble(format=format, layout=layout)
     if layout != 'blocked':
-        raise ValueError("layout %r: only scalar spaces ('blocked') are assembled on the device" % (layout,))
+        raise ValueError("layout %r: only the assemblers of form strings with vector-valued functions know 'packed'" % (layout,))
     if asm.arity == 1:
         return asm.assemble_vector()
     if isinstance(asm, assemblers._DeviceAssembler):
@@ -291,7 +298,13 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
     (vform -> Cython -> gcc).  Here the three built-in forms map to their hand-written kernels, any other
     3D scalar form in u, v, grad, inner, dot goes through the general device form (``pyiga_amd.forms`` ->
     ``IGX_FORM``); assembler classes and objects are accepted as in the reference."""
-    assert bfuns is None and boundary is None, 'custom basis functions / boundary forms are not supported'
+    if isinstance(problem, str) and (bfuns is not None or boundary is not None):
+        # vector-valued basis functions and/or a boundary integral (pyiga/vform.py:1822-1845, pyiga/assemble.py:929-934)
+        from .form_assemblers import FormAssembler
+        if 'geo' not in args:
+            raise ValueError("required input parameter 'geo' missing")
+        return FormAssembler(tuple(kvs), args['geo'], problem, bfuns=bfuns, inputs=args, boundary=boundary)
+    assert bfuns is None and boundary is None, 'custom basis functions / boundary forms need a form string'
     if isinstance(problem, str):
         kind = _KNOWN_FORMS.get(_normalise_form(problem))
         if 'geo' not in args:
@@ -326,14 +339,13 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
 
 def assemble(problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False, format='csr', layout='blocked', **kwargs):
     """Assemble the matrix of a variational form (string, assembler class or assembler object); signature of
-    pyiga/assemble.py:837.  `layout` only concerns vector-valued spaces, which are outside the device path:
-    'blocked' (the reference's default) is accepted, anything else is refused."""
-    if layout != 'blocked':
-        raise ValueError("layout %r: only scalar spaces ('blocked') are assembled on the device" % (layout,))
+    pyiga/assemble.py:837.  `bfuns` (vector-valued basis functions), `boundary` (a face of the patch, forms in ``ds``) and
+    `layout` ('blocked' | 'packed', vector-valued spaces) as in the reference; they go through
+    ``pyiga_amd.form_assemblers.FormAssembler``."""
     args = dict(args or {})
     args.update(kwargs)
     asm = instantiate_assembler(problem, kvs, args, bfuns, boundary)
-    return assemble_entries(asm, symmetric=symmetric, format=format)
+    return assemble_entries(asm, symmetric=symmetric, format=format, layout=layout)
 
 
 ################################################################################

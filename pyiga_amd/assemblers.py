@@ -37,13 +37,15 @@ def _is_nurbs(geo):
 class DevicePatch:
     """RAII wrapper of ``igx_patch``: discretisation + geometry resident on one GPU."""
 
-    def __init__(self, kvs, geo, device=None, row0=None, jacobian=None, bbox=None):
+    def __init__(self, kvs, geo, device=None, row0=None, jacobian=None, bbox=None, nqp=None):
         lib = _lib.load()
         self.ctx = _lib.context(device)
         self.kvs = tuple(kvs)
         self.dim = len(self.kvs)
         assert self.dim in (2, 3), 'libigx assembles 2D and 3D patches'
-        self.nqp = max(kv.p for kv in self.kvs) + 1
+        # Gauss points per span: max p + 1 (pyiga/assemblers.pyx:1338) unless the caller fixes it (a boundary patch uses the
+        # rule of the volume space it belongs to)
+        self.nqp = int(nqp) if nqp else max(kv.p for kv in self.kvs) + 1
         d = _lib.PatchDesc()
         keep = []
         d.dim = self.dim

@@ -542,3 +542,76 @@ def golden_ondemand():
 
 if __name__ == '__main__' and 'ondemand' in sys.argv[1:]:
     golden_ondemand()
+
+
+# ---------------------------------------------------------------------------
+# (12) form strings with vector-valued basis functions and boundary integrals, SURVEY section 8 f1
+#      (test/test_assemble.py:314-400,452-476; pyiga/assemble.py:760-811,837-934)
+VEC_FORMS = {
+    'nonsym': ('inner(as_matrix([[2,1],[0,0]]).dot(u), v) * dx', [('u', 2), ('v', 2)]),
+    'graddiv': ('(inner(grad(u), grad(v)) + div(u) * div(v)) * dx', [('u', 2), ('v', 2)]),
+    'divp': ('div(u) * v * dx', [('u', 2), ('v', 1)]),
+    'weighted': ('(c * inner(grad(u), grad(v)) + inner(dot(K, u), v)) * dx', [('u', 2), ('v', 2)]),
+}
+VEC_FORMS3 = {
+    'curlcurl': ('(inner(curl(u), curl(v)) + inner(u, v)) * dx', [('u', 3), ('v', 3)]),
+}
+BD_MATS3 = (('gradgrad_left', 'inner(grad(u), grad(v)) * ds', 'left'), ('gradgrad_top', 'inner(grad(u), grad(v)) * ds', 'top'),
+            ('tang_front', 'inner(cross(n, grad(u)), cross(n, grad(v))) * ds', 'front'), ('mass_right', 'u * v * ds', 'right'),
+            ('robin_back', '(g * u * v + inner(n, grad(u)) * v) * ds', 'back'))
+BD_MATS2 = (('mass_left', 'u * v * ds', 'left'), ('mass_top', 'u * v * ds', 'top'), ('gradgrad_right', 'inner(grad(u), grad(v)) * ds', 'right'),
+            ('nitsche_bottom', '(inner(n, grad(u)) * v + g * u * v) * ds', 'bottom'))
+
+
+def vec_inputs():
+    return {'c': lambda x, y: 1.0 + x * y, 'K': lambda x, y: np.stack([np.stack([1.0 + x, 0.5 * y], -1), np.stack([0 * x, 2.0 - y], -1)], -2),
+            'f': lambda x, y: x * y ** 2, 'gv': lambda x, y: (y, -x)}
+
+
+def golden_vecforms():
+    out = {}
+    ann = geometry.quarter_annulus()
+    cyl = cylinder()
+    inp = vec_inputs()
+    kvs2 = (bspline.make_knots(2, 0.0, 1.0, 5), bspline.make_knots(3, 0.0, 1.0, 4))
+    for name, (form, bfuns) in VEC_FORMS.items():
+        args = {k: v for k, v in inp.items() if k in form}
+        for layout in ('blocked', 'packed'):
+            put_matrix(out, '%s_%s' % (name, layout), assemble.assemble(form, kvs2, geo=ann, bfuns=bfuns, layout=layout, **args))
+        asm = assemble.instantiate_assembler(form, kvs2, dict(args, geo=ann), bfuns)
+        nd = int(np.prod([kv.numdofs for kv in kvs2]))
+        idx = np.array([(0, 0), (0, 1), (2, 1), (nd - 1, nd - 2), (nd // 2, nd // 2 + 1), (5, nd - 1)], dtype=np.uintp)
+        out[name + '_idx'] = idx
+        out[name + '_blocks'] = np.array(asm.multi_blocks(idx))
+        out[name + '_numcomp'] = np.array(asm.num_components())
+    kvs3 = (bspline.make_knots(2, 0.0, 1.0, 3), bspline.make_knots(2, 0.0, 1.0, 2), bspline.make_knots(3, 0.0, 1.0, 2))
+    for name, (form, bfuns) in VEC_FORMS3.items():
+        put_matrix(out, name + '_blocked', assemble.assemble(form, kvs3, geo=cyl, bfuns=bfuns, layout='blocked'))
+    # arity 1, vector-valued test functions
+    for name, form, bfuns in (('fdiv', 'f * div(v) * dx', [('v', 2)]), ('gdotv', 'inner(gv, v) * dx', [('v', 2)])):
+        args = {k: v for k, v in inp.items() if k in form}
+        for layout in ('blocked', 'packed'):
+            out['%s_%s' % (name, layout)] = assemble.assemble(form, kvs2, geo=ann, bfuns=bfuns, layout=layout, **args)
+    # boundary integrals, 3D (test/test_assemble.py:331-400)
+    kvb = (bspline.make_knots(3, 0.0, 1.0, 3), bspline.make_knots(2, 0.0, 1.0, 4), bspline.make_knots(3, 0.0, 1.0, 5))
+    g3 = lambda x, y, z: 1.0 + x + 2 * y * z
+    for side in ('left', 'right', 'bottom', 'top', 'front', 'back'):
+        out['bd3_v_' + side] = assemble.assemble('v * ds', kvb, geo=cyl, boundary=side)
+        out['bd3_gv_' + side] = assemble.assemble('(g * v + inner(n, grad(v))) * ds', kvb, geo=cyl, boundary=side, g=g3)
+        out['bd3_vn_' + side] = assemble.assemble('inner(v, n) * ds', kvb, bfuns=[('v', 3)], geo=cyl, boundary=side, layout='packed')
+    for name, form, side in BD_MATS3:
+        args = {'g': g3} if 'g *' in form else {}
+        put_matrix(out, 'bd3_' + name, assemble.assemble(form, kvb, geo=cyl, boundary=side, **args))
+    # boundary integrals, 2D
+    g2 = lambda x, y: 1.0 + x * y
+    for side in ('left', 'right', 'bottom', 'top'):
+        out['bd2_v_' + side] = assemble.assemble('g * v * ds', kvs2, geo=ann, boundary=side, g=g2)
+        out['bd2_vn_' + side] = assemble.assemble('inner(v, n) * ds', kvs2, bfuns=[('v', 2)], geo=ann, boundary=side, layout='packed')
+    for name, form, side in BD_MATS2:
+        args = {'g': g2} if 'g *' in form else {}
+        put_matrix(out, 'bd2_' + name, assemble.assemble(form, kvs2, geo=ann, boundary=side, **args))
+    save('vecforms', **out)
+
+
+if __name__ == '__main__' and 'vecforms' in sys.argv[1:]:
+    golden_vecforms()

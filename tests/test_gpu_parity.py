@@ -1324,3 +1324,99 @@ def test_ondemand_bbox_at_c4_size(iga):
     got = np.asarray(S[I, J]).ravel()
     assert np.abs(got - ref).max() <= RTOL * np.abs(ref).max()
     full.patch.close()
+
+
+# ------------------------------------------------------------------------------------------
+# Form strings with vector-valued basis functions and boundary integrals (SURVEY section 8 f1 "full";
+# test/test_assemble.py:314-400,452-476).  Goldens: the reference's assemble() on the same strings (make_golden.py vecforms).
+def _vec_inputs():
+    return {'c': lambda x, y: 1.0 + x * y, 'K': lambda x, y: np.stack([np.stack([1.0 + x, 0.5 * y], -1), np.stack([0 * x, 2.0 - y], -1)], -2),
+            'f': lambda x, y: x * y ** 2, 'gv': lambda x, y: (y, -x)}
+
+
+_VEC_FORMS = {
+    'nonsym': ('inner(as_matrix([[2,1],[0,0]]).dot(u), v) * dx', [('u', 2), ('v', 2)]),
+    'graddiv': ('(inner(grad(u), grad(v)) + div(u) * div(v)) * dx', [('u', 2), ('v', 2)]),
+    'divp': ('div(u) * v * dx', [('u', 2), ('v', 1)]),
+    'weighted': ('(c * inner(grad(u), grad(v)) + inner(dot(K, u), v)) * dx', [('u', 2), ('v', 2)]),
+}
+
+
+def test_vector_valued_forms_vs_reference(iga, golden):
+    g = golden('vecforms')
+    mk = iga.bspline.make_knots
+    ann, cyl = _geo(iga, 'quarter_annulus'), _geo(iga, 'cylinder')
+    kvs2 = (mk(2, 0., 1., 5), mk(3, 0., 1., 4))
+    inp = _vec_inputs()
+    for name, (form, bfuns) in _VEC_FORMS.items():
+        args = {k: v for k, v in inp.items() if k in form}
+        for layout in ('blocked', 'packed'):
+            A = iga.assemble.assemble(form, kvs2, geo=ann, bfuns=bfuns, layout=layout, **args)
+            ref = golden_csr(g, '%s_%s' % (name, layout))
+            assert A.shape == ref.shape and rel_maxdiff(A, ref) <= RTOL, (name, layout)
+        asm = iga.assemble.instantiate_assembler(form, kvs2, dict(args, geo=ann), bfuns)
+        assert tuple(asm.num_components()) == tuple(g[name + '_numcomp']) and asm.arity == 2
+        blocks = np.asarray(asm.multi_blocks(g[name + '_idx']))
+        refb = g[name + '_blocks']
+        assert blocks.shape == refb.shape and np.abs(blocks - refb).max() <= RTOL * np.abs(refb).max()
+    A = iga.assemble.assemble('inner(as_matrix([[2,1],[0,0]]).dot(u), v) * dx', kvs2, geo=ann, bfuns=[('u', 2), ('v', 2)], layout='packed', format='bsr')
+    assert A.format == 'bsr' and A.blocksize == (2, 2) and rel_maxdiff(A.tocsr(), golden_csr(g, 'nonsym_packed')) <= RTOL
+    kvs3 = (mk(2, 0., 1., 3), mk(2, 0., 1., 2), mk(3, 0., 1., 2))
+    A = iga.assemble.assemble('(inner(curl(u), curl(v)) + inner(u, v)) * dx', kvs3, geo=cyl, bfuns=[('u', 3), ('v', 3)])
+    assert rel_maxdiff(A, golden_csr(g, 'curlcurl_blocked')) <= RTOL
+    for name, form in (('fdiv', 'f * div(v) * dx'), ('gdotv', 'inner(gv, v) * dx')):
+        args = {k: v for k, v in inp.items() if k in form}
+        for layout in ('blocked', 'packed'):
+            out = iga.assemble.assemble(form, kvs2, geo=ann, bfuns=[('v', 2)], layout=layout, **args)
+            ref = g['%s_%s' % (name, layout)]
+            assert out.shape == ref.shape and np.abs(out - ref).max() <= RTOL * np.abs(ref).max(), (name, layout)
+
+
+def test_boundary_integrals_vs_reference(iga, golden):
+    g = golden('vecforms')
+    mk = iga.bspline.make_knots
+    ann, cyl = _geo(iga, 'quarter_annulus'), _geo(iga, 'cylinder')
+    kvb = (mk(3, 0., 1., 3), mk(2, 0., 1., 4), mk(3, 0., 1., 5))
+    g3 = lambda x, y, z: 1.0 + x + 2 * y * z
+    asm = iga.assemble.assemble
+
+    def close(a, ref, what):
+        assert a.shape == ref.shape, what
+        assert np.abs(a - ref).max() <= RTOL * max(np.abs(ref).max(), 1e-300), what
+    for side in ('left', 'right', 'bottom', 'top', 'front', 'back'):
+        close(asm('v * ds', kvb, geo=cyl, boundary=side), g['bd3_v_' + side], side)
+        close(asm('(g * v + inner(n, grad(v))) * ds', kvb, geo=cyl, boundary=side, g=g3), g['bd3_gv_' + side], side)
+        close(asm('inner(v, n) * ds', kvb, bfuns=[('v', 3)], geo=cyl, boundary=side, layout='packed'), g['bd3_vn_' + side], side)
+    # the literal checks of test/test_assemble.py:331-372
+    assert np.allclose(asm('v * ds', kvb, geo=cyl, boundary='right').sum(), (2 * 2 * np.pi) / 4)
+    assert np.allclose(asm('inner(v, n) * ds', kvb, bfuns=[('v', 3)], geo=cyl, boundary='left', layout='packed').sum(axis=(0, 1, 2)), [-1, -1, 0])
+    for name, form, side in (('gradgrad_left', 'inner(grad(u), grad(v)) * ds', 'left'), ('gradgrad_top', 'inner(grad(u), grad(v)) * ds', 'top'),
+                             ('tang_front', 'inner(cross(n, grad(u)), cross(n, grad(v))) * ds', 'front'), ('mass_right', 'u * v * ds', 'right'),
+                             ('robin_back', '(g * u * v + inner(n, grad(u)) * v) * ds', 'back')):
+        args = {'g': g3} if 'g *' in form else {}
+        A = asm(form, kvb, geo=cyl, boundary=side, **args)
+        ref = golden_csr(g, 'bd3_' + name)
+        assert A.shape == ref.shape and rel_maxdiff(A, ref) <= RTOL, name
+    # tangential part on the plane face 'front' = the 2D Laplacian of the quarter annulus (test/test_assemble.py:395-400)
+    A = asm('inner(cross(n, grad(u)), cross(n, grad(v))) * ds', kvb, geo=cyl, boundary='front')
+    assert rel_maxdiff(A, iga.assemble.stiffness(kvb[1:], geo=ann)) < 1e-11
+    # 2D patches: the faces are 1D
+    kvs2 = (mk(2, 0., 1., 5), mk(3, 0., 1., 4))
+    g2 = lambda x, y: 1.0 + x * y
+    for side in ('left', 'right', 'bottom', 'top'):
+        close(asm('g * v * ds', kvs2, geo=ann, boundary=side, g=g2), g['bd2_v_' + side], side)
+        close(asm('inner(v, n) * ds', kvs2, bfuns=[('v', 2)], geo=ann, boundary=side, layout='packed'), g['bd2_vn_' + side], side)
+    for name, form, side in (('mass_left', 'u * v * ds', 'left'), ('mass_top', 'u * v * ds', 'top'), ('gradgrad_right', 'inner(grad(u), grad(v)) * ds', 'right'),
+                             ('nitsche_bottom', '(inner(n, grad(u)) * v + g * u * v) * ds', 'bottom')):
+        args = {'g': g2} if 'g *' in form else {}
+        A = asm(form, kvs2, geo=ann, boundary=side, **args)
+        ref = golden_csr(g, 'bd2_' + name)
+        assert A.shape == ref.shape and rel_maxdiff(A, ref) <= RTOL, name
+    sq = iga.geometry.unit_square()
+    kq = 2 * (mk(3, 0., 1., 3),)
+    for side, nv in (('left', [-1, 0]), ('right', [1, 0]), ('bottom', [0, -1]), ('top', [0, 1])):
+        assert np.allclose(asm('inner(v, n) * ds', kq, bfuns=[('v', 2)], geo=sq, boundary=side, layout='packed').sum(axis=(0, 1)), nv)
+    with pytest.raises(ValueError):
+        asm('v * ds', kq, geo=sq, boundary='front')
+    with pytest.raises(ValueError):
+        asm('v * ds', kq, geo=sq)
