@@ -124,6 +124,7 @@ typedef struct {                       /* device time of the last igx_assemble, 
 #define IGX_PATH_GEOA    1   /* geometry + axis-0 sweep fused (k_geoA): timing.fields_ms ~ 0, stage0_ms = k_geoA */
 #define IGX_PATH_FUSED   2   /* sweep + final stage fused (k_bf): timing.stage1_ms = k_bf */
 #define IGX_PATH_MIRROR  4   /* upper triangle by the transposing mirror pass: timing.final_ms = k_mirror */
+#define IGX_PATH_SINGLE  8   /* 2D mass / stiffness in ONE launch (k_single2d: fields, sweep and contraction in LDS): timing.stage1_ms */
 
 int         igx_version(void);
 const char *igx_last_error(void);

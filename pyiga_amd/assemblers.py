@@ -256,9 +256,9 @@ class DevicePatch:
         return scipy.sparse.csr_matrix((data, indices, indptr), shape=self.shape)
 
     def last_path(self):
-        """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'mirror' (include/igx.h IGX_PATH_*)."""
+        """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'mirror', 'single' (include/igx.h IGX_PATH_*)."""
         bits = _lib.load().igx_patch_last_path(self.handle)
-        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror')) if bits & bit}
+        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single')) if bits & bit}
 
     def timing(self):
         t = _lib.Timing()

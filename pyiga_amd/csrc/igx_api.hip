@@ -357,7 +357,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     igx_patch *pt = new (std::nothrow) igx_patch();
     if (pt) {                                   // chain choices: read once, here
         igx_knobs &k = pt->knobs;
-        if (const char *e = getenv("IGX_PATH")) k.path = !strcmp(e, "fused") ? 1 : !strcmp(e, "unfused") ? 2 : 0;
+        if (const char *e = getenv("IGX_PATH")) k.path = !strcmp(e, "fused") ? 1 : !strcmp(e, "unfused") ? 2 : !strcmp(e, "single") ? 3 : 0;
         if (const char *e = getenv("IGX_GEOA")) k.geoa = strcmp(e, "0") != 0;
         if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
         if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");

@@ -110,7 +110,7 @@ struct igx_ctx {
 // Kernel-chain choices of a patch, read from the environment ONCE when the patch is created (igx_patch_create): every
 // assembly of the patch takes the same path, whatever happens to the environment afterwards.  None selects a CPU path.
 struct igx_knobs {
-    int path = 0;                             // IGX_PATH: 0 default (fused in 3D, stage kernels in 2D), 1 fused, 2 unfused
+    int path = 0;                             // IGX_PATH: 0 default (fused in 3D; 2D: one launch for small patches, else stage kernels), 1 fused, 2 unfused, 3 single (2D)
     int geoa = 1;                             // IGX_GEOA=0: separate field and axis-0 sweep kernels
     int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
     int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
@@ -190,6 +190,9 @@ int launch_basis_tables(hipStream_t st, const double *d_kv, int nk, int p, const
                         long long *d_spans /* or null */);
 int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_PI);
 int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields);
+// 2D mass / stiffness in one launch, no intermediates (kern_basis.hip)
+bool single2d_supported(const igx_patch *pt, int kind);
+int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data);
 int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3],
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);
 int launch_fields_dump(hipStream_t st, const igx_patch *pt);

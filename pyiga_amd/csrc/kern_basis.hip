@@ -445,4 +445,170 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     return IGX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 2D mass / stiffness in ONE launch (BASELINE configs 1, 2; pyiga/assemblers.pyx:86-135,234-349 fields + combine).
+// The stage kernels need three dependent launches and two HBM intermediates for a problem whose whole output is a few
+// MB: launch-bound.  Here a block owns R0 x R1 rows (dofs i0 x i1) and keeps everything in LDS:
+//   1. fields (W, or the upper triangle of W J^-1 J^-T) on the Gauss window of its rows, straight from the geometry;
+//   2. per row i0: axis-0 sweep  K1[j0][y][g1] = sum_g0 (V0[j0][tu] * V0[i0][tv]) * field_y(g0, g1)  for every column
+//      partner j0 (the FULL window: no mirror pass) and the terms y of the form;
+//   3. contraction along axis 1 for the block's entries, written to their (contiguous) CSR positions:
+//      entry = (T0 + T3) + (T1 + T2),  T_y = sum_g1 (V1[j1][tu] * V1[i1][tv]) * K1[j0][y][g1].
+// Every product of two basis values is formed once and the sums run over the support intersection in ascending order, so
+// entry (j, i) repeats the arithmetic of entry (i, j) with T1 and T2 exchanged: the matrix is symmetric bit for bit.
+struct Single2DArgs {
+    PatchDev pd;
+    GeoView gv;
+    int geo_kind;
+    const double *jac;         // IGX_GEO_JACOBIAN: resident slab of the user array
+    int R0, R1, NG0, WIN;      // rows per block, LDS extents (planes of axis 0, window points of axis 1)
+    double *data;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_single2d(const Single2DArgs A)
+{
+    constexpr int NF = KIND == IGX_MASS ? 1 : 3, NY = KIND == IGX_MASS ? 1 : 4;
+    // term y: field, axis-0 type of u / v, axis-1 type of u / v (0 value, 1 derivative)
+    // (axis 1: u d d v v... spelled out in step 3: y = 0 (d, d), 1 (v, d), 2 (d, v), 3 (v, v))
+    constexpr int YF[4] = {0, 1, 1, 2}, U0[4] = {0, 1, 0, 1}, W0[4] = {0, 0, 1, 1};
+    extern __shared__ double lds[];
+    const PatchDev &pd = A.pd;
+    const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1];
+    const int q = A0.q, P0 = A0.P, P1 = A1.P, NG0 = A.NG0, WIN = A.WIN, C0M = 2 * P0 - 1;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int i0a = pd.r0_lo + blockIdx.y * A.R0, i0b = min(i0a + A.R0, pd.r0_hi);
+    const int i1a = blockIdx.x * A.R1, i1b = min(i1a + A.R1, A1.N);
+    const int g0b = A0.mslo[i0a] * q, nG0 = A0.mshi[i0b - 1] * q - g0b;
+    const int g1b = A1.mslo[i1a] * q, w1 = A1.mshi[i1b - 1] * q - g1b;
+    double *fld = lds;                                   // [NF][NG0][WIN]
+    double *K1 = fld + NF * NG0 * WIN;                   // [C0M][NY][WIN]
+    double *V1s = K1 + C0M * NY * WIN;                   // [WIN][P1][2]
+    double *c0s = V1s + WIN * P1 * 2;                    // [C0M][NY][NG0]
+    // ---- 1. fields on the window
+    for (int idx = tid; idx < nG0 * w1; idx += NT) {
+        const int a = idx / w1, b = idx - a * w1;
+        const int g[3] = {g0b + a, g1b + b, 0};
+        double t[9];
+        if (A.geo_kind == IGX_GEO_JACOBIAN) {
+            const double *src = A.jac + ((size_t)(g[0] - pd.g0_lo) * A1.G + g[1]) * 4;
+            t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
+        } else {
+            double Jm[MAX_COMP][3], ev[MAX_COMP];
+            physical_jacobian<2>(A.gv, A.geo_kind == IGX_GEO_NURBS, g, 2, Jm, ev);
+            t[0] = Jm[0][0]; t[1] = Jm[0][1]; t[2] = Jm[1][0]; t[3] = Jm[1][1];
+        }
+        double f[6];
+        fields_values<2>(t, A0.w[g[0]] * A1.w[g[1]], KIND, f);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) fld[(k * NG0 + a) * WIN + b] = f[k];
+    }
+    for (int idx = tid; idx < w1 * P1 * 2; idx += NT) V1s[idx] = A1.V[(size_t)g1b * P1 * 2 + idx];
+    __syncthreads();
+    const long long S1 = A1.S;
+    for (int i0 = i0a; i0 < i0b; ++i0) {
+        const int jl = A0.jlo[i0], c0 = A0.jhi[i0] - jl;
+        const int slo_i = A0.mslo[i0], shi_i = A0.mshi[i0];
+        // ---- 2a. axis-0 coefficients of the row's column partners on their common planes (0 elsewhere)
+        for (int idx = tid; idx < c0 * NG0; idx += NT) {
+            const int jj = idx / NG0, a = idx - jj * NG0;
+            const int j0 = jl + jj, g0 = g0b + a, s = g0 / q;
+            const bool on = a < nG0 && s >= max(slo_i, A0.mslo[j0]) && s < min(shi_i, A0.mshi[j0]);
+            double vu[2] = {0.0, 0.0}, vv[2] = {0.0, 0.0};
+            if (on) {
+                const int fa = A0.fa[s];
+                const double *u = A0.V + ((size_t)g0 * P0 + (j0 - fa)) * 2, *v = A0.V + ((size_t)g0 * P0 + (i0 - fa)) * 2;
+                vu[0] = u[0]; vu[1] = u[1]; vv[0] = v[0]; vv[1] = v[1];
+            }
+#pragma unroll
+            for (int y = 0; y < NY; ++y) c0s[(jj * NY + y) * NG0 + a] = KIND == IGX_MASS ? vu[0] * vv[0] : vu[U0[y]] * vv[W0[y]];
+        }
+        __syncthreads();
+        // ---- 2b. sweep of axis 0
+        for (int idx = tid; idx < c0 * NY * w1; idx += NT) {
+            const int jy = idx / w1, b = idx - jy * w1;
+            const int jj = jy / NY, y = jy - jj * NY;
+            const int j0 = jl + jj;
+            const int alo = max(slo_i, A0.mslo[j0]) * q - g0b, ahi = min(shi_i, A0.mshi[j0]) * q - g0b;
+            const double *cf = c0s + (size_t)jy * NG0;
+            const double *fp = fld + (size_t)(KIND == IGX_MASS ? 0 : YF[y]) * NG0 * WIN + b;
+            double acc = 0.0;
+            for (int a = alo; a < ahi; ++a) acc = fma(cf[a], fp[(size_t)a * WIN], acc);
+            K1[(size_t)jy * WIN + b] = acc;
+        }
+        __syncthreads();
+        // ---- 3. contraction along axis 1, entries of the rows (i0, i1a .. i1b)
+        const int C1M = 2 * P1 - 1, per_row = c0 * C1M;
+        const long long base0 = (long long)A0.rp[i0] * S1 - pd.nnz_off;
+        for (int slot = tid; slot < (i1b - i1a) * per_row; slot += NT) {
+            const int r = slot / per_row, e = slot - r * per_row;
+            const int i1 = i1a + r;
+            const int jl1 = A1.jlo[i1], c1 = A1.jhi[i1] - jl1;
+            if (e >= c0 * c1) continue;
+            const int jj = e / c1, j1 = jl1 + (e - jj * c1);
+            const int slo = max(A1.mslo[i1], A1.mslo[j1]), shi = min(A1.mshi[i1], A1.mshi[j1]);
+            double T[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int s = slo; s < shi; ++s) {
+                const int fa = A1.fa[s];
+                for (int l = 0; l < q; ++l) {
+                    const int b = s * q + l - g1b;
+                    const double *vi = V1s + (size_t)(b * P1 + (i1 - fa)) * 2, *vj = V1s + (size_t)(b * P1 + (j1 - fa)) * 2;
+                    const double vj0 = vj[0], vj1 = vj[1], vi0 = vi[0], vi1 = vi[1];
+                    if (KIND == IGX_MASS) T[0] = fma(vj0 * vi0, K1[(size_t)jj * WIN + b], T[0]);
+                    else {
+                        const double *kp = K1 + (size_t)jj * NY * WIN + b;
+                        T[0] = fma(vj1 * vi1, kp[0], T[0]);
+                        T[1] = fma(vj0 * vi1, kp[WIN], T[1]);
+                        T[2] = fma(vj1 * vi0, kp[2 * WIN], T[2]);
+                        T[3] = fma(vj0 * vi0, kp[3 * WIN], T[3]);
+                    }
+                }
+            }
+            A.data[base0 + (long long)c0 * A1.rp[i1] + e] = KIND == IGX_MASS ? T[0] : (T[0] + T[3]) + (T[1] + T[2]);
+        }
+        __syncthreads();
+    }
+}
+
+bool single2d_supported(const igx_patch *pt, int kind)
+{
+    return pt->dim == 2 && (kind == IGX_MASS || kind == IGX_STIFFNESS) && pt->ax[0].q == pt->ax[1].q && pt->ax[0].P <= 6 && pt->ax[1].P <= 6;
+}
+
+int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data)
+{
+    const Axis &A0 = pt->ax[0], &A1 = pt->ax[1];
+    Single2DArgs A{};
+    A.pd = pt->dev;
+    A.gv = make_view(2, pt->gax, pt->d_ctrl, pt->ncomp);
+    A.geo_kind = pt->geo_kind; A.jac = pt->d_jac; A.data = d_data;
+    const int NF = kind == IGX_MASS ? 1 : 3, NY = kind == IGX_MASS ? 1 : 4, q = A0.q;
+    static const int shapes[][2] = {{4, 16}, {2, 16}, {2, 8}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
+    size_t bytes = 0;
+    for (const auto &sh : shapes) {
+        A.R0 = sh[0]; A.R1 = sh[1];
+        A.NG0 = (A.R0 + A0.p) * q; A.WIN = (A.R1 + A1.p) * q;
+        bytes = ((size_t)NF * A.NG0 * A.WIN + (size_t)(2 * A0.P - 1) * NY * A.WIN + (size_t)A.WIN * A1.P * 2 + (size_t)(2 * A0.P - 1) * NY * A.NG0) * sizeof(double);
+        if (bytes <= 72 * 1024) break;
+    }
+    if (bytes > 150 * 1024) { set_error("single-launch 2D kernel: LDS image too large (%zu bytes)", bytes); return IGX_ERR_UNSUPPORTED; }
+    const int nr0 = pt->r0_hi - pt->r0_lo;
+    if (nr0 <= 0) return IGX_OK;
+    dim3 grid((unsigned)((A1.N + A.R1 - 1) / A.R1), (unsigned)((nr0 + A.R0 - 1) / A.R0));
+    int nt = 1024;                                       // the phases of a block are short and serial: many threads, short latency
+#ifdef IGX_ABLATE
+    if (const char *e = getenv("IGX_S2D_NT")) nt = atoi(e);
+#endif
+    if (kind == IGX_MASS) {
+        if (bytes > 64 * 1024) IGX_HIP(hipFuncSetAttribute((const void *)k_single2d<IGX_MASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        k_single2d<IGX_MASS><<<grid, dim3(nt), bytes, st>>>(A);
+    } else {
+        if (bytes > 64 * 1024) IGX_HIP(hipFuncSetAttribute((const void *)k_single2d<IGX_STIFFNESS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        k_single2d<IGX_STIFFNESS><<<grid, dim3(nt), bytes, st>>>(A);
+    }
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 } // namespace igx

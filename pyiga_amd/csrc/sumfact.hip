@@ -1506,8 +1506,18 @@ static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
     return igx_kind_symmetric(kind) && geoA_supported(pt, kind, nslots);
 }
 
+constexpr long long SINGLE2D_MAX_DOFS = 5000;        // measured crossover against the stage-kernel chain (profiles/r03_single2d.txt)
+static bool single2d_wanted(const igx_patch *pt, int kind)
+{
+    // 2D: the single-launch kernel where the stage kernels are launch-bound (small patches), or on request (IGX_PATH=single)
+    if (pt->knobs.final_sel || !single2d_supported(pt, kind)) return false;
+    if (pt->knobs.path == 3) return true;
+    return pt->knobs.path == 0 && (long long)pt->ax[0].N * pt->ax[1].N <= SINGLE2D_MAX_DOFS;
+}
+
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
+    if (single2d_wanted(pt, kind)) return false;
     if (pt->dim != 3 || !igx_kind_symmetric(kind)) return true;
     return !geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 8);
 }
@@ -1581,6 +1591,15 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     const int np0 = sym ? pt->npairs0 : pt->npairs0n;
     const int *d_pl0 = sym ? pt->d_pl0 : pt->d_pl0n;
     if (np0 == 0) return IGX_OK;
+    if (single2d_wanted(pt, kind)) {
+        (void)hipEventRecord(pt->ctx->ev[1], st);
+        (void)hipEventRecord(pt->ctx->ev[2], st);
+        if (int rc = launch_single2d(st, pt, kind, d_data)) return rc;
+        pt->last_path |= IGX_PATH_SINGLE;
+        (void)hipEventRecord(pt->ctx->ev[3], st);
+        (void)hipEventRecord(pt->ctx->ev[4], st);
+        return IGX_OK;
+    }
     const bool fused = fused_applicable(pt);
     if (fused && dim == 2) {
         // 2D: the fields ARE the sweep input (axis 0 swept, axis 1 contracted by the contractors): one kernel + mirror

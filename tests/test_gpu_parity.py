@@ -950,9 +950,10 @@ def _csr_at(A, idx):
     return out
 
 
-@pytest.mark.parametrize('path', ['fused', 'unfused'])
+@pytest.mark.parametrize('path', ['single', 'fused', 'unfused'])
 def test_fullsize_vs_reference_c2(iga, golden, path, monkeypatch):
-    """BASELINE config 2: 2D p=3 n=256 NURBS quarter annulus, 'CSR vs reference within 1e-12'."""
+    """BASELINE config 2: 2D p=3 n=256 NURBS quarter annulus, 'CSR vs reference within 1e-12'; 'single' = the single-launch
+    kernel (the default of small 2D patches) forced at this size."""
     monkeypatch.setenv('IGX_PATH', path)
     g = golden('fullsize')
     kv = iga.bspline.make_knots(3, 0., 1., 256)
@@ -1006,6 +1007,13 @@ def test_fused_equals_unfused(iga, d, p, n, monkeypatch):
         assert not np.isnan(A.data).any()
         assert abs(A - A.T).max() == 0.0
         assert rel_maxdiff(A, B) <= RTOL, (kind, rel_maxdiff(A, B))
+        if d == 2:                                   # everything in one launch (the default of small 2D patches)
+            monkeypatch.setenv('IGX_PATH', 'single')
+            patch = iga.assemblers.DevicePatch(kvs, geo)
+            C = patch.csr(kind, algo='sumfact')
+            assert patch.last_path() == {'single'}
+            assert not np.isnan(C.data).any() and abs(C - C.T).max() == 0.0
+            assert rel_maxdiff(C, B) <= RTOL, (kind, rel_maxdiff(C, B))
 
 
 # ------------------------------------------------------------------------------------------
