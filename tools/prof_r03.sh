@@ -23,6 +23,7 @@ trace)
   for c in c1 c2 c3 c5; do timeout 300 python3 bench.py --config $c --no-cpu-baseline > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
   timeout 300 python3 bench.py --op rhs --no-cpu-baseline > "$OUT/c4_rhs_bench.json" 2>> "$OUT/bench.log"
   timeout 300 python3 bench.py --op entries --no-cpu-baseline > "$OUT/c4_entries_bench.json" 2>> "$OUT/bench.log"
+  for c in c2 c3; do timeout 300 python3 bench.py --op fast --config $c > "$OUT/fast_${c}_bench.json" 2>> "$OUT/bench.log"; done
   IGX_PATH=unfused IGX_GEOA=0 timeout 300 python3 bench.py --no-cpu-baseline --no-api-call > "$OUT/c4_bench_r01_kernels.json" 2>> "$OUT/bench.log"
   head -12 "$OUT/c4_kernel_stats.csv"; cut -c1-400 "$OUT/c4_bench.json"; tail -5 "$OUT/bench.log"
   ;;
