@@ -298,7 +298,8 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
     (vform -> Cython -> gcc).  Here the three built-in forms map to their hand-written kernels, any other
     3D scalar form in u, v, grad, inner, dot goes through the general device form (``pyiga_amd.forms`` ->
     ``IGX_FORM``); assembler classes and objects are accepted as in the reference."""
-    if isinstance(problem, str) and (bfuns is not None or boundary is not None):
+    surface = isinstance(problem, str) and 'geo' in args and getattr(args['geo'], 'dim', None) == len(tuple(kvs)) + 1
+    if isinstance(problem, str) and (bfuns is not None or boundary is not None or surface):
         # vector-valued basis functions and/or a boundary integral (pyiga/vform.py:1822-1845, pyiga/assemble.py:929-934)
         from .form_assemblers import FormAssembler
         if 'geo' not in args:

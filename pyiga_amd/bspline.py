@@ -304,6 +304,14 @@ class BSplineFunc(_BaseSplineFunc):
                                 False, nc, gridaxes, want_jac=True)
         return out[..., 0, :] if self.is_scalar() else out
 
+    def boundary(self, bdspec):
+        """One face of the parameter domain as a spline function with `sdim` reduced by one (pyiga/bspline.py:1014-1036):
+        with open knot vectors the face's control net is the first / last layer of the net along that axis."""
+        from .form_assemblers import parse_bdspec
+        axis, side = parse_bdspec(bdspec, self.sdim)
+        layer = np.take(self.coeffs, 0 if side == 0 else -1, axis=axis)
+        return BSplineFunc(self.kvs[:axis] + self.kvs[axis + 1:], layer)
+
     def as_nurbs(self):
         from .geometry import NurbsFunc
         return NurbsFunc(self.kvs, self.coeffs.copy(), np.ones(self.coeffs.shape[:self.sdim]))

@@ -84,11 +84,15 @@ class FormAssembler:
         self._form = form
         self._device = device
         d = len(kvs)
-        assert geo.sdim == d and geo.dim == d, 'Geometry has wrong dimension'
+        assert geo.sdim == d, 'Geometry has wrong source dimension'
         self.nqp = max(kv.p for kv in kvs) + 1
         inputs = {k: v for k, v in dict(inputs or {}).items() if k != 'geo'}
         self.boundary = None if boundary is None else parse_bdspec(boundary, d)
-        if self.boundary is None:
+        self._surface = boundary is None and geo.dim == d + 1
+        assert self._surface or geo.dim == d, 'Geometry has wrong dimension'
+        if self._surface:
+            self._setup_surface(kvs, geo, form, bfuns, inputs)
+        elif self.boundary is None:
             assert d in (2, 3), 'vector-valued forms are assembled for 2D and 3D patches'
             self._tkvs = kvs
             self.patch = DevicePatch(kvs, geo, device=device)
@@ -103,6 +107,39 @@ class FormAssembler:
             self._setup_boundary(kvs, geo, form, bfuns, inputs)
         self._vector_valued = any(nc > 1 for nc in self._ncs) or bfuns is not None and any(
             not isinstance(bf, str) and len(tuple(bf)) > 1 for bf in bfuns)
+
+    # ---- surface integrals: a d-dimensional patch mapped into (d+1)-dimensional space (pyiga/vform.py:46-54,205-211,1839-1845)
+    def _setup_surface(self, kvs, geo, form, bfuns, inputs):
+        d = len(kvs)
+        self._tkvs = kvs
+        nodes, _ = make_tensor_quadrature([kv.mesh for kv in kvs], self.nqp)
+        G = tuple(len(g) for g in nodes)
+        X = np.asarray(geo.grid_eval(list(nodes))).reshape(G + (d + 1,))
+        Jac = np.asarray(geo.grid_jacobian(list(nodes))).reshape(G + (d + 1, d))
+        if d == 1:
+            un = np.stack([-Jac[..., 1, 0], Jac[..., 0, 0]], axis=-1)
+        else:
+            un = np.cross(Jac[..., :, 0], Jac[..., :, 1])
+        ds = np.sqrt(np.sum(un * un, axis=-1))
+        self.arity, measure, table, self._ncs = tforms.evaluate(form, G, X, inputs, bfuns, normal=un / ds[..., None])
+        if measure != 'ds':
+            raise ValueError('an integral over a surface patch must be written with ds')
+
+        def value_only(jet):
+            if any(e is not None for e in jet[1:]):
+                raise NotImplementedError('derivatives of basis functions in a surface integral')
+            return None if jet[0] is None else np.ascontiguousarray(jet[0] * ds)
+        if self.arity == 2:
+            def block(tab):
+                if any(tab[r][s] is not None for r in range(d + 2) for s in range(d + 2) if r or s):
+                    raise NotImplementedError('derivatives of basis functions in a surface integral')
+                C = [[None] * (d + 1) for _ in range(d + 1)]
+                C[0][0] = None if tab[0][0] is None else np.ascontiguousarray(tab[0][0] * ds)
+                return C
+            self._table = [[block(tab) for tab in row] for row in table]
+        else:
+            self._table = [[value_only(jet)] + [None] * d for jet in table]
+        self.patch = DevicePatch(kvs, _identity_geo(kvs), device=self._device, nqp=self.nqp) if d == 2 else None
 
     # ---- boundary integrals
     def _setup_boundary(self, kvs, geo, form, bfuns, inputs):

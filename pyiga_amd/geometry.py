@@ -70,6 +70,14 @@ class NurbsFunc(_BaseSplineFunc):
         J = _device_grid_eval(self.kvs, self.coeffs, True, self.dim, gridaxes, want_jac=True)
         return np.squeeze(J, -2) if self._isscalar else J
 
+    def boundary(self, bdspec):
+        """One face of the parameter domain as a NURBS function with `sdim` reduced by one (pyiga/geometry.py:188-210): the
+        first / last layer of the homogeneous net along that axis."""
+        from .form_assemblers import parse_bdspec
+        axis, side = parse_bdspec(bdspec, self.sdim)
+        layer = np.take(self.coeffs, 0 if side == 0 else -1, axis=axis)
+        return NurbsFunc(self.kvs[:axis] + self.kvs[axis + 1:], layer.copy(), None, premultiplied=True)
+
     def as_nurbs(self):
         return self
 

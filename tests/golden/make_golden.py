@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms', 'fullsize'} & set(sys.argv[1:]):
+if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms', 'fullsize', 'ondemand', 'vecforms', 'surface'} & set(sys.argv[1:]):
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -615,3 +615,29 @@ def golden_vecforms():
 
 if __name__ == '__main__' and 'vecforms' in sys.argv[1:]:
     golden_vecforms()
+
+
+# ---------------------------------------------------------------------------
+# (13) surface integrals: a patch mapped into a space of one dimension more (test/test_assemble.py:314-330)
+def golden_surface():
+    out = {}
+    cyl = cylinder()
+    ann = geometry.quarter_annulus()
+    kvs2 = (bspline.make_knots(3, 0.0, 1.0, 4), bspline.make_knots(2, 0.0, 1.0, 6))
+    for side in ('left', 'right', 'top', 'back'):
+        geo = cyl.boundary(side)
+        out['s3_v_' + side] = assemble.assemble('v * ds', kvs2, geo=geo)
+        out['s3_xv_' + side] = assemble.assemble('(1.0 + x[0] + 2 * x[1] * x[2]) * v * ds', kvs2, geo=geo)
+        out['s3_vn_' + side] = assemble.assemble('inner(v, n) * ds', kvs2, geo=geo, bfuns=[('v', 3)], layout='packed')
+        put_matrix(out, 's3_mass_' + side, assemble.assemble('(2.5 + x[0]) * u * v * ds', kvs2, geo=geo))
+    kv1 = (bspline.make_knots(3, 0.0, 1.0, 7),)
+    for side in ('left', 'right', 'bottom', 'top'):
+        geo = ann.boundary(side)
+        out['s2_v_' + side] = assemble.assemble('(1.0 + x[0] * x[1]) * v * ds', kv1, geo=geo)
+        out['s2_vn_' + side] = assemble.assemble('inner(v, n) * ds', kv1, geo=geo, bfuns=[('v', 2)], layout='packed')
+        put_matrix(out, 's2_mass_' + side, assemble.assemble('u * v * ds', kv1, geo=geo))
+    save('surface', **out)
+
+
+if __name__ == '__main__' and 'surface' in sys.argv[1:]:
+    golden_surface()

@@ -1428,3 +1428,37 @@ def test_boundary_integrals_vs_reference(iga, golden):
         asm('v * ds', kq, geo=sq, boundary='front')
     with pytest.raises(ValueError):
         asm('v * ds', kq, geo=sq)
+
+
+def test_surface_integrals_vs_reference(iga, golden):
+    """Integrals over a patch that is mapped into a space of one dimension more (test/test_assemble.py:314-330): faces of the
+    quarter-annulus cylinder as 2D -> 3D NURBS surfaces, sides of the quarter annulus as curves.  Goldens: the reference's
+    assemble() on the same strings with geo.boundary(side)."""
+    g = golden('surface')
+    mk = iga.bspline.make_knots
+    cyl, ann = _geo(iga, 'cylinder'), _geo(iga, 'quarter_annulus')
+    asm = iga.assemble.assemble
+    kvs2 = (mk(3, 0., 1., 4), mk(2, 0., 1., 6))
+
+    def close(a, ref, what):
+        assert a.shape == ref.shape, what
+        assert np.abs(a - ref).max() <= RTOL * np.abs(ref).max(), what
+    for side in ('left', 'right', 'top', 'back'):
+        geo = cyl.boundary(side)
+        assert geo.sdim == 2 and geo.dim == 3
+        close(asm('v * ds', kvs2, geo=geo), g['s3_v_' + side], side)
+        close(asm('(1.0 + x[0] + 2 * x[1] * x[2]) * v * ds', kvs2, geo=geo), g['s3_xv_' + side], side)
+        close(asm('inner(v, n) * ds', kvs2, geo=geo, bfuns=[('v', 3)], layout='packed'), g['s3_vn_' + side], side)
+        A = asm('(2.5 + x[0]) * u * v * ds', kvs2, geo=geo)
+        assert rel_maxdiff(A, golden_csr(g, 's3_mass_' + side)) <= RTOL, side
+    # inner and outer mantle: r = 1 and r = 2, a quarter of the circle, height 1 (test/test_assemble.py:327-330)
+    assert np.allclose(asm('v * ds', kvs2, geo=cyl.boundary('left')).sum(), 2 * np.pi / 4)
+    assert np.allclose(asm('v * ds', kvs2, geo=cyl.boundary('right')).sum(), 2 * 2 * np.pi / 4)
+    kv1 = (mk(3, 0., 1., 7),)
+    for side in ('left', 'right', 'bottom', 'top'):
+        geo = ann.boundary(side)
+        close(asm('(1.0 + x[0] * x[1]) * v * ds', kv1, geo=geo), g['s2_v_' + side], side)
+        close(asm('inner(v, n) * ds', kv1, geo=geo, bfuns=[('v', 2)], layout='packed'), g['s2_vn_' + side], side)
+        assert rel_maxdiff(asm('u * v * ds', kv1, geo=geo), golden_csr(g, 's2_mass_' + side)) <= RTOL, side
+    with pytest.raises(NotImplementedError):
+        asm('inner(grad(u), grad(v)) * ds', kvs2, geo=cyl.boundary('left'))
