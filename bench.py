@@ -505,14 +505,28 @@ def bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank):
         dev.append(patch.timing()['entry_ms'])
     dev_ms = float(np.median(dev))
     q = p + 1
+    # arithmetic of the request: Gauss points of every pair's support intersection (uniform open knots: p + 1 - |i - j| spans per
+    # axis, fewer at the ends) x the reference's flops per point of its entry sum (33 for 3D stiffness; 2 d^2 + 3 d + 6 else)
+    pts = np.ones(M)
+    for k, kv in enumerate(kvs):
+        supp = kv.mesh_support_idx_all()
+        lo = np.maximum(supp[I[:, k], 0], supp[J[:, k], 0])
+        hi = np.minimum(supp[I[:, k], 1], supp[J[:, k], 1])
+        pts *= np.maximum(hi - lo, 0) * q
+    flop_pt = {('stiffness', 3): 33.0, ('stiffness', 2): 17.0, ('mass', 3): 7.0, ('mass', 2): 5.0}.get((kind, dim), 2.0 * dim * dim + 3 * dim + 6)
+    tflops = float(pts.sum()) * flop_pt / (dev_ms * 1e-3) / 1e12
+    nfld = {'stiffness': dim * (dim + 1) // 2, 'mass': 1}.get(kind, 9)
+    gbs = float(pts.sum()) * 8.0 * nfld / (dev_ms * 1e-3) / 1e9
     # bytes one entry must read: its fields on the support intersection (avg ((p+1) q / 2)^d points x d(d+1)/2 fields) -- L2-resident reuse aside
     out = {'metric': 'multi_entries pairs/sec', 'value': M / (dev_ms * 1e-3), 'unit': 'entries/s', 'n_gpus': 1, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': dev_ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
            'data': 'synthetic',
            'config': {'workload': '%dD p=%d %s multi_entries, %d random in-pattern pairs, %s spans' % (dim, p, kind, M, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
                       'config': args.config, 'note': 'device time with resident pairs; host-pointer call (upload pairs, download values) %.1f ms' % host_ms},
-           'roofline': {'bound': 'fp64', 'note': 'the entry-wise sum is arithmetic: ~33 flop per Gauss point of the support intersection',
-                        'achieved': None, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}}
+           'roofline': {'bound': 'hbm', 'note': 'every Gauss point of a pair\'s support intersection reads its %d field values (random pairs: no reuse '
+                        'between pairs beyond L2 / Infinity Cache); %.3g points in this request' % (nfld, float(pts.sum())),
+                        'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                        'fp64': {'flops_per_point': flop_pt, 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_PEAK_TFLOPS}}}
     print(json.dumps(out), flush=True)
 
 
