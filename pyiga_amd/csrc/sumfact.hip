@@ -259,7 +259,10 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
     }
 }
 
-template <int P, int Q, bool SYM>
+// ONE: every group carries a single type (the host splits two-type groups): the non-symmetric sweep of a high degree keeps
+// P x P accumulators per type, and with two types (218 registers at P = 6) only two waves fit a SIMD -- too few to keep
+// a streaming kernel's loads in flight; the field of a split group is read twice instead
+template <int P, int Q, bool SYM, bool ONE = false>
 __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double pis[];   // [2][q*4*PP]
@@ -268,11 +271,11 @@ __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
     if (!live) pt = A.NPL - 1;
     const StageAGroup &G = A.grp[blockIdx.y];
     if (!SYM && (G.xfield[0] || G.xfield[1])) {          // (merged slots occur with the non-symmetric forms only)
-        if (G.nt == 2) stageA_body<P, 2, Q, SYM, true>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis, G.xfield[0], G.xfield[1], G.xt[0], G.xt[1]);
+        if (!ONE && G.nt == 2) stageA_body<P, 2, Q, SYM, true>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis, G.xfield[0], G.xfield[1], G.xt[0], G.xt[1]);
         else stageA_body<P, 1, Q, SYM, true>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis, G.xfield[0], nullptr, G.xt[0], 0);
         return;
     }
-    if (G.nt == 2) stageA_body<P, 2, Q, SYM>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
+    if (!ONE && G.nt == 2) stageA_body<P, 2, Q, SYM>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
     else stageA_body<P, 1, Q, SYM>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
 }
 
@@ -1433,8 +1436,9 @@ static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 }
 
 template <int P>
-static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sym, dim3 grid, dim3 block, size_t lds)
+static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sym, bool one, dim3 grid, dim3 block, size_t lds)
 {
+    if (!sym && one && qeq) { k_stageA<P, P, false, true><<<grid, block, lds, st>>>(A); return; }
     if (sym) {
         if (qeq) k_stageA<P, P, true><<<grid, block, lds, st>>>(A);
         else k_stageA<P, 0, true><<<grid, block, lds, st>>>(A);
@@ -1700,6 +1704,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     {
         StageAArgs A{};
         int ng = 0;
+        const bool one_type = !sym && A0.P >= 5 && A0.q == A0.P;      // register budget of the full pair window (k_stageA)
         for (int f = 0; f < nF; ++f) {
             StageAGroup g{};
             for (size_t x = 0; x < X.size(); ++x)
@@ -1712,6 +1717,13 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 }
             if (g.nt == 0) continue;
             g.field = pt->d_fields + (size_t)f * pd.npts_loc;
+            if (one_type && g.nt == 2) {                 // two groups of one type each (see k_stageA)
+                StageAGroup g1 = g;
+                g1.t0 = g.t1; g1.out0 = g.out1; g1.xfield[0] = g.xfield[1]; g1.xt[0] = g.xt[1];
+                g1.nt = g.nt = 1; g1.xfield[1] = g.xfield[1] = nullptr;
+                if (ng >= 15) { set_error("internal: too many stage-A groups"); return IGX_ERR_UNSUPPORTED; }
+                A.grp[ng++] = g1;
+            }
             if (ng >= 16) { set_error("internal: too many stage-A groups"); return IGX_ERR_UNSUPPORTED; }
             A.grp[ng++] = g;
         }
@@ -1725,7 +1737,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         const size_t ldsA = (size_t)2 * A0.q * 4 * ((A0.P * A0.P + 1) & ~1) * sizeof(double);
         if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
         dim3 block(bsA), grid((unsigned)bx, ng, ch.nchunks);
-        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, sym, grid, block, ldsA));
+        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, sym, one_type, grid, block, ldsA));
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
