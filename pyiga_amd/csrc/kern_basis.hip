@@ -419,7 +419,12 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
     const int G1 = pd.L1, G2 = (dim == 3) ? pd.L2 : 1;
     if (pt->geo_kind != IGX_GEO_JACOBIAN && !pt->boxed) {      // (a boxed patch is small: the point-wise kernel)
         const int LN = (dim == 3) ? G2 : G1;
-        const int LPB = std::max(1, 256 / LN);
+        // lines per block: a whole number of 256-thread passes over the block's points where a few lines give one
+        // (576-point lines: 4 lines = 9 passes; one line would leave the third pass a quarter full)
+        int LPB = std::max(1, 256 / LN);
+        if (LN > 256)
+            for (int l = 1; l <= 8; ++l)
+                if ((l * LN) % 256 == 0) { LPB = l; break; }
         const size_t lds = (size_t)LPB * pt->gax[dim - 1].N * pt->ncomp * dim * sizeof(double);
         if (lds <= 64 * 1024) {
             const long long nlines = total / LN;
