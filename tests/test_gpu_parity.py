@@ -1462,3 +1462,23 @@ def test_surface_integrals_vs_reference(iga, golden):
         assert rel_maxdiff(asm('u * v * ds', kv1, geo=geo), golden_csr(g, 's2_mass_' + side)) <= RTOL, side
     with pytest.raises(NotImplementedError):
         asm('inner(grad(u), grad(v)) * ds', kvs2, geo=cyl.boundary('left'))
+
+
+@pytest.mark.parametrize('p,n', [(4, 7), (5, 6)])
+def test_general_form_high_degree(iga, p, n):
+    """Non-symmetric sweeps of degree >= 4 run with one type per group (k_stageA<..., ONE>, two-type groups split on the host):
+    a full general form (diffusion tensor, convection, adjoint convection, reaction) equals the entry-wise kernel and its
+    row slabs reproduce it bit for bit."""
+    form = '(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v + u * inner(b, grad(v)) + c * u * v) * dx'
+    inp = form_inputs()
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv, kv, kv)
+    cyl = _geo(iga, 'cylinder')
+    asm = iga.assemblers.GeneralFormAssembler3D(kvs, cyl, form, inputs=inp)
+    A = asm.patch.csr('form', algo='sumfact')
+    E = asm.patch.csr('form', algo='entrywise')
+    assert rel_maxdiff(A, E) <= RTOL
+    N0 = kv.numdofs
+    parts = [iga.assemblers.GeneralFormAssembler3D(kvs, cyl, form, inputs=inp, row0=r).patch.csr('form', algo='sumfact')
+             for r in ((0, N0 // 2), (N0 // 2, N0))]
+    assert abs(scipy.sparse.vstack(parts).tocsr() - A).max() == 0.0
