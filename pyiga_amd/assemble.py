@@ -349,6 +349,43 @@ def assemble(problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False
     return assemble_entries(asm, symmetric=symmetric, format=format, layout=layout)
 
 
+class Assembler:
+    """Assembler object for a sequence of problems with changing inputs (interface of pyiga/assemble.py:958-1003):
+    ``Assembler(problem, kvs, geo=..., updatable=['geo'])``, then ``assemble(geo=new_geo)`` or ``update(geo=new_geo)`` +
+    ``assemble()``.  `updatable` names must be inputs of the problem (``ValueError``), only they may be updated
+    (``RuntimeError``).  The device assembler is instantiated again when an input changes: the per-patch set-up is a few
+    milliseconds, everything geometry-dependent has to be recomputed anyway."""
+
+    def __init__(self, problem, kvs, args=None, bfuns=None, boundary=None, symmetric=False, updatable=(), **kwargs):
+        self._args = dict(args or {})
+        self._args.update(kwargs)
+        self._problem, self._kvs, self._bfuns, self._boundary = problem, kvs, bfuns, boundary
+        self.symmetric = bool(symmetric)
+        self.updatable = tuple(updatable)
+        self.asm = instantiate_assembler(problem, kvs, self._args, bfuns, boundary)
+        inputs = self._input_names()
+        if not all(name in inputs for name in self.updatable):
+            raise ValueError('Assembler received an updatable argument which is not an assembler input')
+
+    def _input_names(self):
+        if isinstance(self._problem, str):
+            import re
+            words = set(re.findall(r"[^\d\W]\w*", self._problem))
+            return {'geo'} | (words & set(self._args))
+        return set(self.asm.inputs().keys()) if hasattr(self.asm, 'inputs') else {'geo'}
+
+    def update(self, **kwargs):
+        if not all(name in self.updatable for name in kwargs):
+            raise RuntimeError('update() received an argument which was not specified as updatable')
+        self._args.update(kwargs)
+        self.asm = instantiate_assembler(self._problem, self._kvs, self._args, self._bfuns, self._boundary)
+
+    def assemble(self, format='csr', layout='blocked', **upd_fields):
+        if upd_fields:
+            self.update(**upd_fields)
+        return assemble_entries(self.asm, symmetric=self.symmetric, format=format, layout=layout)
+
+
 ################################################################################
 # Convenience functions (pyiga/assemble.py:1009-1049)
 ################################################################################

@@ -1482,3 +1482,22 @@ def test_general_form_high_degree(iga, p, n):
     parts = [iga.assemblers.GeneralFormAssembler3D(kvs, cyl, form, inputs=inp, row0=r).patch.csr('form', algo='sumfact')
              for r in ((0, N0 // 2), (N0 // 2, N0))]
     assert abs(scipy.sparse.vstack(parts).tocsr() - A).max() == 0.0
+
+
+def test_assembler_class_with_updatable_inputs(iga):
+    """The high-level Assembler object (pyiga/assemble.py:958-1003; test/test_assemble.py:417-426)."""
+    kvs = 2 * (iga.bspline.make_knots(2, 0., 1., 10),)
+    geo = iga.geometry.quarter_annulus()
+    A2 = iga.assemble.stiffness(kvs, geo)
+    asm = iga.assemble.Assembler('inner(grad(u), grad(v)) * dx', kvs, geo=geo, symmetric=True, updatable=['geo'])
+    assert rel_maxdiff(asm.assemble(), A2) <= RTOL
+    with pytest.raises(RuntimeError):
+        asm.assemble(f=geo)                                   # not an updatable field
+    with pytest.raises(ValueError):
+        iga.assemble.Assembler('inner(grad(u), grad(v)) * dx', kvs, geo=geo, updatable=['f'])   # f is not an input
+    geo2 = iga.geometry.bspline_quarter_annulus()
+    assert rel_maxdiff(asm.assemble(geo=geo2), iga.assemble.stiffness(kvs, geo2)) <= RTOL
+    asm = iga.assemble.Assembler('c * u * v * dx', kvs, geo=geo, c=lambda x, y: 1.0 + x, updatable=['c'])
+    M1 = asm.assemble()
+    M2 = asm.assemble(c=lambda x, y: 2.0 + 2.0 * x)
+    assert rel_maxdiff(M2, 2.0 * M1) <= RTOL
