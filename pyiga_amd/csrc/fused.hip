@@ -535,20 +535,36 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
     const __amdgpu_buffer_rsrc_t drs0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.data, (short)0, 0, 0x00020000);
     constexpr int NSL = Gm::NSR + Gm::NSC;
     double sv[NSL];
-    int sg[NSL];
 #pragma unroll
-    for (int k = 0; k < NSL; ++k) { sv[k] = 0.0; sg[k] = BF2_OOB; }
-    int s_soff = 0;
-    bool s_on = false;
+    for (int k = 0; k < NSL; ++k) sv[k] = 0.0;
+    int s_soff = 0, s_ddc = 0;
+    bool s_on = false, s_int = true;
+    // The VALUES of a row wait in registers from B2 to the next B1; their OFFSETS are read from the plan in LDS only here (one
+    // ds_read each, a few dozen cycles): eleven more registers across the barrier spill, and a scratch reload in front of a
+    // store waits for vmcnt(0), i.e. for the stores just issued.  Rows without a plan (first / last p of the mid axis) work
+    // their offsets out here.
+    auto issue_stores = [&]() {
+        const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
+        int lq_ = lane;
+        asm volatile("" : "+v"(lq_));
+        const int q0 = cw * 64 + lq_;
+        if (s_int) {
+            const int *myplan = plan + q0;
+            int sg[NSL];
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NCW * 64];
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
+        } else {
+            for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, q0 + k * NCW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[k]); }
+            for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, q0 + k * NCW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[Gm::NSR + k]); }
+        }
+    };
     for (int t = s_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
         BF_SEG_BEGIN();
 #ifndef BF2_NOSTORE
-        {
-            const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
-        }
+        issue_stores();
 #endif
         BF_SEG_END(0);
         // ---- contract the lines of flush dd = t - 1 with the last axis
@@ -663,7 +679,6 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
             int lq_ = lane;
             asm volatile("" : "+v"(lq_));
             const int q0 = cw * 64 + lq_;
-            const int *myplan = plan + q0;
             double *rgw = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR, *cuw = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
 #pragma unroll
             for (int k = 0; k < Gm::NSR; ++k) {
@@ -677,22 +692,13 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                 sv[Gm::NSR + k] = cu[o_];
                 if (NH == 2 && s_on && q0 + k * NCW * 64 <= CCLAMP) cuw[o_] = 0.0;
             }
-            if (ddc >= p && ddc < A.N1 - p) {
-#pragma unroll
-                for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NCW * 64];
-            } else if (s_on) {                              // first and last p rows of the mid axis: offsets worked out here
-                for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, q0 + k * NCW * 64, ddc); sg[k] = g < 0 ? BF2_OOB : g * 8; }
-                for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, q0 + k * NCW * 64, ddc); sg[Gm::NSR + k] = g < 0 ? BF2_OOB : g * 8; }
-            }
+            s_int = !s_on || (ddc >= p && ddc < A.N1 - p);  // (a row that is not stored takes the plan's offsets: its descriptor is empty)
+            s_ddc = ddc;
         }
 #endif
     }
 #ifndef BF2_NOSTORE
-    {                                                     // the last row
-        const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
-#pragma unroll
-        for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
-    }
+    issue_stores();                                       // the last row
 #endif
     BF_SEG_DUMP(cw & 3);
     BF_STAMP_END(wave);
