@@ -105,8 +105,8 @@ class FormAssembler:
             self._table = table
         else:
             self._setup_boundary(kvs, geo, form, bfuns, inputs)
-        self._vector_valued = any(nc > 1 for nc in self._ncs) or bfuns is not None and any(
-            not isinstance(bf, str) and len(tuple(bf)) > 1 for bf in bfuns)
+        # (all functions scalar: the reference forces a scalar assembler even when `bfuns` spells them out, pyiga/vform.py:1854-1856)
+        self._vector_valued = any(nc > 1 for nc in self._ncs)
 
     # ---- surface integrals: a d-dimensional patch mapped into (d+1)-dimensional space (pyiga/vform.py:46-54,205-211,1839-1845)
     def _setup_surface(self, kvs, geo, form, bfuns, inputs):
