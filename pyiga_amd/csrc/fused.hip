@@ -981,7 +981,13 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 // (P = 6: the window of a 192-point tile does not fit LDS next to the rings; two lane groups, 168 registers per wave)
 template <int P, int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
 template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P <= 5 ? 3 : 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
-template <int P> struct BF2Cfg<P, BF_MASK_STIFF3, 1> { static constexpr int NLG = P <= 5 ? BF2_NLG : 2, NCW = P <= 5 ? BF2_NCW : 4, NH = P <= 5 ? BF2_NH : 1; };
+// 3D stiffness, measured per degree (tools/shape_try.py; k_bf2 ms at n = 64 / 128, shapes (NLG, NCW, NH)):
+//   p = 1: (3,4,2) 0.32 / 0.61, (2,4,1) 0.25 / 0.56        p = 2: (3,4,2) 0.29 / 1.53, (2,4,1) 0.21 / 1.53
+//   p = 3: (3,4,2) 0.92 / 6.42, (3,4,1) 0.74 / 4.78, (2,8,1) 0.70 / 4.46   (the halved passes cost more than they balance)
+//   p = 4: (3,4,2) 7.1 at n = 128 (C4), (3,4,1) 7.1, (2,8,1) 8.5
+template <int P> struct BF2Cfg<P, BF_MASK_STIFF3, 1> {
+    static constexpr int NLG = P == 5 ? BF2_NLG : 2, NCW = P == 5 ? BF2_NCW : P == 4 ? 8 : 4, NH = P == 5 ? BF2_NH : 1;
+};
 template <int P> struct BF2Cfg<P, BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
 template <int P, int NY, int MASK, int NA>
 static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks)
