@@ -99,6 +99,9 @@ typedef const int __attribute__((address_space(4))) *cip;
 // early with zero accumulators (warm-up, nothing is written) so that every pair it completes inside
 // its own range has seen all of its spans.
 
+#ifndef SA_XPRE_MINP
+#define SA_XPRE_MINP 6         // second-source values preloaded with the field values from this many functions per axis on
+#endif
 constexpr int SWEEP_MAX_STAGE = 8;     // PI slice values staged per thread (q*4*P*P / blockDim)
 
 struct SweepChunks { int nchunks, len; };
@@ -208,14 +211,27 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
             double bv[Q ? Q : 1];
 #pragma unroll
             for (int l = 0; l < Q; ++l) bv[l] = fp[(long long)l * A.NPL];      // Q loads in flight
+            // the values of the second source as well (single-type groups): loaded inside the loop below each of them is
+            // awaited on its own, Q memory latencies per span in a row
+            double xv[Q ? Q : 1];
+            const bool xpre = HASX && NT == 1 && P >= SA_XPRE_MINP && xp[0];
+            if (xpre) {
+#pragma unroll
+                for (int l = 0; l < Q; ++l) xv[l] = xp[0][(long long)l * A.NPL];
+            }
             __syncthreads();                              // slice `buf` is complete
 #pragma unroll
             for (int l = 0; l < Q; ++l) accumulate(l, bv[l]);
+            if (xpre) {
+#pragma unroll
+                for (int l = 0; l < Q; ++l) accumulate_x(0, xt0, l, xv[l]);
+                xp[0] += (long long)q * A.NPL;
+            }
         } else {
             __syncthreads();
             for (int l = 0; l < q; ++l) accumulate(l, fp[(long long)l * A.NPL]);
         }
-        if (HASX) {
+        if (HASX && !(Q && NT == 1 && P >= SA_XPRE_MINP)) {
 #pragma unroll
             for (int ty = 0; ty < NT; ++ty)
                 if (xp[ty]) {
