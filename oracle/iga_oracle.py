@@ -572,6 +572,49 @@ class Assembler:
         return out
 
 
+def local_entries(kind, kvs, geo, idx, coeff=None, table=None):
+    """Entries (i, j) of a patch that is too large for Assembler (the fields of BASELINE configs 4 and 5 take 12.6 GB + the
+    Jacobians): the same entry sums (orc_entries / genericasm.pxi:677-758) with everything geometry-dependent evaluated on
+    the Gauss points of each pair's support intersection only -- what the reference's on-demand assemblers do with a bounding
+    box (pyiga/codegen/cython.py:541-559).  Pairs with disjoint supports give 0.0."""
+    kvs = tuple(kvs)
+    dim = len(kvs)
+    nqp = max(kv.p for kv in kvs) + 1
+    shape = tuple(kv.numdofs for kv in kvs)
+    supp = [kv.mesh_support_idx_all() for kv in kvs]
+    out = np.zeros(len(idx))
+    for k, (I, J) in enumerate(np.asarray(idx, dtype=np.int64)):
+        i, j = np.unravel_index(int(I), shape), np.unravel_index(int(J), shape)
+        cells = [(max(supp[a][i[a], 0], supp[a][j[a], 0]), min(supp[a][i[a], 1], supp[a][j[a], 1])) for a in range(dim)]
+        if any(lo >= hi for lo, hi in cells):
+            continue
+        sub = Assembler.__new__(Assembler)
+        sub.kind, sub.kvs, sub.dim, sub.nqp = kind, kvs, dim, nqp
+        sub.nder = 1 if kind == 'mass' else 2
+        sub.grid, sub.gw = make_tensor_quadrature([kv.mesh[lo:hi + 1] for kv, (lo, hi) in zip(kvs, cells)], nqp)
+        ng = [g.shape[0] for g in sub.grid]
+        # supports in local Gauss indices (clipped to the box; only the rows of i and j are read)
+        sub.meshsupp = [np.ascontiguousarray(np.clip(nqp * (supp[a] - cells[a][0]), 0, ng[a]), dtype=np.int64) for a in range(dim)]
+        sub.C = [compute_values_derivs(kv, g, sub.nder - 1) for kv, g in zip(kvs, sub.grid)]
+        jac = np.ascontiguousarray(grid_jacobian(geo, sub.grid))
+        if kind == 'convdiff':
+            xphys = grid_eval(geo, sub.grid)
+            c = coeff(xphys[..., 0], xphys[..., 1], xphys[..., 2]) * np.ones(xphys.shape[:-1])
+            sub.fields = np.ascontiguousarray(precompute_fields_convdiff(jac, xphys, c, sub.gw))
+        elif kind == 'form':
+            xphys = grid_eval(geo, sub.grid)
+            G = xphys.shape[:-1]
+            vals = [[None if e is None else np.broadcast_to(e(*(xphys[..., c] for c in range(dim))) if callable(e) else e, G)
+                     for e in row] for row in table]
+            sub.fields = np.ascontiguousarray(precompute_fields_form(jac, vals, sub.gw))
+        else:
+            sub.fields = np.ascontiguousarray(precompute_fields(kind, jac, sub.gw))
+        sub.ndofs = np.array(shape, dtype=np.uintp)
+        sub.ngauss = np.array(ng, dtype=np.uintp)
+        out[k] = sub.multi_entries(np.array([[I, J]], dtype=np.uintp))[0]
+    return out
+
+
 def lower_pattern(kvs):
     """MLStructure.from_kvs + nonzero(lower_tri=True): pyiga/mlmatrix.py:59-65,113-130."""
     bidx = [compute_sparsity_ij(kv, kv) for kv in kvs]

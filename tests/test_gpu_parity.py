@@ -760,7 +760,7 @@ def test_full_size_c3(iga, monkeypatch):
     assert abs(M.sum() - 0.75 * np.pi) < 1e-9
 
 
-def test_full_size_c4(iga, monkeypatch):
+def test_full_size_c4(iga, oracle, monkeypatch):
     """BASELINE config 4 at full size (3D p=4, 128^3 spans, 1.59 G nonzeros), memory-light: the values come
     back without the index arrays; row sums vanish (K 1 = 0), sampled rows agree with the entry-wise kernel,
     sampled entry pairs are exactly symmetric, nothing is left unwritten."""
@@ -791,6 +791,16 @@ def test_full_size_c4(iga, monkeypatch):
         cols = S.indices[S.indptr[r]:S.indptr[r + 1]].astype(np.int64)
         pos_t, _ = _positions(kvs, cols, np.full_like(cols, r))
         assert np.array_equal(data[pos_t], data[lo:lo + ref.size])      # A[J, I] == A[I, J] bit for bit
+    # ... and against the CPU oracle at THIS size: the reference's entry sums with the fields evaluated on each pair's support
+    # intersection only (oracle.local_entries; bit-identical to the oracle assembler that the reference goldens pin)
+    okv = oracle.make_knots(4, 0., 1., 128)
+    def picks(r):
+        cols = S.indices[S.indptr[r]:S.indptr[r + 1]]
+        return np.stack([np.full(3, r), cols[[0, cols.size // 2, -1]]], 1)
+    pr = np.concatenate([picks(r) for r in sample[::6]])
+    ref = oracle.local_entries('stiffness', (okv,) * 3, oracle.geo_cylinder(), pr)
+    pos, _ = _positions(kvs, pr[:, 0].astype(np.int64), pr[:, 1].astype(np.int64))
+    assert np.abs(data[pos] - ref).max() <= RTOL * scale
 
 
 def test_fast_variants_match_fixtures(iga, capsys):
@@ -865,7 +875,7 @@ def test_full_size_c5(iga, monkeypatch):
         assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
 
 
-def test_full_size_c5_affine_coefficient(iga, golden, monkeypatch):
+def test_full_size_c5_affine_coefficient(iga, golden, oracle, monkeypatch):
     """The coefficient of BASELINE config 5 as bench.py passes it -- AffineCoefficient(1, 1): 1 + x evaluated ON THE DEVICE
     through the geometry map -- pinned (i) at p=5 n=24 to the reference's matrix (golden_fullsize p5n24_convdiff, made with
     the host-sampled lambda) and (ii) at full size to the host-sampled lambda on sampled rows and through the row sums."""
@@ -894,6 +904,17 @@ def test_full_size_c5_affine_coefficient(iga, golden, monkeypatch):
     for r in sample:
         ref = S.data[S.indptr[r]:S.indptr[r + 1]]
         assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
+    # (iii) against the CPU oracle at THIS size (oracle.local_entries: the reference's entry sums, fields on the support
+    # intersection of each pair only)
+    okv = oracle.make_knots(5, 0., 1., 96)
+    pr = []
+    for r in sample[::8]:
+        cols = S.indices[S.indptr[r]:S.indptr[r + 1]]
+        pr.append(np.stack([np.full(3, r), cols[[0, cols.size // 2, -1]]], 1))
+    pr = np.concatenate(pr)
+    ref = oracle.local_entries('convdiff', (okv,) * 3, oracle.geo_cylinder(), pr, coeff=lambda x, y, z: 1.0 + x)
+    pos, _ = _positions(kvs, pr[:, 0].astype(np.int64), pr[:, 1].astype(np.int64))
+    assert np.abs(data[pos] - ref).max() <= RTOL * scale
 
 
 def test_repeatability(iga):

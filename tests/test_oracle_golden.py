@@ -155,6 +155,8 @@ def test_golden_entries(oracle, golden):
         assert np.array_equal(out == 0.0, ref == 0.0)          # out-of-pattern pairs give exact 0.0
         assert np.abs(asm.entries_python(idx) - ref).max() <= 1e-14 * scale
         assert np.array_equal(asm.multi_entries(idx, nthreads=4), out)   # thread-count independent
+        # the box-local form used at the BASELINE sizes (fields only on a pair's support intersection): same sums, same bits
+        assert np.array_equal(oracle.local_entries(kind, (kv,) * 3, oracle.geo_cylinder(), idx), out)
     kv2 = oracle.make_knots(3, 0., 1., 6)
     for name, kind in (('stiff2d', 'stiffness'), ('mass2d', 'mass')):
         asm = oracle.Assembler(kind, (kv2,) * 2, oracle.geo_quarter_annulus())
@@ -162,6 +164,7 @@ def test_golden_entries(oracle, golden):
         ref = g[name + '_multi']
         assert np.abs(out - ref).max() <= 1e-14 * np.abs(ref).max()
         assert np.abs(asm.entries_python(g[name + '_idx']) - ref).max() <= 1e-14 * np.abs(ref).max()
+        assert np.array_equal(oracle.local_entries(kind, (kv2,) * 2, oracle.geo_quarter_annulus(), g[name + '_idx']), out)
 
 
 def test_1d_literal_and_kron(oracle, golden):
