@@ -27,7 +27,7 @@ class TExpr:
 
     def __init__(self, a, shape, kind, who=None, const=False):
         self.a, self.shape, self.kind, self.who, self.const = a, tuple(shape), kind, who, const
-        # kind: 'c' coefficient, 'l' linear in basis function `who` (a name), 'b' bilinear (test function first)
+        # kind: 'c' coefficient, 'l' linear in basis function `who` = (name, is_test_function), 'b' bilinear (test function first)
 
     # ---- helpers
     @property
@@ -76,8 +76,8 @@ class TExpr:
             return TExpr(c._expand(0, 0, 4) * b.a, (), 'b')
         if kinds == 'll':
             if self.who == o.who:
-                raise NotImplementedError('the form is not bilinear: two factors contain %s' % self.who)
-            t, s = (self, o) if self.who == _NAMES['test'] else (o, self)       # test function first
+                raise NotImplementedError('the form is not bilinear: two factors contain %s' % self.who[0])
+            t, s = (self, o) if self.who[1] else (o, self)       # test function first
             return TExpr(t._expand(nd, 0, 2) * s._expand(nd, 2, 0), shape, 'b')
         raise NotImplementedError('the form is not bilinear')
 
@@ -147,9 +147,6 @@ class TExpr:
 
     def dot(self, o):
         return dot(self, o)
-
-
-_NAMES = {'test': 'v'}
 
 
 def stack(items):
@@ -238,8 +235,8 @@ def _mul_raw(self, o, nd):
         return TExpr(A * B[..., None, None], (), 'l', self.who, self.const and o.const)
     if kinds == 'll':
         if self.who == o.who:
-            raise NotImplementedError('the form is not bilinear: two factors contain %s' % self.who)
-        if self.who == _NAMES['test']:
+            raise NotImplementedError('the form is not bilinear: two factors contain %s' % self.who[0])
+        if self.who[1]:
             return TExpr(A[..., None, None] * B[..., None, None, :, :], (), 'b')
         return TExpr(B[..., None, None] * A[..., None, None, :, :], (), 'b')
     raise NotImplementedError('the form is not bilinear')
@@ -361,18 +358,18 @@ def evaluate(expr, G, X, inputs, bfuns=None, normal=None):
     bf = normalise_bfuns(expr, bfuns)
     if len(bf) not in (1, 2):
         raise ValueError('arity should be 1 or 2')
-    _NAMES['test'] = bf[-1][0]
     J = d + 1
     ns = {}
     for name, nc in bf:
+        who = (name, name == bf[-1][0])                   # the last function of `bfuns` is the test function
         a = np.zeros((1,) * len(G) + ((nc,) if nc > 1 else ()) + (nc, J))
         if nc > 1:
             for c in range(nc):
                 a[(0,) * len(G) + (c, c, 0)] = 1.0
-            ns[name] = TExpr(a, (nc,), 'l', name, True)
+            ns[name] = TExpr(a, (nc,), 'l', who, True)
         else:
             a[..., 0, 0] = 1.0
-            ns[name] = TExpr(a, (), 'l', name, True)
+            ns[name] = TExpr(a, (), 'l', who, True)
     grad = make_grad(d)
 
     def div(e):
