@@ -1522,3 +1522,32 @@ def test_assembler_class_with_updatable_inputs(iga):
     M1 = asm.assemble()
     M2 = asm.assemble(c=lambda x, y: 2.0 + 2.0 * x)
     assert rel_maxdiff(M2, 2.0 * M1) <= RTOL
+
+
+def test_ondemand_bbox_random_cases(iga):
+    """Bounding-box assemblers on random spaces (degrees 1..4, repeated interior knots, 2D and 3D, NURBS / B-spline geometry): the
+    rows of a random cluster of functions from a boxed assembler equal the whole-patch assembler's."""
+    rng = np.random.default_rng(17)
+    g = iga.geometry
+    for case in range(12):
+        d = 3 if case % 3 else 2
+        kvs = []
+        for k in range(d):
+            p = int(rng.integers(1, 5))
+            kv = iga.bspline.make_knots(p, 0.0, 1.0, int(rng.integers(3, 9)), mult=int(rng.integers(1, max(2, p))))
+            kvs.append(kv)
+        kvs = tuple(kvs)
+        geo = (g.quarter_annulus() if case % 2 else g.bspline_quarter_annulus()) if d == 2 else (_geo(iga, 'cylinder') if case % 2 else g.twisted_box())
+        cls = {2: (iga.assemblers.MassAssembler2D, iga.assemblers.StiffnessAssembler2D),
+               3: (iga.assemblers.MassAssembler3D, iga.assemblers.StiffnessAssembler3D)}[d][case % 2]
+        nd = [kv.numdofs for kv in kvs]
+        centre = [int(rng.integers(0, n)) for n in nd]
+        multi = np.stack([np.clip(c + rng.integers(-1, 2, 6), 0, n - 1) for c, n in zip(centre, nd)], 1)
+        rows = np.unique(np.ravel_multi_index(multi.T, nd))
+        bbox = iga.assemble.bbox_for_rows(kvs, rows)
+        full, boxed = cls(kvs, geo), cls(kvs, geo, bbox=bbox)
+        A = iga.assemble.assemble_partial_rows(full, rows)
+        B = iga.assemble.assemble_partial_rows(boxed, rows)
+        assert np.array_equal(A.indices, B.indices) and np.array_equal(A.indptr, B.indptr)
+        assert np.isfinite(B.data).all()
+        assert np.abs(A.data - B.data).max() <= RTOL * np.abs(A.data).max(), (case, d)
