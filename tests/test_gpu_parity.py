@@ -1551,3 +1551,25 @@ def test_ondemand_bbox_random_cases(iga):
         assert np.array_equal(A.indices, B.indices) and np.array_equal(A.indptr, B.indptr)
         assert np.isfinite(B.data).all()
         assert np.abs(A.data - B.data).max() <= RTOL * np.abs(A.data).max(), (case, d)
+
+
+def test_boundary_integrals_divergence_theorem(iga):
+    """Normals, surface measures and orientation of every face at once: sum over the faces of  F . n  against the volume
+    integral of  div F  (the basis functions sum to one, so summing a load vector integrates its coefficient).  The two sides
+    agree to the accuracy of the Gauss rule on the rational integrands of a NURBS map (1e-9 here); a wrong sign, normal or
+    measure on any face is an O(1) error."""
+    mk = iga.bspline.make_knots
+    asm = iga.assemble.assemble
+    kvs3 = (mk(2, 0., 1., 3), mk(3, 0., 1., 4), mk(2, 0., 1., 5))
+    cyl = _geo(iga, 'cylinder')
+    F3 = lambda x, y, z: (x * z, y * y, z * x + y)
+    vol = asm('d * v * dx', kvs3, geo=cyl, d=lambda x, y, z: z + 2 * y + x).sum()
+    sur = sum(asm('inner(F, n) * v * ds', kvs3, geo=cyl, boundary=s, F=F3).sum() for s in ('left', 'right', 'bottom', 'top', 'front', 'back'))
+    assert abs(vol - sur) <= 1e-7 * abs(vol)
+    for geo in (_geo(iga, 'quarter_annulus'), iga.geometry.bspline_quarter_annulus()):
+        kvs2 = (mk(3, 0., 1., 6), mk(2, 0., 1., 7))
+        F2 = lambda x, y: (x * y, y * y - x)
+        vol = asm('d * v * dx', kvs2, geo=geo, d=lambda x, y: 3 * y).sum()
+        sur = sum(asm('inner(F, n) * v * ds', kvs2, geo=geo, boundary=s, F=F2).sum() for s in ('left', 'right', 'bottom', 'top'))
+        # (the B-spline annulus is an approximate circle: the theorem holds on whatever domain the map describes)
+        assert abs(vol - sur) <= 1e-7 * abs(vol)
