@@ -801,6 +801,16 @@ def test_full_size_c4(iga, oracle, monkeypatch):
     ref = oracle.local_entries('stiffness', (okv,) * 3, oracle.geo_cylinder(), pr)
     pos, _ = _positions(kvs, pr[:, 0].astype(np.int64), pr[:, 1].astype(np.int64))
     assert np.abs(data[pos] - ref).max() <= RTOL * scale
+    # ... and the work-balanced row slabs of the 8-GPU split reproduce their rows of this matrix bit for bit (first, an inner and
+    # the last slab: what every rank of `bench.py --gpus 8` computes)
+    asm.patch.close()
+    for r in (0, 3, 7):
+        lo, hi = iga.distributed.slab_range(N, r, 8, 4)
+        sl = iga.assemblers.DevicePatch(kvs, _geo(iga, 'cylinder'), row0=(lo, hi))
+        part = sl.assemble('stiffness', algo='sumfact', to_host=True)
+        a, b = indptr[lo * N * N], (indptr[hi * N * N] if hi < N else data.size)
+        assert part.size == b - a and np.array_equal(part, data[a:b]), r
+        sl.close()
 
 
 def test_fast_variants_match_fixtures(iga, capsys):
