@@ -10,7 +10,7 @@ import ctypes
 kv = bspline.make_knots(4, 0.0, 1.0, 128)
 geo = geometry.tensor_product(geometry.line_segment(0.0, 1.0), geometry.quarter_annulus())
 patches = []
-for rep in range(8):
+for rep in range(int(os.environ.get("NPATCH", "6"))):
     patch = assemblers.DevicePatch((kv, kv, kv), geo)
     patches.append(patch)
     for _ in range(2):
