@@ -980,7 +980,9 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
 // two lane groups + eight contractors at the 3D forms because the larger tile needs fewer instructions per row.
 // (P = 6: the window of a 192-point tile does not fit LDS next to the rings; two lane groups, 168 registers per wave)
 template <int P, int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
-template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P <= 5 ? 3 : 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
+// mass, measured per degree (k_bf2 ms, (NLG, NCW)): p = 1 n = 96: (3,8) 0.13, (2,4) 0.08; p = 2 n = 64: 0.11 / 0.08;
+// p = 3 n = 96: 1.78 / 1.30; p = 4 n = 128: (3,8) 3.89, (2,4) 4.34
+template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1; };
 // 3D stiffness, measured per degree (tools/shape_try.py; k_bf2 ms at n = 64 / 128, shapes (NLG, NCW, NH)):
 //   p = 1: (3,4,2) 0.32 / 0.61, (2,4,1) 0.25 / 0.56        p = 2: (3,4,2) 0.29 / 1.53, (2,4,1) 0.21 / 1.53
 //   p = 3: (3,4,2) 0.92 / 6.42, (3,4,1) 0.74 / 4.78, (2,8,1) 0.70 / 4.46   (the halved passes cost more than they balance)

@@ -10,7 +10,7 @@ geo = geometry.tensor_product(geometry.line_segment(0.0, 1.0), geometry.quarter_
 out = []
 for p, n in [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or ((1, 96), (2, 64), (3, 64), (4, 48)):
     kv = bspline.make_knots(p, 0.0, 1.0, n)
-    for kind in ("stiffness",):
+    for kind in (os.environ.get("KIND", "stiffness"),):
         patch = assemblers.DevicePatch((kv, kv, kv), geo)
         for _ in range(3):
             patch.assemble(kind, to_host=False)
