@@ -362,6 +362,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
         if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");
         k.poison = getenv("IGX_DEBUG_POISON") != nullptr;
+        if (const char *e = getenv("IGX_STAGE_EVENTS")) k.stage_events = strcmp(e, "0") != 0;
     }
     if (pt) for (int k = 0; k < 16; ++k) pt->form_slot[k] = -1;
     if (!pt) return nullptr;
@@ -386,6 +387,11 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     if (dim == 2) {            // neutral third axis for index arithmetic
         pt->ax[2].N = 1; pt->ax[2].n = 1; pt->ax[2].G = 1; pt->ax[2].S = 1; pt->ax[2].q = q;
         pt->ax[2].dev.N = 1; pt->ax[2].dev.n = 1; pt->ax[2].dev.G = 1; pt->ax[2].dev.S = 1; pt->ax[2].dev.q = q;
+    }
+    if (!rc && pt->knobs.stage_events < 0) {   // default: per-kernel events where the kernels run for milliseconds
+        long long npts = 1;
+        for (int k = 0; k < dim; ++k) npts *= pt->ax[k].G;
+        pt->knobs.stage_events = dim == 3 && npts >= (1ll << 24);
     }
     // span box (on-demand assemblers): fields on a window of every axis, batched entries only
     for (int k = 0; k < dim && !rc; ++k) pt->boxed = pt->boxed || d->box_hi[k] != 0 || d->box_lo[k] != 0;
@@ -621,7 +627,10 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (algo != IGX_ALGO_SUMFACT || sumfact_needs_fields(pt, kind)) rc = ensure_fields(pt, kind);
     if (rc) return rc;
     pt->timing.n_launches = 1;
-    IGX_HIP(hipEventRecord(ev[1], st));
+    // k_single2d: first and last event only (one launch); a chain without stage events likewise
+    const bool one_launch = algo == IGX_ALGO_SUMFACT && !sumfact_needs_fields(pt, kind) && pt->dim == 2;
+    const bool staged = !one_launch && pt->knobs.stage_events;
+    if (staged) IGX_HIP(hipEventRecord(ev[1], st));
     if (algo == IGX_ALGO_SUMFACT) {
         rc = sumfact_assemble(pt, kind, pt->d_data);
         if (rc) return rc;
@@ -629,7 +638,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         rc = launch_entries_csr(st, pt, kind, pt->d_data);
         if (rc) return rc;
         pt->timing.n_launches++;
-        IGX_HIP(hipEventRecord(ev[4], st));
+        if (staged) IGX_HIP(hipEventRecord(ev[4], st));
     }
     IGX_HIP(hipEventRecord(ev[5], st));
     IGX_HIP(hipStreamSynchronize(st));
@@ -638,12 +647,15 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         if (e != hipSuccess) { set_error("igx_assemble: kernel failure: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
     }
     (void)hipEventElapsedTime(&pt->timing.total_ms, ev[0], ev[5]);
-    (void)hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
-    if (algo == IGX_ALGO_SUMFACT) {
+    if (one_launch) pt->timing.stage1_ms = pt->timing.total_ms;
+    if (!staged) {                              // only the whole interval was timed
+    } else if (algo == IGX_ALGO_SUMFACT) {
+        (void)hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
         (void)hipEventElapsedTime(&pt->timing.stage0_ms, ev[1], ev[2]);
         (void)hipEventElapsedTime(&pt->timing.stage1_ms, ev[2], ev[3]);
         (void)hipEventElapsedTime(&pt->timing.final_ms, ev[3], ev[4]);
     } else {
+        (void)hipEventElapsedTime(&pt->timing.fields_ms, ev[0], ev[1]);
         (void)hipEventElapsedTime(&pt->timing.entry_ms, ev[1], ev[4]);
     }
     if (data_out) {

@@ -115,7 +115,14 @@ struct igx_knobs {
     int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
     int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
     int poison = 0;                           // IGX_DEBUG_POISON: NaN-fill the CSR values before an assembly (tests)
+    int stage_events = -1;                    // IGX_STAGE_EVENTS: events between the kernels of a chain (per-kernel device times in
+                                              // igx_last_timing).  A marker costs ~5 us of stream time: default on for 3D patches of
+                                              // >= 2^24 Gauss points (kernels of milliseconds), off below and in 2D (kernels of
+                                              // 5-40 us), where only the whole interval is timed
 };
+
+struct igx_patch;
+static inline void stage_event(const igx_patch *pt, int k, hipStream_t st);
 
 struct igx_patch {
     igx_ctx *ctx = nullptr;
@@ -181,6 +188,12 @@ struct igx_patch {
     igx_timing timing{};
 };
 
+static inline void stage_event(const igx_patch *pt, int k, hipStream_t st)
+{
+    if (pt->knobs.stage_events) (void)hipEventRecord(pt->ctx->ev[k], st);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (defined in the kern_*.hip files)
 namespace igx {
@@ -192,6 +205,7 @@ int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_
 int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields);
 // 2D mass / stiffness in one launch, no intermediates (kern_basis.hip)
 bool single2d_supported(const igx_patch *pt, int kind);
+long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows);   // launch grid of the single-launch kernel (-1: no tile fits), rows per tile
 int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data);
 int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3],
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);

@@ -454,20 +454,25 @@ int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_f
 // ---------------------------------------------------------------------------------------------
 // 2D mass / stiffness in ONE launch (BASELINE configs 1, 2; pyiga/assemblers.pyx:86-135,234-349 fields + combine).
 // The stage kernels need three dependent launches and two HBM intermediates for a problem whose whole output is a few
-// MB: launch-bound.  Here a block owns R0 x R1 rows (dofs i0 x i1) and keeps everything in LDS:
-//   1. fields (W, or the upper triangle of W J^-1 J^-T) on the Gauss window of its rows, straight from the geometry;
-//   2. per row i0: axis-0 sweep  K1[j0][y][g1] = sum_g0 (V0[j0][tu] * V0[i0][tv]) * field_y(g0, g1)  for every column
-//      partner j0 (the FULL window: no mirror pass) and the terms y of the form;
+// MB: launch-bound.  Here a block of 1024 threads owns R0 x R1 rows (dofs i0 x i1) and keeps everything in LDS:
+//   0. every table it needs (basis values of both axes on its Gauss window, supports, first active functions, pair
+//      ranges) is staged ONCE -- the phases below touch no global memory except the control net and the output;
+//   1. fields (W, or the upper triangle of W J^-1 J^-T) on the window: the geometry map line-wise (control net contracted
+//      with the axis-0 basis per Gauss plane first, then (p_g + 1) (nc) products per point);
+//   2. axis-0 sweep  K1[r][j0][y][g1] = sum_g0 (V0[j0][tu] * V0[i0][tv]) * field_y(g0, g1)  for all rows of the tile, every
+//      column partner j0 (the FULL window: no mirror pass) and the terms y of the form;
 //   3. contraction along axis 1 for the block's entries, written to their (contiguous) CSR positions:
-//      entry = (T0 + T3) + (T1 + T2),  T_y = sum_g1 (V1[j1][tu] * V1[i1][tv]) * K1[j0][y][g1].
-// Every product of two basis values is formed once and the sums run over the support intersection in ascending order, so
-// entry (j, i) repeats the arithmetic of entry (i, j) with T1 and T2 exchanged: the matrix is symmetric bit for bit.
+//      entry = (T0 + T3) + (T1 + T2),  T_y = sum_g1 (V1[j1][tu] * V1[i1][tv]) * K1[r][j0][y][g1].
+// Three barriers per block.  Every product of two basis values is formed once and the sums run over the support
+// intersection in ascending order, so entry (j, i) repeats the arithmetic of entry (i, j) with T1 and T2 exchanged: the
+// matrix is symmetric bit for bit.
 struct Single2DArgs {
     PatchDev pd;
     GeoView gv;
     int geo_kind;
     const double *jac;         // IGX_GEO_JACOBIAN: resident slab of the user array
     int R0, R1, NG0, WIN;      // rows per block, LDS extents (planes of axis 0, window points of axis 1)
+    int NCOL;                  // geometry control columns of axis 1 a window can touch (LDS extent of the line coefficients)
     double *data;
 };
 
@@ -475,104 +480,156 @@ template <int KIND>
 __global__ void __launch_bounds__(1024) k_single2d(const Single2DArgs A)
 {
     constexpr int NF = KIND == IGX_MASS ? 1 : 3, NY = KIND == IGX_MASS ? 1 : 4;
-    // term y: field, axis-0 type of u / v, axis-1 type of u / v (0 value, 1 derivative)
-    // (axis 1: u d d v v... spelled out in step 3: y = 0 (d, d), 1 (v, d), 2 (d, v), 3 (v, v))
-    constexpr int YF[4] = {0, 1, 1, 2}, U0[4] = {0, 1, 0, 1}, W0[4] = {0, 0, 1, 1};
+    // term y: field, axis-0 type of u / v (0 value, 1 derivative); axis 1: y = 0 (d, d), 1 (v, d), 2 (d, v), 3 (v, v)
     extern __shared__ double lds[];
     const PatchDev &pd = A.pd;
     const AxisDev &A0 = pd.ax[0], &A1 = pd.ax[1];
-    const int q = A0.q, P0 = A0.P, P1 = A1.P, NG0 = A.NG0, WIN = A.WIN, C0M = 2 * P0 - 1;
+    const int q = A0.q, P0 = A0.P, P1 = A1.P, p0 = P0 - 1, p1 = P1 - 1, NG0 = A.NG0, WIN = A.WIN, C0M = 2 * P0 - 1, NCOL = A.NCOL;
     const int tid = threadIdx.x, NT = blockDim.x;
-    const int i0a = pd.r0_lo + blockIdx.y * A.R0, i0b = min(i0a + A.R0, pd.r0_hi);
-    const int i1a = blockIdx.x * A.R1, i1b = min(i1a + A.R1, A1.N);
-    const int g0b = A0.mslo[i0a] * q, nG0 = A0.mshi[i0b - 1] * q - g0b;
-    const int g1b = A1.mslo[i1a] * q, w1 = A1.mshi[i1b - 1] * q - g1b;
+    const int i0a = pd.r0_lo + blockIdx.y * A.R0, i0b = min(i0a + A.R0, pd.r0_hi), nr0 = i0b - i0a;
+    const int i1a = blockIdx.x * A.R1, i1b = min(i1a + A.R1, A1.N), nr1 = i1b - i1a;
+    const int s0b = A0.mslo[i0a], g0b = s0b * q, nG0 = A0.mshi[i0b - 1] * q - g0b;
+    const int s1b = A1.mslo[i1a], g1b = s1b * q, w1 = A1.mshi[i1b - 1] * q - g1b;
+    // dofs whose tables are staged: the tile's rows and their column partners
+    const int d0lo = max(i0a - p0, 0), nd0 = min(i0b + p0, A0.N) - d0lo;
+    const int d1lo = max(i1a - p1, 0), nd1 = min(i1b + p1, A1.N) - d1lo;
     double *fld = lds;                                   // [NF][NG0][WIN]
-    double *K1 = fld + NF * NG0 * WIN;                   // [C0M][NY][WIN]
-    double *V1s = K1 + C0M * NY * WIN;                   // [WIN][P1][2]
-    double *c0s = V1s + WIN * P1 * 2;                    // [C0M][NY][NG0]
-    // ---- 1. fields on the window
+    double *K1 = fld + NF * NG0 * WIN;                   // [R0][C0M][NY][WIN]
+    double *V0s = K1 + A.R0 * C0M * NY * WIN;            // [NG0][P0][2]
+    double *V1s = V0s + NG0 * P0 * 2;                    // [WIN][P1][2]
+    double *Lc = V1s + WIN * P1 * 2;                     // [NG0][NCOL][MAX_COMP][2]: (value, d/d axis 0) of the net contracted along axis 0
+    int *it = (int *)(Lc + NG0 * NCOL * MAX_COMP * 2);
+    int *ms0 = it, *me0 = ms0 + (A.R0 + 2 * p0), *fa0 = me0 + (A.R0 + 2 * p0);          // supports of the staged dofs, first active per span
+    int *jl0 = fa0 + (A.R0 + p0), *rp0s = jl0 + 2 * A.R0;                                    // (jlo, count) and rp0 of the tile's rows
+    int *ms1 = rp0s + A.R0, *me1 = ms1 + (A.R1 + 2 * p1), *fa1 = me1 + (A.R1 + 2 * p1);
+    int *jl1 = fa1 + (A.R1 + p1), *rp1s = jl1 + 2 * A.R1;
+    // ---- 0. staging
+    for (int i = tid; i < nG0 * P0 * 2; i += NT) V0s[i] = A0.V[(size_t)g0b * P0 * 2 + i];
+    for (int i = tid; i < w1 * P1 * 2; i += NT) V1s[i] = A1.V[(size_t)g1b * P1 * 2 + i];
+    for (int i = tid; i < nd0; i += NT) { ms0[i] = A0.mslo[d0lo + i]; me0[i] = A0.mshi[d0lo + i]; }
+    for (int i = tid; i < nd1; i += NT) { ms1[i] = A1.mslo[d1lo + i]; me1[i] = A1.mshi[d1lo + i]; }
+    for (int i = tid; i < nG0 / q; i += NT) fa0[i] = A0.fa[s0b + i];
+    for (int i = tid; i < w1 / q; i += NT) fa1[i] = A1.fa[s1b + i];
+    for (int i = tid; i < nr0; i += NT) { jl0[2 * i] = A0.jlo[i0a + i]; jl0[2 * i + 1] = A0.jhi[i0a + i] - A0.jlo[i0a + i]; rp0s[i] = A0.rp[i0a + i]; }
+    for (int i = tid; i < nr1; i += NT) { jl1[2 * i] = A1.jlo[i1a + i]; jl1[2 * i + 1] = A1.jhi[i1a + i] - A1.jlo[i1a + i]; rp1s[i] = A1.rp[i1a + i]; }
+    // ---- 1a. geometry: the control net contracted with the axis-0 basis of every plane of the window
+    const bool spline = A.geo_kind != IGX_GEO_JACOBIAN;
+    const int nc = A.gv.nc;
+    int colb = 0, ncol = 0;
+    if (spline) {
+        colb = A.gv.fa[1][g1b];
+        ncol = A.gv.fa[1][g1b + w1 - 1] + A.gv.P[1] - colb;
+        for (int i = tid; i < nG0 * ncol * nc; i += NT) {
+            const int a = i / (ncol * nc), rem = i - a * (ncol * nc), col = rem / nc, c = rem - col * nc;
+            const int g0 = g0b + a, f0 = A.gv.fa[0][g0];
+            const double *Vg = A.gv.V[0] + (size_t)g0 * A.gv.P[0] * 2;
+            double sv = 0.0, sd = 0.0;
+            for (int a0 = 0; a0 < A.gv.P[0]; ++a0) {
+                const double cf = A.gv.ctrl[((size_t)(f0 + a0) * A.gv.N[1] + (colb + col)) * nc + c];
+                sv += Vg[a0 * 2] * cf;
+                sd += Vg[a0 * 2 + 1] * cf;
+            }
+            double *dst = Lc + ((size_t)(a * NCOL + col) * MAX_COMP + c) * 2;
+            dst[0] = sv; dst[1] = sd;
+        }
+    }
+    __syncthreads();
+    // ---- 1b. fields on the window
     for (int idx = tid; idx < nG0 * w1; idx += NT) {
         const int a = idx / w1, b = idx - a * w1;
-        const int g[3] = {g0b + a, g1b + b, 0};
+        const int g0 = g0b + a, g1 = g1b + b;
         double t[9];
-        if (A.geo_kind == IGX_GEO_JACOBIAN) {
-            const double *src = A.jac + ((size_t)(g[0] - pd.g0_lo) * A1.G + g[1]) * 4;
+        if (!spline) {
+            const double *src = A.jac + ((size_t)(g0 - pd.g0_lo) * A1.G + g1) * 4;
             t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
         } else {
+            const double *Vg = A.gv.V[1] + (size_t)g1 * A.gv.P[1] * 2;
+            const double *lc = Lc + (size_t)(a * NCOL + (A.gv.fa[1][g1] - colb)) * MAX_COMP * 2;
+            double val[MAX_COMP], jac[MAX_COMP][3];
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c) { val[c] = 0.0; jac[c][0] = jac[c][1] = jac[c][2] = 0.0; }
+            for (int a1 = 0; a1 < A.gv.P[1]; ++a1) {
+                const double n1 = Vg[a1 * 2], d1 = Vg[a1 * 2 + 1];
+#pragma unroll
+                for (int c = 0; c < MAX_COMP; ++c)
+                    if (c < nc) {
+                        const double e0 = lc[(a1 * MAX_COMP + c) * 2], e1 = lc[(a1 * MAX_COMP + c) * 2 + 1];
+                        val[c] += n1 * e0;
+                        jac[c][0] += n1 * e1;             // d / d axis 0
+                        jac[c][1] += d1 * e0;             // d / d axis 1
+                    }
+            }
             double Jm[MAX_COMP][3], ev[MAX_COMP];
-            physical_jacobian<2>(A.gv, A.geo_kind == IGX_GEO_NURBS, g, 2, Jm, ev);
+            finish_jacobian<2>(val, jac, A.geo_kind == IGX_GEO_NURBS, 2, nc, Jm, ev);
             t[0] = Jm[0][0]; t[1] = Jm[0][1]; t[2] = Jm[1][0]; t[3] = Jm[1][1];
         }
         double f[6];
-        fields_values<2>(t, A0.w[g[0]] * A1.w[g[1]], KIND, f);
+        fields_values<2>(t, A0.w[g0] * A1.w[g1], KIND, f);
 #pragma unroll
         for (int k = 0; k < NF; ++k) fld[(k * NG0 + a) * WIN + b] = f[k];
     }
-    for (int idx = tid; idx < w1 * P1 * 2; idx += NT) V1s[idx] = A1.V[(size_t)g1b * P1 * 2 + idx];
     __syncthreads();
-    const long long S1 = A1.S;
-    for (int i0 = i0a; i0 < i0b; ++i0) {
-        const int jl = A0.jlo[i0], c0 = A0.jhi[i0] - jl;
-        const int slo_i = A0.mslo[i0], shi_i = A0.mshi[i0];
-        // ---- 2a. axis-0 coefficients of the row's column partners on their common planes (0 elsewhere)
-        for (int idx = tid; idx < c0 * NG0; idx += NT) {
-            const int jj = idx / NG0, a = idx - jj * NG0;
-            const int j0 = jl + jj, g0 = g0b + a, s = g0 / q;
-            const bool on = a < nG0 && s >= max(slo_i, A0.mslo[j0]) && s < min(shi_i, A0.mshi[j0]);
-            double vu[2] = {0.0, 0.0}, vv[2] = {0.0, 0.0};
-            if (on) {
-                const int fa = A0.fa[s];
-                const double *u = A0.V + ((size_t)g0 * P0 + (j0 - fa)) * 2, *v = A0.V + ((size_t)g0 * P0 + (i0 - fa)) * 2;
-                vu[0] = u[0]; vu[1] = u[1]; vv[0] = v[0]; vv[1] = v[1];
-            }
+    // ---- 2. sweep of axis 0 for every row of the tile (a thread: one column partner, one point of axis 1, every term)
+    for (int idx = tid; idx < nr0 * C0M * w1; idx += NT) {
+        const int rj = idx / w1, b = idx - rj * w1;
+        const int r = rj / C0M, jj = rj - r * C0M;
+        double acc[NY];
 #pragma unroll
-            for (int y = 0; y < NY; ++y) c0s[(jj * NY + y) * NG0 + a] = KIND == IGX_MASS ? vu[0] * vv[0] : vu[U0[y]] * vv[W0[y]];
-        }
-        __syncthreads();
-        // ---- 2b. sweep of axis 0
-        for (int idx = tid; idx < c0 * NY * w1; idx += NT) {
-            const int jy = idx / w1, b = idx - jy * w1;
-            const int jj = jy / NY, y = jy - jj * NY;
-            const int j0 = jl + jj;
-            const int alo = max(slo_i, A0.mslo[j0]) * q - g0b, ahi = min(shi_i, A0.mshi[j0]) * q - g0b;
-            const double *cf = c0s + (size_t)jy * NG0;
-            const double *fp = fld + (size_t)(KIND == IGX_MASS ? 0 : YF[y]) * NG0 * WIN + b;
-            double acc = 0.0;
-            for (int a = alo; a < ahi; ++a) acc = fma(cf[a], fp[(size_t)a * WIN], acc);
-            K1[(size_t)jy * WIN + b] = acc;
-        }
-        __syncthreads();
-        // ---- 3. contraction along axis 1, entries of the rows (i0, i1a .. i1b)
-        const int C1M = 2 * P1 - 1, per_row = c0 * C1M;
-        const long long base0 = (long long)A0.rp[i0] * S1 - pd.nnz_off;
-        for (int slot = tid; slot < (i1b - i1a) * per_row; slot += NT) {
-            const int r = slot / per_row, e = slot - r * per_row;
-            const int i1 = i1a + r;
-            const int jl1 = A1.jlo[i1], c1 = A1.jhi[i1] - jl1;
-            if (e >= c0 * c1) continue;
-            const int jj = e / c1, j1 = jl1 + (e - jj * c1);
-            const int slo = max(A1.mslo[i1], A1.mslo[j1]), shi = min(A1.mshi[i1], A1.mshi[j1]);
-            double T[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < NY; ++y) acc[y] = 0.0;
+        if (jj < jl0[2 * r + 1]) {
+            const int i0 = i0a + r, j0 = jl0[2 * r] + jj;
+            const int slo = max(ms0[i0 - d0lo], ms0[j0 - d0lo]), shi = min(me0[i0 - d0lo], me0[j0 - d0lo]);
+            const double *fp = fld + b;
             for (int s = slo; s < shi; ++s) {
-                const int fa = A1.fa[s];
+                const int fa = fa0[s - s0b];
+                const double *vu = V0s + (size_t)((s * q - g0b) * P0 + (j0 - fa)) * 2;
+                const double *vv = V0s + (size_t)((s * q - g0b) * P0 + (i0 - fa)) * 2;
                 for (int l = 0; l < q; ++l) {
-                    const int b = s * q + l - g1b;
-                    const double *vi = V1s + (size_t)(b * P1 + (i1 - fa)) * 2, *vj = V1s + (size_t)(b * P1 + (j1 - fa)) * 2;
-                    const double vj0 = vj[0], vj1 = vj[1], vi0 = vi[0], vi1 = vi[1];
-                    if (KIND == IGX_MASS) T[0] = fma(vj0 * vi0, K1[(size_t)jj * WIN + b], T[0]);
+                    const double u0 = vu[l * P0 * 2], u1 = vu[l * P0 * 2 + 1], v0 = vv[l * P0 * 2], v1 = vv[l * P0 * 2 + 1];
+                    const double *f = fp + (size_t)(s * q + l - g0b) * WIN;
+                    if (KIND == IGX_MASS) acc[0] = fma(u0 * v0, f[0], acc[0]);
                     else {
-                        const double *kp = K1 + (size_t)jj * NY * WIN + b;
-                        T[0] = fma(vj1 * vi1, kp[0], T[0]);
-                        T[1] = fma(vj0 * vi1, kp[WIN], T[1]);
-                        T[2] = fma(vj1 * vi0, kp[2 * WIN], T[2]);
-                        T[3] = fma(vj0 * vi0, kp[3 * WIN], T[3]);
+                        const double f1 = f[(size_t)NG0 * WIN];
+                        acc[0] = fma(u0 * v0, f[0], acc[0]);                          // (U0, W0)[y] = (0,0), (1,0), (0,1), (1,1)
+                        acc[1] = fma(u1 * v0, f1, acc[1]);
+                        acc[2] = fma(u0 * v1, f1, acc[2]);
+                        acc[3] = fma(u1 * v1, f[(size_t)2 * NG0 * WIN], acc[3]);
                     }
                 }
             }
-            A.data[base0 + (long long)c0 * A1.rp[i1] + e] = KIND == IGX_MASS ? T[0] : (T[0] + T[3]) + (T[1] + T[2]);
         }
-        __syncthreads();
+#pragma unroll
+        for (int y = 0; y < NY; ++y) K1[((size_t)rj * NY + y) * WIN + b] = acc[y];
+    }
+    __syncthreads();
+    // ---- 3. contraction along axis 1: entries of the rows (i0, i1) of the tile
+    const long long S1 = A1.S;
+    const int C1M = 2 * P1 - 1;
+    for (int slot = tid; slot < nr0 * nr1 * C0M * C1M; slot += NT) {
+        const int rr = slot / (C0M * C1M), e_ = slot - rr * (C0M * C1M);
+        const int r = rr / nr1, r1 = rr - r * nr1;
+        const int c0 = jl0[2 * r + 1], c1 = jl1[2 * r1 + 1];
+        if (e_ >= c0 * c1) continue;
+        const int jj = e_ / c1, i1 = i1a + r1, j1 = jl1[2 * r1] + (e_ - jj * c1);
+        const int slo = max(ms1[i1 - d1lo], ms1[j1 - d1lo]), shi = min(me1[i1 - d1lo], me1[j1 - d1lo]);
+        const double *kp0 = K1 + (size_t)(r * C0M + jj) * NY * WIN;
+        double T[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int s = slo; s < shi; ++s) {
+            const int fa = fa1[s - s1b];
+            for (int l = 0; l < q; ++l) {
+                const int b = s * q + l - g1b;
+                const double *vi = V1s + (size_t)(b * P1 + (i1 - fa)) * 2, *vj = V1s + (size_t)(b * P1 + (j1 - fa)) * 2;
+                const double vj0 = vj[0], vj1 = vj[1], vi0 = vi[0], vi1 = vi[1];
+                if (KIND == IGX_MASS) T[0] = fma(vj0 * vi0, kp0[b], T[0]);
+                else {
+                    T[0] = fma(vj1 * vi1, kp0[b], T[0]);
+                    T[1] = fma(vj0 * vi1, kp0[WIN + b], T[1]);
+                    T[2] = fma(vj1 * vi0, kp0[2 * WIN + b], T[2]);
+                    T[3] = fma(vj0 * vi0, kp0[3 * WIN + b], T[3]);
+                }
+            }
+        }
+        A.data[(long long)rp0s[r] * S1 - pd.nnz_off + (long long)c0 * rp1s[r1] + e_] = KIND == IGX_MASS ? T[0] : (T[0] + T[3]) + (T[1] + T[2]);
     }
 }
 
@@ -581,30 +638,61 @@ bool single2d_supported(const igx_patch *pt, int kind)
     return pt->dim == 2 && (kind == IGX_MASS || kind == IGX_STIFFNESS) && pt->ax[0].q == pt->ax[1].q && pt->ax[0].P <= 6 && pt->ax[1].P <= 6;
 }
 
-int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data)
+// tile shape and LDS image of the single-launch kernel for this patch; false if even the smallest tile does not fit.
+// The largest tile that fits LDS does the least redundant work (its Gauss window overlaps the neighbours' by p spans per
+// side); a small patch is latency-bound instead, so the tile shrinks (down to 2 x 4 rows) while the grid still fits one
+// resident round of the chip.
+constexpr long long SINGLE2D_ROUND = 256;                // blocks of one round: one per CU
+static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t &bytes)
 {
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1];
+    const int NF = kind == IGX_MASS ? 1 : 3, NY = kind == IGX_MASS ? 1 : 4, q = A0.q;
+    const bool spline = pt->geo_kind != IGX_GEO_JACOBIAN;
+    const long long nr0 = std::max(pt->r0_hi - pt->r0_lo, 0);
+    static const int shapes[][2] = {{8, 8}, {6, 6}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
+    constexpr int NSHAPE = 7, SMALLEST_WANTED = 3;
+    auto image = [&](int k, Single2DArgs &S) {
+        S.R0 = shapes[k][0]; S.R1 = shapes[k][1];
+        S.NG0 = (S.R0 + A0.p) * q; S.WIN = (S.R1 + A1.p) * q;
+        // geometry columns a window of axis 1 can touch: one new active function per geometry span it enters
+        S.NCOL = spline ? std::min(pt->gax[1].N, (S.R1 + A1.p) + pt->gax[1].P) : 0;
+        const size_t doubles = (size_t)NF * S.NG0 * S.WIN + (size_t)S.R0 * (2 * A0.P - 1) * NY * S.WIN + (size_t)S.NG0 * A0.P * 2 +
+                               (size_t)S.WIN * A1.P * 2 + (size_t)S.NG0 * S.NCOL * MAX_COMP * 2;
+        const size_t ints = (size_t)3 * (S.R0 + 2 * A0.p) + 3 * S.R0 + (size_t)3 * (S.R1 + 2 * A1.p) + 3 * S.R1 + 16;
+        return doubles * sizeof(double) + ints * sizeof(int);
+    };
+    auto blocks = [&](int k) { return ((A1.N + shapes[k][1] - 1) / shapes[k][1]) * ((nr0 + shapes[k][0] - 1) / shapes[k][0]); };
+    int k = 0;
+    while (k < NSHAPE && (bytes = image(k, A)) > 150 * 1024) ++k;
+    if (k == NSHAPE) return false;
+    while (k < SMALLEST_WANTED && blocks(k + 1) <= SINGLE2D_ROUND) ++k;
+    bytes = image(k, A);
+    return true;
+}
+
+long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows)
+{
     Single2DArgs A{};
+    size_t bytes = 0;
+    if (!single2d_plan(pt, kind, A, bytes)) return -1;
+    if (tile_rows) *tile_rows = A.R0 * A.R1;
+    const long long nr0 = std::max(pt->r0_hi - pt->r0_lo, 0);
+    return ((pt->ax[1].N + A.R1 - 1) / A.R1) * ((nr0 + A.R0 - 1) / A.R0);
+}
+
+int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data)
+{
+    const Axis &A1 = pt->ax[1];
+    Single2DArgs A{};
+    size_t bytes = 0;
+    if (!single2d_plan(pt, kind, A, bytes)) { set_error("single-launch 2D kernel: LDS image too large (%zu bytes)", bytes); return IGX_ERR_UNSUPPORTED; }
     A.pd = pt->dev;
     A.gv = make_view(2, pt->gax, pt->d_ctrl, pt->ncomp);
     A.geo_kind = pt->geo_kind; A.jac = pt->d_jac; A.data = d_data;
-    const int NF = kind == IGX_MASS ? 1 : 3, NY = kind == IGX_MASS ? 1 : 4, q = A0.q;
-    static const int shapes[][2] = {{4, 16}, {2, 16}, {2, 8}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
-    size_t bytes = 0;
-    for (const auto &sh : shapes) {
-        A.R0 = sh[0]; A.R1 = sh[1];
-        A.NG0 = (A.R0 + A0.p) * q; A.WIN = (A.R1 + A1.p) * q;
-        bytes = ((size_t)NF * A.NG0 * A.WIN + (size_t)(2 * A0.P - 1) * NY * A.WIN + (size_t)A.WIN * A1.P * 2 + (size_t)(2 * A0.P - 1) * NY * A.NG0) * sizeof(double);
-        if (bytes <= 72 * 1024) break;
-    }
-    if (bytes > 150 * 1024) { set_error("single-launch 2D kernel: LDS image too large (%zu bytes)", bytes); return IGX_ERR_UNSUPPORTED; }
     const int nr0 = pt->r0_hi - pt->r0_lo;
     if (nr0 <= 0) return IGX_OK;
     dim3 grid((unsigned)((A1.N + A.R1 - 1) / A.R1), (unsigned)((nr0 + A.R0 - 1) / A.R0));
-    int nt = 1024;                                       // the phases of a block are short and serial: many threads, short latency
-#ifdef IGX_ABLATE
-    if (const char *e = getenv("IGX_S2D_NT")) nt = atoi(e);
-#endif
+    const int nt = 1024;                                 // the phases of a block are short and serial: many threads, short latency
     if (kind == IGX_MASS) {
         if (bytes > 64 * 1024) IGX_HIP(hipFuncSetAttribute((const void *)k_single2d<IGX_MASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         k_single2d<IGX_MASS><<<grid, dim3(nt), bytes, st>>>(A);

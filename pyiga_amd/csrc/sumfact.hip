@@ -1470,13 +1470,16 @@ static void launch_stageB(hipStream_t st, const double *K1, double *K2, const St
 }
 
 // split a sweep of `nspans` into chunks so that the launch has enough blocks to fill the chip;
-// each chunk re-walks P-1 warm-up spans, so chunks are kept at least 4*P spans long
-static SweepChunks sweep_chunks(long long blocks_without, int nspans, int P)
+// each chunk re-walks P-1 warm-up spans, so chunks are kept at least min_len = 4*P spans long (3D).  A 2D sweep has so few
+// columns that the walk itself -- one dependent step per Gauss plane -- is the kernel's duration: there the chunks go
+// down to P spans (twice the steps in total, a quarter of them in sequence).
+static SweepChunks sweep_chunks(long long blocks_without, int nspans, int P, int min_len = 0)
 {
     SweepChunks c{1, nspans};
     const long long want = 2048;
-    if (blocks_without >= want || nspans < 8 * P) return c;
-    int n = (int)std::min<long long>((want + blocks_without - 1) / blocks_without, nspans / (4 * P));
+    if (min_len <= 0) min_len = 4 * P;
+    if (blocks_without >= want || nspans < 2 * min_len) return c;
+    int n = (int)std::min<long long>((want + blocks_without - 1) / blocks_without, nspans / min_len);
     n = std::max(n, 1);
     c.len = (nspans + n - 1) / n;
     c.nchunks = (nspans + c.len - 1) / c.len;
@@ -1526,13 +1529,20 @@ static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
     return igx_kind_symmetric(kind) && geoA_supported(pt, kind, nslots);
 }
 
-constexpr long long SINGLE2D_MAX_DOFS = 5000;        // measured crossover against the stage-kernel chain (profiles/r03_single2d.txt)
+// The single launch beats the stage-kernel chain while its grid is one resident round of tiles of at most 6 x 6 rows
+// (a block's duration grows with its tile: 14 us at 2 x 4 rows, 27 us at 6 x 6, 39 us at 8 x 8 against 28-34 us of
+// the chain -- profiles/r03_single2d.txt)
+constexpr long long SINGLE2D_MAX_BLOCKS = 256;
+constexpr int SINGLE2D_MAX_TILE = 36;
 static bool single2d_wanted(const igx_patch *pt, int kind)
 {
     // 2D: the single-launch kernel where the stage kernels are launch-bound (small patches), or on request (IGX_PATH=single)
     if (pt->knobs.final_sel || !single2d_supported(pt, kind)) return false;
     if (pt->knobs.path == 3) return true;
-    return pt->knobs.path == 0 && (long long)pt->ax[0].N * pt->ax[1].N <= SINGLE2D_MAX_DOFS;
+    if (pt->knobs.path != 0) return false;
+    int rows = 0;
+    const long long nb = single2d_blocks(pt, kind, &rows);
+    return nb >= 0 && nb <= SINGLE2D_MAX_BLOCKS && rows <= SINGLE2D_MAX_TILE;
 }
 
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
@@ -1581,7 +1591,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
     if (int rc = launch_bf(st, pt, in, d_data)) return rc;
     pt->last_path |= IGX_PATH_FUSED;
     pt->timing.n_launches++;
-    (void)hipEventRecord(pt->ctx->ev[3], st);
+    stage_event(pt, 3, st);
 #ifdef IGX_ABLATE
     if (sym && !getenv("IGX_NO_MIRROR")) {
 #else
@@ -1594,7 +1604,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         pt->last_path |= IGX_PATH_MIRROR;
         pt->timing.n_launches++;
     }
-    (void)hipEventRecord(pt->ctx->ev[4], st);
+    stage_event(pt, 4, st);
     return IGX_OK;
 }
 
@@ -1612,12 +1622,10 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     const int *d_pl0 = sym ? pt->d_pl0 : pt->d_pl0n;
     if (np0 == 0) return IGX_OK;
     if (single2d_wanted(pt, kind)) {
-        (void)hipEventRecord(pt->ctx->ev[1], st);
-        (void)hipEventRecord(pt->ctx->ev[2], st);
+        // one launch between the caller's first and last event: no stage events (a marker costs a few microseconds of
+        // stream time, as much as this kernel on a small patch); igx_assemble reports the whole interval as stage 1
         if (int rc = launch_single2d(st, pt, kind, d_data)) return rc;
         pt->last_path |= IGX_PATH_SINGLE;
-        (void)hipEventRecord(pt->ctx->ev[3], st);
-        (void)hipEventRecord(pt->ctx->ev[4], st);
         return IGX_OK;
     }
     const bool fused = fused_applicable(pt);
@@ -1629,8 +1637,8 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : t.t[1], t.t[0], pt->d_fields + (size_t)t.f * pd.npts_loc);
         if (ok && fused_supported(in)) {
             in.slice_stride = 0; in.gmid_lo = pd.g0_lo;
-            (void)hipEventRecord(pt->ctx->ev[1], st);
-            (void)hipEventRecord(pt->ctx->ev[2], st);
+            stage_event(pt, 1, st);
+            stage_event(pt, 2, st);
             return run_fused(pt, in, sym, d_data);
         }
     }
@@ -1704,7 +1712,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)nX * np0 * NPLs)) return IGX_ERR_NOMEM;
 
     const int nF = igx_num_fields(dim, kind, pd.form_n);
-    (void)hipEventRecord(pt->ctx->ev[1], st);
+    stage_event(pt, 1, st);
     if (use_geoA) {
         // geometry evaluated inside the sweep: no field arrays (geoa.hip)
         int sf[8], stp[8];
@@ -1748,7 +1756,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         A.NPL = NPL;
         const int bsA = 256;
         const long long bx = (NPL + bsA - 1) / bsA;
-        const SweepChunks ch = sweep_chunks(bx * ng, pt->s0_hi - pt->s0_lo, A0.P);
+        const SweepChunks ch = sweep_chunks(bx * ng, pt->s0_hi - pt->s0_lo, A0.P, dim == 2 ? A0.P : 0);
         A.chunk_len = ch.len;
         const size_t ldsA = (size_t)2 * A0.q * 4 * ((A0.P * A0.P + 1) & ~1) * sizeof(double);
         if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
@@ -1757,7 +1765,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
-    (void)hipEventRecord(pt->ctx->ev[2], st);
+    stage_event(pt, 2, st);
 
     if (fused && dim == 3) {
         BFInputs in{};
@@ -1845,7 +1853,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         F.N1 = 1; F.S1 = 1; F.Smid = 1; F.Slast = A1.S;
         ngroups = np0;
     }
-    (void)hipEventRecord(pt->ctx->ev[3], st);
+    stage_event(pt, 3, st);
 
     F.V = AL.d_V; F.fa = AL.dev.fa; F.mslo = AL.dev.mslo; F.mshi = AL.dev.mshi;
     F.jlo = AL.dev.jlo; F.jhi = AL.dev.jhi; F.rp = AL.dev.rp;
@@ -1894,7 +1902,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 #undef LAUNCH_M
                 IGX_HIP(hipGetLastError());
                 pt->timing.n_launches++;
-                (void)hipEventRecord(pt->ctx->ev[4], st);
+                stage_event(pt, 4, st);
                 return IGX_OK;
             }
         }
@@ -1918,6 +1926,11 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 #endif
                 Q.nsuper = (Q.nchunks + FINALQ_WAVES - 1) / FINALQ_WAVES;
                 Q.lpw = (int)std::max<long long>(16, (Q.ndesc * Q.nsuper * FINALQ_WAVES + target_waves - 1) / target_waves);
+                // a launch of less than one resident round (2 blocks per CU: a 2D patch): as few lines per wave as one
+                // round allows -- the lines of a wave are worked through in sequence
+                const long long slots = 2 * 256, per_super = slots / Q.nsuper;
+                if (per_super > 0 && ((Q.ndesc + 15) / 16) * Q.nsuper <= slots)
+                    Q.lpw = (int)std::max<long long>(4, (Q.ndesc + per_super - 1) / per_super);
                 const long long nblocks = ((Q.ndesc + Q.lpw - 1) / Q.lpw) * Q.nsuper;
                 if (nblocks > 0x7fffffffLL) { set_error("final stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
                 dim3 block(64 * FINALQ_WAVES), grid((unsigned)nblocks);
@@ -1933,7 +1946,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 #undef LAUNCH_Q
                 IGX_HIP(hipGetLastError());
                 pt->timing.n_launches++;
-                (void)hipEventRecord(pt->ctx->ev[4], st);
+                stage_event(pt, 4, st);
                 return IGX_OK;
             }
         }
@@ -1992,7 +2005,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
-    (void)hipEventRecord(pt->ctx->ev[4], st);
+    stage_event(pt, 4, st);
     return IGX_OK;
 }
 
