@@ -113,7 +113,11 @@ typedef struct {
     int32_t reserved;
 } igx_patch_info;
 
-typedef struct {                       /* device time of the last igx_assemble, HIP events on the ctx stream */
+/* Device time of the last igx_assemble (HIP events on the ctx stream), milliseconds.  total_ms is always measured.  The
+   per-kernel fields need events between the kernels and a marker costs ~5 us of stream time: they are recorded for 3D
+   patches of >= 2^24 Gauss points (kernels of milliseconds) or when the patch was created under IGX_STAGE_EVENTS=1, and
+   are 0 otherwise (a single-launch 2D assembly reports its one kernel as stage1_ms = total_ms). */
+typedef struct {
     float total_ms;
     float fields_ms, stage0_ms, stage1_ms, final_ms, entry_ms;
     int32_t algo_used;                 /* IGX_ALGO_ENTRYWISE / IGX_ALGO_SUMFACT; 3 after igx_load_vector (total_ms = its contractions) */
