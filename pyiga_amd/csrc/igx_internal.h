@@ -175,6 +175,8 @@ struct igx_patch {
     size_t *d_ws_ij = nullptr; double *d_ws_out = nullptr;
     size_t ws_ij_cap = 0, ws_out_cap = 0;
     long long aca_batch = 65536;              // igx_patch_set_aca_batch
+    struct S2DPlan { int valid = 0, ok = 0, R0 = 0, R1 = 0, NG0 = 0, WIN = 0, NCOL = 0; size_t bytes = 0; };
+    mutable S2DPlan s2d[2];                   // tile of the single-launch 2D kernel (mass, stiffness), worked out once (kern_basis.hip)
     long long aca_requests = 0, aca_entries = 0; int aca_rank = 0;      // igx_fast_assemble_stats
     double *d_lv_f = nullptr, *d_lv_t1 = nullptr, *d_lv_t2 = nullptr, *d_lv_o = nullptr;
     size_t lv_f_cap = 0, lv_t1_cap = 0, lv_t2_cap = 0, lv_o_cap = 0;

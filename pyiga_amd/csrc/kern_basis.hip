@@ -645,17 +645,34 @@ bool single2d_supported(const igx_patch *pt, int kind)
 constexpr long long SINGLE2D_ROUND = 256;                // blocks of one round: one per CU
 static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t &bytes)
 {
+    igx_patch::S2DPlan &M = pt->s2d[kind == IGX_MASS ? 0 : 1];
+    if (M.valid) {
+        A.R0 = M.R0; A.R1 = M.R1; A.NG0 = M.NG0; A.WIN = M.WIN; A.NCOL = M.NCOL; bytes = M.bytes;
+        return M.ok != 0;
+    }
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1];
     const int NF = kind == IGX_MASS ? 1 : 3, NY = kind == IGX_MASS ? 1 : 4, q = A0.q;
     const bool spline = pt->geo_kind != IGX_GEO_JACOBIAN;
     const long long nr0 = std::max(pt->r0_hi - pt->r0_lo, 0);
     static const int shapes[][2] = {{8, 8}, {6, 6}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
     constexpr int NSHAPE = 7, SMALLEST_WANTED = 3;
+    // geometry control columns of axis 1 under the Gauss window of a tile: the functions active at its first node, plus one
+    // per geometry knot between its first and last node (the geometry's mesh may be finer than the space's)
+    auto geo_columns = [&](int R1) {
+        const GeoAxis &g = pt->gax[1];
+        int most = 0;
+        for (int i1a = 0; i1a < A1.N; i1a += R1) {
+            const int i1b = std::min(i1a + R1, A1.N);
+            const double x0 = A1.nodes[(size_t)A1.mslo[i1a] * q], x1 = A1.nodes[(size_t)A1.mshi[i1b - 1] * q - 1];
+            const long long between = std::upper_bound(g.kv.begin(), g.kv.end(), x1) - std::upper_bound(g.kv.begin(), g.kv.end(), x0);
+            most = std::max(most, (int)between + g.P);
+        }
+        return std::min(most, g.N);
+    };
     auto image = [&](int k, Single2DArgs &S) {
         S.R0 = shapes[k][0]; S.R1 = shapes[k][1];
         S.NG0 = (S.R0 + A0.p) * q; S.WIN = (S.R1 + A1.p) * q;
-        // geometry columns a window of axis 1 can touch: one new active function per geometry span it enters
-        S.NCOL = spline ? std::min(pt->gax[1].N, (S.R1 + A1.p) + pt->gax[1].P) : 0;
+        S.NCOL = spline ? geo_columns(S.R1) : 0;
         const size_t doubles = (size_t)NF * S.NG0 * S.WIN + (size_t)S.R0 * (2 * A0.P - 1) * NY * S.WIN + (size_t)S.NG0 * A0.P * 2 +
                                (size_t)S.WIN * A1.P * 2 + (size_t)S.NG0 * S.NCOL * MAX_COMP * 2;
         const size_t ints = (size_t)3 * (S.R0 + 2 * A0.p) + 3 * S.R0 + (size_t)3 * (S.R1 + 2 * A1.p) + 3 * S.R1 + 16;
@@ -664,10 +681,13 @@ static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t
     auto blocks = [&](int k) { return ((A1.N + shapes[k][1] - 1) / shapes[k][1]) * ((nr0 + shapes[k][0] - 1) / shapes[k][0]); };
     int k = 0;
     while (k < NSHAPE && (bytes = image(k, A)) > 150 * 1024) ++k;
-    if (k == NSHAPE) return false;
-    while (k < SMALLEST_WANTED && blocks(k + 1) <= SINGLE2D_ROUND) ++k;
-    bytes = image(k, A);
-    return true;
+    const bool ok = k < NSHAPE;
+    if (ok) {
+        while (k < SMALLEST_WANTED && blocks(k + 1) <= SINGLE2D_ROUND) ++k;
+        bytes = image(k, A);
+    }
+    M.valid = 1; M.ok = ok; M.R0 = A.R0; M.R1 = A.R1; M.NG0 = A.NG0; M.WIN = A.WIN; M.NCOL = A.NCOL; M.bytes = bytes;
+    return ok;
 }
 
 long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows)

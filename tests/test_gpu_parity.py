@@ -679,6 +679,38 @@ def test_tiny_and_odd_sizes(iga, d, monkeypatch):
             assert abs(A - A.T).max() == 0.0
 
 
+def test_geometry_mesh_finer_than_space(iga, monkeypatch):
+    """A geometry map with many more knot spans than the space (Gauss points of ONE element fall into several geometry
+    spans): the single-launch 2D kernel sizes its control-net window by the geometry knots under a tile's Gauss window, the
+    line kernels by the whole line.  Every path against the entry-wise kernel, which evaluates the map point by point."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    mk = iga.bspline.make_knots
+    gk = (mk(2, 0.0, 1.0, 37), mk(3, 0.0, 1.0, 41))
+    t0, t1 = (np.array([k.kv[i + 1:i + 1 + k.p].mean() for i in range(k.numdofs)]) for k in gk)      # Greville abscissae
+    X, Y = np.meshgrid(t1, t0)                          # last component axis: (x, y); x runs with the LAST grid axis
+    coeffs = np.stack([X + 0.07 * np.sin(3 * Y) * np.cos(2 * X), Y + 0.05 * np.sin(4 * X + Y)], axis=-1)
+    geo = iga.bspline.BSplineFunc(gk, coeffs)
+    for p, n in ((3, (9, 7)), (2, (23, 5)), (1, (4, 30))):
+        kvs = (mk(p, 0.0, 1.0, n[0]), mk(p, 0.0, 1.0, n[1]))
+        for kind in ('mass', 'stiffness'):
+            ref = None
+            for path in ('', 'single', 'unfused'):
+                if path:
+                    monkeypatch.setenv('IGX_PATH', path)
+                else:
+                    monkeypatch.delenv('IGX_PATH', raising=False)
+                patch = iga.assemblers.DevicePatch(kvs, geo)
+                if ref is None:
+                    ref = patch.csr(kind, algo='entrywise')
+                A = patch.csr(kind, algo='sumfact')
+                if path == 'single':
+                    assert patch.last_path() == {'single'}
+                patch.close()
+                assert not np.isnan(A.data).any(), (p, n, kind, path)
+                assert rel_maxdiff(A, ref) <= RTOL, (p, n, kind, path, rel_maxdiff(A, ref))
+                assert abs(A - A.T).max() == 0.0
+
+
 def test_general_forms_2d(iga, golden):
     """2D form strings (entry-wise kernel) against the reference's compiled assemblers; the general form
     against the dedicated 2D stiffness / mass kernels; multi_entries."""
