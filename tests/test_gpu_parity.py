@@ -997,6 +997,29 @@ def test_ablation_variables_have_no_effect(iga, monkeypatch):
     assert np.array_equal(A.data, B.data) and np.array_equal(A.data, C.data)
 
 
+@pytest.mark.parametrize('d', [2, 3])
+def test_stage_events_only_change_the_timing_record(iga, d, monkeypatch):
+    """IGX_STAGE_EVENTS (read at patch creation): events between the kernels of a chain.  Off by default for patches whose
+    kernels run for microseconds (only total_ms is measured), on request the per-kernel times appear; same matrix."""
+    kvs = (iga.bspline.make_knots(3, 0., 1., 40),) * 2 if d == 2 else (iga.bspline.make_knots(2, 0., 1., 9),) * 3
+    geo = _geo(iga, 'quarter_annulus' if d == 2 else 'cylinder')
+    monkeypatch.setenv('IGX_PATH', 'unfused')
+    out = {}
+    for ev in (None, '1', '0'):
+        if ev is None:
+            monkeypatch.delenv('IGX_STAGE_EVENTS', raising=False)
+        else:
+            monkeypatch.setenv('IGX_STAGE_EVENTS', ev)
+        patch = iga.assemblers.DevicePatch(kvs, geo)
+        A = patch.csr('stiffness', algo='sumfact')
+        tm = patch.timing()
+        patch.close()
+        staged = tm['stage0_ms'] > 0 and tm['final_ms'] > 0
+        assert tm['total_ms'] > 0 and staged == (ev == '1'), (ev, tm)
+        out[ev] = A.data
+    assert np.array_equal(out[None], out['1']) and np.array_equal(out[None], out['0'])
+
+
 # ------------------------------------------------------------------------------------------
 # Full-size parity pinned to the REFERENCE (tests/golden/golden_fullsize.npz, make_golden.py 'fullsize'):
 # multi_entries of the reference at seeded in-pattern pairs of BASELINE configs 2 and 3 at their real sizes and of the
