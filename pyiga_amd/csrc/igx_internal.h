@@ -176,7 +176,7 @@ struct igx_patch {
     size_t ws_ij_cap = 0, ws_out_cap = 0;
     long long aca_batch = 65536;              // igx_patch_set_aca_batch
     struct S2DPlan { int valid = 0, ok = 0, R0 = 0, R1 = 0, NG0 = 0, WIN = 0, NCOL = 0; size_t bytes = 0; };
-    mutable S2DPlan s2d[2];                   // tile of the single-launch 2D kernel (mass, stiffness), worked out once (kern_basis.hip)
+    mutable S2DPlan s2d[2][2];                // tile of the single-launch 2D kernel [mass | stiffness][resident rows | whole patch], worked out once (kern_basis.hip)
     long long aca_requests = 0, aca_entries = 0; int aca_rank = 0;      // igx_fast_assemble_stats
     double *d_lv_f = nullptr, *d_lv_t1 = nullptr, *d_lv_t2 = nullptr, *d_lv_o = nullptr;
     size_t lv_f_cap = 0, lv_t1_cap = 0, lv_t2_cap = 0, lv_o_cap = 0;
@@ -207,7 +207,7 @@ int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_
 int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields);
 // 2D mass / stiffness in one launch, no intermediates (kern_basis.hip)
 bool single2d_supported(const igx_patch *pt, int kind);
-long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows);   // launch grid of the single-launch kernel (-1: no tile fits), rows per tile
+long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows, bool whole_patch);   // launch grid of the single-launch kernel (-1: no tile fits), rows per tile; for the resident rows or as if the patch were whole
 int launch_single2d(hipStream_t st, igx_patch *pt, int kind, double *d_data);
 int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const GeoAxis gax[3],
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);

@@ -643,9 +643,9 @@ bool single2d_supported(const igx_patch *pt, int kind)
 // side); a small patch is latency-bound instead, so the tile shrinks (down to 2 x 4 rows) while the grid still fits one
 // resident round of the chip.
 constexpr long long SINGLE2D_ROUND = 256;                // blocks of one round: one per CU
-static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t &bytes)
+static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t &bytes, bool whole_patch = false)
 {
-    igx_patch::S2DPlan &M = pt->s2d[kind == IGX_MASS ? 0 : 1];
+    igx_patch::S2DPlan &M = pt->s2d[kind == IGX_MASS ? 0 : 1][whole_patch ? 1 : 0];
     if (M.valid) {
         A.R0 = M.R0; A.R1 = M.R1; A.NG0 = M.NG0; A.WIN = M.WIN; A.NCOL = M.NCOL; bytes = M.bytes;
         return M.ok != 0;
@@ -653,7 +653,7 @@ static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1];
     const int NF = kind == IGX_MASS ? 1 : 3, NY = kind == IGX_MASS ? 1 : 4, q = A0.q;
     const bool spline = pt->geo_kind != IGX_GEO_JACOBIAN;
-    const long long nr0 = std::max(pt->r0_hi - pt->r0_lo, 0);
+    const long long nr0 = whole_patch ? A0.N : std::max(pt->r0_hi - pt->r0_lo, 0);
     static const int shapes[][2] = {{8, 8}, {6, 6}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
     constexpr int NSHAPE = 7, SMALLEST_WANTED = 3;
     // geometry control columns of axis 1 under the Gauss window of a tile: the functions active at its first node, plus one
@@ -690,13 +690,13 @@ static bool single2d_plan(const igx_patch *pt, int kind, Single2DArgs &A, size_t
     return ok;
 }
 
-long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows)
+long long single2d_blocks(const igx_patch *pt, int kind, int *tile_rows, bool whole_patch)
 {
     Single2DArgs A{};
     size_t bytes = 0;
-    if (!single2d_plan(pt, kind, A, bytes)) return -1;
+    if (!single2d_plan(pt, kind, A, bytes, whole_patch)) return -1;
     if (tile_rows) *tile_rows = A.R0 * A.R1;
-    const long long nr0 = std::max(pt->r0_hi - pt->r0_lo, 0);
+    const long long nr0 = whole_patch ? pt->ax[0].N : std::max(pt->r0_hi - pt->r0_lo, 0);
     return ((pt->ax[1].N + A.R1 - 1) / A.R1) * ((nr0 + A.R0 - 1) / A.R0);
 }
 

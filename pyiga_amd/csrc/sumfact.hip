@@ -1540,8 +1540,10 @@ static bool single2d_wanted(const igx_patch *pt, int kind)
     if (pt->knobs.final_sel || !single2d_supported(pt, kind)) return false;
     if (pt->knobs.path == 3) return true;
     if (pt->knobs.path != 0) return false;
+    // decided on the WHOLE patch, not on the resident row slab: every slab of a patch takes the same path (the two paths sum
+    // in different orders; the slabs of a patch reproduce its rows bit for bit)
     int rows = 0;
-    const long long nb = single2d_blocks(pt, kind, &rows);
+    const long long nb = single2d_blocks(pt, kind, &rows, true);
     return nb >= 0 && nb <= SINGLE2D_MAX_BLOCKS && rows <= SINGLE2D_MAX_TILE;
 }
 

@@ -308,10 +308,11 @@ def test_properties_larger(iga, d, p, n, monkeypatch):
 
 
 @pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
-@pytest.mark.parametrize('d,p,n,G', [(3, 2, 9, 2), (3, 3, 7, 3), (2, 3, 20, 4), (3, 4, 6, 2)])
+@pytest.mark.parametrize('d,p,n,G', [(3, 2, 9, 2), (3, 3, 7, 3), (2, 3, 20, 4), (3, 4, 6, 2), (2, 2, 200, 5), (2, 3, 90, 3)])
 def test_row_slabs_equal_full(iga, d, p, n, G, algo, monkeypatch):
     """Multi-GPU decomposition: each slab of axis-0 dof planes reproduces its rows of the full
-    matrix bit for bit, with no exchange between slabs."""
+    matrix bit for bit, with no exchange between slabs.  (2D, n = 200 / 90: the whole patch is beyond / just inside the
+    single-launch kernel's range while a slab alone would be well inside it: the path is chosen for the patch, not the slab.)"""
     monkeypatch.setenv('IGX_DEBUG_POISON', '1')
     kv = iga.bspline.make_knots(p, 0., 1., n)
     kvs = (kv,) * d
