@@ -129,7 +129,7 @@ struct StageAArgs {
     long long NPL;
 };
 
-template <int P, int NT, int Q, bool SYM, bool HASX = false>
+template <int P, int NT, int Q, bool SYM, bool HASX = false, bool PF = false>
 __device__ __forceinline__ void stageA_body(const double *__restrict__ field, double *__restrict__ out0,
                                             double *__restrict__ out1, const int t0, const int t1,
                                             const StageAArgs &A, const long long pt, const bool live, double *pis,
@@ -151,6 +151,7 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
 #pragma unroll
             for (int b = 0; b < P; ++b) acc[ty][a][b] = 0.0;
 
+    double pfv[Q && PF ? Q : 1];                          // field values of the next span (PF)
     double stg[SWEEP_MAX_STAGE];
     auto stage_load = [&](const int s) {
         const double *src = A.PI0 + (size_t)s * SL;
@@ -207,7 +208,24 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
                 for (int b = 0; b <= (SYM ? a : P - 1); ++b) asm volatile("" : "+v"(acc[ty][a][b]));
             asm volatile("" ::: "memory");
         };
-        if (Q) {
+        if (Q && PF) {
+            // short chunks (2D): the walk of a thread is a handful of spans and the field loads of a span, awaited where they
+            // are issued, are a memory latency each -- the values of the NEXT span are requested before this one is swept
+            if (s == s_begin) {
+#pragma unroll
+                for (int l = 0; l < Q; ++l) pfv[l] = fp[(long long)l * A.NPL];
+            }
+            double bv[Q ? Q : 1];
+#pragma unroll
+            for (int l = 0; l < Q; ++l) bv[l] = pfv[l];
+            if (s + 1 < own_hi) {
+#pragma unroll
+                for (int l = 0; l < Q; ++l) pfv[l] = fp[(long long)(q + l) * A.NPL];
+            }
+            __syncthreads();                              // slice `buf` is complete
+#pragma unroll
+            for (int l = 0; l < Q; ++l) accumulate(l, bv[l]);
+        } else if (Q) {
             double bv[Q ? Q : 1];
 #pragma unroll
             for (int l = 0; l < Q; ++l) bv[l] = fp[(long long)l * A.NPL];      // Q loads in flight
@@ -278,7 +296,7 @@ __device__ __forceinline__ void stageA_body(const double *__restrict__ field, do
 // ONE: every group carries a single type (the host splits two-type groups): the non-symmetric sweep of a high degree keeps
 // P x P accumulators per type, and with two types (218 registers at P = 6) only two waves fit a SIMD -- too few to keep
 // a streaming kernel's loads in flight; the field of a split group is read twice instead
-template <int P, int Q, bool SYM, bool ONE = false>
+template <int P, int Q, bool SYM, bool ONE = false, bool PF = false>
 __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double pis[];   // [2][q*4*PP]
@@ -291,8 +309,8 @@ __global__ void __launch_bounds__(256) k_stageA(const StageAArgs A)
         else stageA_body<P, 1, Q, SYM, true>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis, G.xfield[0], nullptr, G.xt[0], 0);
         return;
     }
-    if (!ONE && G.nt == 2) stageA_body<P, 2, Q, SYM>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
-    else stageA_body<P, 1, Q, SYM>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
+    if (!ONE && G.nt == 2) stageA_body<P, 2, Q, SYM, false, PF>(G.field, G.out0, G.out1, G.t0, G.t1, A, pt, live, pis);
+    else stageA_body<P, 1, Q, SYM, false, PF>(G.field, G.out0, G.out0, G.t0, G.t0, A, pt, live, pis);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1452,11 +1470,12 @@ static int ensure(hipStream_t st, double **buf, size_t *cap, size_t need)
 }
 
 template <int P>
-static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sym, bool one, dim3 grid, dim3 block, size_t lds)
+static void launch_stageA(hipStream_t st, const StageAArgs &A, bool qeq, bool sym, bool one, bool short_chunks, dim3 grid, dim3 block, size_t lds)
 {
     if (!sym && one && qeq) { k_stageA<P, P, false, true><<<grid, block, lds, st>>>(A); return; }
     if (sym) {
-        if (qeq) k_stageA<P, P, true><<<grid, block, lds, st>>>(A);
+        if (qeq && short_chunks) k_stageA<P, P, true, false, true><<<grid, block, lds, st>>>(A);
+        else if (qeq) k_stageA<P, P, true><<<grid, block, lds, st>>>(A);
         else k_stageA<P, 0, true><<<grid, block, lds, st>>>(A);
     } else if (qeq) k_stageA<P, P, false><<<grid, block, lds, st>>>(A);   // measured: compile-time q wins for every p (p=5: 16.8 -> 11.0 ms at C5)
     else k_stageA<P, 0, false><<<grid, block, lds, st>>>(A);
@@ -1763,7 +1782,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         const size_t ldsA = (size_t)2 * A0.q * 4 * ((A0.P * A0.P + 1) & ~1) * sizeof(double);
         if ((size_t)A0.q * 4 * A0.P * A0.P > (size_t)SWEEP_MAX_STAGE * bsA) { set_error("stage A: coefficient slice too large"); return IGX_ERR_UNSUPPORTED; }
         dim3 block(bsA), grid((unsigned)bx, ng, ch.nchunks);
-        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, sym, one_type, grid, block, ldsA));
+        DISPATCH_P(A0.P, launch_stageA<PP>(st, A, A0.q == A0.P, sym, one_type, dim == 2, grid, block, ldsA));
         IGX_HIP(hipGetLastError());
         pt->timing.n_launches++;
     }
