@@ -712,6 +712,33 @@ def test_geometry_mesh_finer_than_space(iga, monkeypatch):
                 assert abs(A - A.T).max() == 0.0
 
 
+def test_multi_entries_edge_inputs(iga):
+    """multi_entries (pyiga/genericasm.pxi:722-758) with the inputs a caller may hand over: no pairs at all, an iterable of
+    tuples instead of an array, a non-contiguous view, pairs outside the pattern (exact 0.0, the reference's zero-initialised
+    output) and repeated pairs."""
+    mk = iga.bspline.make_knots
+    for kvs, geo, cls in (((mk(3, 0., 1., 6), mk(2, 0., 1., 5)), iga.geometry.quarter_annulus(), iga.assemblers.StiffnessAssembler2D),
+                          ((mk(2, 0., 1., 4),) * 3, _geo(iga, 'twisted_box'), iga.assemblers.MassAssembler3D)):
+        asm = cls(kvs, geo)
+        A = asm.assemble_csr()
+        n = A.shape[0]
+        out = asm.multi_entries(np.zeros((0, 2), dtype=np.uintp))
+        assert isinstance(out, np.ndarray) and out.shape == (0,) and out.dtype == np.float64
+        assert asm.multi_entries([]).shape == (0,)
+        pairs = [(0, 0), (n - 1, n - 1), (0, n - 1), (n - 1, 0), (3, 4), (3, 4), (4, 3)]
+        want = np.array([A[i, j] for i, j in pairs])
+        assert want[2] == 0.0 and want[3] == 0.0
+        got_list = asm.multi_entries(iter(pairs))
+        big = np.zeros((len(pairs), 4), dtype=np.uintp)
+        big[:, ::2] = pairs
+        got_view = asm.multi_entries(big[:, ::2])
+        for got in (got_list, got_view):
+            assert got.shape == (len(pairs),)
+            assert got[2] == 0.0 and got[3] == 0.0 and got[4] == got[5]
+            assert np.abs(got - want).max() <= RTOL * abs(A).max()
+        assert abs(asm.entry(3, 4) - want[4]) <= RTOL * abs(A).max()
+
+
 def test_general_forms_2d(iga, golden):
     """2D form strings (entry-wise kernel) against the reference's compiled assemblers; the general form
     against the dedicated 2D stiffness / mass kernels; multi_entries."""
