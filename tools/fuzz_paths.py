@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU box: default sum-factorised chain (k_geoA / k_bf / k_mirror or the stage kernels, as the
 library chooses) against the entry-wise kernels, full patch and row slabs, over random degrees, sizes, knot multiplicities
-and geometries.  usage: python3 tools/fuzz_paths.py [ncases] [seed] [big2d]   (big2d: 2D patches of 40-300 spans per axis only --
+and geometries.  usage: python3 tools/fuzz_paths.py [ncases] [seed] [big2d|-] [pmax]   (big2d: 2D patches of 40-300 spans per axis only --
 the stage kernels of 2D instead of the single launch)"""
 import sys
 
@@ -35,12 +35,13 @@ def main():
              lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus())]
     geos2 = [g.quarter_annulus, g.bspline_quarter_annulus, lambda: g.unit_cube(2, 3)]
     big2d = len(sys.argv) > 3 and sys.argv[3] == 'big2d'
+    pmax = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     worst = 0.0
     for case in range(ncases):
         d = 2 if big2d else 3 if rng.random() < 0.7 else 2
         same = rng.random() < 0.5
-        p0 = int(rng.integers(1, 5))
-        ps = [p0] * d if same else [int(rng.integers(1, 5)) for _ in range(d)]
+        p0 = int(rng.integers(1, pmax + 1))
+        ps = [p0] * d if same else [int(rng.integers(1, pmax + 1)) for _ in range(d)]
         ns = [int(rng.integers(40, 300)) if big2d else int(rng.integers(2, 14 if d == 3 else 40)) for _ in range(d)]
         kvs = tuple(random_kv(rng, p, n) for p, n in zip(ps, ns))
         geo = (geos3 if d == 3 else geos2)[int(rng.integers(0, 4 if d == 3 else 3))]()
