@@ -942,15 +942,52 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
 // host side
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
+// Chunks of the mid axis.  A block walks the rows of its chunk in sequence (plus p warm-up rows and a fixed set-up), the chip
+// holds `slots` blocks at a time, and a launch takes as long as its rounds: ceil(blocks / slots) x the walk of a block.  A
+// whole C4 patch (2600 blocks of 132 rows on 256 slots) is best left alone; an eighth of it (368 blocks: 2 rounds, the second
+// less than half full) finishes sooner in 2 chunks (3 rounds of 70 rows): k_bf2 of a slab of 8 1.13 -> 1.04 ms.  The entries
+// do not depend on the split.  (The mirror pass is bandwidth-bound -- its last, partly filled round is short -- and gains
+// nothing from the same model: measured.)
+static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
+{
+    const int mid_rows = A.mid_hi - A.mid_lo;
+    const long long per_chunk = (long long)A.npairs * A.ntiles;
+    const int mmax = std::max(1, std::min(16, mid_rows / (2 * P)));
+    constexpr int SETUP_ROWS = 4;                        // fixed cost of a block in rows of its walk
+    long long best = -1;
+    for (int m = 1; m <= mmax; ++m) {
+        const int rows = (mid_rows + m - 1) / m, chunks = (mid_rows + rows - 1) / rows;
+        const long long rounds = (per_chunk * chunks + slots - 1) / slots;
+        const long long cost = rounds * (rows + (chunks > 1 ? P - 1 : 0) + SETUP_ROWS);
+        if (best < 0 || cost < best) { best = cost; A.mrows = rows; A.nmchunks = chunks; }
+    }
+}
+
 template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
-static int launch_bf2_k(hipStream_t st, const BFArgs &A, unsigned nblocks)
+static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks)
 {
     using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "k_bf2: LDS");
     static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf2: block size");
+    constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
     IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_bf2<P, NY, MASK, NA, NLG, NCW, NH><<<dim3(nblocks), dim3((bf_nroles(MASK) * NLG + NCW) * 64), lds, st>>>(A);
+    static int per_cu = 0, ncu = 0;                      // resident blocks per CU of this instantiation, CUs of the device
+    if (per_cu == 0) {
+        int occ = 0, dev = 0, n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, nthreads, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        ncu = n; per_cu = occ;
+    }
+    BFArgs A = A0;
+#ifdef IGX_ABLATE
+    if (!getenv("IGX_BF_MCHUNKS"))
+#endif
+    {
+        bf2_choose_chunks(A, (long long)per_cu * ncu, P);
+        nblocks = (unsigned)((long long)A.npairs * A.ntiles * A.nmchunks);
+    }
+    k_bf2<P, NY, MASK, NA, NLG, NCW, NH><<<dim3(nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_BF_STAMP
     {

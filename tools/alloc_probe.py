@@ -2,6 +2,7 @@
 """Do the kernel times of the C4 chain depend on where the big buffers land?  Several patches in ONE process (each allocates
 its own K1 / CSR buffers), optionally with a dummy allocation in between that shifts the addresses."""
 import sys, os, ctypes
+os.environ.setdefault('IGX_STAGE_EVENTS', '1')      # per-kernel times (off by default below 2^24 Gauss points)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyiga_amd import bspline, geometry, assemblers, _lib

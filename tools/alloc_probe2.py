@@ -2,6 +2,7 @@
 """Several patches ALIVE at once in one process (each with its own 12.75 GB CSR buffer and 17 GB K1): do their mirror / fused-stage
 times differ, i.e. does the physical placement of a buffer decide them?"""
 import sys, os
+os.environ.setdefault('IGX_STAGE_EVENTS', '1')      # per-kernel times (off by default below 2^24 Gauss points)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyiga_amd import bspline, geometry, assemblers, _lib

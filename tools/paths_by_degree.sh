@@ -2,6 +2,7 @@
 cd "$GRAFT_REPO_ROOT"
 python - <<'PY'
 import os, time, numpy as np
+os.environ.setdefault('IGX_STAGE_EVENTS', '1')      # per-kernel times (off by default below 2^24 Gauss points)
 import pyiga_amd as iga
 for p, n in ((5, 64), (3, 96), (2, 128)):
     kv = iga.bspline.make_knots(p, 0., 1., n)

@@ -2,6 +2,7 @@
 """k_bf2 time of 3D stiffness patches of several degrees for the library given by IGX_LIB (variant builds with other
 tile / contractor shapes: tools/buildvar.sh).  usage: IGX_LIB=... python3 tools/shape_try.py"""
 import sys, os
+os.environ.setdefault('IGX_STAGE_EVENTS', '1')      # per-kernel times (off by default below 2^24 Gauss points)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyiga_amd import bspline, geometry, assemblers
