@@ -84,6 +84,10 @@ struct BFArgs {
     int sym;                      // symmetric form: in a diagonal outer pair only the lower triangle is formed
     int R2, ntiles;               // rows per tile of the last axis
     int mrows, nmchunks;          // rows per chunk of the mid axis
+    // tail split: the blocks of the last, partly filled round (block ids >= main_blocks) walk a (1 / tail_k)-th of the mid
+    // axis each, so that they fill the chip and the launch ends after a fraction of a round (0: every block alike)
+    unsigned main_blocks;
+    int tail_k, tail_mrows;
     int mid_lo, mid_hi;           // rows of the mid axis to produce
     int span_hi;                  // spans of the mid axis below this one are resident (2D row slabs; else n1)
     int npairs;
@@ -456,19 +460,25 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
     cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned bid = blockIdx.x;
+    const bool tail = A.tail_k > 0 && bid >= A.main_blocks;
     {
-        const unsigned per = gridDim.x / 8;
+        const unsigned per = (A.tail_k > 0 ? A.main_blocks : gridDim.x) / 8;
         if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
     }
+    int mch, mrows;
+    if (tail) {                                          // (nmchunks = 1 with a tail split)
+        const unsigned t = bid - A.main_blocks;
+        mch = (int)(t % (unsigned)A.tail_k); mrows = A.tail_mrows;
+        bid = A.main_blocks + t / (unsigned)A.tail_k;
+    } else { mch = (int)((bid / A.ntiles) % A.nmchunks); mrows = A.mrows; }
     const int tile = (int)(bid % A.ntiles);
-    const int mch = (int)((bid / A.ntiles) % A.nmchunks);
-    const int r0 = (int)(bid / ((unsigned)A.ntiles * A.nmchunks));
+    const int r0 = (int)(bid / ((unsigned)A.ntiles * (tail ? 1 : A.nmchunks)));
     const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
     const bool diag0 = A.sym && i0 == j0;
     const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
     const int sp_lo = row_lo - p;                                      // first span of the window (virtual: may lie before the axis)
     const int win0 = sp_lo * P;
-    const int rlo = A.mid_lo + mch * A.mrows, rhi = min(rlo + A.mrows, A.mid_hi);
+    const int rlo = A.mid_lo + mch * mrows, rhi = min(rlo + mrows, A.mid_hi);
     const int s_begin = max(rlo - p, 0);
 
     for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) {
@@ -961,6 +971,17 @@ static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
         const long long cost = rounds * (rows + (chunks > 1 ? P - 1 : 0) + SETUP_ROWS);
         if (best < 0 || cost < best) { best = cost; A.mrows = rows; A.nmchunks = chunks; }
     }
+    // one chunk per block and several rounds: split the blocks of the last round (C4: 2600 blocks = 10 rounds of 256 and
+    // 40 blocks more -- those 40 become 240 blocks of 22 rows and the launch ends a fifth of a round after the tenth)
+    A.tail_k = 0; A.main_blocks = 0; A.tail_mrows = 0;
+    if (A.nmchunks == 1 && per_chunk > slots && per_chunk % slots != 0) {
+        const long long main = (per_chunk / slots) * slots, rest = per_chunk - main;
+        const int k = (int)std::min<long long>(std::min<long long>(slots / rest, mmax), 16);
+        if (k >= 2) {
+            A.main_blocks = (unsigned)main; A.tail_mrows = (mid_rows + k - 1) / k;
+            A.tail_k = (mid_rows + A.tail_mrows - 1) / A.tail_mrows;
+        }
+    }
 }
 
 template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
@@ -986,6 +1007,7 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks)
     {
         bf2_choose_chunks(A, (long long)per_cu * ncu, P);
         nblocks = (unsigned)((long long)A.npairs * A.ntiles * A.nmchunks);
+        if (A.tail_k > 0) nblocks = A.main_blocks + (nblocks - A.main_blocks) * (unsigned)A.tail_k;
     }
     k_bf2<P, NY, MASK, NA, NLG, NCW, NH><<<dim3(nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
