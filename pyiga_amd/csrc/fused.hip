@@ -974,6 +974,7 @@ static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
     // one chunk per block and several rounds: split the blocks of the last round (C4: 2600 blocks = 10 rounds of 256 and
     // 40 blocks more -- those 40 become 240 blocks of 22 rows and the launch ends a fifth of a round after the tenth)
     A.tail_k = 0; A.main_blocks = 0; A.tail_mrows = 0;
+#ifndef BF2_NO_TAIL_SPLIT
     if (A.nmchunks == 1 && per_chunk > slots && per_chunk % slots != 0) {
         const long long main = (per_chunk / slots) * slots, rest = per_chunk - main;
         const int k = (int)std::min<long long>(std::min<long long>(slots / rest, mmax), 16);
@@ -982,6 +983,7 @@ static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
             A.tail_k = (mid_rows + A.tail_mrows - 1) / A.tail_mrows;
         }
     }
+#endif
 }
 
 template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
