@@ -44,9 +44,15 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 FP64_PEAK_TFLOPS = 78.6        # vector = MFMA FP64 peak on MI355X
 
 
+ALGORITHMIC_BYTES_DEF = ('SURVEY.md 8d: 8 d^2 q^d (Jacobian in) + 8 nnz / n^d (CSR values out); the convection-diffusion form adds '
+                         '8 (1 + d) q^d (diff_coeff and the d coordinate fields of the convection direction: SURVEY 8d quotes C5 = '
+                         '8 (9 + 1 + 3) 216 + 8 * 1427.8 = 33.9 KB/el; rounds 1-2 of this repository used 8 (9 + 1) 216 for C5)')
+
+
 def algorithmic_bytes_per_element(dim, p, nnz, nelem, kind='stiffness'):
     """Jacobian in (8 d^2 q^d) + CSR values out (8 nnz / n^d); the convection-diffusion form adds
-    its coefficient and the d coordinate fields of the convection direction (8 (1 + d) q^d): C5 = 33.9 KB per element."""
+    its coefficient and the d coordinate fields of the convection direction (8 (1 + d) q^d): C5 = 33.9 KB per element,
+    the figure SURVEY 8d itself quotes.  The definition travels with the number (`algorithmic_bytes_def`)."""
     q = p + 1
     return 8.0 * (dim * dim + ((1 + dim) if kind == 'convdiff' else 0)) * q ** dim + 8.0 * nnz / nelem
 
@@ -81,13 +87,19 @@ def algorithmic_flops(dim, p, kvs, kind):
     return out
 
 
-def measured_traffic(config, world):
-    """HBM bytes per assembly from the committed rocprofv3 PMC passes (profiles/r03_traffic.json, tools/make_traffic.py)
-    -- or None when the kernel sources have changed since they were taken (stale numbers are not reported)."""
+TRAFFIC_FILE = 'profiles/r04_traffic.json'
+
+
+def measured_traffic(config, world, op='matrix'):
+    """HBM bytes per assembly from the committed rocprofv3 PMC passes (TRAFFIC_FILE, tools/make_traffic.py) -- or None
+    when the kernel sources have changed since they were taken (stale numbers are not reported).  The counters need
+    passes of their own under rocprofv3, so this is never measured by the run that prints it: `measured_in_this_run`
+    says so on the line."""
     try:
         import glob
         import hashlib
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r03_traffic.json')))[config]
+        key = config if op == 'matrix' else '%s_%s' % (config, op)
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))[key]
         if world != 1:
             return None
         h = hashlib.sha256()
@@ -95,7 +107,7 @@ def measured_traffic(config, world):
             h.update(open(f, 'rb').read())
         if h.hexdigest()[:16] != t.get('kernels_sha'):
             return None
-        return {'bytes': t['chain_bytes'], 'kernels_sha': t['kernels_sha'], 'source': 'profiles/r03_traffic.json',
+        return {'bytes': t['chain_bytes'], 'measured_in_this_run': False, 'kernels_sha': t['kernels_sha'], 'source': TRAFFIC_FILE,
                 'kernels': {k: round(v['read_bytes'] + v['write_bytes']) for k, v in t['kernels'].items()}}
     except Exception:
         return None
@@ -111,13 +123,41 @@ def make_geo(geometry, name):
     return getattr(geometry, name)()
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max, or the v1 files)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        a, b = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if a != 'max':
+            quota = float(a) / float(b)
+    except Exception:
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(dim, p, kind):
     """Oracle (C port of the reference's entry-wise loops, reference compile flags) timed on the
-    host cores on a bounded sample of the same workload.  Runs BEFORE anything touches the GPU (it may start gcc)."""
+    host cores on a bounded sample of the same workload.  Runs BEFORE anything touches the GPU (it may start gcc).
+    `cores` = threads actually used = affinity mask capped by the cgroup quota; the entry kernel is also timed at 1 and
+    8 threads on seeded subsamples of the same index pairs, so that the line shows how the port scales on this host
+    (pyiga/genericasm.pxi:722-758 is the loop being timed; the reference measured 1.55e3 el/s on 8 cores at p = 4)."""
     from oracle import iga_oracle as orc
     orc.build()
-    n = {(3, 4): 24, (3, 2): 48, (2, 3): 256, (3, 5): 14}.get((dim, p), 12)
-    cores = os.cpu_count() or 1
+    cores, quota = host_cores()
+    # bounded sample (about 10-30 s of CPU work): a few more spans on a many-core host, so that the threads have work
+    n = {(3, 4): 32 if cores > 32 else 24, (3, 2): 64 if cores > 32 else 48, (2, 3): 256, (3, 5): 18 if cores > 32 else 14}.get((dim, p), 12)
     kv = orc.make_knots(p, 0.0, 1.0, n)
     geo = orc.geo_cylinder() if dim == 3 else orc.geo_quarter_annulus()
     timing = {}
@@ -129,11 +169,34 @@ def cpu_baseline(dim, p, kind):
         A = orc.assemble(kind, (kv,) * dim, geo, nthreads=cores, fast=True, return_timing=timing)
     dt = time.perf_counter() - t0
     nel = n ** dim
+    # thread scaling of the entry kernel alone: seeded subsamples of the pattern sized for ~2 s each
+    scaling = {}
+    try:
+        asm = orc.Assembler(kind, (kv,) * dim, geo=geo, coeff=COEFF if kind == 'convdiff' else None)
+        I, J = (orc.full_pattern if kind == 'convdiff' else orc.lower_pattern)((kv,) * dim)
+        M = I.shape[0]
+        rate_all = M / timing['entries']                         # entries/s with `cores` threads
+        rng = np.random.default_rng(11)
+        for nt in sorted({1, min(8, cores)}):
+            if nt >= cores:
+                continue
+            m = int(min(M, max(2000, 2.0 * rate_all * nt / cores)))
+            sel = np.sort(rng.choice(M, m, replace=False))
+            idx = np.column_stack((I[sel], J[sel]))
+            t1 = time.perf_counter()
+            asm.multi_entries(idx, nthreads=nt, fast=kind != 'convdiff')
+            scaling[nt] = nel * (m / M) / (time.perf_counter() - t1)
+        scaling[cores] = nel / timing['entries']
+    except Exception as e:                                      # the scaling note is optional; the baseline itself is above
+        scaling = {'error': str(e)[:80]}
     return {
         'value': nel / dt, 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
         'sample': '%dD p=%d n=%d %s, quarter-annulus %s, full assemble() incl. setup+CSR: %.2f s '
-                  '(entry kernel %.2f s = %.3g el/s)' % (dim, p, n, kind, 'cylinder' if dim == 3 else '', dt,
-                                                          timing['entries'], nel / timing['entries']),
+                  '(entry kernel %.2f s = %.3g el/s); entry kernel el/s by threads: %s'
+                  % (dim, p, n, kind, 'cylinder' if dim == 3 else '', dt, timing['entries'], nel / timing['entries'],
+                     ', '.join('%s: %.3g' % (k, v) if not isinstance(v, str) else '%s: %s' % (k, v) for k, v in scaling.items())),
+        'entry_kernel_el_s_by_threads': {str(k): (round(v, 1) if not isinstance(v, str) else v) for k, v in scaling.items()},
+        'host': {'os_cpu_count': os.cpu_count(), 'affinity': cores if quota is None else None, 'cgroup_quota_cores': quota},
         'nnz': int(A.nnz),
     }
 
@@ -220,6 +283,12 @@ def self_launch(args):
             except subprocess.TimeoutExpired:
                 p.kill()
     reader.join(timeout=10)
+    if not failed:                                           # warnings of a passing run (RCCL, HIP) are not lost: rank 0's stderr
+        logs[0].seek(0)
+        err0 = logs[0].read()
+        if err0.strip():
+            sys.stderr.write(err0[-8000:])
+            sys.stderr.flush()
     sys.stdout.write(''.join(c for c in chunks if c))
     sys.stdout.flush()
     if failed:
@@ -302,7 +371,9 @@ def main():
     if not stub:
         from pyiga_amd import _lib
         _lib.context(local_rank).sync()                     # HIP runtime + device context + stream: first GPU call of the process
-    runtime_init_s = time.perf_counter() - t_init
+    # (with several ranks torch / RCCL have created the runtime and the context before this point: the figure is the cost of
+    # the first GPU call of a process only when world == 1, and is reported as null otherwise)
+    runtime_init_s = time.perf_counter() - t_init if dist is None else None
     t_setup = time.perf_counter()
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
@@ -378,9 +449,13 @@ def main():
     # 2D kernel): the per-kernel times then come from a separate pass over a second patch created with IGX_STAGE_EVENTS=1
     kernel_ms_source = 'same pass'
     if not stub and kind in ('stiffness', 'mass') and 'single' not in patch.last_path() and not any(stage_ms.get(k, 0.0) > 0 for k in ('stage0_ms', 'stage1_ms', 'final_ms', 'entry_ms')):
+        prev_ev = os.environ.get('IGX_STAGE_EVENTS')
         os.environ['IGX_STAGE_EVENTS'] = '1'
         p2 = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
-        del os.environ['IGX_STAGE_EVENTS']
+        if prev_ev is None:
+            del os.environ['IGX_STAGE_EVENTS']
+        else:
+            os.environ['IGX_STAGE_EVENTS'] = prev_ev
         stage_ms = {}
         for it in range(args.warmup + args.steps):
             p2.assemble(kind, algo=args.algo, to_host=False)
@@ -405,8 +480,8 @@ def main():
     path = patch.last_path()
     fused = 'fused' in path
     names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_geoA' if 'geoA' in path else 'k_stageA',
-             'stage1_ms': 'k_single2d' if 'single' in path else 'k_bf' if fused else 'k_stageB',
-             'final_ms': 'k_mirror' if 'mirror' in path else 'k_final', 'entry_ms': 'k_entries_csr'}
+             'stage1_ms': 'k_single2d' if 'single' in path else 'k_bf2' if fused else 'k_stageB',
+             'final_ms': ('k_mirror2' if dim == 3 and p in (2, 3, 4) else 'k_mirror') if 'mirror' in path else 'k_final', 'entry_ms': 'k_entries_csr'}
     if 'geoA' in path or 'single' in path:
         stage_ms.pop('fields_ms', None)         # no field kernel: the geometry is evaluated inside k_geoA / k_single2d
     if 'single' in path:
@@ -438,15 +513,17 @@ def main():
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
         'step_ms': {'median': chain_ms, 'min': float(np.min(steps_ms)), 'max': float(np.max(steps_ms))},
         'slab_ms': [round(x, 3) for x in slab_ms],
+        # what the work model of the slabs expects of this split (distributed.scaling_model): the first SCALE curve explains itself
+        **({'scaling_model': distributed.scaling_model(kv0.numdofs, part_world, p)} if part_world > 1 and dim == 3 and not weak else {}),
         'setup_s': round(max(setup_all), 4), 'setup_s_ranks': setup_all,      # patch creation per rank (device context warm)
-        'runtime_init_s': round(runtime_init_s, 3),                            # HIP runtime + context + stream of rank 0: once per process
+        'runtime_init_s': None if runtime_init_s is None else round(runtime_init_s, 3),                            # HIP runtime + context + stream of rank 0: once per process
         'cold_ms': round(max(cold_all), 2), 'cold_ms_ranks': cold_all,         # patch creation + FIRST assembly (workspace allocation), device-resident result
         'api_call_s': api_call_s,                                              # assemble.stiffness() end to end: + pattern, D2H of values and indices, scipy
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': measured_traffic(args.config, world),
             'kernel': 'assembly chain (' + ' + '.join(parts) + '), HIP events on the igx stream; median step',
-            'algorithmic_bytes_per_element': b_el, 'chain_ms': chain_ms, 'kernel_ms': parts, 'kernel_ms_source': kernel_ms_source, 'dominant_kernel': dominant,
+            'algorithmic_bytes_per_element': b_el, 'algorithmic_bytes_def': ALGORITHMIC_BYTES_DEF, 'chain_ms': chain_ms, 'kernel_ms': parts, 'kernel_ms_source': kernel_ms_source, 'dominant_kernel': dominant,
             'fp64': fp64,
         },
     }
@@ -497,7 +574,7 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
                       'note': 'value = device time of the contractions, function values resident (igx_load_vector_d); whole resident call '
                               '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms' % (wall_ms, host_call_ms)},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': None, 'kernel': 'k_contract_axis x %d' % dim, 'algorithmic_bytes_per_element': b_el}}
+                        'traffic': measured_traffic(args.config, world, 'rhs'), 'kernel': 'k_contract_axis x %d' % dim, 'algorithmic_bytes_per_element': b_el}}
     flush_c_stdio()
     print(json.dumps(out), flush=True)
 
@@ -542,7 +619,7 @@ def bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank):
                       'config': args.config, 'note': 'device time with resident pairs; host-pointer call (upload pairs, download values) %.1f ms' % host_ms},
            'roofline': {'bound': 'hbm', 'note': 'every Gauss point of a pair\'s support intersection reads its %d field values (random pairs: no reuse '
                         'between pairs beyond L2 / Infinity Cache); %.3g points in this request' % (nfld, float(pts.sum())),
-                        'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                        'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': measured_traffic(args.config, 1, 'entries'),
                         'fp64': {'flops_per_point': flop_pt, 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_PEAK_TFLOPS}}}
     print(json.dumps(out), flush=True)
 

@@ -253,6 +253,14 @@ int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *o
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */
 int igx_fields(igx_patch *patch, int kind, double *out, int64_t *shape4);
 
+/* Planning query, host arithmetic only (no device, no patch): 1 if the fused sweep + contraction stage and the mirror pass
+   may address a patch of these sizes with their 32-bit buffer offsets, 0 if the library takes the stage kernels with 64-bit
+   addressing instead.  c0max = 2 p0 + 1 columns of axis 0 per row (1 in 2D), S_mid / S_last = number of 1D index pairs
+   (i, j) of the mid / last axis, G_mid / G_last = their Gauss points.  The limits: a row block of one outer row
+   (c0max * S_mid * S_last values) and one slice of the sweep intermediate (G_mid * G_last values) below 2^31 bytes.
+   (No counterpart in the reference: its index type is size_t throughout, pyiga/assemble_tools_cy.pyx:44-49.) */
+int igx_fused_stage_fits(int64_t c0max, int64_t S_mid, int64_t S_last, int64_t G_mid, int64_t G_last);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,8 +168,11 @@ int orc_entries(int dim, int kind, const size_t *ndofs, const size_t *ng,
     c.C[0] = C0; c.C[1] = C1; c.C[2] = C2;
     c.fields = fields;
     if (nthreads < 1) nthreads = 1;
-    /* contiguous chunks, one per thread: chunk_tasks(), assemble_tools_cy.pyx:387-391 */
-#pragma omp parallel for num_threads(nthreads) schedule(static)
+    /* The reference hands one contiguous chunk per thread to a pool (chunk_tasks(), assemble_tools_cy.pyx:387-391); entries
+       near the patch boundary have smaller support intersections, so equal chunks are unequal work.  The values do not
+       depend on the schedule (every entry is summed by one thread, in the reference's order); the baseline timing gets the
+       balanced schedule so that it is not understated by the port. */
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
     for (ptrdiff_t k = 0; k < (ptrdiff_t)M; ++k) {
         size_t I = idx[2 * k], J = idx[2 * k + 1];
         if (dim == 2) {

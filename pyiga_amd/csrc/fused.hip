@@ -950,6 +950,21 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
 
 // ---------------------------------------------------------------------------------------------
 // host side
+
+// k_bf2 reaches the K1 rows of a slice and the CSR values of an outer row through buffer descriptors with 32-bit offsets
+// (scalar row offset + per-lane offset, range-checked against BF2_NUMREC); k_mirror2 does the same inside the row blocks of
+// two outer rows.  A patch beyond these limits would have its stores dropped silently by the range check, so it never gets
+// here: sumfact_assemble takes the stage kernels (64-bit addresses) instead.
+bool fused_offsets_fit(long long c0max, long long S_mid, long long S_last, long long G_mid, long long G_last)
+{
+    constexpr long long LIM = 0x7fff0000LL;
+    if (c0max < 1 || S_mid < 0 || S_last < 0 || G_mid < 0 || G_last < 0) return false;
+    if (S_mid > LIM || S_last > LIM || G_mid > LIM || G_last > LIM) return false;
+    if (c0max * S_mid > LIM / 8 || c0max * S_mid * S_last > LIM / 8) return false;
+    if (G_mid * G_last > LIM / 8) return false;
+    return true;
+}
+
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
 // Chunks of the mid axis.  A block walks the rows of its chunk in sequence (plus p warm-up rows and a fixed set-up), the chip
@@ -987,7 +1002,7 @@ static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
 }
 
 template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
-static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks)
+static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks, int ncu_ctx)
 {
     using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
@@ -995,12 +1010,14 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks)
     static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf2: block size");
     constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
     IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static int per_cu = 0, ncu = 0;                      // resident blocks per CU of this instantiation, CUs of the device
-    if (per_cu == 0) {
-        int occ = 0, dev = 0, n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, nthreads, lds) != hipSuccess || occ < 1) occ = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        ncu = n; per_cu = occ;
+    // resident blocks per CU: a property of the code object (registers, LDS), asked per launch for the CURRENT device -- the
+    // query is host arithmetic over the kernel descriptor (~1 us), so nothing is cached across devices or threads; the CU
+    // count comes from the context the patch belongs to
+    int per_cu = 1, ncu = ncu_ctx;
+    {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, nthreads, lds) == hipSuccess && occ >= 1) per_cu = occ;
+        if (ncu < 1) ncu = 256;
     }
     BFArgs A = A0;
 #ifdef IGX_ABLATE
@@ -1053,10 +1070,10 @@ template <int P> struct BF2Cfg<P, BF_MASK_STIFF3, 1> {
 };
 template <int P> struct BF2Cfg<P, BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
 template <int P, int NY, int MASK, int NA>
-static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks)
+static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks, int ncu)
 {
     using C = BF2Cfg<P, MASK, NA>;
-    return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH>(st, A, nblocks);
+    return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH>(st, A, nblocks, ncu);
 }
 template <int P, int MASK, int NA> constexpr int bf2_rmax()
 {
@@ -1064,12 +1081,12 @@ template <int P, int MASK, int NA> constexpr int bf2_rmax()
     return BF2Geom<P, C::NLG, bf_nroles(MASK), C::NCW, C::NH>::RMAX;
 }
 template <int P>
-static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na)
+static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na, int ncu)
 {
-    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_c<P, 1, BF_MASK_MASS, 1>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 1>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 2>(st, A, nblocks);
-    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF2, 1>(st, A, nblocks);
+    if (ny == 1 && mask == BF_MASK_MASS && na == 1) return launch_bf2_c<P, 1, BF_MASK_MASS, 1>(st, A, nblocks, ncu);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 1>(st, A, nblocks, ncu);
+    if (ny == 4 && mask == BF_MASK_STIFF3 && na == 2) return launch_bf2_c<P, 4, BF_MASK_STIFF3, 2>(st, A, nblocks, ncu);
+    if (ny == 4 && mask == BF_MASK_STIFF2 && na == 1) return launch_bf2_c<P, 4, BF_MASK_STIFF2, 1>(st, A, nblocks, ncu);
     set_error("fused stage: no kernel for this set of types");
     return IGX_ERR_UNSUPPORTED;
 }
@@ -1117,6 +1134,10 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     int ny, mask, na;
     bf_signature(in, ny, mask, na);
     if (!fused_supported(in)) { set_error("fused stage: no kernel for this set of types"); return IGX_ERR_UNSUPPORTED; }
+    if (!fused_offsets_fit(pt->dim == 3 ? 2 * pt->ax[0].p + 1 : 1, AM.S, AL.S, AM.G, AL.G)) {
+        set_error("fused stage: patch beyond the 32-bit offsets of a row block / K1 slice");
+        return IGX_ERR_UNSUPPORTED;
+    }
     for (int y = 0; y < 4; ++y)
         for (int t1 = 0; t1 < 4; ++t1) {
             const int n = in.slot_n[y][t1];
@@ -1153,11 +1174,11 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
     if (blocks == 0) return IGX_OK;
     const unsigned nb = (unsigned)blocks;
     switch (P) {
-    case 2: return launch_bf2_p<2>(st, A, nb, ny, mask, na);
-    case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na);
-    case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na);
-    case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na);
-    case 6: return launch_bf2_p<6>(st, A, nb, ny, mask, na);
+    case 2: return launch_bf2_p<2>(st, A, nb, ny, mask, na, pt->ctx->ncu);
+    case 3: return launch_bf2_p<3>(st, A, nb, ny, mask, na, pt->ctx->ncu);
+    case 4: return launch_bf2_p<4>(st, A, nb, ny, mask, na, pt->ctx->ncu);
+    case 5: return launch_bf2_p<5>(st, A, nb, ny, mask, na, pt->ctx->ncu);
+    case 6: return launch_bf2_p<6>(st, A, nb, ny, mask, na, pt->ctx->ncu);
     default: set_error("fused stage: degree %d unsupported", P - 1); return IGX_ERR_UNSUPPORTED;
     }
 }
@@ -1221,7 +1242,7 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
 #ifdef MIRROR_OLD
     if (false) {
 #else
-    if (pt->dim == 3 && c0max * AM.S * AL.S * 8 < 0x7fff0000LL) {
+    if (pt->dim == 3 && fused_offsets_fit(c0max, AM.S, AL.S, 0, 0)) {
 #endif
         switch (2 * AL.p + 1) {
         case 5: return launch_mirror2_k<5, 0>(st, M, AL.N);

@@ -211,6 +211,10 @@ using namespace igx;
 extern "C" {
 
 int igx_version(void) { return IGX_VERSION; }
+int igx_fused_stage_fits(int64_t c0max, int64_t S_mid, int64_t S_last, int64_t G_mid, int64_t G_last)
+{
+    return igx::fused_offsets_fit(c0max, S_mid, S_last, G_mid, G_last) ? 1 : 0;
+}
 const char *igx_last_error(void) { return g_err; }
 
 igx_ctx *igx_create(int device_id)
@@ -226,6 +230,7 @@ igx_ctx *igx_create(int device_id)
     igx_ctx *ctx = new (std::nothrow) igx_ctx();
     if (!ctx) return nullptr;
     ctx->device = device_id;
+    if (hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ctx->ncu < 1) ctx->ncu = 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
     for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
     return ctx;

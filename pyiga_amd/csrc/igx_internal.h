@@ -103,6 +103,7 @@ struct Plan;                                   // sum-factorisation plan (sumfac
 
 struct igx_ctx {
     int device = 0;
+    int ncu = 0;                              // compute units of THIS context's device (filled by igx_create): launch geometry
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
 };
@@ -251,6 +252,8 @@ struct MirrorInputs {
     int i1_lo, i1_hi;                         // target rows of the mid axis
 };
 int fused_supported(const BFInputs &in);
+// 32-bit buffer offsets of k_bf2 / k_mirror2 (fused.hip): row block of an outer row and a K1 slice below 2^31 bytes
+bool fused_offsets_fit(long long c0max, long long S_mid, long long S_last, long long G_mid, long long G_last);
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)

@@ -1580,7 +1580,9 @@ static bool fused_applicable(const igx_patch *pt)
     if (dim == 2 && pt->knobs.path != 1) return false;
     const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
     if (!AM.simple || !AL.simple || AM.q != AM.P || AL.q != AL.P || AM.P != AL.P || AL.P < 2 || AL.P > 6) return false;
-    return true;
+    // 32-bit offsets inside a row block of an outer row and inside a K1 slice (k_bf2, k_mirror2): larger patches take the
+    // stage kernels.  Decided on the whole axes, like every path choice: all slabs of a patch agree.
+    return fused_offsets_fit(dim == 3 ? 2 * pt->ax[0].p + 1 : 1, AM.S, AL.S, AM.G, AL.G);
 }
 
 // slot table of the fused stage: input array `ptr` enters the sweep with mid-axis type t1 and last-axis type y

@@ -78,6 +78,23 @@ def balanced_slabs(ndofs0, world, p):
     return best
 
 
+def scaling_model(ndofs0, world, p):
+    """What the cost model expects of a `world`-way split of the axis (for the bench line, next to the measured curve):
+    the slab edges, the share of axis-0 spans that are swept twice (the p warm-up spans below every slab but the first),
+    the modelled cost of every slab relative to the whole patch and the speed-up that follows (whole / slowest slab).
+    Fixed per-launch costs and the block quantisation of the fused stage are NOT in the model: the measured speed-up of
+    the round-3 slab emulation was 6.2-6.8 against 6.9 modelled at 8 ranks."""
+    e = balanced_slabs(ndofs0, world, p) if world > 1 else [0, ndofs0]
+    whole = slab_cost(ndofs0, p, 0, ndofs0)
+    costs = [slab_cost(ndofs0, p, e[r], e[r + 1]) for r in range(world)]
+    nspans = ndofs0 - p
+    swept = sum(min(e[r + 1] - 1, ndofs0 - p - 1) - max(e[r] - p, 0) + 1 for r in range(world))
+    return {'edges': [int(x) for x in e], 'halo_fraction': round(swept / nspans - 1.0, 4),
+            'slab_cost_rel': [round(c / whole, 4) for c in costs],
+            'max_over_min': round(max(costs) / min(costs), 4),
+            'predicted_speedup': round(whole / max(costs), 3)}
+
+
 _EDGES = {}
 
 

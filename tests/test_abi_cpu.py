@@ -137,3 +137,34 @@ def test_bbox_for_rows_matches_reference():
         I, J = assemble._nonzeros_for_rows(kvs, kvs, g[name + '_rows'])
         assert np.array_equal(J, g[name + '_indices']) and I.size == g[name + '_indptr'][-1]
     assert assemble.bbox_for_rows(kvs2, []) == ((0, 0), (0, 0))
+
+
+def test_fused_stage_offset_guard(lib):
+    """k_bf2 / k_mirror2 address a row block of one outer row and one K1 slice with 32-bit buffer offsets; the host
+    predicate that keeps larger patches on the stage kernels (64-bit addresses) -- ADVICE r03: without it the hardware
+    range check would drop stores silently."""
+    fits = lib.load().igx_fused_stage_fits
+    LIM = 0x7fff0000
+
+    def S(N, p):                      # 1D index pairs of an axis with single interior knots
+        return N * (2 * p + 1) - p * (p + 1)
+
+    def check(p0, p, N1, N2):
+        G1, G2 = (N1 - p) * (p + 1), (N2 - p) * (p + 1)
+        want = (2 * p0 + 1) * S(N1, p) * S(N2, p) * 8 <= LIM and G1 * G2 * 8 <= LIM
+        assert bool(fits(2 * p0 + 1, S(N1, p), S(N2, p), G1, G2)) == want, (p0, p, N1, N2)
+        return want
+
+    assert check(4, 4, 132, 132)                   # C4
+    assert check(5, 5, 101, 101)                   # C5
+    assert check(2, 2, 66, 66)                     # C3
+    assert not check(4, 4, 612, 612)               # a thin slab such as 8 x 608 x 608 spans (nnz below 2^31, row block above)
+    assert check(4, 4, 609, 609)
+    assert not check(5, 5, 452, 452)
+    assert not check(1, 1, 9000, 9000)             # K1 slice beyond 2^31 bytes
+    for N in range(560, 640, 7):
+        check(4, 4, N, N)
+        check(4, 4, N, 2 * N)
+    assert fits(1, S(258, 3), S(258, 3), 1024, 1024) == 1      # 2D (C2): one trivial outer row
+    assert fits(9, -1, 5, 5, 5) == 0
+    assert fits(9, 1 << 40, 1 << 40, 1, 1) == 0    # no overflow of the products
