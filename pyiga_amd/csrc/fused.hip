@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256) k_mirror(const MirrorArgs M)
 #define MIRROR_VAR 1                                     // tile of the p = 4 case: 1: 33 rows, 0: 44 rows
 #endif
 template <int WW, int VAR> struct Mirror2Geom {
-    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : VAR == 2 ? 22 : VAR == 3 ? 16 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
+    static constexpr int RCM = WW == 9 ? (VAR == 1 ? 33 : VAR == 2 ? 22 : VAR == 3 ? 16 : VAR == 5 ? 20 : 44) : WW == 7 ? 56 : 64;     // rows i2 per block
     static constexpr int IB = MIRROR_IB;                // target rows i1 gathered together
     static constexpr int NJ2 = RCM + WW - 1;
     static constexpr int SG = (NJ2 * WW + 255) / 256;

@@ -50,6 +50,13 @@ struct GeoAArgs {
 #endif
     int field[GA_MAXS], type[GA_MAXS];
     double *out[GA_MAXS];
+    // non-symmetric forms (FORM = 1, the convection-diffusion form): optional second source of a slot (out = sum_g PI0[type] field
+    // + PI0[xtype] xfield; -1: none), the scalar coefficient of the diffusion part -- sampled on the resident Gauss slab
+    // (plane g0_lo first) or affine in the physical coordinates, c = cf[0] + cf[1] x + cf[2] y + cf[3] z
+    int xfield[GA_MAXS], xtype[GA_MAXS];
+    const double *coeff;
+    int g0_lo, coef_affine;
+    double cf[4];
 };
 
 typedef int int8v __attribute__((ext_vector_type(8)));
@@ -76,10 +83,18 @@ __device__ unsigned long long g_ga_stamp[2048 * 8 * 6];
 //             control index (as a double)
 //   [20, 24)  eight ints: number of flush steps after this plane (0 unless it ends a span) | first step | K1 slots of the
 //             first step's P pairs
-constexpr int GA_REC = 24;
+//   matrix-core sweep (k_geoA<.., MF = true>): the lower pairs (i0, j0) that are live on a span keep a ROW of the 16 x 16
+//   accumulator tile for their whole life -- class delta = i0 - j0 owns P - delta rows, pair (j0 + delta, j0) sits in row
+//   base[delta] + j0 mod (P - delta) -- so nothing moves when a dof leaves:
+//   [24, 32)  sixteen ints: row -> a | b << 4 | 256 (local indices of the row's pair on this plane's span), 0: row not live
+//   [32, 40)  sixteen ints: row -> K1 slot of the row's pair if it is COMPLETE after this plane (last plane of its span),
+//             -2: complete but not stored (neither its row nor its column is owned by the slab), -1: not complete
+//   [40]      two ints: smallest stored K1 slot of the plane (the store offsets are relative to it: 32 bits) | unused
+constexpr int GA_REC = 42;
+constexpr int GA_ROWS = 16;
 
 __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const int *fa0g, int P0G, const double *w0, int q,
-                             const int *step_ptr, const int *steps, int G0, double *tab)
+                             const int *step_ptr, const int *steps, int G0, double *tab, const int *rows, int nonsym)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G0) return;
@@ -94,8 +109,25 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
     if (g - s * q == q - 1) {
         const int st0 = step_ptr[s], st1 = step_ptr[s + 1];
         ri[0] = st1 - st0; ri[1] = st0;
-        if (st1 > st0)
+        if (st1 > st0 && !nonsym)
             for (int a = 0; a < P; ++a) ri[2 + a] = steps[(size_t)st0 * 8 + a];
+    }
+    // row tables of the matrix-core sweep (host-built per span: [n][2 GA_ROWS + 2] ints)
+    int *ra = (int *)(r + 24), *rs = (int *)(r + 32), *rb = (int *)(r + 40);
+    for (int m = 0; m < GA_ROWS; ++m) { ra[m] = 0; rs[m] = -1; }
+    rb[0] = 0; rb[1] = 0;
+    if (nonsym) {
+        // table of a non-symmetric form: the 16 ints of the first flush step after the plane (K1 slots of the pairs
+        // (d + a, d) | (d, d + a)) take the place of the row table
+        if (g - s * q == q - 1 && step_ptr[s + 1] > step_ptr[s])
+            for (int m = 0; m < 16; ++m) ra[m] = steps[(size_t)step_ptr[s] * 16 + m];
+    } else if (rows) {
+        const int *sr = rows + (size_t)s * (2 * GA_ROWS + 2);
+        for (int m = 0; m < GA_ROWS; ++m) ra[m] = sr[m];
+        if (g - s * q == q - 1) {
+            for (int m = 0; m < GA_ROWS; ++m) rs[m] = sr[GA_ROWS + m];
+            rb[0] = sr[2 * GA_ROWS];
+        }
     }
 }
 
@@ -104,15 +136,26 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
 // store stream -- tools/ubench/k1_store.hip: 3.1 ms of arithmetic with such loads become 9.4 ms when the stores are on,
 // while the same arithmetic without them overlaps the stores completely.  The block stages the table rows of a batch in
 // LDS with vector loads issued a whole batch ahead.
-template <int P, int NS, int P0G, int NC>
+template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
 __global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 4 : 1, 4)))
 k_geoA(const GeoAArgs A)
 {
+    static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
+    static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
+    constexpr int NF = FORM == 1 ? 9 : 6;                 // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = NS * 64;                           // threads
     constexpr int NRC = NS * GA_REC;                      // doubles of a batch of plane records
     constexpr int KRC = (NRC + NT - 1) / NT;              // ... per thread
-    __shared__ double fld[2][NS][6][64];                  // fields of two batches of planes
+    // fields of two batches of planes, [buffer][plane][field][point]; the matrix-core sweep reads four planes with one
+    // instruction (16 lanes each): its plane stride is padded so that they fall on different banks
+    constexpr int FST = NF * 64 + (MF ? 16 : 0);
+    __shared__ double fld_[2 * NS * FST];
+#define FLD(buf_, j_, k_, ln_) fld_[((buf_) * NS + (j_)) * FST + (k_) * 64 + (ln_)]
+    // matrix-core sweep: products V_b[tu] V_a[tv] of the 16 rows, per plane of a batch and type, rows permuted to
+    // [row mod 4][row / 4] (the four rows of a lane are neighbours), plane stride padded like the fields'
+    constexpr int ATS = 4 * GA_ROWS + 16;
+    __shared__ __attribute__((aligned(16))) double atb[MF ? 2 * NS * ATS : 2];
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
     __shared__ __attribute__((aligned(16))) double rec[3][NS][GA_REC];   // plane records of three batches: swept | evaluated | arriving
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,7 +218,7 @@ k_geoA(const GeoAArgs A)
         }
     };
     // fields of plane j of the batch in buffer gbuf at this lane's point -> fld[buf][j]
-    auto evaluate = [&](const int gbuf, const int buf) {
+    auto evaluate = [&](const int gbuf, const int buf, const int gpl) {
         const double *gt = &rec[gbuf][w][12];
         double V0[2 * P0G];
 #pragma unroll
@@ -198,6 +241,48 @@ k_geoA(const GeoAArgs A)
         }
         double GW = gw0 * GW1;
         GW = GW * GW2;
+        if constexpr (FORM == 1) {
+            // convection-diffusion form: c W JacInv JacInv^T (upper triangle) and beta_a = W sum_r JacInv[a][r] b_r, b = (y, -x, 1)
+            // (fields_convdiff, geo_device.h), with ONE division: M = quotient-rule numerator (J = M / w^2; M = J, w = 1 for a
+            // polynomial map), D = w^5 |det M|:   c W J^-1 J^-T = c GW w^3 / D adj(M) adj(M)^T,
+            // beta = GW det(M) / D adj(M) (Y, -X, w) with the homogeneous coordinates (X, Y, Z, w) of the point
+            double t[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    t[r * 3 + c] = NC == 4 ? jac[r][2 - c] * val[3] - val[r] * jac[3][2 - c] : jac[r][2 - c];
+            double a[9];
+            a[0] = t[4] * t[8] - t[5] * t[7];
+            a[1] = -(t[1] * t[8] - t[2] * t[7]);
+            a[2] = t[1] * t[5] - t[2] * t[4];
+            a[3] = -(t[3] * t[8] - t[5] * t[6]);
+            a[4] = t[0] * t[8] - t[2] * t[6];
+            a[5] = -(t[0] * t[5] - t[2] * t[3]);
+            a[6] = t[3] * t[7] - t[4] * t[6];
+            a[7] = -(t[0] * t[7] - t[1] * t[6]);
+            a[8] = t[0] * t[4] - t[1] * t[3];
+            const double det = (t[0] * a[0] + t[1] * a[3]) + t[2] * a[6];
+            const double wh = NC == 4 ? val[3] : 1.0, wh2 = wh * wh;
+            const double inv = 1.0 / (NC == 4 ? (wh2 * wh2) * (wh * fabs(det)) : fabs(det));
+            // c w^3: affine coefficient from the homogeneous coordinates, or the sampled value of the point
+            double cw3;
+            if (A.coef_affine) cw3 = (((A.cf[0] * wh + A.cf[1] * val[0]) + A.cf[2] * val[1]) + A.cf[3] * val[2]) * (NC == 4 ? wh2 : 1.0);
+            else cw3 = A.coeff[(long long)(gpl - A.g0_lo) * A.NPL + pt] * (NC == 4 ? wh2 * wh : 1.0);
+            const double g_inv = GW * inv;
+            const double sc = cw3 * g_inv, bs = det * g_inv;
+            FLD(buf, w, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+            FLD(buf, w, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
+            FLD(buf, w, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
+            FLD(buf, w, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
+            FLD(buf, w, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
+            FLD(buf, w, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
+            const double X = val[0], Y = val[1];
+            FLD(buf, w, 6, lane) = bs * ((a[0] * Y - a[1] * X) + a[2] * wh);
+            FLD(buf, w, 7, lane) = bs * ((a[3] * Y - a[4] * X) + a[5] * wh);
+            FLD(buf, w, 8, lane) = bs * ((a[6] * Y - a[7] * X) + a[8] * wh);
+            return;
+        }
         if (GA_ONEDIV && NS == 8) {
             // stiffness fields with ONE division (an f64 division is 12 vector instructions).  With the unscaled quotient-rule
             // matrix M = V'W - V W' (J = M / W^2; M = J for a polynomial geometry):
@@ -220,12 +305,12 @@ k_geoA(const GeoAArgs A)
             a[8] = t[0] * t[4] - t[1] * t[3];
             const double det = (t[0] * a[0] + t[1] * a[3]) + t[2] * a[6];
             const double sc = GW / (NC == 4 ? (val[3] * val[3]) * fabs(det) : fabs(det));
-            fld[buf][w][0][lane] = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
-            fld[buf][w][1][lane] = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
-            fld[buf][w][2][lane] = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
-            fld[buf][w][3][lane] = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
-            fld[buf][w][4][lane] = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
-            fld[buf][w][5][lane] = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
+            FLD(buf, w, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+            FLD(buf, w, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
+            FLD(buf, w, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
+            FLD(buf, w, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
+            FLD(buf, w, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
+            FLD(buf, w, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
             return;
         }
         double Jm[MAX_COMP][3], ev[MAX_COMP];
@@ -240,7 +325,7 @@ k_geoA(const GeoAArgs A)
         const int nf = A.kind == IGX_MASS ? 1 : 6;
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            if (k < nf) fld[buf][w][k][lane] = f[k];
+            if (k < nf) FLD(buf, w, k, lane) = f[k];
     };
     // all waves: evaluate the batch that starts at plane gn (table rows in gts[gbuf]).  The column coefficients belong to
     // one span of the geometry's axis 0; a batch that straddles span boundaries is evaluated span by span (uniform control:
@@ -257,7 +342,7 @@ k_geoA(const GeoAArgs A)
                 f0_blk = cur;
                 __syncthreads();
             }
-            if (mine == cur && !GA_OFF(1)) evaluate(gbuf, buf);
+            if (mine == cur && !GA_OFF(1)) evaluate(gbuf, buf, gn + w);
             if (cur == last) break;
             int nxt = last;
             for (int j = jl; j >= 0; --j) {
@@ -269,6 +354,216 @@ k_geoA(const GeoAArgs A)
         }
     };
 
+    // ---- matrix-core sweep (p = 3, 4 stiffness): the wave's K1 array as a 16 x 64 tile of v_mfma_f64_16x16x4_f64 accumulators --
+    // rows = live lower pairs (fixed row per pair, see GA_REC), columns = the 64 points in four 16-point tiles; lane
+    // (g = lane / 16, n = lane % 16) holds rows g, g + 4, g + 8, g + 12 of point 16 nt + n in acc[nt][0..3] (measured layout:
+    // tools/ubench/mfma_layout.hip).  Four consecutive planes of one span are ONE instruction per tile, A = the products of
+    // the 16 rows at the four planes, B = the field at 4 planes x 16 points; planes that do not fill a group of four inside
+    // their span and batch take 16 vector multiply-adds in the same layout.  The instruction adds its four planes in
+    // ascending order with one rounding each (checked bit for bit against an fma chain), so a pair's sum does not depend on
+    // how the batches cut its spans: row slabs and sweep chunks still reproduce the whole patch bit for bit.
+    if constexpr (MF) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        typedef int i2v __attribute__((ext_vector_type(2)));
+        const int t = A.type[w], fi = A.field[w];
+        const int g = lane >> 4, n = lane & 15;
+        const int tu = t & 1, tv = t >> 1;
+        d4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = d4{0.0, 0.0, 0.0, 0.0};
+        const long long tile0 = (long long)tile * 64;
+        const bool full = tile0 + 64 <= A.NPL;                 // (uniform) no point of the tile lies past the plane
+        const unsigned stride8 = (unsigned)(A.stride * 8);      // bytes between K1 slices (spread of a span's slots x stride8 < 2^31: host)
+        constexpr unsigned OOB = 0x7ffffff8u;
+        const double *const outw = A.out[w] + tile0;           // (no scalar load of a kernel argument inside the loop: see above)
+        asm volatile("" :: "s"(outw));
+        // products of the batch that starts at plane gn (records in slot rsl) -> atb[bufn]: wave w = plane w, lane = (type, row)
+        auto products = [&](const int gn, const int rsl, const int bufn) {
+            if (gn + w > g_last) return;
+            const int ty = lane >> 4, m = lane & 15;
+            const int ab = ((const int *)&rec[rsl][w][24])[m];
+            const double va = rec[rsl][w][6 * (ty >> 1) + (ab & 15)], vb = rec[rsl][w][6 * (ty & 1) + ((ab >> 4) & 15)];
+            atb[(bufn * NS + w) * ATS + ty * GA_ROWS + (m & 3) * 4 + (m >> 2)] = (ab & 256) ? vb * va : 0.0;
+        };
+        stage_load(g_begin); stage_store(0);
+        stage_load(g_begin + NS); stage_store(1);
+        __syncthreads();
+        next_batch(g_begin, 0, 0);
+        products(g_begin, 0, 0);
+        __syncthreads();
+        int it = 0, l = 0, sp = s_begin, rs = 0;
+        for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+            const int buf = it & 1;
+            const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
+            stage_load(gb + 2 * NS);
+            const int jend = min(NS, g_end - gb);
+            const double *ab = &atb[buf * NS * ATS + t * GA_ROWS];
+            // four planes of one span: one matrix instruction per tile
+            auto unit4 = [&](const int j) {
+                const double am = ab[(j + g) * ATS + (n & 3) * 4 + (n >> 2)];
+                double bm[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bm[nt] = FLD(buf, j + g, fi, 16 * nt + n);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm[nt], acc[nt], 0, 0, 0);
+            };
+            // one plane: 16 vector multiply-adds in the accumulator layout
+            auto unit1 = [&](const int j) {
+                const d2 *cr = (const d2 *)&ab[j * ATS + 4 * g];
+                const d2 c01 = cr[0], c23 = cr[1];
+                double b1[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b1[nt] = FLD(buf, j, fi, 16 * nt + n);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[nt][0] = fma(c01.x, b1[nt], acc[nt][0]); acc[nt][1] = fma(c01.y, b1[nt], acc[nt][1]);
+                    acc[nt][2] = fma(c23.x, b1[nt], acc[nt][2]); acc[nt][3] = fma(c23.y, b1[nt], acc[nt][3]);
+                }
+            };
+            // end of span sp (its last plane is plane jl of the batch): the rows of the leaving dofs are complete -- stored
+            // (quarter-wave runs of 128 B per row and tile; lanes without a row to store carry an out-of-range offset) and
+            // cleared under an exec mask
+            auto flush = [&](const int jl) {
+                const bool write = sp >= own_lo && !GA_OFF(2);
+                const int *rsl = (const int *)&rec[rs][jl][32];
+                const int sbase = __builtin_amdgcn_readfirstlane(((const int *)&rec[rs][jl][40])[0]);
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(outw + (long long)sbase * A.stride), (short)0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int slot = rsl[g + 4 * v];
+                    const bool done = slot != -1;
+                    const unsigned off = (slot >= 0 && write) ? (unsigned)(slot - sbase) * stride8 + n * 8u : OOB;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const unsigned o = full || tile0 + 16 * nt + n < A.NPL ? off + nt * 128u : OOB;
+                        i2v x; x.x = __double2loint(acc[nt][v]); x.y = __double2hiint(acc[nt][v]);
+                        __builtin_amdgcn_raw_buffer_store_b64(x, rsrc, (int)o, 0, 0);
+                    }
+                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
+                    unsigned long long sv;
+                    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\tv_mov_b64 %[c], 0\n\tv_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]"
+                                 : [a] "+v"(acc[0][v]), [b] "+v"(acc[1][v]), [c] "+v"(acc[2][v]), [d] "+v"(acc[3][v]), [sv] "=&s"(sv) : [m] "s"(dm) : "scc");
+                }
+                ++sp;
+            };
+            // The batch cuts the spans anywhere: (A) the planes that finish the span begun in the last batch, one by one;
+            // (B) whole spans -- one group of four, the rest one by one; (C) the first planes of the span the batch ends in.
+            // (Each phase updates the accumulators in one way only: no register copies where the paths meet.)
+            int j = 0;
+            if (l != 0) {
+                while (j < jend && l < P) { unit1(j); ++j; ++l; }
+                if (l == P) { flush(j - 1); l = 0; }
+            }
+            while (j + P <= jend) {
+                unit4(j);
+#pragma unroll
+                for (int e = 4; e < P; ++e) unit1(j + e);
+                j += P;
+                flush(j - 1);
+            }
+            if (j < jend) {
+                if (j + 4 <= jend) { unit4(j); j += 4; l = 4; }
+                while (j < jend) { unit1(j); ++j; ++l; }
+            }
+            next_batch(gb + NS, rn, buf ^ 1);
+            products(gb + NS, rn, buf ^ 1);
+            stage_store(ra);
+            rs = rn;
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- non-symmetric forms: the full (p+1)^2 pair window, up to two sources per slot, both pair families flushed
+    if constexpr (FORM == 1) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int t = A.type[w], fi = A.field[w], xt = A.xtype[w], xf = A.xfield[w];
+        double *const out = A.out[w] + pt;
+        double acc[P][P];
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+        auto basis_row = [&](double (&v)[PV], const int buf, const int j, const int d) {
+            const d2 *row = (const d2 *)&rec[buf][j][6 * d];
+#pragma unroll
+            for (int k = 0; k < P / 2; ++k) { const d2 x = row[k]; v[2 * k] = x.x; v[2 * k + 1] = x.y; }
+            if (P & 1) v[P - 1] = rec[buf][j][6 * d + P - 1];
+        };
+        // acc[a][b] += V_b[tu] (V_a[tv] f): a = test function (row), b = trial function
+        auto source = [&](const int rsl, const int buf, const int j, const int ty, const int ff) {
+            const double bv = FLD(buf, j, ff, lane);
+            double va[PV], vb[PV];
+            basis_row(va, rsl, j, ty >> 1);
+            basis_row(vb, rsl, j, ty & 1);
+            double c[P];
+#pragma unroll
+            for (int a = 0; a < P; ++a) c[a] = va[a] * bv;
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b < P; ++b) acc[a][b] = fma(vb[b], c[a], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+            asm volatile("" ::: "memory");
+        };
+        stage_load(g_begin); stage_store(0);
+        stage_load(g_begin + NS); stage_store(1);
+        __syncthreads();
+        next_batch(g_begin, 0, 0);
+        __syncthreads();
+        int it = 0, l = 0, sp = s_begin, rs = 0;
+        for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+            const int buf = it & 1;
+            const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
+            stage_load(gb + 2 * NS);
+#pragma unroll 1
+            for (int j = 0; j < NS; ++j) {
+                if (gb + j >= g_end) break;
+                source(rs, buf, j, t, fi);
+                if (xf >= 0) source(rs, buf, j, xt, xf);
+                if (++l < q) continue;
+                const bool write = sp >= own_lo && !GA_OFF(2);
+                const int *fr = (const int *)&rec[rs][j][20];
+                const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
+                for (int st = st0; st < st0 + nst; ++st) {
+                    int pr[16];
+                    if (st == st0) {
+                        const int *f16 = (const int *)&rec[rs][j][24];
+#pragma unroll
+                        for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(f16[a]);
+#pragma unroll
+                        for (int a = 1; a < P; ++a) pr[8 + a] = __builtin_amdgcn_readfirstlane(f16[8 + a]);
+                    } else {                              // (several dofs leave at the end of the axis)
+                        const int8v r0 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 16);
+                        const int8v r1 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 16 + 8);
+#pragma unroll
+                        for (int a = 0; a < P; ++a) { pr[a] = r0[a]; pr[8 + a] = r1[a]; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < P; ++a)
+                        if (pr[a] >= 0 && write) out[(long long)pr[a] * A.stride] = acc[a][0];
+#pragma unroll
+                    for (int a = 1; a < P; ++a)
+                        if (pr[8 + a] >= 0 && write) out[(long long)pr[8 + a] * A.stride] = acc[0][a];
+#pragma unroll
+                    for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                        for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+                    for (int b = 0; b < P; ++b) { acc[P - 1][b] = 0.0; acc[b][P - 1] = 0.0; }
+                }
+                l = 0; ++sp;
+            }
+            next_batch(gb + NS, rn, buf ^ 1);
+            stage_store(ra);
+            rs = rn;
+            __syncthreads();
+        }
+        return;
+    }
     // ---- sweep state of this wave
     const int t = A.type[w], fi = A.field[w];
     double *const out = A.out[w] + pt;
@@ -307,7 +602,7 @@ k_geoA(const GeoAArgs A)
         // that wait the stores are half an iteration old by then, instead of draining at full HBM latency once per batch
         // in front of the barrier.
         stage_load(gb + 2 * NS);
-        double bv = fld[buf][0][fi][lane];
+        double bv = FLD(buf, 0, fi, lane);
         double va[PV], vb[PV];                            // V[.][tv] (test functions, rows a), V[.][tu] (trial functions, columns b)
         basis_row(va, rs, 0, tv);
         if (GA_READBOTH || tu != tv) basis_row(vb, rs, 0, tu);
@@ -320,7 +615,7 @@ k_geoA(const GeoAArgs A)
             if (gb + j >= g_end) break;
             // the rows of the next plane replace these right after their last use: the LDS reads are in flight under the FMAs
             const int jn = j + 1 < NS ? j + 1 : j;
-            const double bvn = fld[buf][jn][fi][lane];
+            const double bvn = FLD(buf, jn, fi, lane);
             double c[P];
 #pragma unroll
             for (int a = 0; a < P; ++a) c[a] = va[a] * bv;
@@ -388,11 +683,11 @@ k_geoA(const GeoAArgs A)
 #endif
 }
 
-template <int P, int NS, int P0G>
+template <int P, int NS, int P0G, bool MF = false, int FORM = 0>
 static int launch_geoA_k(hipStream_t st, const GeoAArgs &A, int nc, dim3 grid)
 {
-    if (nc == 4) k_geoA<P, NS, P0G, 4><<<grid, dim3(NS * 64), 0, st>>>(A);
-    else k_geoA<P, NS, P0G, 3><<<grid, dim3(NS * 64), 0, st>>>(A);
+    if (nc == 4) k_geoA<P, NS, P0G, 4, MF, FORM><<<grid, dim3(NS * 64), 0, st>>>(A);
+    else k_geoA<P, NS, P0G, 3, MF, FORM><<<grid, dim3(NS * 64), 0, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_GA_STAMP
     {
@@ -422,11 +717,13 @@ static int launch_geoA_g(hipStream_t st, const GeoAArgs &A, int nc, int p0g, dim
 
 bool geoA_supported(const igx_patch *pt, int kind, int nslots)
 {
-    if (pt->dim != 3 || (kind != IGX_STIFFNESS && kind != IGX_MASS)) return false;
+    if (pt->dim != 3 || (kind != IGX_STIFFNESS && kind != IGX_MASS && kind != IGX_CONVDIFF)) return false;
     if (pt->geo_kind != IGX_GEO_BSPLINE && pt->geo_kind != IGX_GEO_NURBS) return false;
     if (nslots != (kind == IGX_MASS ? 1 : 8)) return false;
     const int P = pt->ax[0].P;
     if (P < 2 || P > 6) return false;
+    // the convection-diffusion form (non-symmetric, eight merged slots): kernels for p = 2 .. 5, whole Gauss planes resident
+    if (kind == IGX_CONVDIFF && (P < 3 || pt->boxed)) return false;
     const int p0g = pt->gax[0].P;
     if (p0g < 2 || p0g > 3) return false;
     // the column coefficients are recomputed (by the whole block, with barriers) at every span boundary of the geometry's
@@ -437,22 +734,79 @@ bool geoA_supported(const igx_patch *pt, int kind, int nslots)
 }
 
 int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
-                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks)
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield, const int *slot_xtype)
 {
+    const bool nonsym = kind == IGX_CONVDIFF;
+    if (nonsym) {
+        if (!pt->d_coeff) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
+        if (!pt->d_stepsn) { set_error("internal: flush records of the non-symmetric form are missing"); return IGX_ERR_UNSUPPORTED; }
+        if (!pt->d_geoa_tabn) {                          // per-plane records with the 16-int flush steps of the non-symmetric sweep
+            double *tab = nullptr;
+            const Axis &A0n = pt->ax[0];
+            if (hipMalloc((void **)&tab, (size_t)A0n.G * GA_REC * sizeof(double)) != hipSuccess) { set_error("per-plane table (non-symmetric form): out of device memory"); return IGX_ERR_NOMEM; }
+            k_geoa_table<<<dim3((A0n.G + 127) / 128), dim3(128), 0, st>>>(A0n.d_V, A0n.P, pt->gax[0].d_V, pt->gax[0].d_fa, pt->gax[0].P, pt->dev.ax[0].w, A0n.q,
+                                                                           pt->stepA_ptr, pt->d_stepsn, A0n.G, tab, nullptr, 1);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { (void)hipFree(tab); set_error("per-plane table (non-symmetric form): %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+            pt->d_geoa_tabn = tab;
+        }
+    }
     const PatchDev &pd = pt->dev;
     const Axis &A0 = pt->ax[0];
-    if (!pt->d_geoa_tab) {                               // per-plane records of axis 0: once per patch
+    if (!nonsym && !pt->d_geoa_tab) {                    // per-plane records of axis 0: once per patch
+        // row tables of the matrix-core sweep, per span: [16] row -> a | b << 4 | 256, [16] row -> K1 slot of the pair when
+        // it is complete after the span (-2: complete, not processed by this slab; -1: not complete), [2] smallest slot
+        std::vector<int> rows;
+        bool mf_ok = A0.P >= 2 && A0.P * (A0.P + 1) / 2 <= GA_ROWS;
+        if (mf_ok) {
+            const int P = A0.P, W = 2 * GA_ROWS + 2;
+            std::vector<int> slot_of(A0.S, -1);
+            for (size_t r = 0; r + 1 < pt->h_pl0.size(); r += 2) {
+                const int i0 = pt->h_pl0[r], j0 = pt->h_pl0[r + 1];
+                slot_of[A0.rp[i0] + (j0 - A0.jlo[i0])] = (int)(r / 2);
+            }
+            int base[8] = {0};
+            for (int d = 1; d < P; ++d) base[d] = base[d - 1] + (P - (d - 1));
+            rows.assign((size_t)A0.n * W, 0);
+            for (int sp = 0; sp < A0.n; ++sp) {
+                int *r = &rows[(size_t)sp * W];
+                for (int m = 0; m < GA_ROWS; ++m) r[GA_ROWS + m] = -1;
+                const int f = A0.fa[sp], fnext = sp + 1 < A0.n ? A0.fa[sp + 1] : f + P;
+                int lo = -1, hi = -1;
+                for (int j0 = f; j0 < f + P; ++j0)
+                    for (int i0 = j0; i0 < f + P; ++i0) {
+                        const int d = i0 - j0, m = base[d] + j0 % (P - d);
+                        r[m] = (i0 - f) | ((j0 - f) << 4) | 256;
+                        if (j0 < fnext) {
+                            const int sl = slot_of[A0.rp[i0] + (j0 - A0.jlo[i0])];
+                            r[GA_ROWS + m] = sl >= 0 ? sl : -2;
+                            if (sl >= 0) { lo = lo < 0 ? sl : std::min(lo, sl); hi = std::max(hi, sl); }
+                        }
+                    }
+                r[2 * GA_ROWS] = std::max(lo, 0);
+                // store offsets relative to the smallest slot of the span are 32-bit
+                if (lo >= 0 && ((long long)(hi - lo) * slice_stride + 64) * 8 >= 0x7ff00000LL) mf_ok = false;
+            }
+        }
+        int *d_rows = nullptr;
+        if (mf_ok) {
+            IGX_HIP(hipMalloc((void **)&d_rows, rows.size() * sizeof(int)));
+            if (hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipFree(d_rows); set_error("row tables of the matrix-core sweep: upload failed"); return IGX_ERR_HIP; }
+        }
         double *tab = nullptr;                           // committed to the patch only when the build has been launched
-        IGX_HIP(hipMalloc((void **)&tab, (size_t)A0.G * GA_REC * sizeof(double)));
+        if (hipMalloc((void **)&tab, (size_t)A0.G * GA_REC * sizeof(double)) != hipSuccess) { (void)hipFree(d_rows); set_error("per-plane table of the fused geometry + axis-0 sweep: out of device memory"); return IGX_ERR_NOMEM; }
         k_geoa_table<<<dim3((A0.G + 127) / 128), dim3(128), 0, st>>>(A0.d_V, A0.P, pt->gax[0].d_V, pt->gax[0].d_fa, pt->gax[0].P, pd.ax[0].w, A0.q,
-                                                                     pt->stepA_ptr, pt->stepA_rec, A0.G, tab);
-        const hipError_t e = hipGetLastError();
+                                                                     pt->stepA_ptr, pt->stepA_rec, A0.G, tab, d_rows, 0);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);   // (`rows` and d_rows are released below)
+        (void)hipFree(d_rows);
         if (e != hipSuccess) {
             (void)hipFree(tab);
             set_error("per-plane table of the fused geometry + axis-0 sweep: %s", hipGetErrorString(e));
             return IGX_ERR_HIP;
         }
         pt->d_geoa_tab = tab;
+        pt->geoa_mf = mf_ok ? 1 : 0;
     }
     GeoAArgs A{};
     A.gv = make_view(3, pt->gax, pt->d_ctrl, pt->ncomp);
@@ -460,15 +814,36 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
     A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
-    A.tab = pt->d_geoa_tab; A.steps = pt->stepA_rec;
+    A.tab = nonsym ? pt->d_geoa_tabn : pt->d_geoa_tab; A.steps = nonsym ? pt->d_stepsn : pt->stepA_rec;
+    A.coeff = pt->d_coeff; A.g0_lo = pd.g0_lo; A.coef_affine = pt->coef_affine;
+    for (int k = 0; k < 4; ++k) A.cf[k] = pt->coef_c[k];
     A.s_lo = pt->s0_lo; A.s_hi = pt->s0_hi; A.q = A0.q; A.chunk_len = chunk_len;
 #ifdef IGX_ABLATE
     { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
 #endif
-    for (int x = 0; x < nslots; ++x) { A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x]; }
+    for (int x = 0; x < nslots; ++x) {
+        A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x];
+        A.xfield[x] = slot_xfield ? slot_xfield[x] : -1; A.xtype[x] = slot_xtype ? slot_xtype[x] : 0;
+    }
     A.ntiles = (int)((A.NPL + 63) / 64);
     dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs
     const int nc = pt->ncomp, p0g = pt->gax[0].P;
+    if (nonsym) {
+#define GEOA_N(PV) case PV: return p0g == 2 ? launch_geoA_k<PV, 8, 2, false, 1>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<PV, 8, 3, false, 1>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED
+        switch (A0.P) {
+            GEOA_N(3); GEOA_N(4); GEOA_N(5); GEOA_N(6);
+        }
+#undef GEOA_N
+        set_error("fused geometry + stage A (non-symmetric): unsupported degree %d", A0.p);
+        return IGX_ERR_UNSUPPORTED;
+    }
+    // matrix-core sweep (opt-in, IGX_GEOA=mfma): eight slots (3D stiffness), p = 3, 4 (15 / 10 live pairs on 16 rows; below
+    // that the vector form issues fewer cycles, above it the pairs do not fit one tile).  One choice per patch: every slab
+    // and chunk agrees.
+    if (nslots == 8 && pt->geoa_mf && pt->knobs.geoa_mf && (A0.P == 5 || A0.P == 4) && A0.q == A0.P) {
+        if (A0.P == 5) return p0g == 2 ? launch_geoA_k<5, 8, 2, true>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<5, 8, 3, true>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED;
+        return p0g == 2 ? launch_geoA_k<4, 8, 2, true>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<4, 8, 3, true>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED;
+    }
 #define GEOA_P(PV) case PV: return nslots == 1 ? launch_geoA_g<PV, 1>(st, A, nc, p0g, grid) : launch_geoA_g<PV, 8>(st, A, nc, p0g, grid)
     switch (A0.P) {
         GEOA_P(2); GEOA_P(3); GEOA_P(4); GEOA_P(5); GEOA_P(6);

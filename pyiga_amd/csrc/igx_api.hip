@@ -347,7 +347,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
-    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
+    (void)hipFree(pt->d_geoa_tab); (void)hipFree(pt->d_geoa_tabn); (void)hipFree(pt->d_zeros); (void)hipFree(pt->d_triv); (void)hipFree(pt->d_tpairs);
     (void)hipFree(pt->d_ws_ij); (void)hipFree(pt->d_ws_out);
     (void)hipFree(pt->d_lv_f); (void)hipFree(pt->d_lv_t1); (void)hipFree(pt->d_lv_t2); (void)hipFree(pt->d_lv_o);
     delete pt;
@@ -363,7 +363,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     if (pt) {                                   // chain choices: read once, here
         igx_knobs &k = pt->knobs;
         if (const char *e = getenv("IGX_PATH")) k.path = !strcmp(e, "fused") ? 1 : !strcmp(e, "unfused") ? 2 : !strcmp(e, "single") ? 3 : 0;
-        if (const char *e = getenv("IGX_GEOA")) k.geoa = strcmp(e, "0") != 0;
+        if (const char *e = getenv("IGX_GEOA")) { k.geoa = strcmp(e, "0") != 0; k.geoa_mf = strcmp(e, "mfma") == 0; }
         if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
         if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");
         k.poison = getenv("IGX_DEBUG_POISON") != nullptr;
@@ -511,6 +511,7 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     IGX_HIP(hipMemcpyAsync(pt->d_coeff, coeff + (pt->boxed ? 0 : (size_t)pt->dev.g0_lo * per_plane), n * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream));
     IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     pt->fields_kind = -1;
+    pt->coef_affine = 0;
     return IGX_OK;
 }
 
@@ -524,6 +525,10 @@ int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
     if (int rc = launch_coeff_affine(pt->ctx->stream, pt, c, pt->d_coeff)) return rc;
     IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     pt->fields_kind = -1;
+    // (the sampled values stay for the kernels that read them -- entry-wise, stage kernels; the fused geometry + axis-0 sweep
+    // evaluates the coefficient itself from the physical coordinates it has at hand)
+    pt->coef_affine = 1;
+    for (int k = 0; k < 4; ++k) pt->coef_c[k] = c[k];
     return IGX_OK;
 }
 

@@ -113,6 +113,8 @@ struct igx_ctx {
 struct igx_knobs {
     int path = 0;                             // IGX_PATH: 0 default (fused in 3D; 2D: one launch for small patches, else stage kernels), 1 fused, 2 unfused, 3 single (2D)
     int geoa = 1;                             // IGX_GEOA=0: separate field and axis-0 sweep kernels
+    int geoa_mf = 0;                          // IGX_GEOA=mfma: the FP64 matrix-core form of the axis-0 sweep inside k_geoA at p = 3, 4 (built and
+                                              // measured in round 4: 5.08 against 4.50 ms for the vector form at C4 -- DESIGN.md section 3; off by default)
     int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
     int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
     int poison = 0;                           // IGX_DEBUG_POISON: NaN-fill the CSR values before an assembly (tests)
@@ -139,6 +141,8 @@ struct igx_patch {
     double *d_formc = nullptr;                // IGX_FORM: physical coefficient fields [n][npts_loc]
     int form_slot[16];                        //   4*r+s -> row of d_formc or -1
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
+    int coef_affine = 0;                      // ... set by igx_patch_set_coeff_affine: k_geoA evaluates it from the geometry map
+    double coef_c[4] = {0, 0, 0, 0};
     // slab
     int r0_lo = 0, r0_hi = 0, s0_lo = 0, s0_hi = 0;
     long long row_lo = 0, row_hi = 0, nnz = 0, nnz_off = 0, nrows_total = 0, nelem_owned = 0;
@@ -170,6 +174,8 @@ struct igx_patch {
     int *d_steps = nullptr;                   // flush-step tables of the sweeps (one allocation)
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
     double *d_geoa_tab = nullptr;             // per-plane records of axis 0 for k_geoA (geoa.hip), built on first use
+    int geoa_mf = 0;                          // ... and whether they carry the row tables of the matrix-core sweep
+    double *d_geoa_tabn = nullptr;            // the same for the non-symmetric sweep (16-int flush steps), built on first use
     double *d_K1 = nullptr, *d_K2 = nullptr;
     size_t K1_cap = 0, K2_cap = 0;
     // persistent workspaces of the batched-entry and load-vector entry points (grow-only, freed with the patch)
@@ -259,7 +265,7 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);
 int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
-                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks);
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield = nullptr, const int *slot_xtype = nullptr);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);

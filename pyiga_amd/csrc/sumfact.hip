@@ -1545,8 +1545,9 @@ static int launch_final(hipStream_t st, const double *K, double *data, const Fin
 static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
 {
     if (!pt->knobs.geoa) return false;
-    return igx_kind_symmetric(kind) && geoA_supported(pt, kind, nslots);
+    return (igx_kind_symmetric(kind) || kind == IGX_CONVDIFF) && geoA_supported(pt, kind, nslots);
 }
+static bool fused_applicable(const igx_patch *pt);
 
 // The single launch beats the stage-kernel chain while its grid is one resident round of tiles of at most 6 x 6 rows
 // (a block's duration grows with its tile: 14 us at 2 x 4 rows, 27 us at 6 x 6, 39 us at 8 x 8 against 28-34 us of
@@ -1569,7 +1570,9 @@ static bool single2d_wanted(const igx_patch *pt, int kind)
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
     if (single2d_wanted(pt, kind)) return false;
-    if (pt->dim != 3 || !igx_kind_symmetric(kind)) return true;
+    if (pt->dim != 3) return true;
+    // the convection-diffusion form: its eight merged slots exist where the fused stage runs (sumfact_assemble)
+    if (!igx_kind_symmetric(kind)) return !(kind == IGX_CONVDIFF && fused_applicable(pt) && geoA_wanted(pt, kind, 8));
     return !geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 8);
 }
 
@@ -1727,7 +1730,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     for (const XA &x : X) nX = std::max(nX, x.slot + 1);
     if (!merged || dim == 2) nX = (int)X.size();
     // K1 slice stride: padded when both producer (geoA) and consumer (k_bf) take a stride (experiment: IGX_K1PAD doubles)
-    const bool use_geoA = geoA_wanted(pt, kind, nX);
+    const bool use_geoA = (sym || merged) && geoA_wanted(pt, kind, nX);
     long long NPLs = NPL;
 #ifdef IGX_ABLATE
     if (use_geoA && fused && dim == 3) { const char *e = getenv("IGX_K1PAD"); NPLs = NPL + (e ? atoi(e) : 0); }
@@ -1738,11 +1741,16 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     stage_event(pt, 1, st);
     if (use_geoA) {
         // geometry evaluated inside the sweep: no field arrays (geoa.hip)
-        int sf[8], stp[8];
+        int sf[8], stp[8], sxf[8], sxt[8];
         double *so[8];
-        for (int x = 0; x < nX; ++x) { sf[x] = X[x].f; stp[x] = X[x].t0; so[x] = pt->d_K1 + (size_t)X[x].slot * np0 * NPLs; }
+        for (const XA &xa : X) {
+            if (xa.alias) continue;                      // (merged slots with identical sources share one array)
+            const int x = merged ? xa.slot : (int)(&xa - X.data());
+            sf[x] = xa.f; stp[x] = xa.t0; sxf[x] = xa.xf; sxt[x] = xa.xt0 < 0 ? 0 : xa.xt0;
+            so[x] = pt->d_K1 + (size_t)xa.slot * np0 * NPLs;
+        }
         const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P);
-        int rc = launch_geoA(st, pt, kind, nX, sf, stp, so, NPLs, ch.len, ch.nchunks);
+        int rc = launch_geoA(st, pt, kind, nX, sf, stp, so, NPLs, ch.len, ch.nchunks, sxf, sxt);
         if (rc) return rc;
         pt->last_path |= IGX_PATH_GEOA;
         pt->timing.n_launches++;

@@ -14,9 +14,11 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int NPL = 20;                 // planes resident in LDS (ring)
-constexpr int PST = 6 * 64 + 16;        // doubles per plane (padded: the four plane groups of an MFMA operand on different banks)
+constexpr int PST = 6 * 64 + 16;
+constexpr int PST2 = 6 * 64 + 1;        // MODE 2 (16-byte lane stride): odd plane stride puts the two plane groups of a half wave on different banks        // doubles per plane (padded: the four plane groups of an MFMA operand on different banks)
 
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, double x)
 {
@@ -24,11 +26,11 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, 0, 0);
 }
 
-template <int MODE, int GEO>
+template <int MODE, int GEO, int NOST>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_sweep(double *out, long long stride, long long xstride, int nspans, const double *init)
 {
-    __shared__ double fld[NPL * PST];
+    __shared__ double fld[NPL * PST];          // (PST >= PST2)
     __shared__ __attribute__((aligned(16))) double rec[NPL][12];       // basis rows [value | derivative][6]
     __shared__ __attribute__((aligned(16))) double atab[4][5][16];     // products per type, plane of the span, slot
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +89,7 @@ k_sweep(double *out, long long stride, long long xstride, int nspans, const doub
                 if (++cnt == 8) { cnt = 0; geo(); __syncthreads(); }
             }
 #pragma unroll
-            for (int a = 0; a < 5; ++a) o[(long long)(5 * (s + a) + 4 - a) * stride] = acc[a][0];
+            for (int a = 0; a < 5; ++a) if (!NOST) o[(long long)(5 * (s + a) + 4 - a) * stride] = acc[a][0];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -96,7 +98,7 @@ k_sweep(double *out, long long stride, long long xstride, int nspans, const doub
             for (int b = 0; b < 5; ++b) acc[4][b] = 0.0;
         }
         if (acc[0][0] == 1.234e300) out[0] = acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4] + acc[3][1];
-    } else {
+    } else if (MODE == 1) {
         double4_t acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = {0, 0, 0, 0};
@@ -142,7 +144,7 @@ k_sweep(double *out, long long stride, long long xstride, int nspans, const doub
                 const unsigned off = done ? (unsigned)((5 * dl[v] + 4 - dl[v]) * stride * 8) + n * 8 : 0x7ffffff8u;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    bstore(rs, off + (done ? nt * 128 : 0), acc[nt][v]);
+                    if (!NOST) bstore(rs, off + (done ? nt * 128 : 0), acc[nt][v]);
                     acc[nt][v] = done ? 0.0 : acc[nt][v];
                 }
                 ph[v] = ph[v] + 1 >= per[v] ? 0 : ph[v] + 1;
@@ -150,21 +152,87 @@ k_sweep(double *out, long long stride, long long xstride, int nspans, const doub
             if (cnt >= 8) { cnt -= 8; geo(); __syncthreads(); }
         }
         if (acc[0][0] == 1.234e300) out[0] = acc[1][1] + acc[2][2] + acc[3][3];
+    } else if (MODE == 2) {
+        // lean form: row i of the accumulator tile = lane / 16 + 4 v (measured layout), points interleaved so that a lane holds
+        // two neighbouring points per register pair (16-byte stores, 256 B per completed row and store); completed rows are
+        // found with one compare per register (phase counters of the five slot classes packed into one scalar), cleared
+        // under an exec mask
+        double4_t acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = {0, 0, 0, 0};
+        const int g = lane >> 4, n = lane & 15;
+        int sh[4], rr[4];
+        unsigned cst[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = g + 4 * v;
+            const int dl = m < 5 ? 0 : m < 9 ? 1 : m < 12 ? 2 : m < 14 ? 3 : 4;
+            rr[v] = m < 5 ? m : m < 9 ? m - 5 : m < 12 ? m - 9 : m < 14 ? m - 12 : m < 15 ? 0 : 15;
+            sh[v] = 4 * dl;
+            cst[v] = (unsigned)((5 * dl + 4 - dl) * stride * 8) + n * 8;
+        }
+        int pl = 0, cnt = 0;
+        unsigned phw = 0;                             // s mod (5 - delta) in nibble delta (scalar)
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        const double *xbase = out + (long long)w * xstride + pt;
+        // point of (tile nt, column n): 2 n + (nt & 1) + 32 (nt >> 1)
+        for (int s = 0; s < nspans; ++s) {
+            const double am = atab[t][g][n];
+            const d2 *cr = (const d2 *)&atab[t][4][4 * g];
+            const d2 c01 = cr[0], c23 = cr[1];
+            const int pl4 = pl + 4 >= NPL ? pl + 4 - NPL : pl + 4;
+            int pk = pl + g; pk = pk >= NPL ? pk - NPL : pk;
+            double bm[4], b5[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bm[nt] = fld[pk * PST + fi * 64 + 16 * nt + n];
+                b5[nt] = fld[pl4 * PST + fi * 64 + 16 * nt + n];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt][0] = fma(c01.x, b5[nt], acc[nt][0]); acc[nt][1] = fma(c01.y, b5[nt], acc[nt][1]);
+                acc[nt][2] = fma(c23.x, b5[nt], acc[nt][2]); acc[nt][3] = fma(c23.y, b5[nt], acc[nt][3]);
+            }
+            pl = pl + 5 >= NPL ? pl + 5 - NPL : pl + 5;
+            cnt += 5;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xbase + (long long)(5 * s) * stride), (short)0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bool done = (int)((phw >> sh[v]) & 15u) == rr[v];
+                const unsigned off = done ? cst[v] : 0x7ffffff8u;
+                if (!NOST) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) bstore(rs, off + nt * 128u, acc[nt][v]);   // (out-of-range lanes stay out of range)
+                }
+                {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(done);
+                    unsigned long long sv;
+                    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\tv_mov_b64 %[c], 0\n\tv_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]"
+                                 : [a] "+v"(acc[0][v]), [b] "+v"(acc[1][v]), [c] "+v"(acc[2][v]), [d] "+v"(acc[3][v]), [sv] "=&s"(sv) : [m] "s"(m) : "scc");
+                }
+            }
+            p0 = p0 == 4 ? 0 : p0 + 1; p1 = p1 == 3 ? 0 : p1 + 1; p2 = p2 == 2 ? 0 : p2 + 1; p3 = p3 ^ 1;
+            phw = (unsigned)(p0 | (p1 << 4) | (p2 << 8) | (p3 << 12));
+            if (cnt >= 8) { cnt -= 8; geo(); __syncthreads(); }
+        }
+        if (acc[0][0] == 1.234e300) out[0] = acc[1][1] + acc[2][2] + acc[3][3];
     }
     if (g0 + g1 + g2 + g3 == 1.234e300) out[1] = g0;
 }
 
-template <int MODE, int GEO>
+template <int MODE, int GEO, int NOST = 0>
 static float run(double *out, long long stride, long long xstride, int nspans, const double *init, int blocks)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k_sweep<MODE, GEO><<<blocks, 512>>>(out, stride, xstride, nspans, init);
+    k_sweep<MODE, GEO, NOST><<<blocks, 512>>>(out, stride, xstride, nspans, init);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int r = 0; r < 3; ++r) {
         hipEventRecord(e0);
-        k_sweep<MODE, GEO><<<blocks, 512>>>(out, stride, xstride, nspans, init);
+        k_sweep<MODE, GEO, NOST><<<blocks, 512>>>(out, stride, xstride, nspans, init);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
@@ -185,8 +253,9 @@ int main()
     for (int i = 0; i < 4096; ++i) h[i] = 0.5 + rand() / (double)RAND_MAX * 1e-3;
     hipMemcpy(init, h, sizeof h, hipMemcpyHostToDevice);
     printf("C4-shaped sweep: %d blocks x 8 waves x 64 points, %d spans of 5 planes, K1 %.1f GB\n", blocks, nspans, blocks * 64.0 * 8 * 5 * nspans * 8 / 1e9);
-    printf("geometry stand-in 0 FMAs/8 planes:     VALU %.2f ms   MFMA %.2f ms\n", run<0, 0>(out, stride, xstride, nspans, init, blocks), run<1, 0>(out, stride, xstride, nspans, init, blocks));
-    printf("geometry stand-in 128 FMAs/8 planes:   VALU %.2f ms   MFMA %.2f ms\n", run<0, 128>(out, stride, xstride, nspans, init, blocks), run<1, 128>(out, stride, xstride, nspans, init, blocks));
-    printf("geometry stand-in 256 FMAs/8 planes:   VALU %.2f ms   MFMA %.2f ms\n", run<0, 256>(out, stride, xstride, nspans, init, blocks), run<1, 256>(out, stride, xstride, nspans, init, blocks));
+#define ROW(G) printf("geometry stand-in %3d FMAs / 8 planes:  VALU %.2f  MFMA(first form) %.2f  MFMA(lean) %.2f ms   | without the K1 stores: %.2f  %.2f  %.2f ms\n", G, \
+        run<0, G>(out, stride, xstride, nspans, init, blocks), run<1, G>(out, stride, xstride, nspans, init, blocks), run<2, G>(out, stride, xstride, nspans, init, blocks), \
+        run<0, G, 1>(out, stride, xstride, nspans, init, blocks), run<1, G, 1>(out, stride, xstride, nspans, init, blocks), run<2, G, 1>(out, stride, xstride, nspans, init, blocks))
+    ROW(0); ROW(128); ROW(256);
     return 0;
 }
