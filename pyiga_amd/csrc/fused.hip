@@ -497,8 +497,14 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         constexpr int tmap[16] = {0, 1, 2, 3, 6, 7, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15};
         task = tmap[wave & 15];
     } else if (NR == 4 && NLG == 3 && NCW == 4) {
-        constexpr int tmap[16] = {12, 13, 14, 15, 9, 3, 0, 2, 10, 4, 1, 7, 11, 6, 5, 8};
-        task = tmap[wave & 15];
+#ifndef BF2_TMAP
+#define BF2_TMAP 0
+#endif
+        // (waves w, w + 4, w + 8, w + 12 share a SIMD; tasks 0-2 role 0, 3-5 role 1, 6-8 role 2, 9-11 role 3, 12-15 contractors)
+        constexpr int tmaps[3][16] = {{12, 13, 14, 15, 9, 3, 0, 2, 10, 4, 1, 7, 11, 6, 5, 8},
+                                      {12, 13, 14, 15, 0, 1, 2, 5, 9, 11, 4, 7, 10, 3, 6, 8},
+                                      {12, 13, 14, 15, 0, 1, 2, 5, 6, 3, 4, 7, 9, 10, 11, 8}};
+        task = tmaps[BF2_TMAP][wave & 15];
     } else if (NR == 4 && NLG == 2 && NCW == 4) {
         const int sd = wave & 3, k = wave >> 2;
         if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
@@ -732,6 +738,7 @@ struct MirrorArgs {
     int i1_rows, ni1;            // rows i1 per block, blocks per (pair, chunk)
     const int *tpairs;           // [ntp][2] target pairs
     int ntp, RC, nchunks;
+    int chunk_fastest;           // block order: the chunks of the last axis of one (pair, row range) are neighbours (k_mirror2)
 };
 
 template <int WW> struct MirrorGeom {
@@ -863,7 +870,10 @@ __global__ void __launch_bounds__(256) k_mirror2(const MirrorArgs M)
         const unsigned per = gridDim.x / 8;
         if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
     }
-    const int ib = (int)(bid % M.ni1), chunk = (int)((bid / M.ni1) % M.nchunks), tp = (int)(bid / ((unsigned)M.ni1 * M.nchunks));
+    int ib, chunk;
+    if (M.chunk_fastest) { chunk = (int)(bid % M.nchunks); ib = (int)((bid / M.nchunks) % M.ni1); }
+    else { ib = (int)(bid % M.ni1); chunk = (int)((bid / M.ni1) % M.nchunks); }
+    const int tp = (int)(bid / ((unsigned)M.ni1 * M.nchunks));
     const int i0 = ((cip)M.tpairs)[2 * tp], j0 = ((cip)M.tpairs)[2 * tp + 1];
     const bool diag = i0 == j0;
     const int c0i = jhi0[i0] - jlo0[i0], c0j = jhi0[j0] - jlo0[j0];
@@ -1237,6 +1247,10 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
     M.rp1 = AM.dev.rp; M.rp2 = AL.dev.rp;
     M.N1 = AM.N; M.N2 = AL.N; M.p = AL.p; M.i1_lo = in.i1_lo; M.i1_hi = in.i1_hi;
     M.tpairs = in.tpairs; M.ntp = in.ntp;
+    M.chunk_fastest = 0;
+#ifdef IGX_ABLATE
+    if (const char *e = getenv("IGX_MIRROR_ORDER")) M.chunk_fastest = atoi(e);
+#endif
     // 32-bit offsets inside a row block (k_mirror2): c0 S1 S2 values of 8 bytes below 2^31
     const long long c0max = 2 * pt->ax[0].p + 1;
 #ifdef MIRROR_OLD

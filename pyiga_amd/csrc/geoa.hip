@@ -136,17 +136,24 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
 // store stream -- tools/ubench/k1_store.hip: 3.1 ms of arithmetic with such loads become 9.4 ms when the stores are on,
 // while the same arithmetic without them overlaps the stores completely.  The block stages the table rows of a batch in
 // LDS with vector loads issued a whole batch ahead.
+// FORM = 1 (non-symmetric): the block carries GA_NGW extra GEOMETRY waves -- the sweep of the full (p+1)^2 window holds 72
+// accumulator registers at p = 5 and the slots with two sources sweep twice as long as the others, so the eight sweep waves
+// only sweep and four more waves evaluate the planes of the next batch beside them (two planes each).
+constexpr int GA_NGW = 4;
+constexpr int geoa_threads(int NS, int FORM) { return (NS + (FORM == 1 ? GA_NGW : 0)) * 64; }
 template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
-__global__ void __launch_bounds__(NS * 64) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 4 : 1, 4)))
+__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 3 : NS >= 8 ? 4 : 1, FORM == 1 ? 3 : 4)))
 k_geoA(const GeoAArgs A)
 {
+    constexpr int NGW = FORM == 1 ? GA_NGW : 0;           // geometry waves (0: every sweep wave evaluates the plane of its own number)
     static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
     static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
     constexpr int NF = FORM == 1 ? 9 : 6;                 // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
-    constexpr int NT = NS * 64;                           // threads
+    constexpr int NT = (NS + NGW) * 64;                   // threads
     constexpr int NRC = NS * GA_REC;                      // doubles of a batch of plane records
-    constexpr int KRC = (NRC + NT - 1) / NT;              // ... per thread
+    constexpr int NTS = NGW ? NGW * 64 : NT;              // threads that stage them (the geometry waves where they exist)
+    constexpr int KRC = (NRC + NTS - 1) / NTS;            // ... per thread
     // fields of two batches of planes, [buffer][plane][field][point]; the matrix-core sweep reads four planes with one
     // instruction (16 lanes each): its plane stride is padded so that they fall on different banks
     constexpr int FST = NF * 64 + (MF ? 16 : 0);
@@ -183,15 +190,15 @@ k_geoA(const GeoAArgs A)
     auto stage_load = [&](const int gb) {
 #pragma unroll
         for (int k = 0; k < KRC; ++k) {
-            const int i = tid + k * NT, j = i / GA_REC;
-            if (i < NRC) rc_reg[k] = A.tab[(size_t)min(gb + j, g_last) * GA_REC + (i - j * GA_REC)];
+            const int i = tid - (NT - NTS) + k * NTS, j = i / GA_REC;
+            if (i >= 0 && i < NRC) rc_reg[k] = A.tab[(size_t)min(gb + j, g_last) * GA_REC + (i - j * GA_REC)];
         }
     };
     auto stage_store = [&](const int slot) {
 #pragma unroll
         for (int k = 0; k < KRC; ++k) {
-            const int i = tid + k * NT;
-            if (i < NRC) (&rec[slot][0][0])[i] = rc_reg[k];
+            const int i = tid - (NT - NTS) + k * NTS;
+            if (i >= 0 && i < NRC) (&rec[slot][0][0])[i] = rc_reg[k];
         }
     };
 
@@ -204,7 +211,7 @@ k_geoA(const GeoAArgs A)
     auto columns = [&](const int f0) {
         const double *V1 = gv.V[1] + (size_t)g1 * gv.P[1] * 2, *V2 = gv.V[2] + (size_t)g2 * gv.P[2] * 2;
         const int f1 = gv.fa[1][g1], f2 = gv.fa[2][g2];
-        for (int e = w; e < P0G * NC; e += NS) {
+        for (int e = NGW ? w - NS : w; e >= 0 && e < P0G * NC; e += NGW ? NGW : NS) {
             const int a0 = e / NC, c = e - a0 * NC;
             double sv = 0.0, s1 = 0.0, s2 = 0.0;
             for (int a1 = 0; a1 < gv.P[1]; ++a1)
@@ -218,8 +225,8 @@ k_geoA(const GeoAArgs A)
         }
     };
     // fields of plane j of the batch in buffer gbuf at this lane's point -> fld[buf][j]
-    auto evaluate = [&](const int gbuf, const int buf, const int gpl) {
-        const double *gt = &rec[gbuf][w][12];
+    auto evaluate = [&](const int gbuf, const int buf, const int jp, const int gpl) {
+        const double *gt = &rec[gbuf][jp][12];
         double V0[2 * P0G];
 #pragma unroll
         for (int e = 0; e < 2 * P0G; ++e) V0[e] = gt[e];
@@ -271,16 +278,16 @@ k_geoA(const GeoAArgs A)
             else cw3 = A.coeff[(long long)(gpl - A.g0_lo) * A.NPL + pt] * (NC == 4 ? wh2 * wh : 1.0);
             const double g_inv = GW * inv;
             const double sc = cw3 * g_inv, bs = det * g_inv;
-            FLD(buf, w, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
-            FLD(buf, w, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
-            FLD(buf, w, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
-            FLD(buf, w, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
-            FLD(buf, w, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
-            FLD(buf, w, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
+            FLD(buf, jp, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+            FLD(buf, jp, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
+            FLD(buf, jp, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
+            FLD(buf, jp, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
+            FLD(buf, jp, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
+            FLD(buf, jp, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
             const double X = val[0], Y = val[1];
-            FLD(buf, w, 6, lane) = bs * ((a[0] * Y - a[1] * X) + a[2] * wh);
-            FLD(buf, w, 7, lane) = bs * ((a[3] * Y - a[4] * X) + a[5] * wh);
-            FLD(buf, w, 8, lane) = bs * ((a[6] * Y - a[7] * X) + a[8] * wh);
+            FLD(buf, jp, 6, lane) = bs * ((a[0] * Y - a[1] * X) + a[2] * wh);
+            FLD(buf, jp, 7, lane) = bs * ((a[3] * Y - a[4] * X) + a[5] * wh);
+            FLD(buf, jp, 8, lane) = bs * ((a[6] * Y - a[7] * X) + a[8] * wh);
             return;
         }
         if (GA_ONEDIV && NS == 8) {
@@ -305,12 +312,12 @@ k_geoA(const GeoAArgs A)
             a[8] = t[0] * t[4] - t[1] * t[3];
             const double det = (t[0] * a[0] + t[1] * a[3]) + t[2] * a[6];
             const double sc = GW / (NC == 4 ? (val[3] * val[3]) * fabs(det) : fabs(det));
-            FLD(buf, w, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
-            FLD(buf, w, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
-            FLD(buf, w, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
-            FLD(buf, w, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
-            FLD(buf, w, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
-            FLD(buf, w, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
+            FLD(buf, jp, 0, lane) = sc * ((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+            FLD(buf, jp, 1, lane) = sc * ((a[0] * a[3] + a[1] * a[4]) + a[2] * a[5]);
+            FLD(buf, jp, 2, lane) = sc * ((a[0] * a[6] + a[1] * a[7]) + a[2] * a[8]);
+            FLD(buf, jp, 3, lane) = sc * ((a[3] * a[3] + a[4] * a[4]) + a[5] * a[5]);
+            FLD(buf, jp, 4, lane) = sc * ((a[3] * a[6] + a[4] * a[7]) + a[5] * a[8]);
+            FLD(buf, jp, 5, lane) = sc * ((a[6] * a[6] + a[7] * a[7]) + a[8] * a[8]);
             return;
         }
         double Jm[MAX_COMP][3], ev[MAX_COMP];
@@ -325,7 +332,7 @@ k_geoA(const GeoAArgs A)
         const int nf = A.kind == IGX_MASS ? 1 : 6;
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            if (k < nf) FLD(buf, w, k, lane) = f[k];
+            if (k < nf) FLD(buf, jp, k, lane) = f[k];
     };
     // all waves: evaluate the batch that starts at plane gn (table rows in gts[gbuf]).  The column coefficients belong to
     // one span of the geometry's axis 0; a batch that straddles span boundaries is evaluated span by span (uniform control:
@@ -333,7 +340,6 @@ k_geoA(const GeoAArgs A)
     auto next_batch = [&](const int gn, const int gbuf, const int buf) {
         if (gn >= g_end) return;
         const int jl = min(NS - 1, g_last - gn);
-        const int mine = w <= jl ? __builtin_amdgcn_readfirstlane((int)rec[gbuf][w][19]) : -1;
         const int last = __builtin_amdgcn_readfirstlane((int)rec[gbuf][jl][19]);
         int cur = __builtin_amdgcn_readfirstlane((int)rec[gbuf][0][19]);
         for (;;) {
@@ -342,7 +348,12 @@ k_geoA(const GeoAArgs A)
                 f0_blk = cur;
                 __syncthreads();
             }
-            if (mine == cur && !GA_OFF(1)) evaluate(gbuf, buf, gn + w);
+            if (NGW == 0) {
+                if (w <= jl && __builtin_amdgcn_readfirstlane((int)rec[gbuf][w][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, w, gn + w);
+            } else if (w >= NS) {
+                for (int jp = w - NS; jp <= jl; jp += NGW)
+                    if (__builtin_amdgcn_readfirstlane((int)rec[gbuf][jp][19]) == cur) evaluate(gbuf, buf, jp, gn + jp);
+            }
             if (cur == last) break;
             int nxt = last;
             for (int j = jl; j >= 0; --j) {
@@ -351,6 +362,26 @@ k_geoA(const GeoAArgs A)
             }
             cur = nxt;
             __syncthreads();                              // the columns are rewritten next
+        }
+    };
+
+    // the same walk over the geometry spans of a batch for waves that evaluate nothing (FORM = 1: the sweep waves): the
+    // barriers of next_batch, nothing else
+    auto next_batch_barriers = [&](const int gn, const int gbuf) {
+        if (gn >= g_end) return;
+        const int jl = min(NS - 1, g_last - gn);
+        const int last = __builtin_amdgcn_readfirstlane((int)rec[gbuf][jl][19]);
+        int cur = __builtin_amdgcn_readfirstlane((int)rec[gbuf][0][19]);
+        for (;;) {
+            if (cur != f0_blk) { f0_blk = cur; __syncthreads(); }
+            if (cur == last) break;
+            int nxt = last;
+            for (int j = jl; j >= 0; --j) {
+                const int v = __builtin_amdgcn_readfirstlane((int)rec[gbuf][j][19]);
+                if (v > cur) nxt = v;
+            }
+            cur = nxt;
+            __syncthreads();
         }
     };
 
@@ -368,7 +399,7 @@ k_geoA(const GeoAArgs A)
         typedef int i2v __attribute__((ext_vector_type(2)));
         const int t = A.type[w], fi = A.field[w];
         const int g = lane >> 4, n = lane & 15;
-        const int tu = t & 1, tv = t >> 1;
+        (void)0;
         d4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = d4{0.0, 0.0, 0.0, 0.0};
@@ -476,6 +507,26 @@ k_geoA(const GeoAArgs A)
     }
     // ---- non-symmetric forms: the full (p+1)^2 pair window, up to two sources per slot, both pair families flushed
     if constexpr (FORM == 1) {
+        // The geometry waves stage the plane records and evaluate the next batch; the sweep waves sweep: two loops that meet
+        // only at the barriers, so that no value of one role is live in the other (the pair window of a sweep wave alone is 72
+        // registers at p = 5; anything spilled around it is reloaded behind a vmcnt(0), i.e. behind the K1 stores).
+        if (w >= NS) {
+            stage_load(g_begin); stage_store(0);
+            stage_load(g_begin + NS); stage_store(1);
+            __syncthreads();
+            next_batch(g_begin, 0, 0);
+            __syncthreads();
+            int it = 0, rs = 0;
+            for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+                const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
+                stage_load(gb + 2 * NS);
+                next_batch(gb + NS, rn, (it & 1) ^ 1);
+                stage_store(ra);
+                rs = rn;
+                __syncthreads();
+            }
+            return;
+        }
         typedef double d2 __attribute__((ext_vector_type(2)));
         const int t = A.type[w], fi = A.field[w], xt = A.xtype[w], xf = A.xfield[w];
         double *const out = A.out[w] + pt;
@@ -493,12 +544,19 @@ k_geoA(const GeoAArgs A)
         // acc[a][b] += V_b[tu] (V_a[tv] f): a = test function (row), b = trial function
         auto source = [&](const int rsl, const int buf, const int j, const int ty, const int ff) {
             const double bv = FLD(buf, j, ff, lane);
-            double va[PV], vb[PV];
-            basis_row(va, rsl, j, ty >> 1);
-            basis_row(vb, rsl, j, ty & 1);
             double c[P];
+            {
+                double va[PV];
+                basis_row(va, rsl, j, ty >> 1);
 #pragma unroll
-            for (int a = 0; a < P; ++a) c[a] = va[a] * bv;
+                for (int a = 0; a < P; ++a) c[a] = va[a] * bv;
+            }
+            // (the row of the trial functions is requested after the products: one row of basis values in registers at a time)
+#pragma unroll
+            for (int a = 0; a < P; ++a) asm volatile("" : "+v"(c[a]));
+            asm volatile("" ::: "memory");
+            double vb[PV];
+            basis_row(vb, rsl, j, ty & 1);
 #pragma unroll
             for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -509,16 +567,13 @@ k_geoA(const GeoAArgs A)
                 for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
             asm volatile("" ::: "memory");
         };
-        stage_load(g_begin); stage_store(0);
-        stage_load(g_begin + NS); stage_store(1);
         __syncthreads();
-        next_batch(g_begin, 0, 0);
+        next_batch_barriers(g_begin, 0);
         __syncthreads();
         int it = 0, l = 0, sp = s_begin, rs = 0;
         for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
             const int buf = it & 1;
-            const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
-            stage_load(gb + 2 * NS);
+            const int rn = rs == 2 ? 0 : rs + 1;
 #pragma unroll 1
             for (int j = 0; j < NS; ++j) {
                 if (gb + j >= g_end) break;
@@ -557,8 +612,7 @@ k_geoA(const GeoAArgs A)
                 }
                 l = 0; ++sp;
             }
-            next_batch(gb + NS, rn, buf ^ 1);
-            stage_store(ra);
+            next_batch_barriers(gb + NS, rn);
             rs = rn;
             __syncthreads();
         }
@@ -686,8 +740,8 @@ k_geoA(const GeoAArgs A)
 template <int P, int NS, int P0G, bool MF = false, int FORM = 0>
 static int launch_geoA_k(hipStream_t st, const GeoAArgs &A, int nc, dim3 grid)
 {
-    if (nc == 4) k_geoA<P, NS, P0G, 4, MF, FORM><<<grid, dim3(NS * 64), 0, st>>>(A);
-    else k_geoA<P, NS, P0G, 3, MF, FORM><<<grid, dim3(NS * 64), 0, st>>>(A);
+    if (nc == 4) k_geoA<P, NS, P0G, 4, MF, FORM><<<grid, dim3(geoa_threads(NS, FORM)), 0, st>>>(A);
+    else k_geoA<P, NS, P0G, 3, MF, FORM><<<grid, dim3(geoa_threads(NS, FORM)), 0, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_GA_STAMP
     {

@@ -7,6 +7,7 @@
 // the reference does with transposed collocation matrices (tensor.apply_tprod).  All three stages
 // stream their input once: HBM-bound, 8 B read per Gauss point in the first one.
 #include "igx_internal.h"
+#include <algorithm>
 
 namespace igx {
 
@@ -99,6 +100,121 @@ __global__ void __launch_bounds__(256) k_contract_last(const double *__restrict_
     }
 }
 
+// 3D, first two contractions in ONE kernel (round 4): a WAVE owns (Gauss plane g0, chunk of spans of the mid axis) and
+// walks its grid lines g1 in sequence.  Per line: f and W arrive with 16-byte loads (the loads of the next line are in flight
+// under the arithmetic of this one), their products go to a wave-private LDS buffer, lane i2 (+ 64, + 128 ..) sums over its
+// support with the dense table Vt[k][i2] of the last axis' basis values (block-shared LDS, read without bank conflicts), and
+// the line's N2 values enter the sliding window of the mid axis in registers -- acc[a] += V1[g1][a] t -- exactly like the
+// sweeps of the matrix path.  The intermediate [G0][G1][N2] (0.43 GB written and read back at C4) never exists and no
+// barrier is needed after the table is staged.  A dof of the mid axis whose support lies inside the chunk is stored; the
+// (at most p) dofs shared with the neighbouring chunk are ADDED onto zeros: two addends commute, the sum does not
+// depend on which chunk comes first (chunks are at least P spans long: never three addends).
+constexpr int LV_MAXPASS = 4;                            // N2 <= 256
+typedef const double __attribute__((address_space(4))) *lv_cdp;
+typedef const int __attribute__((address_space(4))) *lv_cip;
+template <bool WEIGHT, int P, int MAXPC>               // MAXPC: 128-point pieces of a line held in registers (G2 <= 128 MAXPC)
+__global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, const double *__restrict__ wfield, double *__restrict__ t2,
+                                              const AxisDev a1, const AxisDev a2, int G0, int chunk_spans, int nchunks, int deriv1, int deriv2)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int q = a2.q, PQ = P * q, N2 = a2.N, G2 = a2.G;
+    double *Vt = lds;                                    // [PQ][N2]: basis value of dof i2 at point k of its support (0 past its end)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *buf = lds + ((PQ * N2 + 1) & ~1) + wave * ((G2 + 1) & ~1);    // this wave's line of products
+    for (int e = threadIdx.x; e < PQ * N2; e += blockDim.x) {
+        const int k = e / N2, i = e - k * N2;
+        const int s_lo = a2.mslo[i], nsup = (a2.mshi[i] - s_lo) * q;
+        double v = 0.0;
+        if (k < nsup) { const int g = s_lo * q + k; v = a2.V[((size_t)g * P + (i - a2.fa[g / q])) * 2 + deriv2]; }
+        Vt[e] = v;
+    }
+    __syncthreads();
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    if (unit >= (long long)G0 * nchunks) return;
+    const int g0 = (int)(unit / nchunks), ch = (int)(unit - (long long)g0 * nchunks);
+    const int s_a = ch * chunk_spans, s_b = min(s_a + chunk_spans, a1.n);
+    const int q1 = a1.q, G1 = a1.G, N1 = a1.N;
+    int gfirst[LV_MAXPASS];
+#pragma unroll
+    for (int k = 0; k < LV_MAXPASS; ++k) { const int i2 = min(lane + 64 * k, N2 - 1); gfirst[k] = a2.mslo[i2] * q; }
+    const int npass = (N2 + 63) >> 6;
+    double acc[P][LV_MAXPASS];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int k = 0; k < LV_MAXPASS; ++k) acc[a][k] = 0.0;
+    // a line as 16-byte pieces: piece e of the line = doubles 2 e, 2 e + 1 (G2 even: checked on the host)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int npc = (G2 / 2 + 63) >> 6;
+    d2 vf[MAXPC], vw[MAXPC];
+    auto request = [&](const int g1) {
+        const d2 *pf = (const d2 *)(f + ((long long)g0 * G1 + g1) * G2);
+        const d2 *pw = WEIGHT ? (const d2 *)(wfield + ((long long)g0 * G1 + g1) * G2) : pf;
+#pragma unroll
+        for (int c = 0; c < MAXPC; ++c)
+            if (c < npc) {
+                const int e = min(lane + 64 * c, G2 / 2 - 1);
+                vf[c] = pf[e];
+                if (WEIGHT) vw[c] = pw[e];
+            }
+    };
+    const int g_a = s_a * q1, g_b = s_b * q1;
+    request(g_a);
+    lv_cdp V1 = (lv_cdp)a1.V;
+    lv_cip fa1 = (lv_cip)a1.fa, mslo1 = (lv_cip)a1.mslo;
+    int l = 0, sp = s_a;
+    for (int g1 = g_a; g1 < g_b; ++g1) {
+        // products of this line -> LDS; then the loads of the next line (their registers are free again)
+#pragma unroll
+        for (int c = 0; c < MAXPC; ++c)
+            if (c < npc) {
+                const int e = lane + 64 * c;
+                d2 x = vf[c];
+                if (WEIGHT) { x.x *= vw[c].x; x.y *= vw[c].y; }
+                if (e < G2 / 2) ((d2 *)buf)[e] = x;
+            }
+        if (g1 + 1 < g_b) request(g1 + 1);
+        // last-axis contraction of the line, then the mid-axis window
+        double v1[P];
+#pragma unroll
+        for (int a = 0; a < P; ++a) v1[a] = V1[((size_t)g1 * P + a) * 2 + deriv1];
+#pragma unroll
+        for (int k = 0; k < LV_MAXPASS; ++k)
+            if (k < npass) {
+                const int i2 = min(lane + 64 * k, N2 - 1);
+                const double *bl = buf + gfirst[k];
+                double r = 0.0;
+                for (int m = 0; m < PQ; ++m) r = fma(Vt[m * N2 + i2], bl[min(m, G2 - 1 - gfirst[k])], r);
+#pragma unroll
+                for (int a = 0; a < P; ++a) acc[a][k] = fma(v1[a], r, acc[a][k]);
+            }
+        if (++l < q1) continue;
+        // end of span sp: the dofs that leave the active set; at the end of the chunk every dof that is still active
+        const int base = fa1[sp];
+        const int nleave = sp + 1 < a1.n ? (sp + 1 < s_b ? fa1[sp + 1] - base : P) : P;
+        for (int j = 0; j < nleave; ++j) {
+            const int i1 = base + j;
+            if (i1 < N1) {
+                const bool whole = mslo1[i1] >= s_a && (sp + 1 < s_b || sp + 1 == a1.n || j < fa1[min(sp + 1, a1.n - 1)] - base);
+                double *dst = t2 + ((long long)g0 * N1 + i1) * N2;
+#pragma unroll
+                for (int k = 0; k < LV_MAXPASS; ++k)
+                    if (k < npass && lane + 64 * k < N2) {
+                        if (whole) dst[lane + 64 * k] = acc[0][k];
+                        else (void)__hip_atomic_fetch_add(dst + lane + 64 * k, acc[0][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                for (int k = 0; k < LV_MAXPASS; ++k) acc[a][k] = acc[a + 1][k];
+#pragma unroll
+            for (int k = 0; k < LV_MAXPASS; ++k) acc[P - 1][k] = 0.0;
+        }
+        l = 0; ++sp;
+    }
+}
+
 // d_f: function values on the RESIDENT Gauss slab (G0_loc x G1 [x G2]); d_W: mass field on the same slab;
 // d_out: (r0_hi - r0_lo) x N1 [x N2]; tmp1/tmp2: workspaces (sizes below)
 // deriv_axis: grid axis whose basis functions are differentiated (-1: none); accumulate: add to d_out;
@@ -117,6 +233,36 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
     const AxisDev &a0 = pd.ax[0], &a1 = pd.ax[1], &a2 = pd.ax[2];
     const int n0 = pd.r0_hi - pd.r0_lo;
     if (dim == 3) {
+        // fused first two contractions (k_lv12): single-digit degrees, even G2 (16-byte pieces), lines and table in LDS
+        const int PQ = a2.P * a2.q;
+        const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + 4 * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
+        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 1280 && lds12 <= 64 * 1024
+            && a1.n >= a1.P) {
+            // chunks of the mid axis: enough waves for the chip, never shorter than P spans (a shared dof gets two addends)
+            int nch = (int)std::min<long long>(std::max<long long>(1, (8192 + G0 - 1) / std::max<long long>(G0, 1)), std::max(1, a1.n / std::max(a1.P, 8)));
+            int clen = (a1.n + nch - 1) / nch;
+            clen = std::max(clen, a1.P);
+            nch = (a1.n + clen - 1) / clen;
+            if (nch > 1 && a1.n - (nch - 1) * clen < a1.P) { --nch; }     // a short last chunk joins its neighbour
+            // (the last chunk then runs to the end of the axis: the kernel clamps with a1.n)
+            const long long units = G0 * nch;
+            IGX_HIP(hipMemsetAsync(d_t2, 0, (size_t)G0 * a1.N * a2.N * sizeof(double), st));
+            const dim3 grid((unsigned)((units + 3) / 4));
+#define LV12(PP) case PP: \
+                if (d_W && a2.G <= 640) k_lv12<true, PP, 5><<<grid, 256, lds12, st>>>(d_f, d_W, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
+                else if (d_W) k_lv12<true, PP, 10><<<grid, 256, lds12, st>>>(d_f, d_W, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
+                else if (a2.G <= 640) k_lv12<false, PP, 5><<<grid, 256, lds12, st>>>(d_f, nullptr, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
+                else k_lv12<false, PP, 10><<<grid, 256, lds12, st>>>(d_f, nullptr, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
+                break
+            switch (a2.P) { LV12(2); LV12(3); LV12(4); LV12(5); LV12(6); }
+#undef LV12
+            const long long B = (long long)a1.N * a2.N, n = (long long)n0 * B;
+            AxisDev ax0 = a0;
+            ax0.G = (int)G0;
+            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv_axis == 0, accumulate);
+            IGX_HIP(hipGetLastError());
+            return IGX_OK;
+        }
         // [G0,G1,G2] -> [G0,G1,N2]
         {
             const long long A = G0 * a1.G, n = A * a2.N;

@@ -1713,6 +1713,14 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 if (same >= 0) { X[a].slot = X[same].slot; X[a].alias = 1; }
                 else { X[a].slot = na++; X[a].alias = 0; }
             }
+            // arrays with two sources first: in k_geoA (non-symmetric) array x is swept by wave x, a workgroup's waves go to the
+            // four SIMDs cyclically, and a two-source array takes twice the sweep -- at most one of them per SIMD
+            std::vector<int> perm(na, -1);
+            int nxt = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (const XA &x : X)
+                    if (!x.alias && (x.xf >= 0) == (pass == 0)) perm[x.slot] = nxt++;
+            for (XA &x : X) x.slot = perm[x.slot];
         }
     }
     for (size_t i = 0; i < terms.size() && !merged; ++i) {

@@ -1242,6 +1242,82 @@ def test_geometry_in_sweep_multi_span(iga, deg0, spans0, nurbs, p, n, monkeypatc
         assert np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
 
 
+@pytest.mark.parametrize('deg0,spans0,nurbs', [(1, 1, True), (2, 4, True), (1, 3, False)])
+@pytest.mark.parametrize('p,n', [(4, 7), (3, 9), (4, 13)])
+def test_matrix_core_axis0_sweep(iga, deg0, spans0, nurbs, p, n, monkeypatch):
+    """IGX_GEOA=mfma (round 4, opt-in: measured slower than the vector form): the axis-0 sweep of
+    k_geoA on v_mfma_f64_16x16x4_f64 -- fixed accumulator rows per pair, four planes per instruction, single planes by
+    vector multiply-adds.  Same matrix as the default chain to rounding, exactly symmetric, and the row slabs reproduce
+    the whole patch bit for bit (the instruction adds its four planes in order, one rounding each: a pair's sum does not
+    depend on how the batches of planes cut its spans)."""
+    geo = _wavy_box(iga, deg0, spans0, nurbs) if spans0 > 1 or deg0 > 1 else _geo(iga, 'cylinder')
+    kv = iga.bspline.make_knots(p, 0., 1., n)
+    kvs = (kv, iga.bspline.make_knots(p, 0., 1., n - 2), kv)
+    ref = iga.assemblers.DevicePatch(kvs, geo)
+    R = ref.csr('stiffness', algo='sumfact')
+    ref.close()
+    monkeypatch.setenv('IGX_GEOA', 'mfma')
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    A = patch.csr('stiffness', algo='sumfact')
+    assert 'geoA' in patch.last_path() and not np.isnan(A.data).any()
+    A2 = patch.csr('stiffness', algo='sumfact')
+    patch.close()
+    assert np.array_equal(A.data, A2.data)
+    assert rel_maxdiff(A, R) <= 1e-13 and abs(A - A.T).max() == 0.0
+    N0 = kv.numdofs
+    parts = []
+    for lo, hi in ((0, 3), (3, N0 - 4), (N0 - 4, N0)):
+        sl = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+        parts.append(sl.csr('stiffness', algo='sumfact'))
+        sl.close()
+    S = scipy.sparse.vstack(parts).tocsr()
+    assert np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
+
+
+@pytest.mark.parametrize('deg0,spans0,nurbs', [(1, 1, True), (2, 4, True), (2, 9, False)])
+@pytest.mark.parametrize('p,n', [(2, 9), (3, 7), (4, 6), (5, 7)])
+def test_convdiff_geometry_in_sweep(iga, oracle, deg0, spans0, nurbs, p, n, monkeypatch):
+    """Round 4: the convection-diffusion form with geometry, coefficient and fields evaluated inside the axis-0 sweep
+    (k_geoA, non-symmetric: full pair window, two-source slots, geometry waves beside the sweep waves) against the field
+    kernel + k_stageA chain (IGX_GEOA=0), the entry-wise kernels and -- on the cylinder -- the CPU oracle; sampled and
+    affine coefficient; row slabs bit for bit."""
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    cyl = spans0 == 1 and deg0 == 1
+    geo = _geo(iga, 'cylinder') if cyl else _wavy_box(iga, deg0, spans0, nurbs)
+    kvs = (iga.bspline.make_knots(p, 0., 1., n), iga.bspline.make_knots(p, 0., 1., n + 1), iga.bspline.make_knots(p, 0., 1., n - 1))
+    coeff = lambda x, y, z: 1.0 + 0.5 * x - 0.25 * y + 0.125 * z
+    asm = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff)                # sampled on the host, read per point
+    A = asm.assemble_csr(algo='sumfact')
+    assert 'geoA' in asm.patch.last_path() and 'fused' in asm.patch.last_path() and not np.isnan(A.data).any()
+    E = asm.assemble_csr(algo='entrywise')
+    asm.patch.close()
+    aff = iga.assemblers.ConvDiffAssembler3D(kvs, geo, iga.assemblers.AffineCoefficient(1.0, 0.5, -0.25, 0.125))
+    F = aff.assemble_csr(algo='sumfact')                                     # evaluated in the kernel from the geometry map
+    assert 'geoA' in aff.patch.last_path()
+    aff.patch.close()
+    monkeypatch.setenv('IGX_GEOA', '0')
+    old = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff)
+    monkeypatch.delenv('IGX_GEOA')
+    B = old.assemble_csr(algo='sumfact')
+    assert 'geoA' not in old.patch.last_path()
+    old.patch.close()
+    assert rel_maxdiff(A, B) <= RTOL and rel_maxdiff(A, E) <= RTOL and rel_maxdiff(F, A) <= RTOL
+    assert abs(A - A.T).max() > 1e-3 * abs(A).max()
+    if cyl and p <= 3:
+        okvs = tuple(oracle.KnotVector(kv.kv, kv.p) for kv in kvs)
+        R = oracle.assemble_nonsymmetric('convdiff', okvs, oracle.geo_cylinder(), coeff=coeff, nthreads=8)
+        assert np.array_equal(A.indices, R.indices) and rel_maxdiff(A, R) <= RTOL
+    N0 = kvs[0].numdofs
+    parts = []
+    for lo, hi in ((0, 2), (2, N0 - 3), (N0 - 3, N0)):
+        sl = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff, row0=(lo, hi))
+        parts.append(sl.assemble_csr(algo='sumfact'))
+        sl.patch.close()
+    S = scipy.sparse.vstack(parts).tocsr()
+    assert np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
+
+
 def test_set_form_device_and_failed_call(iga):
     """igx_patch_set_form_d (coefficients already on the device, resident slab) == the host entry point; a call that fails
     validation leaves the previous form in place."""
