@@ -316,6 +316,9 @@ def main():
     ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
     ap.add_argument('--strong', action='store_true', help='(default) strong scaling: the patch is fixed, its rows are split')
     ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank run on this one GPU (no collectives)')
+    ap.add_argument('--placement-tries', type=int, default=6,
+                    help='candidate buffers for the CSR values, timed under the mirror pass at the FIRST assembly (outside the timed region; '
+                         'IGX_PLACEMENT_TRIES: the pass follows where the driver put the buffer); 1: plain allocation')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -353,6 +356,8 @@ def main():
     import pyiga_amd
     from pyiga_amd import bspline, geometry, assemblers, distributed
     os.environ['IGX_DEVICE'] = str(local_rank)
+    if args.placement_tries > 1 and 'IGX_PLACEMENT_TRIES' not in os.environ:
+        os.environ['IGX_PLACEMENT_TRIES'] = str(args.placement_tries)      # read when a patch is created
 
     geo = make_geo(geometry, gname)
     part_rank, part_world = (rank, world) if emu is None else emu
@@ -518,6 +523,9 @@ def main():
         'setup_s': round(max(setup_all), 4), 'setup_s_ranks': setup_all,      # patch creation per rank (device context warm)
         'runtime_init_s': None if runtime_init_s is None else round(runtime_init_s, 3),                            # HIP runtime + context + stream of rank 0: once per process
         'cold_ms': round(max(cold_all), 2), 'cold_ms_ranks': cold_all,         # patch creation + FIRST assembly (workspace allocation), device-resident result
+        # opt-in of this caller (--placement-tries): the CSR buffer is the fastest of n allocations under the mirror pass, chosen at the
+        # first assembly (its cost is part of cold_ms); ms of the pass on the kept / the slowest candidate
+        'placement': (patch.placement() if hasattr(patch, 'placement') else None),
         'api_call_s': api_call_s,                                              # assemble.stiffness() end to end: + pattern, D2H of values and indices, scipy
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -253,6 +253,13 @@ int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *o
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */
 int igx_fields(igx_patch *patch, int kind, double *out, int64_t *shape4);
 
+/* Opt-in buffer placement (environment IGX_PLACEMENT_TRIES=n at igx_patch_create, 3D symmetric forms): the first
+   igx_assemble allocates up to n candidate buffers for the CSR values, times the mirror pass of the patch on each and keeps
+   the fastest (the pass follows where the driver put the buffer physically: +-10 % between allocations, stable over the life
+   of a buffer).  Reports how many candidates were timed (0: the search did not run) and the device time of the pass on the
+   kept and on the slowest one.  (No counterpart in the reference.) */
+int igx_patch_placement(const igx_patch *patch, int *tried, float *best_ms, float *worst_ms);
+
 /* Planning query, host arithmetic only (no device, no patch): 1 if the fused sweep + contraction stage and the mirror pass
    may address a patch of these sizes with their 32-bit buffer offsets, 0 if the library takes the stage kernels with 64-bit
    addressing instead.  c0max = 2 p0 + 1 columns of axis 0 per row (1 in 2D), S_mid / S_last = number of 1D index pairs

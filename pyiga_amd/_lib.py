@@ -80,6 +80,7 @@ SYMBOLS = [
     ('igx_entries', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, _dp]),
     ('igx_fields', C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     ('igx_fused_stage_fits', C.c_int, [C.c_int64] * 5),
+    ('igx_patch_placement', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ('igx_load_vector', C.c_int, [C.c_void_p, _dp, _dp]),
     ('igx_load_vector_jet', C.c_int, [C.c_void_p, _dp * 4, _dp]),
     ('igx_entries_d', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -260,6 +260,13 @@ class DevicePatch:
         bits = _lib.load().igx_patch_last_path(self.handle)
         return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single')) if bits & bit}
 
+    def placement(self):
+        """Outcome of the opt-in buffer placement search (IGX_PLACEMENT_TRIES, include/igx.h igx_patch_placement):
+        {'tried': n, 'best_ms': .., 'worst_ms': ..}; tried == 0: the search did not run."""
+        n, b, w = C.c_int(0), C.c_float(0), C.c_float(0)
+        _lib.check(_lib.load().igx_patch_placement(self.handle, C.byref(n), C.byref(b), C.byref(w)), 'igx_patch_placement')
+        return {'tried': n.value, 'best_ms': round(b.value, 4), 'worst_ms': round(w.value, 4)}
+
     def timing(self):
         t = _lib.Timing()
         _lib.check(_lib.load().igx_last_timing(self.handle, C.byref(t)), 'igx_last_timing')

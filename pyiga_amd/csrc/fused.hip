@@ -196,18 +196,19 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
 //     (scalar row base of the step) + (per-lane offset worked out once): no address arithmetic per element on interior rows
 //     of the mid axis; the first and last p rows take a general path;
 //   * K1 loads are (scalar base) + (per-lane offset): the row advance is scalar arithmetic.
-template <int P, int NLG, int NRO, int NCW, int NH> struct BF2Geom {
+template <int P, int NLG, int NRO, int NCW, int NH, int NSTW = 0> struct BF2Geom {
+    static constexpr int NSW_ = NSTW > 0 ? NSTW : NCW;      // waves that store the finished rows (NSTW > 0: sweepers of the last role)
     static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
     static constexpr int ROWR = p * W, ROWC = P * W;        // doubles per row in the ring / cur parts
     static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
-    static constexpr int nslots(int R, int per) { return (R * per * W + 64 * NCW - 1) / (64 * NCW); }
+    static constexpr int nslots(int R, int per) { return (R * per * W + 64 * NSW_ - 1) / (64 * NSW_); }
     // LDS image (doubles): lines [W][LS] | ring [P+1][R][p][W] | cur [2][R][P][W] | basis values [TL][P][2] | store plan
     // (ints) [NSR + NSC][NCW * 64];  R = rows of the last axis per tile: as many as the window and 160 KB allow
     static constexpr int off_ring() { return (W * LS + 1) & ~1; }
     static constexpr int off_cur(int R) { return (off_ring() + (P + 1) * R * ROWR + 1) & ~1; }
     static constexpr int off_v2(int R) { return (off_cur(R) + 2 * R * ROWC + 1) & ~1; }
     static constexpr int off_plan(int R) { return off_v2(R) + TL * P * 2; }
-    static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * NCW * 32; }
+    static constexpr int lds_doubles(int R) { return off_plan(R) + (nslots(R, p) + nslots(R, P)) * NSW_ * 32; }
     static constexpr int rmax()
     {
         int R = TL / P - p;
@@ -312,12 +313,94 @@ __device__ __forceinline__ int bf2_goff(const BFArgs &A, const BF2Blk &B, const 
     return B.c0i * c1 * ((cip)A.rp2)[i2] + (B.cj0 * c1 + m) * c2 + o;
 }
 
-template <int P, int MASK, int RI, int NA, int NLG>
+// The store duty of the fused stage -- read the finished row of the rings behind B2, store it behind the next B1 -- as an
+// object that either a contractor wave (the default) or a sweeper wave of the last role (NSTW > 0) carries through its loop.
+template <class Gm, int P, int NSW, int NH>
+struct BF2Store {
+    static constexpr int p = P - 1, NSL = Gm::NSR + Gm::NSC, RMAX = Gm::RMAX;
+    static constexpr int RCLAMP = RMAX * Gm::ROWR - 1, CCLAMP = RMAX * Gm::ROWC - 1;
+    double sv[NSL];
+    int s_soff = 0, s_ddc = 0;
+    bool s_on = false, s_int = true;
+    __amdgpu_buffer_rsrc_t drs, drs0;
+    long long rstep;
+    __device__ __forceinline__ void init(const BFArgs &A, const BF2Blk &B, int *plan, const int sw, const int lane)
+    {
+        cip rp0 = (cip)A.rp0;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) sv[k] = 0.0;
+        int *myplan = plan + sw * 64 + lane;
+        const int ddi = min(p, max(A.N1 - P, 0));                      // any interior row gives the same offsets
+#pragma unroll
+        for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, (k * NSW + sw) * 64 + lane, ddi); myplan[k * NSW * 64] = g < 0 ? BF2_OOB : g * 8; }
+#pragma unroll
+        for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, (k * NSW + sw) * 64 + lane, ddi); myplan[(Gm::NSR + k) * NSW * 64] = g < 0 ? BF2_OOB : g * 8; }
+        drs = bf2_rsrc(A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off));
+        drs0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.data, (short)0, 0, 0x00020000);
+        rstep = (long long)B.c0i * A.S2 * 8;
+    }
+    // behind B1: the row read at the end of the last step goes out
+    __device__ __forceinline__ void issue(const BFArgs &A, const BF2Blk &B, const int *plan, const int sw, const int lane)
+    {
+        const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
+        int lq_ = lane;
+        asm volatile("" : "+v"(lq_));
+        const int q0 = sw * 64 + lq_;
+        if (s_int) {
+            const int *myplan = plan + q0;
+            int sg[NSL];
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NSW * 64];
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
+        } else {
+            for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, q0 + k * NSW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[k]); }
+            for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, q0 + k * NSW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[Gm::NSR + k]); }
+        }
+    }
+    // behind B2 of step t: the entries of mid-axis row t - 1 are complete -- into registers (and cleared where halves add)
+    __device__ __forceinline__ void fetch(const BFArgs &A, const BF2Blk &B, double *ring, double *cur, const int t, const int sw, const int lane)
+    {
+        cip rp1 = (cip)A.rp1;
+        const int dd2 = t - 1;
+        s_on = dd2 >= B.rlo && dd2 < B.rhi;
+        const int ddc = min(max(dd2, 0), A.N1 - 1);
+        s_soff = (int)(rstep * rp1[ddc]);
+        double *rg = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR;
+        double *cu = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
+        int lq_ = lane;
+        asm volatile("" : "+v"(lq_));
+        const int q0 = sw * 64 + lq_;
+#pragma unroll
+        for (int k = 0; k < Gm::NSR; ++k) {
+            const int o_ = (k + 1) * NSW * 64 <= RCLAMP + 1 ? q0 + k * NSW * 64 : min(q0 + k * NSW * 64, RCLAMP);
+            sv[k] = rg[o_];
+            if (NH == 2 && s_on && q0 + k * NSW * 64 <= RCLAMP) rg[o_] = 0.0;      // (only the element's owner clears it)
+        }
+#pragma unroll
+        for (int k = 0; k < Gm::NSC; ++k) {
+            const int o_ = (k + 1) * NSW * 64 <= CCLAMP + 1 ? q0 + k * NSW * 64 : min(q0 + k * NSW * 64, CCLAMP);
+            sv[Gm::NSR + k] = cu[o_];
+            if (NH == 2 && s_on && q0 + k * NSW * 64 <= CCLAMP) cu[o_] = 0.0;
+        }
+        s_int = !s_on || (ddc >= p && ddc < A.N1 - p);  // (a row that is not stored takes the plan's offsets: its descriptor is empty)
+        s_ddc = ddc;
+    }
+};
+
+struct BF2StoreCtx { int *plan; double *ring, *cur; const BF2Blk *B; int sw; };
+
+template <int P, int MASK, int RI, int NA, int NLG, class Gm, int NSTW, int NH>
 __device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
-                                            const int rhi, double *lines, const int LS)
+                                            const int rhi, double *lines, const int LS, const BF2StoreCtx &sc)
 {
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = 64 * NLG;
+    // NSTW > 0: the sweepers of the LAST role (the lightest: one input array at the 3D stiffness form) carry the store duty
+    constexpr bool ST = NSTW > 0 && RI == bf_nroles(MASK) - 1;
+    BF2Store<Gm, P, (NSTW > 0 ? NSTW : 1), NH> store;
+    const int slane = threadIdx.x & 63;
+    if constexpr (ST) store.init(A, *sc.B, sc.plan, sc.sw, slane);
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_S);
     cdp V1 = (cdp)A.V1;
@@ -370,6 +453,7 @@ __device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const
     int t = s_begin;
     for (; t < t_sw; ++t) {
         bar_lds();                                       // B1
+        if constexpr (ST) store.issue(A, *sc.B, sc.plan, sc.sw, slane);
         const int tn = min(t + 1, t_sw - 1);
         cdp cf = V1 + (size_t)t * P * P * 2;
         double v[P][2];
@@ -424,29 +508,42 @@ __device__ __forceinline__ void bf2_sweeper(const BFArgs &A, const int r0, const
         }
         bar_lds();                                       // B2: the contractors have read the previous lines
         flush();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.ring, sc.cur, t, sc.sw, slane);
     }
-    for (; t < rhi; ++t) { bar_lds(); bar_lds(); flush(); }          // spans past the end of the axis: the window only drains
-    for (; t < rhi + 1; ++t) { bar_lds(); bar_lds(); }                // the contractors finish the last row
+    for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
+        bar_lds();
+        if constexpr (ST) store.issue(A, *sc.B, sc.plan, sc.sw, slane);
+        bar_lds(); flush();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.ring, sc.cur, t, sc.sw, slane);
+    }
+    for (; t < rhi + 1; ++t) {                           // the contractors finish the last row
+        bar_lds();
+        if constexpr (ST) store.issue(A, *sc.B, sc.plan, sc.sw, slane);
+        bar_lds();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.ring, sc.cur, t, sc.sw, slane);
+    }
+    if constexpr (ST) store.issue(A, *sc.B, sc.plan, sc.sw, slane);       // the last row
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
-template <int P, int MASK, int NA, int NLG, int RI, bool END = (RI >= bf_nroles(MASK))>
+template <int P, int MASK, int NA, int NLG, class Gm, int NSTW, int NH, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BF2SweepDispatch {
-    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS, const BF2StoreCtx &sc)
     {
-        if (role == RI) bf2_sweeper<P, MASK, RI, NA, NLG>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
-        else BF2SweepDispatch<P, MASK, NA, NLG, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        if (role == RI) bf2_sweeper<P, MASK, RI, NA, NLG, Gm, NSTW, NH>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        else BF2SweepDispatch<P, MASK, NA, NLG, Gm, NSTW, NH, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
     }
 };
-template <int P, int MASK, int NA, int NLG, int RI>
-struct BF2SweepDispatch<P, MASK, NA, NLG, RI, true> {
-    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+template <int P, int MASK, int NA, int NLG, class Gm, int NSTW, int NH, int RI>
+struct BF2SweepDispatch<P, MASK, NA, NLG, Gm, NSTW, NH, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BF2StoreCtx &) {}
 };
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int NSTW = 0>
 __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(const BFArgs A)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
+    static_assert(NSTW == 0 || NSTW == NLG, "store duty on the sweepers: one store wave per lane group of the last role");
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH, NSTW>;
     constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
     constexpr int RMAX = Gm::RMAX, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
     constexpr int LS = Gm::LS;
@@ -510,11 +607,15 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
         else task = k < 2 ? k : NSW + 3;
     }
+    BF2Blk B;
+    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.cj0 = j0 - jlo0[i0]; B.rlo = rlo; B.rhi = rhi;
+    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2;
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);              // points outside the axis: any finite value (their spans are skipped)
-        BF2SweepDispatch<P, MASK, NA, NLG, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        const BF2StoreCtx sc{plan, ring, cur, &B, lg};
+        BF2SweepDispatch<P, MASK, NA, NLG, Gm, NSTW, NH, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
         return;
     }
 
@@ -522,65 +623,26 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
     const int cw = task - NSW;
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_C);
-    BF2Blk B;
-    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.cj0 = j0 - jlo0[i0]; B.rlo = rlo; B.rhi = rhi;
-    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2;
     // store plan of the interior rows of the mid axis (p <= i1 < N1 - p: the segment has 2p + 1 lines, the first one is
     // j1 = i1 - p): offset of element q inside the row block, or -1.  Element q of slot k: q = (k * NCW + cw) * 64 + lane.
     // (kept in LDS, one int per element, written and read by the same wave: the registers belong to the element matrices)
-    {
-        int *myplan = plan + cw * 64 + lane;
-        const int ddi = min(p, max(A.N1 - P, 0));                      // any interior row gives the same offsets
-#pragma unroll
-        for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, (k * NCW + cw) * 64 + lane, ddi); myplan[k * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
-#pragma unroll
-        for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, (k * NCW + cw) * 64 + lane, ddi); myplan[(Gm::NSR + k) * NCW * 64] = g < 0 ? BF2_OOB : g * 8; }
-    }
-    const int nlines = diag0 ? P : W;
-    const int npieces = nlines * NPC;
-    cip rp0 = (cip)A.rp0, rp1 = (cip)A.rp1;
-    // the row blocks of outer row i0 through one descriptor: (scalar) offset of mid-axis row i1 = 8 c0i rp1[i1] S2 bytes
-    const __amdgpu_buffer_rsrc_t drs = bf2_rsrc(A.data + ((long long)rp0[i0] * B.S12 - A.nnz_off));
-    const long long rstep = (long long)B.c0i * A.S2 * 8;               // (a block of c0i * S1 * S2 values is < 2^31 bytes: checked on the host)
-    // the last read of a part may not leave it (the slots are padded to whole waves)
-    constexpr int RCLAMP = RMAX * Gm::ROWR - 1, CCLAMP = RMAX * Gm::ROWC - 1;
     // Stores: the entries of mid-axis row t - 1 are complete behind the barrier B2 of step t.  They (and their offsets) are
     // read from LDS there -- while the sweepers flush -- and stored right behind the next B1, from registers: the LDS latency
     // lies in the barrier wait, not in front of the pass.  A row that is not stored goes through a descriptor of length 0
-    // (every lane out of range): no branch around the stores.
-    const __amdgpu_buffer_rsrc_t drs0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.data, (short)0, 0, 0x00020000);
-    constexpr int NSL = Gm::NSR + Gm::NSC;
-    double sv[NSL];
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) sv[k] = 0.0;
-    int s_soff = 0, s_ddc = 0;
-    bool s_on = false, s_int = true;
-    // The VALUES of a row wait in registers from B2 to the next B1; their OFFSETS are read from the plan in LDS only here (one
-    // ds_read each, a few dozen cycles): eleven more registers across the barrier spill, and a scratch reload in front of a
-    // store waits for vmcnt(0), i.e. for the stores just issued.  Rows without a plan (first / last p of the mid axis) work
-    // their offsets out here.
-    auto issue_stores = [&]() {
-        const __amdgpu_buffer_rsrc_t d = s_on ? drs : drs0;
-        int lq_ = lane;
-        asm volatile("" : "+v"(lq_));
-        const int q0 = cw * 64 + lq_;
-        if (s_int) {
-            const int *myplan = plan + q0;
-            int sg[NSL];
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) sg[k] = myplan[k * NCW * 64];
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) bf2_buffer_store(d, sg[k], s_soff, sv[k]);
-        } else {
-            for (int k = 0; k < Gm::NSR; ++k) { const int g = bf2_goff<P>(A, B, false, q0 + k * NCW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[k]); }
-            for (int k = 0; k < Gm::NSC; ++k) { const int g = bf2_goff<P>(A, B, true, q0 + k * NCW * 64, s_ddc); bf2_buffer_store(d, g < 0 || !s_on ? BF2_OOB : g * 8, s_soff, sv[Gm::NSR + k]); }
-        }
-    };
+    // (every lane out of range): no branch around the stores.  The VALUES of a row wait in registers from B2 to the next B1;
+    // their OFFSETS are read from the plan in LDS only at store time (one ds_read each): eleven more registers across the
+    // barrier spill, and a scratch reload in front of a store waits for vmcnt(0), i.e. for the stores just issued.  Rows
+    // without a plan (first / last p of the mid axis) work their offsets out at store time.  (BF2Store; with NSTW > 0 the
+    // sweepers of the last role carry it instead.)
+    BF2Store<Gm, P, NCW, NH> store;
+    if constexpr (NSTW == 0) store.init(A, B, plan, cw, lane);
+    const int nlines = diag0 ? P : W;
+    const int npieces = nlines * NPC;
     for (int t = s_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
         BF_SEG_BEGIN();
 #ifndef BF2_NOSTORE
-        issue_stores();
+        if constexpr (NSTW == 0) store.issue(A, B, plan, cw, lane);
 #endif
         BF_SEG_END(0);
         // ---- contract the lines of flush dd = t - 1 with the last axis
@@ -685,36 +747,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
         BF_SEG_END(1);
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
 #ifndef BF2_NOSTORE
-        {
-            const int dd2 = t - 1;
-            s_on = dd2 >= rlo && dd2 < rhi;
-            const int ddc = min(max(dd2, 0), A.N1 - 1);
-            s_soff = (int)(rstep * rp1[ddc]);
-            const double *rg = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR;
-            const double *cu = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
-            int lq_ = lane;
-            asm volatile("" : "+v"(lq_));
-            const int q0 = cw * 64 + lq_;
-            double *rgw = ring + (size_t)(ddc % (P + 1)) * RMAX * Gm::ROWR, *cuw = cur + (size_t)(ddc & 1) * RMAX * Gm::ROWC;
-#pragma unroll
-            for (int k = 0; k < Gm::NSR; ++k) {
-                const int o_ = (k + 1) * NCW * 64 <= RCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, RCLAMP);
-                sv[k] = rg[o_];
-                if (NH == 2 && s_on && q0 + k * NCW * 64 <= RCLAMP) rgw[o_] = 0.0;      // (only the element's owner clears it)
-            }
-#pragma unroll
-            for (int k = 0; k < Gm::NSC; ++k) {
-                const int o_ = (k + 1) * NCW * 64 <= CCLAMP + 1 ? q0 + k * NCW * 64 : min(q0 + k * NCW * 64, CCLAMP);
-                sv[Gm::NSR + k] = cu[o_];
-                if (NH == 2 && s_on && q0 + k * NCW * 64 <= CCLAMP) cuw[o_] = 0.0;
-            }
-            s_int = !s_on || (ddc >= p && ddc < A.N1 - p);  // (a row that is not stored takes the plan's offsets: its descriptor is empty)
-            s_ddc = ddc;
-        }
+        if constexpr (NSTW == 0) store.fetch(A, B, ring, cur, t, cw, lane);
 #endif
     }
 #ifndef BF2_NOSTORE
-    issue_stores();                                       // the last row
+    if constexpr (NSTW == 0) store.issue(A, B, plan, cw, lane);       // the last row
 #endif
     BF_SEG_DUMP(cw & 3);
     BF_STAMP_END(wave);
@@ -1011,22 +1048,22 @@ static void bf2_choose_chunks(BFArgs &A, long long slots, int P)
 #endif
 }
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH>
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int NSTW = 0>
 static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks, int ncu_ctx)
 {
-    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH>;
+    using Gm = BF2Geom<P, NLG, bf_nroles(MASK), NCW, NH, NSTW>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "k_bf2: LDS");
     static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf2: block size");
     constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
-    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IGX_HIP(hipFuncSetAttribute((const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH, NSTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // resident blocks per CU: a property of the code object (registers, LDS), asked per launch for the CURRENT device -- the
     // query is host arithmetic over the kernel descriptor (~1 us), so nothing is cached across devices or threads; the CU
     // count comes from the context the patch belongs to
     int per_cu = 1, ncu = ncu_ctx;
     {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH>, nthreads, lds) == hipSuccess && occ >= 1) per_cu = occ;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_bf2<P, NY, MASK, NA, NLG, NCW, NH, NSTW>, nthreads, lds) == hipSuccess && occ >= 1) per_cu = occ;
         if (ncu < 1) ncu = 256;
     }
     BFArgs A = A0;
@@ -1038,7 +1075,7 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks, int 
         nblocks = (unsigned)((long long)A.npairs * A.ntiles * A.nmchunks);
         if (A.tail_k > 0) nblocks = A.main_blocks + (nblocks - A.main_blocks) * (unsigned)A.tail_k;
     }
-    k_bf2<P, NY, MASK, NA, NLG, NCW, NH><<<dim3(nblocks), dim3(nthreads), lds, st>>>(A);
+    k_bf2<P, NY, MASK, NA, NLG, NCW, NH, NSTW><<<dim3(nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_BF_STAMP
     {
@@ -1067,28 +1104,32 @@ static int launch_bf2_k(hipStream_t st, const BFArgs &A0, unsigned nblocks, int 
 // its longest wave as much as by the SIMDs: three lane groups + four contractors (two of them take two passes per step) beat
 // two lane groups + eight contractors at the 3D forms because the larger tile needs fewer instructions per row.
 // (P = 6: the window of a 192-point tile does not fit LDS next to the rings; two lane groups, 168 registers per wave)
-template <int P, int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
+#ifndef BF2_NSTW
+#define BF2_NSTW 0                                       // 3: the sweepers of the last role store the finished rows (p = 4 stiffness)
+#endif
+template <int P, int MASK, int NA> struct BF2Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1, NSTW = 0; };
 // mass, measured per degree (k_bf2 ms, (NLG, NCW)): p = 1 n = 96: (3,8) 0.13, (2,4) 0.08; p = 2 n = 64: 0.11 / 0.08;
 // p = 3 n = 96: 1.78 / 1.30; p = 4 n = 128: (3,8) 3.89, (2,4) 4.34
-template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1; };
+template <int P> struct BF2Cfg<P, BF_MASK_MASS, 1> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1, NSTW = 0; };
 // 3D stiffness, measured per degree (tools/shape_try.py; k_bf2 ms at n = 64 / 128, shapes (NLG, NCW, NH)):
 //   p = 1: (3,4,2) 0.32 / 0.61, (2,4,1) 0.25 / 0.56        p = 2: (3,4,2) 0.29 / 1.53, (2,4,1) 0.21 / 1.53
 //   p = 3: (3,4,2) 0.92 / 6.42, (3,4,1) 0.74 / 4.78, (2,8,1) 0.70 / 4.46   (the halved passes cost more than they balance)
 //   p = 4: (3,4,2) 7.1 at n = 128 (C4), (3,4,1) 7.1, (2,8,1) 8.5
 template <int P> struct BF2Cfg<P, BF_MASK_STIFF3, 1> {
     static constexpr int NLG = P == 5 ? BF2_NLG : 2, NCW = P == 5 ? BF2_NCW : P == 4 ? 8 : 4, NH = P == 5 ? BF2_NH : 1;
+    static constexpr int NSTW = P == 5 && BF2_NSTW ? NLG : 0;
 };
-template <int P> struct BF2Cfg<P, BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
+template <int P> struct BF2Cfg<P, BF_MASK_STIFF2, 1> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1, NSTW = 0; };
 template <int P, int NY, int MASK, int NA>
 static int launch_bf2_c(hipStream_t st, const BFArgs &A, unsigned nblocks, int ncu)
 {
     using C = BF2Cfg<P, MASK, NA>;
-    return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH>(st, A, nblocks, ncu);
+    return launch_bf2_k<P, NY, MASK, NA, C::NLG, C::NCW, C::NH, C::NSTW>(st, A, nblocks, ncu);
 }
 template <int P, int MASK, int NA> constexpr int bf2_rmax()
 {
     using C = BF2Cfg<P, MASK, NA>;
-    return BF2Geom<P, C::NLG, bf_nroles(MASK), C::NCW, C::NH>::RMAX;
+    return BF2Geom<P, C::NLG, bf_nroles(MASK), C::NCW, C::NH, C::NSTW>::RMAX;
 }
 template <int P>
 static int launch_bf2_p(hipStream_t st, const BFArgs &A, unsigned nblocks, int ny, int mask, int na, int ncu)

@@ -139,10 +139,13 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
 // FORM = 1 (non-symmetric): the block carries GA_NGW extra GEOMETRY waves -- the sweep of the full (p+1)^2 window holds 72
 // accumulator registers at p = 5 and the slots with two sources sweep twice as long as the others, so the eight sweep waves
 // only sweep and four more waves evaluate the planes of the next batch beside them (two planes each).
-constexpr int GA_NGW = 4;
+#ifndef GA_NGW_N
+#define GA_NGW_N 4
+#endif
+constexpr int GA_NGW = GA_NGW_N;
 constexpr int geoa_threads(int NS, int FORM) { return (NS + (FORM == 1 ? GA_NGW : 0)) * 64; }
 template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
-__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 3 : NS >= 8 ? 4 : 1, FORM == 1 ? 3 : 4)))
+__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? (GA_NGW > 4 ? 4 : 3) : NS >= 8 ? 4 : 1, FORM == 1 ? (GA_NGW > 4 ? 4 : 3) : 4)))
 k_geoA(const GeoAArgs A)
 {
     constexpr int NGW = FORM == 1 ? GA_NGW : 0;           // geometry waves (0: every sweep wave evaluates the plane of its own number)

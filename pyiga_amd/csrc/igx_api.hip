@@ -367,6 +367,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
         if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");
         k.poison = getenv("IGX_DEBUG_POISON") != nullptr;
+        if (const char *e = getenv("IGX_PLACEMENT_TRIES")) k.placement_tries = std::max(1, std::min(16, atoi(e)));
         if (const char *e = getenv("IGX_STAGE_EVENTS")) k.stage_events = strcmp(e, "0") != 0;
     }
     if (pt) for (int k = 0; k < 16; ++k) pt->form_slot[k] = -1;
@@ -622,8 +623,32 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
     if (algo != IGX_ALGO_SUMFACT && algo != IGX_ALGO_ENTRYWISE) { set_error("igx_assemble: unknown algo %d", algo); return IGX_ERR_ARG; }
     if (!pt->d_data) {
-        hipError_t e = hipMalloc((void **)&pt->d_data, ((size_t)std::max(pt->nnz, pt->nnz_ext) + IGX_DUMP_PAD) * sizeof(double));   // + halo rows of the mirror pass / dump slots of masked stores
+        const size_t bytes = ((size_t)std::max(pt->nnz, pt->nnz_ext) + IGX_DUMP_PAD) * sizeof(double);   // + halo rows of the mirror pass / dump slots of masked stores
+        hipError_t e = hipMalloc((void **)&pt->d_data, bytes);
         if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for CSR values failed", pt->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+        // opt-in (IGX_PLACEMENT_TRIES): keep the candidate buffer on which the mirror pass of this patch runs fastest.  The
+        // candidates are alive together (the driver must not hand the same pages out again); a failed allocation or probe ends
+        // the search with what there is.
+        if (pt->knobs.placement_tries > 1 && algo == IGX_ALGO_SUMFACT && igx_kind_symmetric(kind) && pt->sumfact_ok) {
+            std::vector<double *> cand(1, pt->d_data);
+            std::vector<float> ms(1, sumfact_probe_mirror(pt, pt->d_data));
+            for (int k = 1; k < pt->knobs.placement_tries && ms[0] >= 0.0f; ++k) {
+                double *b = nullptr;
+                if (hipMalloc((void **)&b, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                const float t = sumfact_probe_mirror(pt, b);
+                if (t < 0.0f) { (void)hipFree(b); break; }
+                cand.push_back(b); ms.push_back(t);
+            }
+            size_t best = 0;
+            for (size_t k = 1; k < cand.size(); ++k)
+                if (ms[k] < ms[best]) best = k;
+            for (size_t k = 0; k < cand.size(); ++k)
+                if (k != best) (void)hipFree(cand[k]);
+            pt->d_data = cand[best];
+            pt->placement_ms_best = ms[best];
+            pt->placement_ms_worst = *std::max_element(ms.begin(), ms.end());
+            pt->placement_tried = (int)cand.size();
+        }
     }
     if (pt->knobs.poison)                         // every value must be written exactly once
         IGX_HIP(hipMemsetAsync(pt->d_data, 0xFF, (size_t)pt->nnz * sizeof(double), st));
@@ -672,6 +697,15 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         IGX_HIP(hipMemcpyAsync(data_out, pt->d_data, (size_t)pt->nnz * sizeof(double), hipMemcpyDeviceToHost, st));
         IGX_HIP(hipStreamSynchronize(st));
     }
+    return IGX_OK;
+}
+
+int igx_patch_placement(const igx_patch *pt, int *tried, float *best_ms, float *worst_ms)
+{
+    if (!pt) { set_error("igx_patch_placement: null patch"); return IGX_ERR_ARG; }
+    if (tried) *tried = pt->placement_tried;
+    if (best_ms) *best_ms = pt->placement_ms_best;
+    if (worst_ms) *worst_ms = pt->placement_ms_worst;
     return IGX_OK;
 }
 

@@ -118,6 +118,8 @@ struct igx_knobs {
     int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
     int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
     int poison = 0;                           // IGX_DEBUG_POISON: NaN-fill the CSR values before an assembly (tests)
+    int placement_tries = 1;                  // IGX_PLACEMENT_TRIES=n (opt-in, 3D symmetric forms): the CSR value buffer is the fastest of n
+                                              // allocations under the mirror pass, timed once at its first assembly
     int stage_events = -1;                    // IGX_STAGE_EVENTS: events between the kernels of a chain (per-kernel device times in
                                               // igx_last_timing).  A marker costs ~5 us of stream time: default on for 3D patches of
                                               // >= 2^24 Gauss points (kernels of milliseconds), off below and in 2D (kernels of
@@ -173,6 +175,8 @@ struct igx_patch {
     bool ldesc_ok = false;
     int *d_steps = nullptr;                   // flush-step tables of the sweeps (one allocation)
     const int *stepA_ptr = nullptr, *stepA_rec = nullptr, *stepB_ptr = nullptr, *stepB_rec = nullptr;
+    float placement_ms_best = 0, placement_ms_worst = 0;   // IGX_PLACEMENT_TRIES: mirror pass on the kept / the slowest candidate
+    int placement_tried = 0;
     double *d_geoa_tab = nullptr;             // per-plane records of axis 0 for k_geoA (geoa.hip), built on first use
     int geoa_mf = 0;                          // ... and whether they carry the row tables of the matrix-core sweep
     double *d_geoa_tabn = nullptr;            // the same for the non-symmetric sweep (16-int flush steps), built on first use
@@ -267,6 +271,9 @@ bool geoA_supported(const igx_patch *pt, int kind, int nslots);
 int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
                 double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield = nullptr, const int *slot_xtype = nullptr);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
+// device time of the mirror pass of this patch on `buf` (access pattern only: the values are whatever the buffer holds);
+// < 0 when the patch has no such pass
+float sumfact_probe_mirror(igx_patch *pt, double *buf);
 int sumfact_supported(const igx_patch *pt);
 int sumfact_prepare(igx_patch *pt);
 int sumfact_supports_kind(const igx_patch *pt, int kind);

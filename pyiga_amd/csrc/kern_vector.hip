@@ -110,10 +110,13 @@ __global__ void __launch_bounds__(256) k_contract_last(const double *__restrict_
 // (at most p) dofs shared with the neighbouring chunk are ADDED onto zeros: two addends commute, the sum does not
 // depend on which chunk comes first (chunks are at least P spans long: never three addends).
 constexpr int LV_MAXPASS = 4;                            // N2 <= 256
+constexpr int LV_WAVES = 4;                              // waves of a block: they share the table of the last axis (three blocks per CU at
+                                                         // C4: twelve waves, each with a line of loads in flight; measured: 6 waves per
+                                                         // block and a shorter unrolled support loop 1.25 ms against 1.01)
 typedef const double __attribute__((address_space(4))) *lv_cdp;
 typedef const int __attribute__((address_space(4))) *lv_cip;
-template <bool WEIGHT, int P, int MAXPC>               // MAXPC: 128-point pieces of a line held in registers (G2 <= 128 MAXPC)
-__global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, const double *__restrict__ wfield, double *__restrict__ t2,
+template <bool WEIGHT, int P, int MAXPC, int NPASS>    // MAXPC: 128-point pieces of a line held in registers (G2 <= 128 MAXPC); NPASS: N2 <= 64 NPASS
+__global__ void __launch_bounds__(LV_WAVES * 64) k_lv12(const double *__restrict__ f, const double *__restrict__ wfield, double *__restrict__ t2,
                                               const AxisDev a1, const AxisDev a2, int G0, int chunk_spans, int nchunks, int deriv1, int deriv2)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -129,20 +132,20 @@ __global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, cons
         Vt[e] = v;
     }
     __syncthreads();
-    const long long unit = (long long)blockIdx.x * 4 + wave;
+    const long long unit = (long long)blockIdx.x * LV_WAVES + wave;
     if (unit >= (long long)G0 * nchunks) return;
     const int g0 = (int)(unit / nchunks), ch = (int)(unit - (long long)g0 * nchunks);
     const int s_a = ch * chunk_spans, s_b = min(s_a + chunk_spans, a1.n);
     const int q1 = a1.q, G1 = a1.G, N1 = a1.N;
-    int gfirst[LV_MAXPASS];
+    int gfirst[NPASS];
 #pragma unroll
-    for (int k = 0; k < LV_MAXPASS; ++k) { const int i2 = min(lane + 64 * k, N2 - 1); gfirst[k] = a2.mslo[i2] * q; }
-    const int npass = (N2 + 63) >> 6;
-    double acc[P][LV_MAXPASS];
+    for (int k = 0; k < NPASS; ++k) { const int i2 = min(lane + 64 * k, N2 - 1); gfirst[k] = a2.mslo[i2] * q; }
+    constexpr int npass = NPASS;
+    double acc[P][NPASS];
 #pragma unroll
     for (int a = 0; a < P; ++a)
 #pragma unroll
-        for (int k = 0; k < LV_MAXPASS; ++k) acc[a][k] = 0.0;
+        for (int k = 0; k < NPASS; ++k) acc[a][k] = 0.0;
     // a line as 16-byte pieces: piece e of the line = doubles 2 e, 2 e + 1 (G2 even: checked on the host)
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int npc = (G2 / 2 + 63) >> 6;
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, cons
 #pragma unroll
         for (int a = 0; a < P; ++a) v1[a] = V1[((size_t)g1 * P + a) * 2 + deriv1];
 #pragma unroll
-        for (int k = 0; k < LV_MAXPASS; ++k)
+        for (int k = 0; k < NPASS; ++k)
             if (k < npass) {
                 const int i2 = min(lane + 64 * k, N2 - 1);
                 const double *bl = buf + gfirst[k];
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, cons
                 const bool whole = mslo1[i1] >= s_a && (sp + 1 < s_b || sp + 1 == a1.n || j < fa1[min(sp + 1, a1.n - 1)] - base);
                 double *dst = t2 + ((long long)g0 * N1 + i1) * N2;
 #pragma unroll
-                for (int k = 0; k < LV_MAXPASS; ++k)
+                for (int k = 0; k < NPASS; ++k)
                     if (k < npass && lane + 64 * k < N2) {
                         if (whole) dst[lane + 64 * k] = acc[0][k];
                         else (void)__hip_atomic_fetch_add(dst + lane + 64 * k, acc[0][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -207,9 +210,9 @@ __global__ void __launch_bounds__(256) k_lv12(const double *__restrict__ f, cons
 #pragma unroll
             for (int a = 0; a < P - 1; ++a)
 #pragma unroll
-                for (int k = 0; k < LV_MAXPASS; ++k) acc[a][k] = acc[a + 1][k];
+                for (int k = 0; k < NPASS; ++k) acc[a][k] = acc[a + 1][k];
 #pragma unroll
-            for (int k = 0; k < LV_MAXPASS; ++k) acc[P - 1][k] = 0.0;
+            for (int k = 0; k < NPASS; ++k) acc[P - 1][k] = 0.0;
         }
         l = 0; ++sp;
     }
@@ -233,10 +236,11 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
     const AxisDev &a0 = pd.ax[0], &a1 = pd.ax[1], &a2 = pd.ax[2];
     const int n0 = pd.r0_hi - pd.r0_lo;
     if (dim == 3) {
-        // fused first two contractions (k_lv12): single-digit degrees, even G2 (16-byte pieces), lines and table in LDS
+        // fused first two contractions (k_lv12): single-digit degrees, even G2 <= 640 (five 16-byte pieces per lane: a longer line
+        // would spill the prefetched pieces), lines and table in LDS; anything else takes the three separate contractions below
         const int PQ = a2.P * a2.q;
-        const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + 4 * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
-        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 1280 && lds12 <= 64 * 1024
+        const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + LV_WAVES * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
+        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 640 && lds12 <= 80 * 1024
             && a1.n >= a1.P) {
             // chunks of the mid axis: enough waves for the chip, never shorter than P spans (a shared dof gets two addends)
             int nch = (int)std::min<long long>(std::max<long long>(1, (8192 + G0 - 1) / std::max<long long>(G0, 1)), std::max(1, a1.n / std::max(a1.P, 8)));
@@ -247,15 +251,17 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
             // (the last chunk then runs to the end of the axis: the kernel clamps with a1.n)
             const long long units = G0 * nch;
             IGX_HIP(hipMemsetAsync(d_t2, 0, (size_t)G0 * a1.N * a2.N * sizeof(double), st));
-            const dim3 grid((unsigned)((units + 3) / 4));
+            const dim3 grid((unsigned)((units + LV_WAVES - 1) / LV_WAVES));
+            const int npass = (a2.N + 63) / 64;
+#define LV12K(W_, PP, PC, NP) k_lv12<W_, PP, PC, NP><<<grid, LV_WAVES * 64, lds12, st>>>(d_f, d_W, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2)
+#define LV12P(W_, PP, PC) do { if (npass <= 2) LV12K(W_, PP, PC, 2); else if (npass == 3) LV12K(W_, PP, PC, 3); else LV12K(W_, PP, PC, 4); } while (0)
 #define LV12(PP) case PP: \
-                if (d_W && a2.G <= 640) k_lv12<true, PP, 5><<<grid, 256, lds12, st>>>(d_f, d_W, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
-                else if (d_W) k_lv12<true, PP, 10><<<grid, 256, lds12, st>>>(d_f, d_W, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
-                else if (a2.G <= 640) k_lv12<false, PP, 5><<<grid, 256, lds12, st>>>(d_f, nullptr, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
-                else k_lv12<false, PP, 10><<<grid, 256, lds12, st>>>(d_f, nullptr, d_t2, a1, a2, (int)G0, clen, nch, deriv_axis == 1, deriv_axis == 2); \
+                if (d_W) LV12P(true, PP, 5); else LV12P(false, PP, 5); \
                 break
             switch (a2.P) { LV12(2); LV12(3); LV12(4); LV12(5); LV12(6); }
 #undef LV12
+#undef LV12K
+#undef LV12P
             const long long B = (long long)a1.N * a2.N, n = (long long)n0 * B;
             AxisDev ax0 = a0;
             ax0.G = (int)G0;

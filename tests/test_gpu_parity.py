@@ -857,7 +857,11 @@ def test_full_size_c4(iga, oracle, monkeypatch):
     def picks(r):
         cols = S.indices[S.indptr[r]:S.indptr[r + 1]]
         return np.stack([np.full(3, r), cols[[0, cols.size // 2, -1]]], 1)
-    pr = np.concatenate([picks(r) for r in sample[::6]])
+    # every row of one line of the last axis (all positions inside all tiles of the fused stage: one whole tile column of
+    # k_bf2), three entries each, and every entry of one interior row
+    full_row = int(line[57])
+    fr_cols = S.indices[S.indptr[full_row]:S.indptr[full_row + 1]]
+    pr = np.concatenate([picks(r) for r in sample[::6]] + [picks(r) for r in line] + [np.stack([np.full(fr_cols.size, full_row), fr_cols], 1)])
     ref = oracle.local_entries('stiffness', (okv,) * 3, oracle.geo_cylinder(), pr)
     pos, _ = _positions(kvs, pr[:, 0].astype(np.int64), pr[:, 1].astype(np.int64))
     assert np.abs(data[pos] - ref).max() <= RTOL * scale
@@ -1023,6 +1027,35 @@ def test_ablation_variables_have_no_effect(iga, monkeypatch):
     C = patch.csr('stiffness', algo='sumfact')
     patch.close()
     assert np.array_equal(A.data, B.data) and np.array_equal(A.data, C.data)
+
+
+def test_placement_tries_opt_in(iga, monkeypatch):
+    """IGX_PLACEMENT_TRIES (read at patch creation): the first assembly times the mirror pass on n candidate buffers for
+    the CSR values and keeps the fastest.  Same matrix, the search is reported, and without the variable it does not run."""
+    kvs = (iga.bspline.make_knots(3, 0., 1., 12),) * 3
+    geo = _geo(iga, 'cylinder')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    A = patch.csr('stiffness', algo='sumfact')
+    assert patch.placement()['tried'] == 0
+    patch.close()
+    monkeypatch.setenv('IGX_PLACEMENT_TRIES', '3')
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    monkeypatch.delenv('IGX_PLACEMENT_TRIES')
+    B = patch.csr('stiffness', algo='sumfact')
+    pl = patch.placement()
+    assert pl['tried'] == 3 and 0.0 < pl['best_ms'] <= pl['worst_ms']
+    C2 = patch.csr('stiffness', algo='sumfact')                            # (the buffer is chosen once)
+    assert patch.placement() == pl
+    patch.close()
+    assert np.array_equal(A.data, B.data) and np.array_equal(A.data, C2.data) and not np.isnan(B.data).any()
+    # a form without a mirror pass: nothing to time, plain allocation
+    monkeypatch.setenv('IGX_PLACEMENT_TRIES', '3')
+    asm = iga.assemblers.ConvDiffAssembler3D(kvs, geo, lambda x, y, z: 1.0 + x)
+    monkeypatch.delenv('IGX_PLACEMENT_TRIES')
+    asm.assemble_csr(algo='sumfact')
+    assert asm.patch.placement()['tried'] == 0
+    asm.patch.close()
 
 
 @pytest.mark.parametrize('d', [2, 3])

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r03_traffic.json from the PMC passes of tools/prof_r03.sh (gpurun_out/r03/pmc/*): memory-side bytes per kernel
-of one C4 assembly, with the hash of the kernel sources they were measured on (bench.py drops the figure when the
-sources have changed since).  usage: python3 tools/make_traffic.py gpurun_out/r03/pmc [config]
+"""profiles/r04_traffic.json from the PMC passes of tools/prof_r04.sh pmc (gpurun_out/r04/pmc_<key>/{fetch,write}): memory-side
+bytes per kernel of ONE pass of the timed operation -- keys c2, c3, c4, c5 (one assembly), c4_rhs (one load vector),
+c4_entries (one batched multi_entries request) -- with the hash of the kernel sources they were measured on (bench.py drops
+the figure when the sources have changed since).  usage: python3 tools/make_traffic.py gpurun_out/r04
 
 Reads: 2 * FETCH_SIZE * 1024 for EVERY kernel -- a read request is a whole 128-byte line and the counter tallies it at 64
 bytes, for coalesced streams and for the 72-byte gathers of the mirror pass alike (profiles/r03_fetch_calibration.txt,
-tools/ubench/fetch_calib.hip).  Writes: WRITE_SIZE * 1024 (exact on the K1 stream of k_geoA)."""
+tools/ubench/fetch_calib.hip).  Writes: WRITE_SIZE * 1024 (exact on the K1 stream of k_geoA).  Per kernel the MEAN over its
+dispatches in the profiled process (the cold pass and the timed step launch the same kernels on the same data)."""
 import csv
 import glob
 import hashlib
@@ -16,6 +18,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# set-up kernels (basis tables, pattern, coefficient sampling, per-plane records) are not part of a timed step; every other
+# igx kernel of the profiled process is
+SETUP = {'k_basis_tables', 'k_pi_tables', 'k_pattern', 'k_coeff_affine', 'k_geoa_table', 'k_grid_geo', 'k_box_pairs'}
 
 
 def kernels_sha():
@@ -25,31 +30,46 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-def main():
-    root, config = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'c4')
+def one(root, key):
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
+    for f in glob.glob(os.path.join(root, 'pmc_' + key) + '/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
             name = re.sub(r'[<(].*', '', row['Kernel_Name']).replace('void igx::', '').replace('igx::', '')
-            name = {'k_bf2': 'k_bf', 'k_mirror2': 'k_mirror'}.get(name, name)
-            if name in ('k_geoA', 'k_bf', 'k_mirror', 'k_geo_fields', 'k_stageA', 'k_stageB', 'k_final', 'k_final_q'):
+            if name.startswith('k_') and name not in SETUP:
                 acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
     kernels, total = {}, 0.0
     for name, c in sorted(acc.items()):
         if not c['FETCH_SIZE'] or not c['WRITE_SIZE']:
             continue
+        # launches per step: dispatches seen / passes of the operation in the process (cold pass + one timed step)
         fetch = sum(c['FETCH_SIZE']) / len(c['FETCH_SIZE']) * 1024
         write = sum(c['WRITE_SIZE']) / len(c['WRITE_SIZE']) * 1024
-        kernels[name] = {'write_bytes': write, 'read_bytes': 2 * fetch}
-        total += write + 2 * fetch
-    out = {config: {'config': config,
-                    'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r03.sh), '
-                              'summary in profiles/r03_c4_pmc_summary.txt',
-                    'correction': 'read bytes = 2 * FETCH_SIZE * 1024 (128-byte requests tallied at 64 bytes; calibrated for streams and '
-                                  'for 72-byte gathers: profiles/r03_fetch_calibration.txt), write bytes = WRITE_SIZE * 1024',
-                    'kernels': kernels, 'chain_bytes': total, 'kernels_sha': kernels_sha()}}
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r03_traffic.json'), 'w'), indent=1)
-    print(json.dumps(out, indent=1))
+        kernels[name] = {'write_bytes': write, 'read_bytes': 2 * fetch, 'dispatches_seen': len(c['FETCH_SIZE'])}
+    if not kernels:
+        return None
+    # kernels launched several times per step (k_contract_axis: twice in the old load vector, once now): bytes per LAUNCH are
+    # reported, the chain total counts every launch of one step
+    passes = min(v['dispatches_seen'] for v in kernels.values())
+    for v in kernels.values():
+        v['launches_per_step'] = v['dispatches_seen'] // max(passes, 1)
+        total += (v['write_bytes'] + v['read_bytes']) * v['launches_per_step']
+    return {'config': key,
+            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r04.sh pmc)',
+            'correction': 'read bytes = 2 * FETCH_SIZE * 1024 (128-byte requests tallied at 64 bytes; calibrated for streams and '
+                          'for 72-byte gathers: profiles/r03_fetch_calibration.txt), write bytes = WRITE_SIZE * 1024',
+            'kernels': kernels, 'chain_bytes': total, 'kernels_sha': kernels_sha()}
+
+
+def main():
+    root = sys.argv[1]
+    out = {}
+    for key in ('c4', 'c5', 'c3', 'c2', 'c4_rhs', 'c4_entries'):
+        r = one(root, key)
+        if r:
+            out[key] = r
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r04_traffic.json'), 'w'), indent=1)
+    print(json.dumps({k: {'chain_GB': round(v['chain_bytes'] / 1e9, 3), 'kernels': {n: [round(x['read_bytes'] / 1e9, 3), round(x['write_bytes'] / 1e9, 3)] for n, x in v['kernels'].items()}}
+                      for k, v in out.items()}, indent=1))
 
 
 if __name__ == '__main__':
