@@ -57,6 +57,7 @@ struct GeoAArgs {
     const double *coeff;
     int g0_lo, coef_affine;
     double cf[4];
+    int soff_ok;                // every K1 slice offset (pairs x stride x 8 bytes) fits 32 bits: scalar-offset stores
 };
 
 typedef int int8v __attribute__((ext_vector_type(8)));
@@ -136,6 +137,33 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
 // store stream -- tools/ubench/k1_store.hip: 3.1 ms of arithmetic with such loads become 9.4 ms when the stores are on,
 // while the same arithmetic without them overlaps the stores completely.  The block stages the table rows of a batch in
 // LDS with vector loads issued a whole batch ahead.
+// K1 store of one completed pair: (descriptor of the wave's array: scalar) + (slice offset of the pair: scalar, 32 bits) +
+// (this lane's point: a constant) -- no vector instruction for the address (the flat form costs a 64-bit multiply-add per
+// store).  Arrays beyond 4 GB (soff_ok = 0, decided on the host) keep 64-bit addresses.
+struct K1Store {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff, ok;
+    __device__ __forceinline__ K1Store(double *base, const long long pt, const int tile, const int soff_ok)
+    {
+        const long long t0 = (long long)tile * 64;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + t0), (short)0, 0x7ffffff0, 0x00020000);
+        voff = (int)(pt - t0) * 8;
+#ifdef GA_K1_FLAT
+        ok = 0;                                              // (A/B build: 64-bit addresses everywhere)
+#else
+        ok = soff_ok;
+#endif
+    }
+    __device__ __forceinline__ void store(double *out, const int slot, const long long stride, const double x) const
+    {
+        if (ok) {
+            typedef int i2s __attribute__((ext_vector_type(2)));
+            i2s v; v.x = __double2loint(x); v.y = __double2hiint(x);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, (int)((unsigned)slot * (unsigned)(stride * 8)), 0);
+        } else out[(long long)slot * stride] = x;
+    }
+};
+
 // FORM = 1 (non-symmetric): the block carries GA_NGW extra GEOMETRY waves -- the sweep of the full (p+1)^2 window holds 72
 // accumulator registers at p = 5 and the slots with two sources sweep twice as long as the others, so the eight sweep waves
 // only sweep and four more waves evaluate the planes of the next batch beside them (two planes each).
@@ -533,6 +561,7 @@ k_geoA(const GeoAArgs A)
         typedef double d2 __attribute__((ext_vector_type(2)));
         const int t = A.type[w], fi = A.field[w], xt = A.xtype[w], xf = A.xfield[w];
         double *const out = A.out[w] + pt;
+        const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
         double acc[P][P];
 #pragma unroll
         for (int a = 0; a < P; ++a)
@@ -602,10 +631,10 @@ k_geoA(const GeoAArgs A)
                     }
 #pragma unroll
                     for (int a = 0; a < P; ++a)
-                        if (pr[a] >= 0 && write) out[(long long)pr[a] * A.stride] = acc[a][0];
+                        if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);
 #pragma unroll
                     for (int a = 1; a < P; ++a)
-                        if (pr[8 + a] >= 0 && write) out[(long long)pr[8 + a] * A.stride] = acc[0][a];
+                        if (pr[8 + a] >= 0 && write) k1s.store(out, pr[8 + a], A.stride, acc[0][a]);
 #pragma unroll
                     for (int a = 0; a < P - 1; ++a)
 #pragma unroll
@@ -624,6 +653,7 @@ k_geoA(const GeoAArgs A)
     // ---- sweep state of this wave
     const int t = A.type[w], fi = A.field[w];
     double *const out = A.out[w] + pt;
+    const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
     double acc[P][P];
 #pragma unroll
     for (int a = 0; a < P; ++a)
@@ -715,7 +745,7 @@ k_geoA(const GeoAArgs A)
                 }
 #pragma unroll
                 for (int a = 0; a < P; ++a)
-                    if (pr[a] >= 0 && write) out[(long long)pr[a] * A.stride] = acc[a][0];
+                    if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);
 #pragma unroll
                 for (int a = 0; a < P - 1; ++a)
 #pragma unroll
@@ -871,6 +901,7 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
     A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
+    A.soff_ok = (long long)(nonsym ? pt->npairs0n : pt->npairs0) * slice_stride * 8 < 0xffff0000LL ? 1 : 0;
     A.tab = nonsym ? pt->d_geoa_tabn : pt->d_geoa_tab; A.steps = nonsym ? pt->d_stepsn : pt->stepA_rec;
     A.coeff = pt->d_coeff; A.g0_lo = pd.g0_lo; A.coef_affine = pt->coef_affine;
     for (int k = 0; k < 4; ++k) A.cf[k] = pt->coef_c[k];
