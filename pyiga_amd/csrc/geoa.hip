@@ -139,7 +139,7 @@ __global__ void k_geoa_table(const double *V0s, int P, const double *V0g, const 
 // LDS with vector loads issued a whole batch ahead.
 // K1 store of one completed pair: (descriptor of the wave's array: scalar) + (slice offset of the pair: scalar, 32 bits) +
 // (this lane's point: a constant) -- no vector instruction for the address (the flat form costs a 64-bit multiply-add per
-// store).  Arrays beyond 4 GB (soff_ok = 0, decided on the host) keep 64-bit addresses.
+// store).  Arrays of 2 GB and more (soff_ok = 0, decided on the host) keep 64-bit addresses.
 struct K1Store {
     __amdgpu_buffer_rsrc_t rs;
     int voff, ok;
@@ -901,7 +901,10 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
     A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
-    A.soff_ok = (long long)(nonsym ? pt->npairs0n : pt->npairs0) * slice_stride * 8 < 0xffff0000LL ? 1 : 0;
+    // (the hardware's range check adds the scalar offset to the lane offset before it compares with the length of the
+    // descriptor: a slice offset at or above 2^31 - 16 would have its stores DROPPED -- found in round 4 by the WRITE_SIZE counter
+    // of C5 reading 6 of 8 arrays' worth; C4's largest offset is 2.127e9, just below)
+    A.soff_ok = (long long)(nonsym ? pt->npairs0n : pt->npairs0) * slice_stride * 8 + 1024 < 0x7ffffff0LL ? 1 : 0;
     A.tab = nonsym ? pt->d_geoa_tabn : pt->d_geoa_tab; A.steps = nonsym ? pt->d_stepsn : pt->stepA_rec;
     A.coeff = pt->d_coeff; A.g0_lo = pd.g0_lo; A.coef_affine = pt->coef_affine;
     for (int k = 0; k < 4; ++k) A.cf[k] = pt->coef_c[k];

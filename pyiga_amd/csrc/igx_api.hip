@@ -645,9 +645,11 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
             for (size_t k = 0; k < cand.size(); ++k)
                 if (k != best) (void)hipFree(cand[k]);
             pt->d_data = cand[best];
-            pt->placement_ms_best = ms[best];
-            pt->placement_ms_worst = *std::max_element(ms.begin(), ms.end());
-            pt->placement_tried = (int)cand.size();
+            if (ms[0] >= 0.0f) {                         // (a patch without a mirror pass -- 2D, other paths -- has nothing to time)
+                pt->placement_ms_best = ms[best];
+                pt->placement_ms_worst = *std::max_element(ms.begin(), ms.end());
+                pt->placement_tried = (int)cand.size();
+            }
         }
     }
     if (pt->knobs.poison)                         // every value must be written exactly once

@@ -31,30 +31,26 @@ def kernels_sha():
 
 
 def one(root, key):
+    """Per kernel the LAST dispatch of the profiled process: the timed step (earlier dispatches are the cold pass of the same
+    operation -- same kernels, same data; for the batched entries the warm-up request is a small one)."""
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(root, 'pmc_' + key) + '/**/*counter_collection.csv', recursive=True):
-        for row in csv.DictReader(open(f)):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
+        for row in rows:
             name = re.sub(r'[<(].*', '', row['Kernel_Name']).replace('void igx::', '').replace('igx::', '')
-            if name.startswith('k_') and name not in SETUP:
+            if name.startswith('k_') and name not in SETUP and not (key.endswith(('_rhs', '_entries')) and name.startswith('k_geo_fields')):
                 acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
     kernels, total = {}, 0.0
     for name, c in sorted(acc.items()):
         if not c['FETCH_SIZE'] or not c['WRITE_SIZE']:
             continue
-        # launches per step: dispatches seen / passes of the operation in the process (cold pass + one timed step)
-        fetch = sum(c['FETCH_SIZE']) / len(c['FETCH_SIZE']) * 1024
-        write = sum(c['WRITE_SIZE']) / len(c['WRITE_SIZE']) * 1024
+        fetch, write = c['FETCH_SIZE'][-1] * 1024, c['WRITE_SIZE'][-1] * 1024
         kernels[name] = {'write_bytes': write, 'read_bytes': 2 * fetch, 'dispatches_seen': len(c['FETCH_SIZE'])}
+        total += write + 2 * fetch
     if not kernels:
         return None
-    # kernels launched several times per step (k_contract_axis: twice in the old load vector, once now): bytes per LAUNCH are
-    # reported, the chain total counts every launch of one step
-    passes = min(v['dispatches_seen'] for v in kernels.values())
-    for v in kernels.values():
-        v['launches_per_step'] = v['dispatches_seen'] // max(passes, 1)
-        total += (v['write_bytes'] + v['read_bytes']) * v['launches_per_step']
     return {'config': key,
-            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r04.sh pmc)',
+            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r04.sh pmc), plain buffer allocation',
             'correction': 'read bytes = 2 * FETCH_SIZE * 1024 (128-byte requests tallied at 64 bytes; calibrated for streams and '
                           'for 72-byte gathers: profiles/r03_fetch_calibration.txt), write bytes = WRITE_SIZE * 1024',
             'kernels': kernels, 'chain_bytes': total, 'kernels_sha': kernels_sha()}

@@ -12,7 +12,7 @@ OUT=${2:-gpurun_out/r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 pmc() { local key=$1 name=$2; shift 2; local ctr=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc_$key/$name" -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-api-call > "$OUT/pmc_${key}_$name.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc_$key/$name" -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-api-call --placement-tries 1 > "$OUT/pmc_${key}_$name.log" 2>&1
   echo "pmc $key $name rc=$?"; rm -f "$OUT"/pmc_$key/*/*/*kernel_trace.csv "$OUT"/pmc_$key/*/*/*agent_info.csv; }
 case $STAGE in
 trace)
