@@ -512,6 +512,37 @@ def test_load_vector_slabs_and_oracle(iga, oracle, d, p, n, G):
     assert np.array_equal(np.concatenate(parts, axis=0), full)
 
 
+@pytest.mark.parametrize('p,n1', [(2, 37), (3, 40), (4, 48), (5, 33)])
+def test_load_vector_fused_chunks(iga, oracle, p, n1):
+    """k_lv12 (round 4: the first two contractions of the 3D load vector in one kernel) with SEVERAL chunks of the mid axis:
+    the dofs shared by two chunks are added onto zeros (two addends: the order cannot matter) -- against the oracle,
+    repeatable bit for bit, slab by slab, and with a differentiated basis (the jet functional)."""
+    mk = iga.bspline.make_knots
+    kvs = (mk(p, 0., 1., 4), mk(p, 0., 1., n1), mk(p, 0., 1., 6))
+    geo = _geo(iga, 'cylinder')
+    full = iga.assemble.inner_products(kvs, _f3, f_physical=True, geo=geo)
+    okvs = tuple(oracle.make_knots(p, 0., 1., n) for n in (4, n1, 6))
+    ref = oracle.inner_products(okvs, _f3, f_physical=True, geo=oracle.geo_cylinder())
+    assert _close(full, ref)
+    for _ in range(3):
+        assert np.array_equal(iga.assemble.inner_products(kvs, _f3, f_physical=True, geo=geo), full)
+    N0 = kvs[0].numdofs
+    parts, fvals = [], None
+    for lo, hi in ((0, 2), (2, N0)):
+        patch = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+        if fvals is None:
+            fvals = iga.utils.grid_eval_transformed(_f3, tuple(patch.gauss(a)[0] for a in range(3)), geo)
+        parts.append(patch.load_vector(fvals))
+        patch.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), full)
+    # gradient functional (differentiated basis functions on each axis in turn): the basis is a partition of unity, so the
+    # whole vector of  inner(c, grad(v)) dx  sums to zero; against the separate contractions of an unequal-degree space
+    cube = iga.geometry.unit_cube()
+    fz = iga.assemble.assemble('inner((1.0, 2.0, -3.0), grad(v)) * dx', kvs, geo=cube)
+    assert fz.shape == full.shape and abs(fz.sum()) <= 1e-12 * np.abs(fz).max() * fz.size
+    assert np.array_equal(iga.assemble.assemble('inner((1.0, 2.0, -3.0), grad(v)) * dx', kvs, geo=cube), fz)
+
+
 def test_partial_rows(iga):
     """arbitrary row subsets through batched multi_entries (pyiga/_hdiscr.py:5-11)."""
     mk = iga.bspline.make_knots
