@@ -166,6 +166,19 @@ int igx_patch_set_coeff(igx_patch *patch, const double *coeff);
    evaluated on the device through the geometry map, nothing is sampled or shipped by the host. */
 int igx_patch_set_coeff_affine(igx_patch *patch, const double c[4]);
 
+/* The same coefficient as an EXPRESSION in the physical coordinates: `expr` is a C expression in the doubles x, y, z (and
+   pi), e.g. "1.0 + x * x + 0.5 * sin(pi * z)".  The library emits a kernel for it, compiles it with hiprtc for the device
+   of the patch, keeps the code object on disk under the hash of its source ($IGX_CACHE_DIR, default ~/.cache/igx) and
+   evaluates it on the resident Gauss points from the geometry map -- nothing is sampled on the host.  *cache_hit (may be
+   NULL) = 1 when the code object came from the cache.  Spline geometries only.  The analogue of the reference's run-time
+   compiled assemblers and their source-hash module cache (pyiga/compile.py:58-73,120-132), for the one input the jet-form
+   kernels cannot express themselves. */
+int igx_patch_set_coeff_expr(igx_patch *patch, const char *expr, int *cache_hit);
+
+/* Host only (no device, no patch): compile the coefficient kernel of `expr` for the architecture `arch` ("gfx950") into the
+   cache, or find it there; path_out (may be NULL) receives the file name.  What igx_patch_set_coeff_expr does first. */
+int igx_rtc_compile(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+
 /* Coefficients of IGX_FORM: coef[4*r + s] is P_rs on the FULL tensor Gauss grid (G0 x G1 x G2, C order, host
    pointer) or NULL for an absent (zero) coefficient; r = jet index of the test function v, s = of the trial
    function u.  Copied.  Replaces the previous form of the patch. */

@@ -80,6 +80,8 @@ SYMBOLS = [
     ('igx_entries', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, _dp]),
     ('igx_fields', C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     ('igx_fused_stage_fits', C.c_int, [C.c_int64] * 5),
+    ('igx_patch_set_coeff_expr', C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    ('igx_rtc_compile', C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     ('igx_patch_placement', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ('igx_load_vector', C.c_int, [C.c_void_p, _dp, _dp]),
     ('igx_load_vector_jet', C.c_int, [C.c_void_p, _dp * 4, _dp]),

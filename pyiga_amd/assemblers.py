@@ -300,6 +300,14 @@ class DevicePatch:
         arr = (C.c_double * 4)(*[float(v) for v in c])
         _lib.check(_lib.load().igx_patch_set_coeff_affine(self.handle, arr), 'igx_patch_set_coeff_affine')
 
+    def set_coeff_expr(self, c_expr):
+        """Coefficient given as a C expression in x, y, z (ExprCoefficient.c_source): compiled at run time for the device
+        (hiprtc, code object cached on disk by source hash) and evaluated on the resident Gauss points.  Returns True when
+        the code object came from the cache."""
+        hit = C.c_int(0)
+        _lib.check(_lib.load().igx_patch_set_coeff_expr(self.handle, c_expr.encode(), C.byref(hit)), 'igx_patch_set_coeff_expr')
+        return bool(hit.value)
+
     def load_vector(self, fvals):
         """Inner products of the owned basis functions with a function given by its values on the full
         tensor Gauss grid (scalar: shape G; vector-valued: G + trailing component axes)."""
@@ -469,6 +477,65 @@ class AffineCoefficient:
         return self.c[0] + self.c[1] * x + self.c[2] * y + self.c[3] * z
 
 
+class ExprCoefficient:
+    """A coefficient function given as an expression string in the physical coordinates, e.g.
+    ``ExprCoefficient('1 + x**2 + 0.5 * sin(pi * z)')``.  Callable like any coefficient function -- numpy evaluates the
+    expression, so it also works with the reference -- and the device assemblers recognise it: the expression is translated
+    to C, compiled for the GPU at run time and evaluated there on the Gauss points (``igx_patch_set_coeff_expr``: the
+    counterpart of the reference's run-time compiled assemblers, pyiga/compile.py:58-73), instead of being sampled on the
+    host and shipped as one double per Gauss point.
+
+    Grammar: numbers, ``x y z pi``, ``+ - * / **``, unary minus, and the functions sin cos tan exp log sqrt tanh sinh cosh
+    abs minimum maximum power (numpy names; also min / max / pow / fabs)."""
+
+    _FUNCS = {'sin': 'sin', 'cos': 'cos', 'tan': 'tan', 'exp': 'exp', 'log': 'log', 'sqrt': 'sqrt', 'tanh': 'tanh', 'sinh': 'sinh',
+              'cosh': 'cosh', 'abs': 'fabs', 'fabs': 'fabs', 'minimum': 'fmin', 'maximum': 'fmax', 'min': 'fmin', 'max': 'fmax',
+              'power': 'pow', 'pow': 'pow', 'arctan': 'atan', 'atan': 'atan', 'arctan2': 'atan2', 'atan2': 'atan2'}
+    _ARITY = {'fmin': 2, 'fmax': 2, 'pow': 2, 'atan2': 2}
+
+    def __init__(self, expr):
+        import ast
+        self.expr = str(expr)
+        self._tree = ast.parse(self.expr, mode='eval')
+        self._c = self._emit(self._tree.body)          # validates the grammar
+
+    def _emit(self, n):
+        import ast
+        if isinstance(n, ast.Constant) and isinstance(n.value, (int, float)) and not isinstance(n.value, bool):
+            return repr(float(n.value))
+        if isinstance(n, ast.Name) and n.id in ('x', 'y', 'z', 'pi'):
+            return n.id
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, (ast.USub, ast.UAdd)):
+            return '(%s%s)' % ('-' if isinstance(n.op, ast.USub) else '+', self._emit(n.operand))
+        if isinstance(n, ast.BinOp):
+            a, b = self._emit(n.left), self._emit(n.right)
+            ops = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*', ast.Div: '/'}
+            if type(n.op) in ops:
+                return '(%s %s %s)' % (a, ops[type(n.op)], b)
+            if isinstance(n.op, ast.Pow):
+                if isinstance(n.right, ast.Constant) and n.right.value in (2, 3, 4):        # small integer powers as products (as numpy does)
+                    return '(' + ' * '.join([a] * int(n.right.value)) + ')'
+                return 'pow(%s, %s)' % (a, b)
+        if isinstance(n, ast.Call) and not n.keywords:
+            f = n.func
+            name = f.id if isinstance(f, ast.Name) else f.attr if (isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in ('np', 'numpy', 'math')) else None
+            if name in self._FUNCS:
+                cf = self._FUNCS[name]
+                if len(n.args) == self._ARITY.get(cf, 1):
+                    return '%s(%s)' % (cf, ', '.join(self._emit(a) for a in n.args))
+        raise ValueError('ExprCoefficient: unsupported construct in %r' % self.expr)
+
+    def c_source(self):
+        return self._c
+
+    def __call__(self, x, y, z):
+        ns = {k: getattr(np, k) for k in ('sin', 'cos', 'tan', 'exp', 'log', 'sqrt', 'tanh', 'sinh', 'cosh', 'abs', 'fabs', 'minimum',
+                                          'maximum', 'power', 'arctan', 'arctan2')}
+        ns.update(min=np.minimum, max=np.maximum, pow=np.power, atan=np.arctan, atan2=np.arctan2, np=np, numpy=np, math=np, pi=np.pi,
+                  x=np.asarray(x, dtype=float), y=np.asarray(y, dtype=float), z=np.asarray(z, dtype=float))
+        return eval(compile(self._tree, '<ExprCoefficient>', 'eval'), {'__builtins__': {}}, ns) + 0.0 * ns['x']
+
+
 class ConvDiffAssembler3D(_DeviceAssembler):
     """Assembler for the variational form
 
@@ -491,6 +558,9 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         super().__init__(kvs0, geo, device=device, row0=row0, bbox=bbox)
         if isinstance(diff_coeff, AffineCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
             self.patch.set_coeff_affine(diff_coeff.c)             # evaluated on the device: nothing sampled on the host
+            return
+        if isinstance(diff_coeff, ExprCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None:
+            self.coeff_cache_hit = self.patch.set_coeff_expr(diff_coeff.c_source())     # compiled for the device at run time
             return
         # (any other geometry object: the coefficient is sampled through geo.grid_eval like a plain callable)
         grid = [self.patch.gauss(k)[0] for k in range(3)]

@@ -533,6 +533,27 @@ int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
     return IGX_OK;
 }
 
+int igx_patch_set_coeff_expr(igx_patch *pt, const char *expr, int *cache_hit)
+{
+    if (!pt || !expr) { set_error("igx_patch_set_coeff_expr: null argument"); return IGX_ERR_ARG; }
+    if (pt->dim != 3) { set_error("igx_patch_set_coeff_expr: the coefficient belongs to the 3D convection-diffusion form"); return IGX_ERR_UNSUPPORTED; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    const size_t n = (size_t)pt->dev.npts_loc;
+    double *buf = nullptr;                               // committed to the patch only when the kernel has run
+    IGX_HIP(hipMalloc((void **)&buf, std::max<size_t>(1, n) * sizeof(double)));
+    if (int rc = launch_coeff_expr(pt->ctx->stream, pt, expr, buf, cache_hit)) { (void)hipFree(buf); return rc; }
+    if (pt->d_coeff) (void)hipFree(pt->d_coeff);
+    pt->d_coeff = buf;
+    pt->fields_kind = -1;
+    pt->coef_affine = 0;
+    return IGX_OK;
+}
+
+int igx_rtc_compile(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit)
+{
+    return rtc_compile_expr(expr, arch, path_out, path_len, cache_hit);
+}
+
 // coefficient table of IGX_FORM: validated into locals, committed to the patch only when everything (allocation, copies)
 // has succeeded -- a failed call leaves the previous form in place.  `on_device`: the arrays are device pointers over the
 // RESIDENT Gauss slab (igx_patch_gauss_slab), else host pointers over the full grid.

@@ -224,6 +224,9 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);
 int launch_fields_dump(hipStream_t st, const igx_patch *pt);
 int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], double *d_coeff);
+// run-time compiled coefficient expressions (rtc.hip)
+int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *cache_hit);
+int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 // boxes of the reordered tensor X[r0][r1][r2] (r_k = index of a 1D pair (i_k, j_k) with overlapping supports): the entries

@@ -168,3 +168,39 @@ def test_fused_stage_offset_guard(lib):
     assert fits(1, S(258, 3), S(258, 3), 1024, 1024) == 1      # 2D (C2): one trivial outer row
     assert fits(9, -1, 5, 5, 5) == 0
     assert fits(9, 1 << 40, 1 << 40, 1, 1) == 0    # no overflow of the products
+
+
+def test_rtc_compile_and_cache(lib, tmp_path, monkeypatch):
+    """Run-time compiled coefficient kernels (SURVEY 8 f1 "full": an emitter + an on-disk code-object cache keyed by the
+    source hash, the analogue of pyiga/compile.py:58-73,120-132): hiprtc cross-compiles without a GPU.  First call compiles
+    into the cache, the second finds the code object there; a different expression gets a different file; a broken
+    expression comes back with the compiler's message; the Python front-end translates a restricted expression grammar."""
+    cdll = lib.load()
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    buf = ctypes.create_string_buffer(1024)
+    hit = ctypes.c_int(-1)
+    expr = b'1.0 + x * x + 0.5 * sin(pi * z) - fmax(y, 0.25) / 3.0'
+    assert cdll.igx_rtc_compile(expr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0
+    path = buf.value.decode()
+    assert path.startswith(str(tmp_path / 'cache')) and path.endswith('.hsaco')
+    assert open(path, 'rb').read(4) == b'\x7fELF' and os.path.getsize(path) > 1000
+    assert cdll.igx_rtc_compile(expr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 1
+    assert buf.value.decode() == path
+    assert cdll.igx_rtc_compile(b'2.0 * y', b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0
+    assert buf.value.decode() != path
+    # a truncated cache file is not trusted: compiled again and replaced
+    open(path, 'wb').write(b'\x7fEL')
+    assert cdll.igx_rtc_compile(expr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0
+    assert open(path, 'rb').read(4) == b'\x7fELF'
+    assert cdll.igx_rtc_compile(b'1.0 + nosuchfunction(x)', b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+    assert b'nosuchfunction' in cdll.igx_last_error()
+    # front-end
+    from pyiga_amd.assemblers import ExprCoefficient
+    e = ExprCoefficient('1 + x**2 + 0.5 * np.sin(pi * z) - maximum(y, 0.25) / 3')
+    x, y, z = np.random.default_rng(0).random((3, 50))
+    assert np.allclose(e(x, y, z), 1 + x ** 2 + 0.5 * np.sin(np.pi * z) - np.maximum(y, 0.25) / 3, rtol=0, atol=1e-15)
+    assert e(0.5, 0.5, 0.5).shape == ()
+    assert cdll.igx_rtc_compile(e.c_source().encode(), b'gfx950', buf, 1024, ctypes.byref(hit)) == 0
+    for bad in ('__import__("os")', 'x if y else z', 'open("f")', 'x.real', 'lambda: 1', 'q + 1'):
+        with pytest.raises((ValueError, SyntaxError)):
+            ExprCoefficient(bad)

@@ -1382,6 +1382,43 @@ def test_convdiff_geometry_in_sweep(iga, oracle, deg0, spans0, nurbs, p, n, monk
     assert np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
 
 
+def test_coefficient_expression_compiled_at_run_time(iga, tmp_path, monkeypatch):
+    """igx_patch_set_coeff_expr (round 4, SURVEY 8 f1 "full"): the coefficient of the convection-diffusion form as an
+    expression, compiled with hiprtc for the device and cached on disk by source hash, evaluated on the Gauss points from the
+    geometry map -- against the same function sampled on the host and shipped (the reference's way), NURBS and B-spline
+    geometries, row slabs, the cache (miss, then hit, also from a second patch), a failing expression."""
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    Expr = iga.assemblers.ExprCoefficient
+    text = '1 + x**2 + 0.5 * sin(pi * z) - maximum(y, 0.25) / 3'
+    fn = lambda x, y, z: 1 + x ** 2 + 0.5 * np.sin(np.pi * z) - np.maximum(y, 0.25) / 3
+    kvs = (iga.bspline.make_knots(3, 0., 1., 7), iga.bspline.make_knots(3, 0., 1., 8), iga.bspline.make_knots(3, 0., 1., 6))
+    first = True
+    for geo in (_geo(iga, 'cylinder'), _wavy_box(iga, 2, 4, False)):
+        host = iga.assemblers.ConvDiffAssembler3D(kvs, geo, fn)
+        R = host.assemble_csr(algo='sumfact')
+        host.patch.close()
+        dev = iga.assemblers.ConvDiffAssembler3D(kvs, geo, Expr(text))
+        assert dev.coeff_cache_hit == (not first)            # compiled once per source and architecture, then found on disk
+        first = False
+        A = dev.assemble_csr(algo='sumfact')
+        E = dev.assemble_csr(algo='entrywise')
+        dev.patch.close()
+        assert rel_maxdiff(A, R) <= RTOL and rel_maxdiff(E, R) <= RTOL
+        N0 = kvs[0].numdofs
+        parts = []
+        for lo, hi in ((0, 3), (3, N0)):
+            sl = iga.assemblers.ConvDiffAssembler3D(kvs, geo, Expr(text), row0=(lo, hi))
+            assert sl.coeff_cache_hit
+            parts.append(sl.assemble_csr(algo='sumfact'))
+            sl.patch.close()
+        assert np.array_equal(scipy.sparse.vstack(parts).tocsr().data, A.data)
+    assert len(os.listdir(str(tmp_path / 'cache'))) == 1
+    patch = iga.assemblers.DevicePatch(kvs, _geo(iga, 'cylinder'))
+    with pytest.raises(iga._lib.IgxError, match='nosuch'):
+        patch.set_coeff_expr('1.0 + nosuch(x)')
+    patch.close()
+
+
 def test_set_form_device_and_failed_call(iga):
     """igx_patch_set_form_d (coefficients already on the device, resident slab) == the host entry point; a call that fails
     validation leaves the previous form in place."""
