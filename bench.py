@@ -37,6 +37,10 @@ CONFIGS = {
     'c2': (2, 3, 256, 'stiffness', 'quarter_annulus'),
     'c1': (2, 3, 15, 'stiffness', 'bspline_quarter_annulus'),
     'tiny': (3, 2, 12, 'stiffness', 'cylinder'),
+    # what a patch OUTSIDE the fused chain pays: C4 with double interior knots on the mid axis (C^2 instead of C^3
+    # there) -- the stage kernels with 64-bit addresses; and C4 at degree 4 x 3 x 4 (unequal degrees on the mid / last axis)
+    'c4k': (3, 4, 128, 'stiffness', 'cylinder'),
+    'c4m': (3, 4, 128, 'stiffness', 'cylinder'),
     # BASELINE config 5: the run-time compiled (vform) convection-diffusion form, non-symmetric
     'c5': (3, 5, 96, 'convdiff', 'cylinder'),
 }
@@ -386,6 +390,10 @@ def main():
     kv0 = bspline.make_knots(p, 0.0, 1.0, n0)
     kv = bspline.make_knots(p, 0.0, 1.0, n)
     kvs = (kv0,) + (kv,) * (dim - 1)
+    if args.config == 'c4k':
+        kvs = (kv0, bspline.make_knots(p, 0.0, 1.0, n // 2, mult=2), kv)
+    elif args.config == 'c4m':
+        kvs = (kv0, bspline.make_knots(p - 1, 0.0, 1.0, n), kv)
     row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world, p if dim == 3 else None)      # balanced by work
     if kind == 'convdiff':
         patch = assemblers.ConvDiffAssembler3D(kvs, geo, assemblers.AffineCoefficient(1.0, 1.0), device=local_rank, row0=row0 if part_world > 1 else None).patch
@@ -393,7 +401,7 @@ def main():
         patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
     patch.ctx.sync()
     setup_s = time.perf_counter() - t_setup                 # knots, tables, plan, coefficient sampling + upload (context warm)
-    nel_total = n0 * n ** (dim - 1)
+    nel_total = int(np.prod([k.numspans for k in kvs]))
     if emu is not None:
         nel_total //= part_world        # one slab's share
     nnz_local = patch.nnz
@@ -512,9 +520,10 @@ def main():
         'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak' if weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (launcher test, no device work)',
-        'config': {'workload': '%dD p=%d %s, %s spans, NURBS quarter-annulus %s, uniform open knots'
-                               % (dim, p, kind, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1)),
-                                  'cylinder' if dim == 3 else gname),
+        'config': {'workload': '%dD p=%s %s, %s spans, NURBS quarter-annulus %s, %s'
+                               % (dim, p if len({k.p for k in kvs}) == 1 else 'x'.join(str(k.p) for k in kvs), kind,
+                                  'x'.join(str(k.numspans) for k in kvs), 'cylinder' if dim == 3 else gname,
+                                  'double interior knots on the mid axis' if args.config == 'c4k' else 'uniform open knots'),
                    'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
                    'path': ' + '.join(parts),
