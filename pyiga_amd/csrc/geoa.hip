@@ -430,7 +430,6 @@ k_geoA(const GeoAArgs A)
         typedef int i2v __attribute__((ext_vector_type(2)));
         const int t = A.type[w], fi = A.field[w];
         const int g = lane >> 4, n = lane & 15;
-        (void)0;
         d4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = d4{0.0, 0.0, 0.0, 0.0};
@@ -931,9 +930,10 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     // matrix-core sweep (opt-in, IGX_GEOA=mfma): eight slots (3D stiffness), p = 3, 4 (15 / 10 live pairs on 16 rows; below
     // that the vector form issues fewer cycles, above it the pairs do not fit one tile).  One choice per patch: every slab
     // and chunk agrees.
-    if (nslots == 8 && pt->geoa_mf && pt->knobs.geoa_mf && (A0.P == 5 || A0.P == 4) && A0.q == A0.P) {
-        if (A0.P == 5) return p0g == 2 ? launch_geoA_k<5, 8, 2, true>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<5, 8, 3, true>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED;
-        return p0g == 2 ? launch_geoA_k<4, 8, 2, true>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<4, 8, 3, true>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED;
+    // (geometries of degree 1 along axis 0 only: with three column sets the LDS image leaves one block per CU)
+    if (nslots == 8 && pt->geoa_mf && pt->knobs.geoa_mf && (A0.P == 5 || A0.P == 4) && A0.q == A0.P && p0g == 2) {
+        if (A0.P == 5) return launch_geoA_k<5, 8, 2, true>(st, A, nc, grid);
+        return launch_geoA_k<4, 8, 2, true>(st, A, nc, grid);
     }
 #define GEOA_P(PV) case PV: return nslots == 1 ? launch_geoA_g<PV, 1>(st, A, nc, p0g, grid) : launch_geoA_g<PV, 8>(st, A, nc, p0g, grid)
     switch (A0.P) {
