@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(LV_WAVES * 64) k_lv12(const double *__restrict
     const long long unit = (long long)blockIdx.x * LV_WAVES + wave;
     if (unit >= (long long)G0 * nchunks) return;
     const int g0 = (int)(unit / nchunks), ch = (int)(unit - (long long)g0 * nchunks);
-    const int s_a = ch * chunk_spans, s_b = min(s_a + chunk_spans, a1.n);
+    const int s_a = ch * chunk_spans, s_b = ch == nchunks - 1 ? a1.n : s_a + chunk_spans;     // (the last chunk takes a short remainder along)
     const int q1 = a1.q, G1 = a1.G, N1 = a1.N;
     int gfirst[NPASS];
 #pragma unroll
@@ -240,15 +240,15 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
         // would spill the prefetched pieces), lines and table in LDS; anything else takes the three separate contractions below
         const int PQ = a2.P * a2.q;
         const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + LV_WAVES * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
-        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 640 && lds12 <= 80 * 1024
+        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 640 && lds12 <= 64 * 1024
             && a1.n >= a1.P) {
             // chunks of the mid axis: enough waves for the chip, never shorter than P spans (a shared dof gets two addends)
             int nch = (int)std::min<long long>(std::max<long long>(1, (8192 + G0 - 1) / std::max<long long>(G0, 1)), std::max(1, a1.n / std::max(a1.P, 8)));
             int clen = (a1.n + nch - 1) / nch;
             clen = std::max(clen, a1.P);
             nch = (a1.n + clen - 1) / clen;
-            if (nch > 1 && a1.n - (nch - 1) * clen < a1.P) { --nch; }     // a short last chunk joins its neighbour
-            // (the last chunk then runs to the end of the axis: the kernel clamps with a1.n)
+            if (nch > 1 && a1.n - (nch - 1) * clen < a1.P) { --nch; }     // a short last chunk joins its neighbour: the kernel lets
+            // the last chunk run to the end of the axis (found by tools/fuzz_rhs.py: 65 spans at p = 5 lost their last two)
             const long long units = G0 * nch;
             IGX_HIP(hipMemsetAsync(d_t2, 0, (size_t)G0 * a1.N * a2.N * sizeof(double), st));
             const dim3 grid((unsigned)((units + LV_WAVES - 1) / LV_WAVES));

@@ -512,7 +512,7 @@ def test_load_vector_slabs_and_oracle(iga, oracle, d, p, n, G):
     assert np.array_equal(np.concatenate(parts, axis=0), full)
 
 
-@pytest.mark.parametrize('p,n1', [(2, 37), (3, 40), (4, 48), (5, 33)])
+@pytest.mark.parametrize('p,n1', [(2, 37), (3, 40), (4, 48), (5, 33), (5, 65), (4, 41), (3, 67)])
 def test_load_vector_fused_chunks(iga, oracle, p, n1):
     """k_lv12 (round 4: the first two contractions of the 3D load vector in one kernel) with SEVERAL chunks of the mid axis:
     the dofs shared by two chunks are added onto zeros (two addends: the order cannot matter) -- against the oracle,
