@@ -21,14 +21,16 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     g = iga.geometry
     geos = [lambda: g.tensor_product(g.line_segment(0.0, 1.0), g.quarter_annulus()), g.twisted_box, lambda: g.unit_cube(),
-            lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus())]
+            lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus()),
+            lambda: g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0)),        # degree 2 (NURBS) along axis 0
+            lambda: g.tensor_product(g.bspline_quarter_annulus(), g.line_segment(0.0, 1.5, intervals=2))]
     worst = 0.0
     for case in range(ncases):
         p = int(rng.integers(2, 6))
-        ns = [int(rng.integers(p + 1, 12)) for _ in range(3)]
+        ns = [int(rng.integers(p + 1, 12 if rng.random() < 0.8 else 26)) for _ in range(3)]
         mult = rng.random() < 0.2
         kvs = tuple(iga.bspline.make_knots(p, 0.0, 1.0, n, mult=2 if (mult and k == 1 and p > 1) else 1) for k, n in enumerate(ns))
-        geo = geos[int(rng.integers(0, 4))]()
+        geo = geos[int(rng.integers(0, len(geos)))]()
         c = [float(x) for x in (1.0 + rng.random(), *(0.3 * rng.standard_normal(3)))]
         if rng.random() < 0.5:
             coeff, cname = iga.assemblers.AffineCoefficient(*c), 'affine'

@@ -32,7 +32,8 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     g = iga.geometry
     geos3 = [lambda: g.tensor_product(g.line_segment(0.0, 1.0), g.quarter_annulus()), g.twisted_box, lambda: g.unit_cube(3, 2),
-             lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus())]
+             lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus()),
+             lambda: g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0))]     # degree 2 (NURBS) along axis 0
     geos2 = [g.quarter_annulus, g.bspline_quarter_annulus, lambda: g.unit_cube(2, 3)]
     big2d = len(sys.argv) > 3 and sys.argv[3] == 'big2d'
     pmax = int(sys.argv[4]) if len(sys.argv) > 4 else 4
@@ -44,7 +45,7 @@ def main():
         ps = [p0] * d if same else [int(rng.integers(1, pmax + 1)) for _ in range(d)]
         ns = [int(rng.integers(40, 300)) if big2d else int(rng.integers(2, 14 if d == 3 else 40)) for _ in range(d)]
         kvs = tuple(random_kv(rng, p, n) for p, n in zip(ps, ns))
-        geo = (geos3 if d == 3 else geos2)[int(rng.integers(0, 4 if d == 3 else 3))]()
+        geo = (geos3 if d == 3 else geos2)[int(rng.integers(0, len(geos3) if d == 3 else 3))]()
         kind = 'stiffness' if rng.random() < 0.7 else 'mass'
         patch = iga.assemblers.DevicePatch(kvs, geo)
         A = patch.csr(kind, algo='sumfact')
