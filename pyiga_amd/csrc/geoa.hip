@@ -29,6 +29,9 @@ constexpr int GA_MAXS = 8;
 #ifndef GA_ONEDIV
 #define GA_ONEDIV 1           // stiffness fields from the unscaled quotient-rule matrix: one division per point
 #endif
+#ifndef GA_SPREAD
+#define GA_SPREAD 0           // 1: the K1 stores of a span end go out one per plane of the next span (vector form; measured below)
+#endif
 #ifndef GA_READBOTH
 #define GA_READBOTH 1         // both basis rows of a plane are read from LDS even when they are the same row (no register copies)
 #endif
@@ -658,6 +661,13 @@ k_geoA(const GeoAArgs A)
     for (int a = 0; a < P; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+#if GA_SPREAD
+    double park[P];
+    int pslot[P];
+    bool have = false;
+#pragma unroll
+    for (int a = 0; a < P; ++a) { park[a] = 0.0; pslot[a] = -1; }
+#endif
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int tu = t & 1, tv = t >> 1;
     auto basis_row = [&](double (&v)[PV], const int buf, const int j, const int d) {
@@ -726,12 +736,24 @@ k_geoA(const GeoAArgs A)
                 for (int k = 0; k < PV; ++k) vb[k] = va[k];
             }
             bv = bvn;
+#if GA_SPREAD
+            // the completed pairs of the LAST span go out one per plane of this one (q >= P planes: all are out before the
+            // next span end parks new ones): the store path sees a steady trickle instead of a burst of P stores per wave
+            if (have) {
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+                    if (l == a && pslot[a] >= 0) k1s.store(out, pslot[a], A.stride, park[a]);
+            }
+#endif
             GA_T(1);                                      // sweep arithmetic (+ parked stores)
             if (++l < q) continue;
             // dofs that leave the active set after span sp: their pairs are complete
             const bool write = sp >= own_lo && !GA_OFF(2);
             const int *fr = (const int *)&rec[rs][j][20];
             const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
+#if GA_SPREAD
+            have = false;
+#endif
             for (int st = st0; st < st0 + nst; ++st) {
                 int pr[P];
                 if (st == st0) {
@@ -742,6 +764,13 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
                     for (int a = 0; a < P; ++a) pr[a] = rec[a];
                 }
+#if GA_SPREAD
+                if (nst == 1 && gb + j + 1 < g_end) {      // (one dof leaves and the sweep goes on: park; else store at once)
+#pragma unroll
+                    for (int a = 0; a < P; ++a) { park[a] = acc[a][0]; pslot[a] = write ? pr[a] : -1; }
+                    have = true;
+                } else
+#endif
 #pragma unroll
                 for (int a = 0; a < P; ++a)
                     if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);

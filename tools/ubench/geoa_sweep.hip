@@ -98,6 +98,63 @@ k_sweep(double *out, long long stride, long long xstride, int nspans, const doub
             for (int b = 0; b < 5; ++b) acc[4][b] = 0.0;
         }
         if (acc[0][0] == 1.234e300) out[0] = acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4] + acc[3][1];
+    } else if (MODE == 3) {
+        double acc[5][5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[a][b] = 0.0;
+        double *o = out + (long long)w * xstride + pt + lane;
+        int pl = 0, cnt = 0;
+        auto row = [&](double (&v)[6], const int p_, const int d) {
+            const d2 *r = (const d2 *)&rec[p_][6 * d];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const d2 x = r[k]; v[2 * k] = x.x; v[2 * k + 1] = x.y; }
+            v[4] = rec[p_][6 * d + 4];
+        };
+        double bv = fld[fi * 64 + lane], va[6], vb[6];
+        double park[5] = {0, 0, 0, 0, 0};
+        long long poff[5] = {0, 0, 0, 0, 0};
+        bool have = false;
+        row(va, 0, tv); row(vb, 0, tu);
+        for (int s = 0; s < nspans; ++s) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pn = pl + 1 == NPL ? 0 : pl + 1;
+                const double bvn = fld[pn * PST + fi * 64 + lane];
+                double c[5];
+#pragma unroll
+                for (int a = 0; a < 5; ++a) c[a] = va[a] * bv;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) asm volatile("" : "+v"(c[a]));
+                asm volatile("" ::: "memory");
+                row(va, pn, tv);
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) acc[a][b] = fma(vb[b], c[a], acc[a][b]);
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[a][b]));
+                asm volatile("" ::: "memory");
+                row(vb, pn, tu);
+                if (have && !NOST) o[poff[j]] = park[j];      // the completed pair j of the LAST span goes out with plane j of this one
+                bv = bvn;
+                pl = pn;
+                if (++cnt == 8) { cnt = 0; geo(); __syncthreads(); }
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) { park[a] = acc[a][0]; poff[a] = (long long)(5 * (s + a) + 4 - a) * stride; }
+            have = true;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) acc[4][b] = 0.0;
+        }
+        if (acc[0][0] == 1.234e300) out[0] = acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4] + acc[3][1];
     } else if (MODE == 1) {
         double4_t acc[4];
 #pragma unroll
@@ -253,8 +310,8 @@ int main()
     for (int i = 0; i < 4096; ++i) h[i] = 0.5 + rand() / (double)RAND_MAX * 1e-3;
     hipMemcpy(init, h, sizeof h, hipMemcpyHostToDevice);
     printf("C4-shaped sweep: %d blocks x 8 waves x 64 points, %d spans of 5 planes, K1 %.1f GB\n", blocks, nspans, blocks * 64.0 * 8 * 5 * nspans * 8 / 1e9);
-#define ROW(G) printf("geometry stand-in %3d FMAs / 8 planes:  VALU %.2f  MFMA(first form) %.2f  MFMA(lean) %.2f ms   | without the K1 stores: %.2f  %.2f  %.2f ms\n", G, \
-        run<0, G>(out, stride, xstride, nspans, init, blocks), run<1, G>(out, stride, xstride, nspans, init, blocks), run<2, G>(out, stride, xstride, nspans, init, blocks), \
+#define ROW(G) printf("geometry stand-in %3d FMAs / 8 planes:  VALU %.2f  VALU, stores spread over the next span %.2f  MFMA(first form) %.2f  MFMA(lean) %.2f ms   | without the K1 stores: %.2f  %.2f  %.2f ms\n", G, \
+        run<0, G>(out, stride, xstride, nspans, init, blocks), run<3, G>(out, stride, xstride, nspans, init, blocks), run<1, G>(out, stride, xstride, nspans, init, blocks), run<2, G>(out, stride, xstride, nspans, init, blocks), \
         run<0, G, 1>(out, stride, xstride, nspans, init, blocks), run<1, G, 1>(out, stride, xstride, nspans, init, blocks), run<2, G, 1>(out, stride, xstride, nspans, init, blocks))
     ROW(0); ROW(128); ROW(256);
     return 0;
