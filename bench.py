@@ -317,9 +317,10 @@ def main():
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api-call', action='store_true', help='skip the end-to-end assemble.stiffness() call (host copy of the matrix)')
-    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries', 'fast'],
+    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries', 'fast', 'structured'],
                     help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs; '
-                         'fast: the low-rank (ACA) assembler against the exact assembly (use --config c2 / c3: the reordered tensor lives on the host)')
+                         'fast: the low-rank (ACA) assembler against the exact assembly (use --config c2 / c3: the reordered tensor lives on the host); '
+                         'structured: the opt-in Kronecker expansion for geometries that are separable along axis 0 (the cylinder of the 3D configs)')
     ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
     ap.add_argument('--strong', action='store_true', help='(default) strong scaling: the patch is fixed, its rows are split')
     ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank run on this one GPU (no collectives)')
@@ -420,6 +421,8 @@ def main():
         return bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank)
     if args.op == 'fast':
         return bench_fast(args, patch, kvs, dim, p, kind, n0, n, nel_total)
+    if args.op == 'structured':
+        return bench_structured(args, patch, kvs, geo, dim, p, kind, nel_total, assemblers)
     # cold assembly: the first one of the patch allocates the workspaces (K1, CSR values) and builds the per-plane table
     t_cold = time.perf_counter()
     patch.assemble(kind, algo=args.algo, to_host=False)
@@ -641,6 +644,46 @@ def bench_entries(args, patch, kvs, dim, p, kind, n0, n, rank):
                         'between pairs beyond L2 / Infinity Cache); %.3g points in this request' % (nfld, float(pts.sum())),
                         'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': measured_traffic(args.config, 1, 'entries'),
                         'fp64': {'flops_per_point': flop_pt, 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_PEAK_TFLOPS}}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_structured(args, patch, kvs, geo, dim, p, kind, nel_total, assemblers):
+    """Opt-in structured path: for a geometry that is separable along axis 0 the matrix is
+    M0 (x) K2D + K0 (x) M2D; the 2D matrices of the cross-section are assembled by the regular 2D path and expanded into the CSR
+    values by one store-bound kernel.  NOT the headline: the general quadrature chain is (it serves every geometry)."""
+    from pyiga_amd import assemble
+    assert dim == 3 and kind in ('mass', 'stiffness'), 'the structured path knows the 3D mass and stiffness forms'
+    t0 = time.perf_counter()
+    terms = assemble.separable_terms(kvs, geo, patch)
+    if terms is None:
+        raise SystemExit('bench.py --op structured: the geometry of this config is not separable along axis 0')
+    geo2, m0, k0 = terms
+    p2 = assemblers.DevicePatch(kvs[1:], geo2, nqp=patch.nqp)
+    setup_s = time.perf_counter() - t0
+    for _ in range(max(1, args.warmup)):
+        patch.assemble_kron(kind, p2, m0, k0, to_host=False)
+    dev, t0 = [], time.perf_counter()
+    for _ in range(args.steps):
+        patch.assemble_kron(kind, p2, m0, k0, to_host=False)
+        dev.append(patch.timing()['total_ms'])
+    wall_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    dev_ms = float(np.median(dev))
+    nnz = patch.nnz
+    gbs = 8.0 * nnz / (dev_ms * 1e-3) / 1e9
+    b_el = algorithmic_bytes_per_element(dim, p, nnz, nel_total, kind)
+    out = {'metric': 'assembled elements/sec, separable geometry (Kronecker expansion, opt-in)', 'value': nel_total / (wall_ms * 1e-3), 'unit': 'elements/s',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall_ms, 'higher_is_better': True, 'scaling': 'strong',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%dD p=%d %s, %s spans, geometry separable along axis 0' % (dim, p, kind, 'x'.join(str(k.numspans) for k in kvs)),
+                      'config': args.config, 'elements': nel_total, 'nnz': nnz,
+                      'note': 'a step = both 2D assemblies of the cross-section + the expansion (wall clock per call); k_kron3 alone %.3f ms; '
+                              'set-up (separability test on the control net, 1D matrices on the host, 2D patch) %.3f s' % (dev_ms, setup_s)},
+           'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                        'kernel': 'k_kron3 (store stream of the CSR values)', 'kernel_ms': {'k_kron3': round(dev_ms, 4)},
+                        'algorithmic_bytes_per_element': 8.0 * nnz / nel_total,
+                        'note': 'bytes = the CSR values written (this algorithm reads no Jacobians); with the bytes of SURVEY 8d (%.0f B/el) the '
+                                'same time would read as %.2f of the roof' % (b_el, b_el * nel_total / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)}}
+    p2.close()
     print(json.dumps(out), flush=True)
 
 

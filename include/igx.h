@@ -129,6 +129,7 @@ typedef struct {
 #define IGX_PATH_FUSED   2   /* sweep + final stage fused (k_bf): timing.stage1_ms = k_bf */
 #define IGX_PATH_MIRROR  4   /* upper triangle by the transposing mirror pass: timing.final_ms = k_mirror */
 #define IGX_PATH_SINGLE  8   /* 2D mass / stiffness in ONE launch (k_single2d: fields, sweep and contraction in LDS): timing.stage1_ms */
+#define IGX_PATH_KRON   16   /* separable geometry: 2D matrices of the cross-section expanded by k_kron3 (igx_assemble_kron3): timing.final_ms */
 
 int         igx_version(void);
 const char *igx_last_error(void);
@@ -265,6 +266,18 @@ int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *o
 /* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */
 int igx_fields(igx_patch *patch, int kind, double *out, int64_t *shape4);
+
+/* Mass / stiffness matrix of a 3D patch whose geometry is SEPARABLE along axis 0 -- G(xi0, xi1, xi2) = (g(xi1, xi2), z(xi0)),
+   an extruded cross-section -- as the sum of Kronecker products
+       mass:  M0 (x) M2D            stiffness:  M0 (x) K2D + K0 (x) M2D
+   patch2: the 2D patch of the cross-section (axes 1, 2 of patch3: same knot vectors and the SAME number of Gauss points
+   per span; the map g); m0, k0 (host, [ndofs0][2 p0 + 1], row i0, column jlo(i0) + k, zeros where no column): the 1D matrices
+   int phi_i phi_j |z'| and int phi_i' phi_j' / |z'| on the Gauss rule of axis 0 of patch3 (k0 unused for the mass form).
+   The library assembles the 2D matrices on patch2 and expands them into the canonical CSR values of the owned rows of
+   patch3 (device-resident like igx_assemble; data_out as there, may be NULL).  The caller establishes separability (the
+   Python front-end inspects the control net: geometry.split_axis0).  What the reference does for geo = None with 1D
+   matrices (pyiga/assemble.py:125-190,236-282), extended to separable geometry maps. */
+int igx_assemble_kron3(igx_patch *patch3, igx_patch *patch2, int kind, const double *m0, const double *k0, double *data_out);
 
 /* Opt-in buffer placement (environment IGX_PLACEMENT_TRIES=n at igx_patch_create, 3D symmetric forms): the first
    igx_assemble allocates up to n candidate buffers for the CSR values, times the mirror pass of the patch on each and keeps

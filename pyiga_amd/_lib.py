@@ -80,6 +80,7 @@ SYMBOLS = [
     ('igx_entries', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, _dp]),
     ('igx_fields', C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     ('igx_fused_stage_fits', C.c_int, [C.c_int64] * 5),
+    ('igx_assemble_kron3', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]),
     ('igx_patch_set_coeff_expr', C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     ('igx_rtc_compile', C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     ('igx_patch_placement', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -238,6 +238,17 @@ class DevicePatch:
                                             _lib.dptr(out) if to_host else None), 'igx_assemble')
         return out
 
+    def assemble_kron(self, kind, patch2, m0, k0=None, to_host=True):
+        """Mass / stiffness values of this 3D patch from the 2D patch of its cross-section and the weighted 1D matrices of
+        axis 0 (igx_assemble_kron3: separable geometry, see ``geometry.split_axis0`` and ``assemble.separable_terms``)."""
+        out = np.empty(self.nnz) if to_host else None
+        m0 = _lib.f64(m0)
+        k0 = None if k0 is None else _lib.f64(k0)
+        _lib.check(_lib.load().igx_assemble_kron3(self.handle, patch2.handle, _lib.KINDS[kind], _lib.dptr(m0),
+                                                  None if k0 is None else _lib.dptr(k0), _lib.dptr(out) if to_host else None),
+                   'igx_assemble_kron3')
+        return out
+
     def fast_assemble(self, kind, tol=1e-10, maxiter=100, skipcount=3, tolcount=3, verbose=0, batch=None):
         """Low-rank (ACA) assembly (igx_fast_assemble): scipy CSR, plus the number of crosses, of evaluated entries and of
         batched device requests in ``self.aca_stats``.  `batch`: slices (3D) / matrices (2D) of the reordered tensor with at
@@ -258,7 +269,7 @@ class DevicePatch:
     def last_path(self):
         """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'mirror', 'single' (include/igx.h IGX_PATH_*)."""
         bits = _lib.load().igx_patch_last_path(self.handle)
-        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single')) if bits & bit}
+        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single'), (16, 'kron')) if bits & bit}
 
     def placement(self):
         """Outcome of the opt-in buffer placement search (IGX_PLACEMENT_TRIES, include/igx.h igx_patch_placement):

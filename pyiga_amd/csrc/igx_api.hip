@@ -723,6 +723,71 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     return IGX_OK;
 }
 
+int igx_assemble_kron3(igx_patch *p3, igx_patch *p2, int kind, const double *m0, const double *k0, double *data_out)
+{
+    if (!p3 || !p2 || !m0) { set_error("igx_assemble_kron3: null argument"); return IGX_ERR_ARG; }
+    if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_assemble_kron3: mass or stiffness"); return IGX_ERR_ARG; }
+    if (kind == IGX_STIFFNESS && !k0) { set_error("igx_assemble_kron3: the stiffness form needs k0"); return IGX_ERR_ARG; }
+    if (p3->dim != 3 || p2->dim != 2 || p3->boxed || p2->boxed) { set_error("igx_assemble_kron3: a 3D patch and the 2D patch of its cross-section"); return IGX_ERR_ARG; }
+    if (p3->ctx != p2->ctx) { set_error("igx_assemble_kron3: both patches must live in one context"); return IGX_ERR_ARG; }
+    for (int k = 0; k < 2; ++k) {
+        const Axis &a = p3->ax[1 + k], &b = p2->ax[k];
+        if (a.N != b.N || a.P != b.P || a.q != b.q || a.S != b.S || a.kv != b.kv) { set_error("igx_assemble_kron3: axis %d of the cross-section does not match (knots, degree or Gauss points per span)", k); return IGX_ERR_ARG; }
+    }
+    if (p2->r0_lo != 0 || p2->r0_hi != p2->ax[0].N) { set_error("igx_assemble_kron3: the cross-section patch must be whole"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(p3->ctx->device));
+    hipStream_t st = p3->ctx->stream;
+    const int C0 = 2 * p3->ax[0].p + 1, N0 = p3->ax[0].N;
+    for (int i = 0; i < N0; ++i)
+        if (p3->ax[0].jhi[i] - p3->ax[0].jlo[i] > C0) { set_error("igx_assemble_kron3: more than 2 p + 1 columns per row on axis 0"); return IGX_ERR_UNSUPPORTED; }
+    if (!p3->d_data) {
+        const size_t bytes = ((size_t)std::max(p3->nnz, p3->nnz_ext) + IGX_DUMP_PAD) * sizeof(double);
+        if (hipMalloc((void **)&p3->d_data, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %.2f GB for CSR values failed", p3->nnz * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+    }
+    if (p3->knobs.poison) IGX_HIP(hipMemsetAsync(p3->d_data, 0xFF, (size_t)p3->nnz * sizeof(double), st));
+    // 2D matrices of the cross-section: the regular 2D path (mass first: its values move aside, the stiffness values stay in
+    // the patch's own buffer)
+    double *d_M2 = nullptr, *d_band = nullptr;
+    const size_t n2 = (size_t)p2->nnz;
+    int rc = igx_assemble(p2, IGX_MASS, IGX_ALGO_AUTO, nullptr);
+    if (rc) return rc;
+    const double *A2 = p2->d_data, *B2 = nullptr;
+    if (kind == IGX_STIFFNESS) {
+        if (hipMalloc((void **)&d_M2, std::max<size_t>(1, n2) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("igx_assemble_kron3: out of device memory"); return IGX_ERR_NOMEM; }
+        if (hipMemcpyAsync(d_M2, p2->d_data, n2 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(d_M2); set_error("igx_assemble_kron3: copy failed"); return IGX_ERR_HIP; }
+        rc = igx_assemble(p2, IGX_STIFFNESS, IGX_ALGO_AUTO, nullptr);
+        if (rc) { (void)hipFree(d_M2); return rc; }
+        A2 = p2->d_data; B2 = d_M2;                         // K = M0 (x) K2D + K0 (x) M2D
+    }
+    const size_t nb = (size_t)N0 * C0;
+    if (hipMalloc((void **)&d_band, 2 * nb * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_M2); set_error("igx_assemble_kron3: out of device memory"); return IGX_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(d_band, m0, nb * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_band + nb, kind == IGX_STIFFNESS ? k0 : m0, nb * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);       // (m0 / k0 belong to the caller: no copy in flight on return)
+    memset(&p3->timing, 0, sizeof(p3->timing));
+    p3->timing.algo_used = IGX_ALGO_SUMFACT;
+    p3->last_path = 0;
+    hipEvent_t *ev = p3->ctx->ev;
+    if (e == hipSuccess) {
+        (void)hipEventRecord(ev[0], st);
+        rc = launch_kron3(st, p3, d_band, B2 ? d_band + nb : nullptr, C0, A2, B2);
+        (void)hipEventRecord(ev[5], st);
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_band); (void)hipFree(d_M2);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("igx_assemble_kron3: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+    (void)hipEventElapsedTime(&p3->timing.total_ms, ev[0], ev[5]);
+    p3->timing.final_ms = p3->timing.total_ms;
+    p3->timing.n_launches = 1;
+    p3->last_path = IGX_PATH_KRON;
+    if (data_out) {
+        IGX_HIP(hipMemcpyAsync(data_out, p3->d_data, (size_t)p3->nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+        IGX_HIP(hipStreamSynchronize(st));
+    }
+    return IGX_OK;
+}
+
 int igx_patch_placement(const igx_patch *pt, int *tried, float *best_ms, float *worst_ms)
 {
     if (!pt) { set_error("igx_patch_placement: null patch"); return IGX_ERR_ARG; }

@@ -224,6 +224,8 @@ int launch_grid_geo(hipStream_t st, int dim, int ncomp_total, bool nurbs, const 
                     const int G[3], const double *d_ctrl, double *d_jac, double *d_eval);
 int launch_fields_dump(hipStream_t st, const igx_patch *pt);
 int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], double *d_coeff);
+// Kronecker expansion of a separable geometry (kron.hip)
+int launch_kron3(hipStream_t st, igx_patch *p3, const double *d_a0, const double *d_b0, int C0, const double *d_A2, const double *d_B2);
 // run-time compiled coefficient expressions (rtc.hip)
 int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *cache_hit);
 int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);

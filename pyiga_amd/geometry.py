@@ -89,6 +89,41 @@ class NurbsFunc(_BaseSplineFunc):
         return NurbsFunc(self.kvs, vals, w)
 
 
+def split_axis0(geo, tol=8.0):
+    """Is the 3D spline map `geo` SEPARABLE along its first parametric axis -- G(xi0, xi1, xi2) = (g(xi1, xi2), z(xi0)) in
+    some order of the components, an extruded cross-section such as ``tensor_product(line_segment(..), quarter_annulus())``?
+    Decided on the control net alone (up to `tol` units in the last place, what forming the products of a tensor-product net
+    costs).  Returns ``(zc, geo2d)`` -- the control values of the polynomial z on ``geo.kvs[0]`` and the 2D map of the
+    cross-section -- or None.  (A rational z, i.e. weights that vary along axis 0, is not recognised.)"""
+    if not isinstance(geo, (BSplineFunc, NurbsFunc)) or geo.sdim != 3 or geo.dim != 3:
+        return None
+    C = np.asarray(geo.coeffs, dtype=float)
+    nurbs = isinstance(geo, NurbsFunc)
+    eps = tol * np.finfo(float).eps
+    same = lambda a, b: np.abs(a - b).max() <= eps * max(np.abs(a).max(), np.abs(b).max(), 1e-300)
+    W = C[..., 3] if nurbs else None
+    if nurbs and not all(same(W[a], W[0]) for a in range(1, W.shape[0])):
+        return None                                         # weights vary along axis 0
+    for cz in range(3):
+        xy = [c for c in range(3) if c != cz]
+        if not all(same(C[a][..., xy], C[0][..., xy]) for a in range(1, C.shape[0])):
+            continue                                        # the other two components must not depend on axis 0
+        Z = C[..., cz]
+        ref = W[0] if nurbs else np.ones_like(Z[0])         # homogeneous: Z = z(a0) * w(a1, a2)
+        k = np.unravel_index(np.argmax(np.abs(ref)), ref.shape)
+        zc = Z[(slice(None),) + k] / ref[k]
+        if not same(Z, zc[:, None, None] * ref[None]):
+            continue
+        if np.ptp(zc) == 0.0:
+            return None                                     # degenerate: no extent along axis 0
+        if nurbs:
+            g2 = NurbsFunc(geo.kvs[1:], np.concatenate((C[0][..., xy], W[0][..., None]), axis=-1).copy(), None, premultiplied=True)
+        else:
+            g2 = BSplineFunc(geo.kvs[1:], C[0][..., xy].copy())
+        return np.array(zc, dtype=float), g2
+    return None
+
+
 # ---------------------------------------------------------------------------------------------
 # 2D geometries
 def unit_square(num_intervals=1):

@@ -204,3 +204,25 @@ def test_rtc_compile_and_cache(lib, tmp_path, monkeypatch):
     for bad in ('__import__("os")', 'x if y else z', 'open("f")', 'x.real', 'lambda: 1', 'q + 1'):
         with pytest.raises((ValueError, SyntaxError)):
             ExprCoefficient(bad)
+
+
+def test_separable_geometry_detection():
+    """geometry.split_axis0 (host only): which control nets are an extruded cross-section along axis 0."""
+    from pyiga_amd import geometry as g, bspline
+    cyl = g.tensor_product(g.line_segment(0.0, 1.0), g.quarter_annulus())
+    zc, g2 = g.split_axis0(cyl)
+    assert np.array_equal(zc, [0.0, 1.0]) and isinstance(g2, g.NurbsFunc) and g2.sdim == 2 and g2.dim == 2
+    assert np.array_equal(g2.coeffs, g.quarter_annulus().coeffs)
+    zc, g2 = g.split_axis0(g.tensor_product(g.line_segment(0.5, 2.0, intervals=3), g.bspline_quarter_annulus()))
+    assert np.allclose(zc, [0.5, 1.0, 1.5, 2.0]) and isinstance(g2, bspline.BSplineFunc)
+    assert g.split_axis0(g.unit_cube()) is not None
+    assert g.split_axis0(g.twisted_box()) is None
+    assert g.split_axis0(g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0))) is None     # separable along the LAST axis only
+    assert g.split_axis0(g.quarter_annulus()) is None and g.split_axis0(None) is None
+    # a perturbed net is not separable; weights that vary along axis 0 are not recognised
+    bad = cyl.copy()
+    bad.coeffs[1, 1, 1, 0] += 1e-9
+    assert g.split_axis0(bad) is None
+    rat = cyl.copy()
+    rat.coeffs[1] *= 1.5
+    assert g.split_axis0(rat) is None

@@ -1419,6 +1419,54 @@ def test_coefficient_expression_compiled_at_run_time(iga, tmp_path, monkeypatch)
     patch.close()
 
 
+@pytest.mark.parametrize('ps,ns,gname', [((3, 3, 3), (5, 6, 7), 'cylinder'), ((4, 2, 3), (4, 7, 5), 'seg3_bspline_annulus'),
+                                         ((2, 2, 2), (6, 6, 6), 'unit_cube'), ((1, 3, 2), (5, 4, 6), 'cylinder'),
+                                         ((5, 5, 5), (3, 7, 4), 'cylinder')])
+def test_separable_geometry_kronecker(iga, oracle, ps, ns, gname, monkeypatch):
+    """Round 4 (opt-in, IGX_SEPARABLE=1 / DevicePatch.assemble_kron): a geometry that is separable along axis 0 -- an extruded
+    cross-section, like the cylinder of the BASELINE configs -- gives  M = M0 (x) M2D,  K = M0 (x) K2D + K0 (x) M2D  with weighted
+    1D matrices of axis 0 and the 2D matrices of the cross-section (the reference's Kronecker path, pyiga/assemble.py:125-190,
+    for geo = None, extended to separable maps).  Same pattern, exactly symmetric, equal to the general quadrature chain to
+    rounding and to the CPU oracle; row slabs of the expansion reproduce it bit for bit; other geometries are left alone."""
+    g = iga.geometry
+    geo = {'cylinder': lambda: _geo(iga, 'cylinder'), 'unit_cube': g.unit_cube,
+           'seg3_bspline_annulus': lambda: g.tensor_product(g.line_segment(0.5, 2.0, intervals=3), g.bspline_quarter_annulus())}[gname]()
+    kvs = tuple(iga.bspline.make_knots(p, 0., 1., n) for p, n in zip(ps, ns))
+    assert g.split_axis0(geo) is not None
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    for kind in ('mass', 'stiffness'):
+        B = getattr(iga.assemble, kind)(kvs, geo)                          # general chain
+        monkeypatch.setenv('IGX_SEPARABLE', '1')
+        A = getattr(iga.assemble, kind)(kvs, geo)
+        monkeypatch.delenv('IGX_SEPARABLE')
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and not np.isnan(A.data).any()
+        assert rel_maxdiff(A, B) <= 1e-14 and abs(A - A.T).max() == 0.0
+        if gname == 'cylinder' and max(ps) <= 3:
+            okvs = tuple(oracle.make_knots(p, 0., 1., n) for p, n in zip(ps, ns))
+            assert rel_maxdiff(A, oracle.assemble(kind, okvs, oracle.geo_cylinder(), nthreads=8)) <= RTOL
+        # explicit device API, whole and in slabs
+        p3 = iga.assemblers.DevicePatch(kvs, geo)
+        geo2, m0, k0 = iga.assemble.separable_terms(kvs, geo, p3)
+        p2 = iga.assemblers.DevicePatch(kvs[1:], geo2, nqp=p3.nqp)
+        full = p3.assemble_kron(kind, p2, m0, k0)
+        assert p3.last_path() == {'kron'} and np.array_equal(full, A.data)
+        N0 = kvs[0].numdofs
+        parts = []
+        for lo, hi in ((0, 2), (2, N0 - 1), (N0 - 1, N0)):
+            sl = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+            parts.append(sl.assemble_kron(kind, p2, m0, k0))
+            sl.close()
+        assert np.array_equal(np.concatenate(parts), full)
+        p2.close(); p3.close()
+    # not separable along axis 0: the switch changes nothing
+    for other in (g.twisted_box(), g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0))):
+        assert g.split_axis0(other) is None
+    kv = iga.bspline.make_knots(2, 0., 1., 4)
+    R = iga.assemble.stiffness((kv,) * 3, g.twisted_box())
+    monkeypatch.setenv('IGX_SEPARABLE', '1')
+    assert np.array_equal(iga.assemble.stiffness((kv,) * 3, g.twisted_box()).data, R.data)
+
+
 def test_set_form_device_and_failed_call(iga):
     """igx_patch_set_form_d (coefficients already on the device, resident slab) == the host entry point; a call that fails
     validation leaves the previous form in place."""
