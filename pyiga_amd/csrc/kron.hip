@@ -31,7 +31,7 @@ template <bool TWO>
 __global__ void __launch_bounds__(256) k_kron3(const KronArgs K)
 {
     constexpr int MAXL = 128;                             // (2p+1)^2 <= 121 for p <= 5
-    __shared__ double sa[4][MAXL], sb[4][MAXL];
+    __shared__ double sa[4][MAXL], sb[4][MAXL], s0a[4][16], s0b[4][16];    // 2D row; 1D entries of row i0 (2 p0 + 1 <= 11)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long r2 = (long long)blockIdx.x * 4 + wave;
     const int i0 = K.i0_lo + blockIdx.y;
@@ -46,13 +46,16 @@ __global__ void __launch_bounds__(256) k_kron3(const KronArgs K)
     // (wave-private LDS rows: in-order within the wave)
     const int c0 = K.jhi0[i0] - K.jlo0[i0];
     double *dst = K.out + ((long long)K.rp0[i0] * K.S12 + (long long)c0 * ip2 - K.nnz_off);
-    const double *a0 = K.a0 + (size_t)i0 * K.C0, *b0 = K.b0 + (size_t)i0 * K.C0;
+    if (lane < c0) {
+        s0a[wave][lane] = K.a0[(size_t)i0 * K.C0 + lane];
+        if (TWO) s0b[wave][lane] = K.b0[(size_t)i0 * K.C0 + lane];
+    }
     const int total = c0 * L2;
     int k = 0, e = lane;                                   // flat index f = k L2 + e walks the row 64 entries at a time
     while (e >= L2) { e -= L2; ++k; }
     for (int f = lane; f < total; f += 64) {
-        const double va = a0[k] * sa[wave][e];
-        dst[f] = TWO ? fma(b0[k], sb[wave][e], va) : va;
+        const double va = s0a[wave][k] * sa[wave][e];
+        dst[f] = TWO ? fma(s0b[wave][k], sb[wave][e], va) : va;
         e += 64;
         while (e >= L2) { e -= L2; ++k; }
     }
