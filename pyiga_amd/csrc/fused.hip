@@ -660,9 +660,6 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
             auto unit = [&](auto h_, const int pass) {
                 constexpr int H = decltype(h_)::value;                 // 0: whole pass, 1: rows 0 .. AH-1, 2: rows AH .. p
                 constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P;
-                // (per-lane constants are worked out again where they are used, from an opaque copy of the lane number: held in
-                // registers across the element matrices they would be spilled, and a scratch reload waits for vmcnt(0), i.e. for
-                // this wave's stores)
                 int ln_ = min(lane, PPP * PL - 1);                     // (lanes past the last piece repeat its last item: nobody reads them)
                 asm volatile("" : "+v"(ln_));
                 const int ps = ln_ / PL, x = ln_ - ps * PL;              // piece slot of the pass, span of the piece
@@ -697,14 +694,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                             else out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
                         }
                 }
-                int lw_ = lane;
-                asm volatile("" : "+v"(lw_));
-                const int ps2 = lw_ / PL, x2 = lw_ - ps2 * PL;
-                const int pid2 = pass * PPP + ps2;
-                const int k9w = pid2 / NPC, s1w = (pid2 - k9w * NPC) * RP + x2;
-                const int law = k9w <= p ? k9w : k9w - p;
-                const int row1w = k9w <= p ? dd + law : dd, col1w = k9w <= p ? dd : dd + law;
-                const bool lokw = ps2 < PPP && pid2 < npieces && row1w >= rlo && row1w < rhi && col1w < A.N1;
+                // (the per-lane constants of the pass are kept across the element matrix: since the store duty became an object the
+                // contractors have registers to spare -- 116 of 128 -- and working them out again cost 0.13 ms: r04_a_c4_bf2_keep_consts_ab.txt)
+                const int x2 = x, k9w = k9, s1w = s1;
+                const int law = la, row1w = row1, col1w = col1;
+                const bool lokw = lane < PPP * PL && lok;
                 const int r3 = s1w - p;                                // row of the tile
                 if (lokw && x2 >= p && r3 < nrows) {
                     const int i2 = row_lo + r3;
