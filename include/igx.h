@@ -189,6 +189,24 @@ int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
    variant leaves the previously set form untouched. */
 int igx_patch_set_form_d(igx_patch *patch, const double *const d_coef[16]);
 
+/* Parametric jet form for IGX_FORM -- forms with second derivatives (hess, Dx(.., times=2)) and parametric derivatives
+   (parametric=True) of the reference (pyiga/vform.py:592-625 physical Hessians from parametric ones, :1518-1586 Dx / grad /
+   hess), which its code generator differentiates symbolically (pyiga/vform.py:540-607) and compiles per form:
+
+       a(u, v) = sum_k  integral over the parameter domain of  c_k(xi) * D^(mv_k) v(xi) * D^(mu_k) u(xi)  d xi
+
+   with n <= 16 terms per call.  masks[2k] = mv_k, masks[2k+1] = mu_k: bit a set = on GRID axis a the function enters with
+   slot 1 of that axis' basis table, else with slot 0.  The slots hold the derivative orders set by igx_patch_set_basis_orders
+   ((0, 1) = value / first derivative by default), so one call covers the terms whose derivative orders fit one choice of two
+   orders per axis; the host (pyiga_amd/pforms.py) splits a form into such passes and adds the results.  coef[k]: host array
+   over the FULL Gauss grid, WITHOUT the Gauss weights (the geometry factors -- |det J|, J^-1, the Hessian of the geometry map --
+   are the caller's: they are part of c_k).  Copied; replaces the previous form of the patch (either kind). */
+int igx_patch_set_pform(igx_patch *patch, int n, const int *masks, const double *const *coef);
+/* Derivative orders (0 <= slot0[a] < slot1[a] <= 2, one pair per axis) held by the two slots of the basis tables.  With
+   anything but (0, 1) on every axis the patch assembles a parametric jet form only (every other call fails with
+   IGX_ERR_ARG until the default is restored). */
+int igx_patch_set_basis_orders(igx_patch *patch, const int *slot0, const int *slot1);
+
 /* Gauss grid and weights of axis k (host copies; length ngauss[k]) */
 int igx_patch_gauss(const igx_patch *patch, int axis, double *nodes, double *weights);
 

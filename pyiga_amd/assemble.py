@@ -390,7 +390,12 @@ def instantiate_assembler(problem, kvs, args, bfuns=None, boundary=None):
             if len(kvs) not in (2, 3):
                 raise NotImplementedError('general form strings are supported for 2D and 3D patches')
             cls = assemblers.GeneralFormAssembler2D if len(kvs) == 2 else assemblers.GeneralFormAssembler3D
-            return cls(kvs, args['geo'], problem, inputs=args)
+            try:
+                return cls(kvs, args['geo'], problem, inputs=args)
+            except NotImplementedError:
+                # second derivatives / parametric derivatives: parametric jet form assembled in passes (pyiga_amd.pforms)
+                cls = assemblers.ParametricFormAssembler2D if len(kvs) == 2 else assemblers.ParametricFormAssembler3D
+                return cls(kvs, args['geo'], problem, inputs=args)
         if kind == 'convdiff':
             if 'diff_coeff' not in args:
                 raise ValueError("required input parameter 'diff_coeff' missing")

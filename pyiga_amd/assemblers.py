@@ -355,6 +355,29 @@ class DevicePatch:
             raise ValueError('the form has no non-zero coefficient')
         _lib.check(_lib.load().igx_patch_set_form(self.handle, ptrs), 'igx_patch_set_form')
 
+    def set_basis_orders(self, slot0=None, slot1=None):
+        """Derivative orders held by the two slots of every axis' basis table (default (0, 1): value and first derivative); with
+        other orders the patch assembles parametric jet forms only (igx_patch_set_basis_orders)."""
+        d = self.dim
+        s0 = (C.c_int * 3)(*(tuple(slot0) if slot0 is not None else (0,) * d), *([0] * (3 - d)))
+        s1 = (C.c_int * 3)(*(tuple(slot1) if slot1 is not None else (1,) * d), *([1] * (3 - d)))
+        _lib.check(_lib.load().igx_patch_set_basis_orders(self.handle, s0, s1), 'igx_patch_set_basis_orders')
+
+    def set_pform(self, terms):
+        """Parametric jet form of IGX_FORM: list of (mask_v, mask_u, coefficient array on the full Gauss grid) -- at most 16
+        terms, masks over the grid axes (igx_patch_set_pform)."""
+        G = self.resident_grid()
+        n = len(terms)
+        masks = (C.c_int * (2 * n))()
+        ptrs = (_lib._dp * n)()
+        keep = []
+        for k, (mv, mu, c) in enumerate(terms):
+            masks[2 * k], masks[2 * k + 1] = int(mv), int(mu)
+            arr = _lib.f64(np.broadcast_to(c, G))
+            keep.append(arr)
+            ptrs[k] = _lib.dptr(arr)
+        _lib.check(_lib.load().igx_patch_set_pform(self.handle, n, masks, ptrs), 'igx_patch_set_pform')
+
     def load_vector_jet(self, jet):
         """Load vector of  sum_r F_r D_r v  (jet[0]: coefficient of v, jet[1..d]: of its physical derivatives;
         arrays on the full Gauss grid or None)."""
@@ -618,6 +641,70 @@ class _GeneralFormAssembler(_DeviceAssembler):
                 full[r][s] = table[r][s]
         self.table_mask = [[e is not None for e in row] for row in table]
         self.patch.set_form(full)
+
+
+class _ParametricFormAssembler(_DeviceAssembler):
+    """Scalar bilinear forms with second derivatives and / or parametric derivatives of u and v -- ``hess``, ``Dx(., k, times=2)``,
+    ``div(grad(.))``, ``grad(., parametric=True)`` (pyiga/vform.py:1518-1600; transformation of physical second derivatives:
+    pyiga/vform.py:592-625).  ``pyiga_amd.pforms`` turns the string into a parametric jet form (coefficient arrays on the Gauss
+    grid, the geometry factors worked out on the host); the device assembles it in passes -- the basis tables of a pass hold the
+    two derivative orders per axis its terms need (``pforms.plan_passes``) -- and the passes are added up here."""
+    _symmetric_form = False
+    _kind = 'form'
+
+    def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
+        from . import pforms
+        super().__init__(kvs0, geo, device=device, row0=row0)
+        d = self._dim
+        grid = [self.patch.gauss(k)[0] for k in range(d)]
+        G = tuple(len(g) for g in grid)
+        X = np.asarray(geo.grid_eval(grid))
+        Jac = np.asarray(geo.grid_jacobian(grid))
+        if hasattr(geo, 'parametric_derivatives'):
+            H2 = geo.parametric_derivatives(grid)[2]
+        else:
+            from .bspline import _hessian_index_pairs
+            Hl = np.asarray(geo.grid_hessian(grid))               # shape(grid) x d x num_hess, linearised upper triangle
+            H2 = np.empty(G + (d, d, d))
+            for n, (i, j) in enumerate(_hessian_index_pairs(d)):
+                H2[..., i, j] = H2[..., j, i] = Hl[..., n]
+        self.terms = pforms.evaluate(form, G, X, Jac, H2, dict(inputs or {}))
+        self.passes = pforms.plan_passes(self.terms, d)
+
+    def _run(self, call):
+        """Sum of call() over the passes, the basis tables set for each; the default tables are restored afterwards."""
+        total = None
+        try:
+            for slot0, slot1, terms in self.passes:
+                self.patch.set_basis_orders(slot0, slot1)
+                self.patch.set_pform(terms)
+                r = call()
+                total = r if total is None else total + r
+        finally:
+            self.patch.set_basis_orders()
+        return total
+
+    def multi_entries(self, indices):
+        idx = (np.asarray(indices, order='C', dtype=np.uintp) if isinstance(indices, np.ndarray)
+               else np.array(list(indices), dtype=np.uintp)).reshape(-1, 2)
+        return self._run(lambda: self.patch.entries('form', idx))
+
+    def entry(self, i, j):
+        return float(self.multi_entries(np.array([[i, j]], dtype=np.uintp))[0])
+
+    def assemble_csr(self, algo='auto'):
+        data = self._run(lambda: self.patch.assemble('form', algo=algo))
+        indptr, indices = self.patch.pattern()
+        nrows = self.patch.row_range[1] - self.patch.row_range[0]
+        return scipy.sparse.csr_matrix((data, indices, indptr), shape=(nrows, self.patch.shape[1]))
+
+
+class ParametricFormAssembler2D(_ParametricFormAssembler):
+    _dim = 2
+
+
+class ParametricFormAssembler3D(_ParametricFormAssembler):
+    _dim = 3
 
 
 class GeneralFormAssembler2D(_GeneralFormAssembler):

@@ -181,6 +181,51 @@ def collocation(kv, nodes):
     return scipy.sparse.csr_matrix((values[0].ravel(), indices, indptr), shape=(m, kv.numdofs))
 
 
+def _derivative_matrices(kv, nodes, maxorder):
+    """Dense ``len(nodes) x numdofs`` matrices of the basis and its derivatives up to `maxorder` at `nodes`."""
+    nodes = _lib.f64(nodes)
+    first, vals = collocation_derivs_info(kv, nodes, derivs=maxorder)      # (maxorder+1) x len(nodes) x (p+1)
+    cols = first[:, None] + np.arange(kv.p + 1)[None, :]
+    rows = np.broadcast_to(np.arange(nodes.shape[0])[:, None], cols.shape)
+    mats = np.zeros((maxorder + 1, nodes.shape[0], kv.numdofs))
+    for r in range(maxorder + 1):
+        mats[r][rows, cols] = vals[r]
+    return mats
+
+
+def tensor_partials(kvs, coeffs, gridaxes, maxorder=2):
+    """All partial derivatives up to total order `maxorder` of a tensor-product spline on a tensor grid:
+    dict ``orders -> array``, `orders` a tuple with one derivative order per GRID axis (the order of `kvs`), arrays of shape
+    ``shape(grid) + coeffs.shape[sdim:]``.  The 1D derivative values come from the device (``active_deriv``), the
+    contractions over the axes run in numpy: a set-up helper for the geometry Hessians of forms with second derivatives
+    (pyiga/bspline.py:923-975 ``grid_hessian``), sized for the patches those forms are assembled on."""
+    import itertools
+    sdim = len(kvs)
+    mats = [_derivative_matrices(kv, ax, maxorder) for kv, ax in zip(kvs, gridaxes)]
+    out = {}
+    for orders in itertools.product(range(maxorder + 1), repeat=sdim):
+        if sum(orders) > maxorder:
+            continue
+        vals = np.asarray(coeffs, dtype=float)
+        for a in range(sdim):
+            vals = np.moveaxis(np.tensordot(mats[a][orders[a]], vals, axes=(1, a)), 0, a)
+        out[orders] = vals
+    return out
+
+
+def _hessian_index_pairs(sdim):
+    """(i, j), i <= j, in the order of the linearised Hessians: (xx, xy, yy) resp. (xx, xy, xz, yy, yz, zz)."""
+    return [(i, j) for i in range(sdim) for j in range(i, sdim)]
+
+
+def _orders_of(sdim, *xyz):
+    """Derivative orders per grid axis for derivatives along the coordinates `xyz` (x = LAST grid axis)."""
+    o = [0] * sdim
+    for k in xyz:
+        o[sdim - 1 - k] += 1
+    return tuple(o)
+
+
 # ---------------------------------------------------------------------------------------------
 def _geo_desc(kvs, coeffs, nurbs):
     """Fill the geometry part of an igx_patch_desc; returns (desc, keepalive)."""
@@ -303,6 +348,16 @@ class BSplineFunc(_BaseSplineFunc):
         out = _device_grid_eval(self.kvs, self.coeffs.reshape(self.coeffs.shape[:self.sdim] + (nc,)),
                                 False, nc, gridaxes, want_jac=True)
         return out[..., 0, :] if self.is_scalar() else out
+
+    def grid_hessian(self, gridaxes):
+        """Second derivatives ``shape(grid) x dim x num_hess`` (the `dim` axis is dropped for scalar functions), the
+        symmetric part linearised as (xx, xy, yy) resp. (xx, xy, xz, yy, yz, zz), x = last grid axis
+        (pyiga/bspline.py:923-975)."""
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        nc = self._ncomp()
+        part = tensor_partials(self.kvs, self.coeffs.reshape(self.coeffs.shape[:self.sdim] + (nc,)), gridaxes, 2)
+        H = np.stack([part[_orders_of(self.sdim, i, j)] for i, j in _hessian_index_pairs(self.sdim)], axis=-1)
+        return H[..., 0, :] if self.is_scalar() else H
 
     def boundary(self, bdspec):
         """One face of the parameter domain as a spline function with `sdim` reduced by one (pyiga/bspline.py:1014-1036):

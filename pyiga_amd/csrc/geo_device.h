@@ -132,10 +132,15 @@ __device__ inline void fields_convdiff(const double t[9], double GW, const doubl
 // IGX_FORM: parametric jet coefficients  M = W * T P T^t,  T = diag(1, JacInv)  (JacInv[a][r] = d xi_a / d x_r),
 // so that  sum_rs P_rs D_r v D_s u  (physical jets)  =  sum_ab M_ab Dhat_a v Dhat_b u  (parametric jets).
 // Only the terms listed in form_ab are stored (field t <-> form_ab[t] = 4 a + b).
+// form_par: the coefficients are parametric already (igx_patch_set_pform): field k = Gauss weight * coefficient k.
 template <int DIM>
-__device__ inline void fields_form(const double t[9], double GW, const FormView &fv, const int form_n, const int *form_ab,
+__device__ inline void fields_form(const double t[9], double GW, const FormView &fv, const int form_n, const int *form_ab, const int form_par,
                                    double *fields, long long stride, long long pt)
 {
+    if (form_par) {
+        for (int k = 0; k < form_n; ++k) fields[(long long)k * stride + pt] = GW * fv.c[(long long)k * stride + pt];
+        return;
+    }
     constexpr int NJ = DIM + 1;
     double T[4][4];
     for (int r = 0; r < 4; ++r)

@@ -593,8 +593,72 @@ static int set_form_impl(igx_patch *pt, const double *const coef[16], bool on_de
     pt->d_formc = d_new;
     for (int k = 0; k < 16; ++k) { pt->form_slot[k] = slot[k]; pt->dev.form_ab[k] = k < nt ? form_ab[k] : 0; }
     pt->dev.form_n = nt;
+    pt->dev.form_par = 0;
     pt->fields_kind = -1;
     return IGX_OK;
+}
+
+// Parametric jet form (include/igx.h): up to 16 terms  c_k * (slot mv_k of v) * (slot mu_k of u); the coefficients are host
+// arrays over the full Gauss grid.  Committed only when every copy has succeeded.
+int igx_patch_set_pform(igx_patch *pt, int n, const int *masks, const double *const *coef)
+{
+    if (!pt || !masks || !coef) { set_error("igx_patch_set_pform: null argument"); return IGX_ERR_ARG; }
+    if (n < 1 || n > 16) { set_error("igx_patch_set_pform: %d terms (1..16 per call)", n); return IGX_ERR_ARG; }
+    const int full = (1 << pt->dim) - 1;
+    for (int k = 0; k < n; ++k) {
+        if (!coef[k]) { set_error("igx_patch_set_pform: coefficient %d is null", k); return IGX_ERR_ARG; }
+        if ((masks[2 * k] & ~full) || (masks[2 * k + 1] & ~full)) { set_error("igx_patch_set_pform: term %d names an axis the patch does not have", k); return IGX_ERR_ARG; }
+    }
+    if (pt->boxed) { set_error("igx_patch_set_pform: the patch holds a span box"); return IGX_ERR_UNSUPPORTED; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    const size_t npts = (size_t)pt->dev.npts_loc, per_plane = npts / (size_t)pt->dev.G0_loc;
+    double *d_new = nullptr;
+    hipError_t e = hipMalloc((void **)&d_new, std::max<size_t>(1, (size_t)n * npts) * sizeof(double));
+    if (e != hipSuccess) { set_error("hipMalloc of %.2f GB for the form coefficients failed", n * npts * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+    for (int k = 0; k < n && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(d_new + (size_t)k * npts, coef[k] + (size_t)pt->dev.g0_lo * per_plane, npts * sizeof(double), hipMemcpyHostToDevice, pt->ctx->stream);
+    const hipError_t es = hipStreamSynchronize(pt->ctx->stream);
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) { (void)hipFree(d_new); set_error("igx_patch_set_pform: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
+    (void)hipFree(pt->d_formc);
+    pt->d_formc = d_new;
+    for (int k = 0; k < 16; ++k) { pt->form_slot[k] = k < n ? k : -1; pt->dev.form_ab[k] = k < n ? ((masks[2 * k] << 3) | masks[2 * k + 1]) : 0; }
+    pt->dev.form_n = n;
+    pt->dev.form_par = 1;
+    pt->fields_kind = -1;
+    return IGX_OK;
+}
+
+// Derivative orders (0..2) held by the two slots of every axis' basis table; (0, 1) is what every built-in form expects, so
+// anything else is accepted by IGX_FORM with a parametric jet form only (basis_orders_ok).
+int igx_patch_set_basis_orders(igx_patch *pt, const int *slot0, const int *slot1)
+{
+    if (!pt || !slot0 || !slot1) { set_error("igx_patch_set_basis_orders: null argument"); return IGX_ERR_ARG; }
+    for (int k = 0; k < pt->dim; ++k)
+        if (slot0[k] < 0 || slot1[k] > 2 || slot0[k] >= slot1[k]) { set_error("igx_patch_set_basis_orders: axis %d: orders (%d, %d), expected 0 <= first < second <= 2", k, slot0[k], slot1[k]); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    bool def = true;
+    for (int k = 0; k < pt->dim; ++k) {
+        Axis &A = pt->ax[k];
+        if (A.ord[0] != slot0[k] || A.ord[1] != slot1[k]) {
+            int rc;
+            if ((rc = launch_basis_tables(st, A.d_kv, (int)A.kv.size(), A.p, A.d_nodes, (size_t)A.G, slot1[k], nullptr, A.d_V, nullptr, nullptr, slot0[k], slot1[k]))) return rc;
+            if ((rc = launch_pi_tables(st, A.d_V, A.G, A.P, A.d_PI))) return rc;
+            A.ord[0] = slot0[k]; A.ord[1] = slot1[k];
+        }
+        def = def && A.ord[0] == 0 && A.ord[1] == 1;
+    }
+    IGX_HIP(hipStreamSynchronize(st));
+    pt->basis_default = def;
+    return IGX_OK;
+}
+
+static int basis_orders_ok(const igx_patch *pt, int kind, const char *who)
+{
+    if (pt->basis_default || (kind == IGX_FORM && pt->dev.form_par)) return IGX_OK;
+    set_error("%s: the basis tables hold derivative orders other than (0, 1) (igx_patch_set_basis_orders): only a parametric jet form can be assembled", who);
+    return IGX_ERR_ARG;
 }
 
 int igx_patch_set_form(igx_patch *pt, const double *const coef[16]) { return set_form_impl(pt, coef, false, "igx_patch_set_form"); }
@@ -637,6 +701,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (!pt) { set_error("igx_assemble: null patch"); return IGX_ERR_ARG; }
     if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_assemble: unknown kind %d", kind); return IGX_ERR_ARG; }
     if (pt->boxed) { set_error("igx_assemble: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
+    if (int rc = basis_orders_ok(pt, kind, "igx_assemble")) return rc;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     if (algo == IGX_ALGO_AUTO) algo = (pt->sumfact_ok && sumfact_supports_kind(pt, kind)) ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
@@ -728,6 +793,7 @@ int igx_assemble_kron3(igx_patch *p3, igx_patch *p2, int kind, const double *m0,
     if (!p3 || !p2 || !m0) { set_error("igx_assemble_kron3: null argument"); return IGX_ERR_ARG; }
     if (kind != IGX_MASS && kind != IGX_STIFFNESS) { set_error("igx_assemble_kron3: mass or stiffness"); return IGX_ERR_ARG; }
     if (kind == IGX_STIFFNESS && !k0) { set_error("igx_assemble_kron3: the stiffness form needs k0"); return IGX_ERR_ARG; }
+    if (int rcb = basis_orders_ok(p2, kind, "igx_assemble_kron3")) return rcb;
     if (p3->dim != 3 || p2->dim != 2 || p3->boxed || p2->boxed) { set_error("igx_assemble_kron3: a 3D patch and the 2D patch of its cross-section"); return IGX_ERR_ARG; }
     if (p3->ctx != p2->ctx) { set_error("igx_assemble_kron3: both patches must live in one context"); return IGX_ERR_ARG; }
     for (int k = 0; k < 2; ++k) {
@@ -812,6 +878,7 @@ int igx_entries_d(igx_patch *pt, int kind, const size_t *d_ij, size_t M, double 
 {
     if (!pt || (M && (!d_ij || !d_out))) { set_error("igx_entries_d: null argument"); return IGX_ERR_ARG; }
     if (kind < IGX_MASS || kind > IGX_FORM) { set_error("igx_entries_d: unknown kind %d", kind); return IGX_ERR_ARG; }
+    if (int rcb = basis_orders_ok(pt, kind, "igx_entries_d")) return rcb;
     if (M == 0) return IGX_OK;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
@@ -915,6 +982,7 @@ int igx_load_vector_d(igx_patch *pt, const double *d_fvals, double *d_out)
 {
     if (!pt || !d_fvals || !d_out) { set_error("igx_load_vector_d: null argument"); return IGX_ERR_ARG; }
     if (pt->boxed) { set_error("igx_load_vector_d: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
+    if (int rcb = basis_orders_ok(pt, IGX_MASS, "igx_load_vector_d")) return rcb;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab
@@ -1003,6 +1071,7 @@ int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
 {
     if (!pt || !coef || !out) { set_error("igx_load_vector_jet: null argument"); return IGX_ERR_ARG; }
     if (pt->boxed) { set_error("igx_load_vector_jet: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
+    if (int rcb = basis_orders_ok(pt, IGX_MASS, "igx_load_vector_jet")) return rcb;
     const int dim = pt->dim;
     for (int r = dim + 1; r < 4; ++r)
         if (coef[r]) { set_error("igx_load_vector_jet: coefficient %d does not exist in %dD", r, dim); return IGX_ERR_ARG; }

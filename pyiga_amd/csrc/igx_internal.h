@@ -51,8 +51,12 @@ struct PatchDev {
     long long nnz_off;        // global indptr[row_lo]
     // IGX_FORM: the terms that are present, in field order; ab = 4 * (jet index of v) + (jet index of u),
     // jet index 0 = value, 1..3 = PARAMETRIC derivative in (x, y, z) order (x = last grid axis)
+    // form_par (igx_patch_set_pform): the fields ARE the parametric coefficients (times the Gauss weight); term k differentiates
+    // v on the grid axes of mask form_ab[k] >> 3 and u on those of mask form_ab[k] & 7 ("differentiates" = takes slot 1 of the
+    // axis' basis table, whose two slots hold the derivative orders chosen with igx_patch_set_basis_orders)
     int form_n;
     int form_ab[16];
+    int form_par;
 };
 
 // index of Gauss point (g0, g1, g2) in the resident field arrays
@@ -86,6 +90,7 @@ struct Axis {
     // device
     double *d_kv = nullptr, *d_nodes = nullptr, *d_w = nullptr, *d_V = nullptr, *d_PI = nullptr;
     int *d_ints = nullptr;                    // one allocation: fa | mslo | mshi | jlo | jhi | rp | pair_i | pair_j
+    int ord[2] = {0, 1};                      // derivative orders in the two slots of V (and PI)
     AxisDev dev{};
 };
 
@@ -132,6 +137,7 @@ static inline void stage_event(const igx_patch *pt, int k, hipStream_t st);
 struct igx_patch {
     igx_ctx *ctx = nullptr;
     igx_knobs knobs;
+    bool basis_default = true;                // every axis' table holds (value, first derivative) (igx_patch_set_basis_orders)
     bool boxed = false;                       // fields only on a span box (igx_patch_desc.box_*): batched entries only
     int dim = 0, nqp = 0;
     igx::Axis ax[3];
@@ -213,7 +219,7 @@ namespace igx {
 int launch_basis_tables(hipStream_t st, const double *d_kv, int nk, int p, const double *d_u, size_t nu,
                         int numderiv, double *d_out_nd_p_n /* (nd+1,P,nu) or null */,
                         double *d_V /* [nu][P][2] or null */, int *d_fa /* [nu] or null */,
-                        long long *d_spans /* or null */);
+                        long long *d_spans /* or null */, int o0 = 0, int o1 = 1 /* derivative orders of the two V slots */);
 int launch_pi_tables(hipStream_t st, const double *d_V, int G, int P, double *d_PI);
 int launch_geo_fields(hipStream_t st, const igx_patch *pt, int kind, double *d_fields);
 // 2D mass / stiffness in one launch, no intermediates (kern_basis.hip)

@@ -75,8 +75,10 @@ __device__ inline int dev_active_deriv(const double *kv, int nk, int p, double u
     return span;
 }
 
+// V slots: (value, first derivative) unless the patch assembles a parametric jet form of higher order
+// (igx_patch_set_basis_orders): then slot s holds the derivative of order os.
 __global__ void k_basis_tables(const double *kv, int nk, int p, const double *u, size_t nu, int nd,
-                               double *out, double *V, int *fa, long long *spans)
+                               double *out, double *V, int *fa, long long *spans, int o0, int o1)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nu) return;
@@ -84,21 +86,22 @@ __global__ void k_basis_tables(const double *kv, int nk, int p, const double *u,
     double *o = out, *v = V;
     int span = dev_active_deriv(kv, nk, p, u[i], nd, [=](int k, int r, double val) {
         if (o) o[((size_t)k * P + r) * nu + i] = val;
-        if (v && k < 2) v[(i * P + r) * 2 + k] = val;
+        if (v && k == o0) v[(i * P + r) * 2] = val;
+        if (v && k == o1) v[(i * P + r) * 2 + 1] = val;
     });
-    if (v && nd < 1)
+    if (v && nd < o1)
         for (int r = 0; r < P; ++r) v[(i * P + r) * 2 + 1] = 0.0;
     if (fa) fa[i] = span - p;
     if (spans) spans[i] = span;
 }
 
 int launch_basis_tables(hipStream_t st, const double *d_kv, int nk, int p, const double *d_u, size_t nu,
-                        int numderiv, double *d_out, double *d_V, int *d_fa, long long *d_spans)
+                        int numderiv, double *d_out, double *d_V, int *d_fa, long long *d_spans, int o0, int o1)
 {
     if (nu == 0) return IGX_OK;
     const int bs = 64;
     k_basis_tables<<<dim3((unsigned)((nu + bs - 1) / bs)), dim3(bs), 0, st>>>(d_kv, nk, p, d_u, nu, numderiv,
-                                                                              d_out, d_V, d_fa, d_spans);
+                                                                              d_out, d_V, d_fa, d_spans, o0, o1);
     IGX_HIP(hipGetLastError());
     return IGX_OK;
 }
@@ -302,7 +305,7 @@ __global__ void k_geo_fields(GeoView gv, int geo_kind, const double *jac_in, con
     double GW = w0[g[0]] * w1[g[1]];
     if (DIM == 3) GW = GW * w2[g[2]];
     // FORM is a separate instantiation: its 4x4 products would cost the other kinds a third of their occupancy
-    if (FORM) fields_form<DIM>(t, GW, fv, pd.form_n, pd.form_ab, fields, total, idx);
+    if (FORM) fields_form<DIM>(t, GW, fv, pd.form_n, pd.form_ab, pd.form_par, fields, total, idx);
     else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(t, GW, ev, coeff[idx], fields, total, idx);
     else fields_from_jac<DIM>(t, GW, kind, fields, total, idx);
 }
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(256) k_geo_fields_lines(GeoView gv, bool nurbs
         else { g0 = g0_lo + (int)line; g1 = gL; }
         double GW = w0[g0] * w1[g1];
         if (DIM == 3) GW = GW * w2[gL];
-        if (FORM) fields_form<DIM>(tt, GW, fv, pd.form_n, pd.form_ab, fields, total, line * LN + gL);
+        if (FORM) fields_form<DIM>(tt, GW, fv, pd.form_n, pd.form_ab, pd.form_par, fields, total, line * LN + gL);
         else if (DIM == 3 && kind == IGX_CONVDIFF) fields_convdiff(tt, GW, ev, coeff[line * LN + gL], fields, total, line * LN + gL);
         else fields_from_jac<DIM>(tt, GW, kind, fields, total, line * LN + gL);
     }

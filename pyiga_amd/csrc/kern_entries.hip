@@ -74,8 +74,13 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                     for (int t = 0; t < pd.form_n; ++t) {
                         const int ab = pd.form_ab[t];
                         double dv = Dv[0], du = Du[0];
+                        if (pd.form_par) {           // masks over the grid axes: slot 1 of the table on the axes of the mask
+                            dv = v0[(ab >> 3) & 1] * v1[(ab >> 4) & 1];
+                            du = u0[ab & 1] * u1[(ab >> 1) & 1];
+                        } else {
 #pragma unroll
-                        for (int c = 1; c < 3; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                            for (int c = 1; c < 3; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                        }
                         e += (fields[t * stride + pt] * du) * dv;
                     }
                     r += e;
@@ -101,8 +106,13 @@ __device__ inline double entry_value(const PatchDev &pd, const double *fields, c
                         for (int t = 0; t < pd.form_n; ++t) {
                             const int ab = pd.form_ab[t];
                             double dv = Dv[0], du = Du[0];
+                            if (pd.form_par) {
+                                dv = v0[(ab >> 3) & 1] * v1[(ab >> 4) & 1] * v2[(ab >> 5) & 1];
+                                du = u0[ab & 1] * u1[(ab >> 1) & 1] * u2[(ab >> 2) & 1];
+                            } else {
 #pragma unroll
-                            for (int c = 1; c < 4; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                                for (int c = 1; c < 4; ++c) { if ((ab >> 2) == c) dv = Dv[c]; if ((ab & 3) == c) du = Du[c]; }
+                            }
                             e += (fields[t * stride + pt] * du) * dv;
                         }
                         r += e;

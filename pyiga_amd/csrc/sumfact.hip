@@ -49,6 +49,14 @@ static std::vector<Term> form_terms(int dim, int kind, const PatchDev *pd = null
     if (kind == IGX_FORM) {
         // one term per stored field; jet index c >= 1 differentiates grid axis dim - c (x is the LAST axis)
         for (int k = 0; k < pd->form_n; ++k) {
+            if (pd->form_par) {                  // parametric jet form: masks over the grid axes (igx_patch_set_pform)
+                const int mv = pd->form_ab[k] >> 3, mu = pd->form_ab[k] & 7;
+                Term t{};
+                t.f = k;
+                for (int ax = 0; ax < 3; ++ax) t.t[ax] = ax < dim ? ((mu >> ax) & 1) + 2 * ((mv >> ax) & 1) : 0;
+                T.push_back(t);
+                continue;
+            }
             const int a = pd->form_ab[k] >> 2, b = pd->form_ab[k] & 3;     // a: test function v, b: trial function u
             Term t{};
             t.f = k;

@@ -57,8 +57,8 @@ class _Coef:
         return _Coef(self.a[..., k] if self.rank == 1 else self.a[..., k, :], self.rank - 1)
 
     def _bin(self, other, op):
-        if isinstance(other, (_Lin, _Bil, _Dx)):
-            return NotImplemented
+        if isinstance(other, (_Lin, _Bil, _Dx)) or getattr(other, '_is_form_expr', False):
+            return NotImplemented           # (expressions in u, v -- also those of pyiga_amd.pforms -- handle the product)
         o = _Coef.wrap(other, ())
         r = max(self.rank, o.rank)
         if self.rank and o.rank and self.rank != o.rank:
@@ -221,7 +221,14 @@ def make_namespace(G, X, inputs):
     def basis(who):
         return _Lin(who, False, s=one)
 
-    def grad(e):
+    def higher(name):
+        def f(*a, **k):
+            raise NotImplementedError('%s(): second / parametric derivatives are the business of pyiga_amd.pforms' % name)
+        return f
+
+    def grad(e, dims=None, parametric=False):
+        if dims is not None or parametric:
+            raise NotImplementedError('grad(dims=..., parametric=...): see pyiga_amd.pforms')
         if not (isinstance(e, _Lin) and not e.vector and e.w is None):
             raise NotImplementedError('grad() of anything but u or v (times a constant)')
         if e.s.ndim and not np.all(e.s == e.s.flat[0]):
@@ -285,6 +292,7 @@ def make_namespace(G, X, inputs):
         raise NotImplementedError('dot() of these coefficient shapes')
 
     ns = {'u': basis('u'), 'v': basis('v'), 'grad': grad, 'inner': inner, 'dot': dot, 'dx': _Dx(),
+          'hess': higher('hess'), 'Dx': higher('Dx'), 'div': higher('div'), 'tr': higher('tr'),
           'x': _Coef(X, 1),
           'sqrt': lambda c: _Coef(np.sqrt(_Coef.wrap(c, G).a), _Coef.wrap(c, G).rank),
           'exp': lambda c: _Coef(np.exp(_Coef.wrap(c, G).a), _Coef.wrap(c, G).rank),

@@ -70,6 +70,33 @@ class NurbsFunc(_BaseSplineFunc):
         J = _device_grid_eval(self.kvs, self.coeffs, True, self.dim, gridaxes, want_jac=True)
         return np.squeeze(J, -2) if self._isscalar else J
 
+    def parametric_derivatives(self, gridaxes):
+        """(value, first, second) parametric derivatives of the rational function on a tensor grid: arrays of shape
+        ``shape(grid) x dim``, ``... x dim x sdim`` and ``... x dim x sdim x sdim`` (derivative indices in (x, y, z) order, x =
+        last grid axis), by the quotient rule on the homogeneous spline N / w:
+            d_a f = (d_a N - f d_a w) / w,   d_ab f = (d_ab N - d_a f d_b w - d_b f d_a w - f d_ab w) / w."""
+        sd = self.sdim
+        part = bspline.tensor_partials(self.kvs, self.coeffs, gridaxes, 2)
+        o = lambda *xyz: part[bspline._orders_of(sd, *xyz)]
+        N, w = o()[..., :-1], o()[..., -1:]
+        f = N / w
+        d1 = np.stack([(o(a)[..., :-1] - f * o(a)[..., -1:]) / w for a in range(sd)], axis=-1)
+        d2 = np.empty(f.shape + (sd, sd))
+        for a in range(sd):
+            for b in range(a, sd):
+                h = (o(a, b)[..., :-1] - d1[..., a] * o(b)[..., -1:] - d1[..., b] * o(a)[..., -1:] - f * o(a, b)[..., -1:]) / w
+                d2[..., a, b] = h
+                d2[..., b, a] = h
+        return f, d1, d2
+
+    def grid_hessian(self, gridaxes):
+        """Second derivatives, symmetric part linearised as (xx, xy, yy) resp. (xx, xy, xz, yy, yz, zz); shape
+        ``shape(grid) x dim x num_hess``, the `dim` axis dropped for scalar functions (pyiga/geometry.py:125-150)."""
+        assert len(gridaxes) == self.sdim, 'Input has wrong dimension'
+        d2 = self.parametric_derivatives(gridaxes)[2]
+        H = np.stack([d2[..., i, j] for i, j in bspline._hessian_index_pairs(self.sdim)], axis=-1)
+        return np.squeeze(H, -2) if self._isscalar else H
+
     def boundary(self, bdspec):
         """One face of the parameter domain as a NURBS function with `sdim` reduced by one (pyiga/geometry.py:188-210): the
         first / last layer of the homogeneous net along that axis."""

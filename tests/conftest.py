@@ -141,3 +141,37 @@ def form2d_cases():
           [lambda x, y: -b2(x, y)[1], lambda x, y: K2(x, y)[..., 1, 0], lambda x, y: K2(x, y)[..., 1, 1]]]
     return {'reactdiff': ('(inner(grad(u), grad(v)) + c*u*v) * dx', dict(c=cc), t1),
             'full': ('(inner(dot(K, grad(u)), grad(v)) + inner(b, grad(u)) * v - u * inner(b, grad(v)) + 3 * u * v) * dx', dict(K=K2, b=b2), t2)}
+
+
+# forms with second derivatives / parametric derivatives (golden_pforms.npz: the strings make_golden.py gave the reference)
+PFORMS2 = {
+    'biharm': ('inner(hess(u), hess(v)) * dx', ()),
+    'laplap': ('div(grad(u)) * div(grad(v)) * dx', ()),
+    'dxx_dyy': ('Dx(u, 0, times=2) * Dx(v, 1, times=2) * dx', ()),
+    'pgrad': ('inner(grad(u, parametric=True), grad(v, parametric=True)) * dx', ()),
+    'phess': ('inner(hess(u, parametric=True), hess(v, parametric=True)) * dx', ()),
+    'mixed': ('(c * tr(hess(u)) * v + inner(b, grad(u)) * v + 0.5 * inner(hess(u), hess(v)) + u * Dx(v, 0, parametric=True)) * dx', ('c', 'b')),
+    'hxy': ('(hess(u)[0, 1] * v - u * hess(v)[1, 1]) * dx', ()),
+    'khess': ('inner(dot(K, grad(u)), grad(v)) * dx + tr(dot(K, hess(u))) * v * dx', ('K',)),
+}
+PFORMS3 = {
+    'biharm': ('inner(hess(u), hess(v)) * dx', ()),
+    'laplap': ('div(grad(u)) * div(grad(v)) * dx', ()),
+    'dxx_dzz': ('Dx(u, 0, times=2) * Dx(v, 2, times=2) * dx', ()),
+    'phess': ('inner(hess(u, parametric=True), grad(grad(v, parametric=True), parametric=True)) * dx', ()),
+    'mixed': ('(c * tr(hess(u)) * v + inner(b, grad(u)) * v + 0.5 * inner(hess(u), hess(v)) + u * Dx(v, 1, parametric=True)) * dx', ('c', 'b')),
+    'hxz': ('(hess(u)[0, 2] * v - Dx(Dx(u, 1), 2) * Dx(v, 0)) * dx', ()),
+}
+
+
+def pform_inputs2():
+    import numpy as np
+
+    def K2(x, y):
+        one = np.ones_like(x * y)
+        return np.stack([np.stack(((1.5 + y) * one, 0.4 * x * one), -1), np.stack((-0.3 * one, (2.0 + x * y) * one), -1)], -2)
+
+    def b2(x, y):
+        one = np.ones_like(x * y)
+        return (y * one, (1.0 - x) * one)
+    return dict(c=lambda x, y: 1.0 + x * y, b=b2, K=K2)

@@ -243,7 +243,7 @@ def golden_knots():
     save('knots', **out)
 
 
-if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms', 'fullsize', 'ondemand', 'vecforms', 'surface'} & set(sys.argv[1:]):
+if __name__ == '__main__' and not {'convdiff', 'rhs', 'forms', 'fullsize', 'ondemand', 'vecforms', 'surface', 'pforms'} & set(sys.argv[1:]):
     golden_knots()
     golden_bspline()
     golden_sparsity()
@@ -641,3 +641,65 @@ def golden_surface():
 
 if __name__ == '__main__' and 'surface' in sys.argv[1:]:
     golden_surface()
+
+
+# (14) form strings with second derivatives and parametric derivatives (pyiga/vform.py:1518-1600, transformation of physical
+#      Hessians :592-625), and the Hessians of spline / NURBS functions (pyiga/bspline.py:923-975, pyiga/geometry.py:125-150)
+PFORMS2 = {
+    'biharm': ('inner(hess(u), hess(v)) * dx', ()),
+    'laplap': ('div(grad(u)) * div(grad(v)) * dx', ()),
+    'dxx_dyy': ('Dx(u, 0, times=2) * Dx(v, 1, times=2) * dx', ()),
+    'pgrad': ('inner(grad(u, parametric=True), grad(v, parametric=True)) * dx', ()),
+    'phess': ('inner(hess(u, parametric=True), hess(v, parametric=True)) * dx', ()),
+    'mixed': ('(c * tr(hess(u)) * v + inner(b, grad(u)) * v + 0.5 * inner(hess(u), hess(v)) + u * Dx(v, 0, parametric=True)) * dx', ('c', 'b')),
+    'hxy': ('(hess(u)[0, 1] * v - u * hess(v)[1, 1]) * dx', ()),
+    'khess': ('inner(dot(K, grad(u)), grad(v)) * dx + tr(dot(K, hess(u))) * v * dx', ('K',)),
+}
+PFORMS3 = {
+    'biharm': ('inner(hess(u), hess(v)) * dx', ()),
+    'laplap': ('div(grad(u)) * div(grad(v)) * dx', ()),
+    'dxx_dzz': ('Dx(u, 0, times=2) * Dx(v, 2, times=2) * dx', ()),
+    'phess': ('inner(hess(u, parametric=True), grad(grad(v, parametric=True), parametric=True)) * dx', ()),
+    'mixed': ('(c * tr(hess(u)) * v + inner(b, grad(u)) * v + 0.5 * inner(hess(u), hess(v)) + u * Dx(v, 1, parametric=True)) * dx', ('c', 'b')),
+    'hxz': ('(hess(u)[0, 2] * v - Dx(Dx(u, 1), 2) * Dx(v, 0)) * dx', ()),
+}
+
+
+def golden_pforms():
+    out = {}
+    inp = form_inputs()
+    ann, bann, cyl, tbox = geometry.quarter_annulus(), geometry.bspline_quarter_annulus(), cylinder(), geometry.twisted_box()
+
+    def K2(x, y):
+        one = np.ones_like(x * y)
+        return np.stack([np.stack(((1.5 + y) * one, 0.4 * x * one), -1), np.stack((-0.3 * one, (2.0 + x * y) * one), -1)], -2)
+
+    def b2(x, y):
+        one = np.ones_like(x * y)
+        return (y * one, (1.0 - x) * one)
+    in2 = dict(c=lambda x, y: 1.0 + x * y, b=b2, K=K2)
+    spaces2 = {'ann': ((bspline.make_knots(3, 0.0, 1.0, 4), bspline.make_knots(2, 0.0, 1.0, 5, mult=2)), ann),
+               'bann': ((bspline.make_knots(4, 0.0, 1.0, 3), bspline.make_knots(4, 0.0, 1.0, 6)), bann)}
+    for sname, (kvs, geo) in spaces2.items():
+        for fname, (form, names) in PFORMS2.items():
+            put_matrix(out, 'd2_%s_%s' % (sname, fname), assemble.assemble(form, kvs, geo=geo, **{k: in2[k] for k in names}))
+    spaces3 = {'cyl_p2': ((bspline.make_knots(2, 0.0, 1.0, 3),) * 3, cyl),
+               'tbox_mixed': ((bspline.make_knots(3, 0.0, 1.0, 2), bspline.make_knots(2, 0.0, 1.0, 4, mult=2),
+                               bspline.make_knots(2, 0.0, 1.0, 3)), tbox)}
+    for sname, (kvs, geo) in spaces3.items():
+        for fname, (form, names) in PFORMS3.items():
+            put_matrix(out, 'd3_%s_%s' % (sname, fname), assemble.assemble(form, kvs, geo=geo, **{k: inp[k] for k in names}))
+    # Hessians of geometry maps on Gauss-like grids
+    g2 = (np.linspace(0.02, 0.97, 7), np.linspace(0.05, 0.9, 5))
+    g3 = (np.linspace(0.1, 0.9, 3), np.linspace(0.02, 0.97, 4), np.linspace(0.05, 0.9, 5))
+    out['hess_grid2_0'], out['hess_grid2_1'] = g2
+    out['hess_grid3_0'], out['hess_grid3_1'], out['hess_grid3_2'] = g3
+    out['hess_ann'] = ann.grid_hessian(g2)
+    out['hess_bann'] = bann.grid_hessian(g2)
+    out['hess_cyl'] = cyl.grid_hessian(g3)
+    out['hess_tbox'] = tbox.grid_hessian(g3)
+    save('pforms', **out)
+
+
+if __name__ == '__main__' and 'pforms' in sys.argv[1:]:
+    golden_pforms()

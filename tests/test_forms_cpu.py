@@ -153,3 +153,83 @@ def test_tensor_forms_tables():
     for bad in ('inner(grad(u), grad(u)) * dx', 'grad(c * u) * dx', 'u * v', 'inner(u, grad(v)) * dx'):
         with pytest.raises(NotImplementedError):
             tforms.evaluate(bad, G, X, {'c': lambda x, y: x}, bfuns=[('u', 2), ('v', 2)])
+
+
+# ---------------------------------------------------------------------------------------------
+# second derivatives / parametric derivatives (pyiga_amd/pforms.py): host logic only
+def _polar_geometry(G):
+    """x = (1 + s) cos t, y = (1 + s) sin t on a grid: coordinates, Jacobians and Hessians of the map, (x, y) index order."""
+    t, s = np.meshgrid(np.linspace(0.1, 1.2, G[0]), np.linspace(0.0, 1.0, G[1]), indexing='ij')   # grid axes (y-like, x-like)
+    r = 1.0 + s
+    X = np.stack([r * np.cos(t), r * np.sin(t)], -1)
+    Jac = np.empty(G + (2, 2))                       # Jac[i, k] = d x_i / d xi_k, xi = (s, t)
+    Jac[..., 0, 0], Jac[..., 0, 1] = np.cos(t), -r * np.sin(t)
+    Jac[..., 1, 0], Jac[..., 1, 1] = np.sin(t), r * np.cos(t)
+    H2 = np.zeros(G + (2, 2, 2))                     # H2[m, e, u]
+    H2[..., 0, 0, 1] = H2[..., 0, 1, 0] = -np.sin(t)
+    H2[..., 0, 1, 1] = -r * np.cos(t)
+    H2[..., 1, 0, 1] = H2[..., 1, 1, 0] = np.cos(t)
+    H2[..., 1, 1, 1] = -r * np.sin(t)
+    return X, Jac, H2
+
+
+def test_physical_second_derivatives_transform():
+    """The parametric terms of a physical second derivative reproduce the Hessian of f(x, y) = x^2 y + 3 x y^2 from the
+    parametric derivatives of f o F (chain rule forwards, transformation backwards)."""
+    from pyiga_amd import pforms
+    G = (5, 4)
+    X, Jac, H2 = _polar_geometry(G)
+    x, y = X[..., 0], X[..., 1]
+    f1 = np.stack([2 * x * y + 3 * y ** 2, x ** 2 + 6 * x * y], -1)
+    f2 = np.empty(G + (2, 2))
+    f2[..., 0, 0], f2[..., 0, 1], f2[..., 1, 0], f2[..., 1, 1] = 2 * y, 2 * x + 6 * y, 2 * x + 6 * y, 6 * x
+    gp = np.einsum('...i,...ik->...k', f1, Jac)
+    Hp = np.einsum('...ij,...ie,...ju->...eu', f2, Jac, Jac) + np.einsum('...i,...ieu->...eu', f1, H2)
+    geo = pforms._Geo(G, Jac, H2)
+    for (i, j) in ((0, 0), (0, 1), (1, 1)):
+        jet = pforms._Jet('u', {((0, 0), False): 1.0}).derivative(i, 1, False).derivative(j, 1, False)
+        val = 0.0
+        for alpha, c in jet.parametric_terms(geo).items():
+            ks = [k for k in range(2) for _ in range(alpha[k])]
+            val = val + c * (gp[..., ks[0]] if len(ks) == 1 else Hp[..., ks[0], ks[1]])
+        assert np.abs(val - f2[..., i, j]).max() <= 1e-12 * np.abs(f2).max()
+    # first derivatives likewise
+    for i in range(2):
+        jet = pforms._Jet('u', {((0, 0), False): 1.0}).derivative(i, 1, False)
+        val = sum(c * gp[..., [k for k in range(2) if alpha[k]][0]] for alpha, c in jet.parametric_terms(geo).items())
+        assert np.abs(val - f1[..., i]).max() <= 1e-12 * np.abs(f1).max()
+
+
+def test_pform_terms_and_passes():
+    from pyiga_amd import pforms
+    G = (3, 4)
+    X = np.stack(np.meshgrid(np.linspace(0, 1, 3), np.linspace(0, 1, 4), indexing='ij')[::-1], -1)
+    Jac = np.broadcast_to(np.eye(2), G + (2, 2)).copy()
+    H2 = np.zeros(G + (2, 2, 2))
+    # identity geometry: physical = parametric; orders are per GRID axis (x last)
+    t = pforms.evaluate('inner(hess(u), hess(v)) * dx', G, X, Jac, H2, {})
+    assert sorted((ov, ou, float(c.flat[0])) for ov, ou, c in t) == [((0, 2), (0, 2), 1.0), ((1, 1), (1, 1), 2.0), ((2, 0), (2, 0), 1.0)]
+    t = pforms.evaluate('(Dx(u, 0, times=2) * v + 2 * u * Dx(v, 1, parametric=True)) * dx', G, X, 2.0 * Jac, H2, {})
+    got = {(ov, ou): float(c.flat[0]) for ov, ou, c in t}
+    assert got == {((0, 0), (0, 2)): 1.0, ((1, 0), (0, 0)): 8.0}          # |det| = 4, d/dx = (1/2) d/dxi
+    t3 = pforms.evaluate('(c * tr(hess(u)) * v + inner(hess(u), hess(v)) + inner(grad(u), grad(v)) + u * v) * dx', (2, 2, 2),
+                         np.zeros((2, 2, 2, 3)), np.broadcast_to(np.eye(3), (2, 2, 2, 3, 3)).copy(), np.zeros((2, 2, 2, 3, 3, 3)),
+                         dict(c=lambda x, y, z: 2.0 + x))
+    for terms, d in ((t, 2), (t3, 3)):
+        passes = pforms.plan_passes(terms, d)
+        seen = []
+        for slot0, slot1, chunk in passes:
+            assert 1 <= len(chunk) <= pforms.MAX_TERMS_PER_CALL and all(a < b for a, b in zip(slot0, slot1))
+            per_type = {}
+            for mv, mu, c in chunk:
+                ov = tuple((slot1 if (mv >> a) & 1 else slot0)[a] for a in range(d))
+                ou = tuple((slot1 if (mu >> a) & 1 else slot0)[a] for a in range(d))
+                seen.append((ov, ou))
+                ty = ((mu >> (d - 1)) & 1) + 2 * ((mv >> (d - 1)) & 1)
+                per_type[ty] = per_type.get(ty, 0) + 1
+            assert max(per_type.values()) <= pforms.MAX_TERMS_PER_LAST_TYPE
+        assert sorted(seen) == sorted((ov, ou) for ov, ou, _ in terms)      # every term in exactly one pass
+    for bad in ('Dx(u, 0, times=3) * v * dx', 'Dx(c * u, 0) * v * dx', 'Dx(Dx(u, 0, parametric=True), 1) * v * dx',
+                'hess(u) * v * dx', 'hess(u)[0, 0] * hess(u)[1, 1] * dx', 'u * v'):
+        with pytest.raises(NotImplementedError):
+            pforms.evaluate(bad, G, X, Jac, H2, dict(c=lambda x, y: x))
