@@ -189,6 +189,16 @@ int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
    variant leaves the previously set form untouched. */
 int igx_patch_set_form_d(igx_patch *patch, const double *const d_coef[16]);
 
+/* The same table given as C expressions in the physical coordinates x, y, z (and pi; the grammar of
+   igx_patch_set_coeff_expr): expr[4*r + s] or NULL.  ONE kernel that evaluates every present coefficient at the resident
+   Gauss points is generated, compiled for the device with hiprtc and cached on disk under the hash of its source -- the
+   reference compiles a module per form and caches it the same way (pyiga/compile.py:58-73,120-132,
+   pyiga/codegen/cython.py:325-387); nothing is sampled on the host.  Needs a spline geometry.  *cache_hit (may be NULL):
+   1 if the code object came from the cache. */
+int igx_patch_set_form_expr(igx_patch *patch, const char *const expr[16], int *cache_hit);
+/* Host only: compile the kernel of the n expressions for `arch` into the cache (what igx_patch_set_form_expr does first). */
+int igx_rtc_compile_form(int n, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+
 /* Parametric jet form for IGX_FORM -- forms with second derivatives (hess, Dx(.., times=2)) and parametric derivatives
    (parametric=True) of the reference (pyiga/vform.py:592-625 physical Hessians from parametric ones, :1518-1586 Dx / grad /
    hess), which its code generator differentiates symbolically (pyiga/vform.py:540-607) and compiles per form:

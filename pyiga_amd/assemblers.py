@@ -11,6 +11,7 @@ the whole matrix on the device (what ``assemble_entries`` uses) -- the reference
 through ``multi_entries`` with one index pair per nonzero, which at 3D p=4 n=128 would be
 25 GB of index pairs.
 """
+import os
 import ctypes as C
 import weakref
 
@@ -355,6 +356,19 @@ class DevicePatch:
             raise ValueError('the form has no non-zero coefficient')
         _lib.check(_lib.load().igx_patch_set_form(self.handle, ptrs), 'igx_patch_set_form')
 
+    def set_form_expr(self, table):
+        """Coefficient table of IGX_FORM as C expressions in x, y, z (4x4 nested list of strings or None): ONE kernel generated,
+        compiled for the device at run time and cached on disk evaluates them at the Gauss points (igx_patch_set_form_expr).
+        Returns True if the code object came from the cache."""
+        exprs = (C.c_char_p * 16)()
+        for r in range(4):
+            for s in range(4):
+                if table[r][s] is not None:
+                    exprs[4 * r + s] = table[r][s].encode()
+        hit = C.c_int(0)
+        _lib.check(_lib.load().igx_patch_set_form_expr(self.handle, exprs, C.byref(hit)), 'igx_patch_set_form_expr')
+        return bool(hit.value)
+
     def set_basis_orders(self, slot0=None, slot1=None):
         """Derivative orders held by the two slots of every axis' basis table (default (0, 1): value and first derivative); with
         other orders the patch assembles parametric jet forms only (igx_patch_set_basis_orders)."""
@@ -596,6 +610,20 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         if isinstance(diff_coeff, ExprCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None:
             self.coeff_cache_hit = self.patch.set_coeff_expr(diff_coeff.c_source())     # compiled for the device at run time
             return
+        if callable(diff_coeff) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None \
+                and os.environ.get('IGX_FORM_RTC', '1') != '0':
+            # a plain Python callable: traced into a C expression (pyiga_amd.symbolic) and compiled like an ExprCoefficient;
+            # what cannot be traced (comparisons, np.where, ...) is sampled on the host below
+            from . import symbolic
+            try:
+                X = symbolic.coordinates(3)
+                src = symbolic.c_source(np.broadcast_to(np.asarray(diff_coeff(X[..., 0], X[..., 1], X[..., 2]), dtype=object), (1, 1, 1)))
+            except Exception:
+                src = None
+            if src is not None:
+                self.coeff_cache_hit = self.patch.set_coeff_expr(src)
+                self.coeff_traced = True
+                return
         # (any other geometry object: the coefficient is sampled through geo.grid_eval like a plain callable)
         grid = [self.patch.gauss(k)[0] for k in range(3)]
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
@@ -623,6 +651,30 @@ class _GeneralFormAssembler(_DeviceAssembler):
         from . import forms
         super().__init__(kvs0, geo, device=device, row0=row0, bbox=bbox)
         d = self._dim
+        # (1) the coefficients as generated device code: the string and its callable inputs are traced into C expressions in
+        # the physical coordinates, one kernel per form is compiled at run time and cached (the reference: one compiled module
+        # per form, pyiga/compile.py:58-73) -- nothing is sampled on the host.  IGX_FORM_RTC=0 switches it off.
+        self.compiled, self.coeff_cache_hit = False, None
+        if isinstance(form, str) and bbox is None and os.environ.get('IGX_FORM_RTC', '1') != '0' \
+                and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
+            try:
+                traced = forms.symbolic_table(form, d, dict(inputs or {}))
+            except NotImplementedError:
+                raise                                             # the form itself is outside this front-end
+            except Exception:
+                traced = None                                     # an input that cannot be traced: sampled below
+            if traced is not None:
+                full = [[None] * 4 for _ in range(4)]
+                for r in range(d + 1):
+                    for s in range(d + 1):
+                        full[r][s] = traced[r][s]
+                if not any(e is not None for row in full for e in row):
+                    raise ValueError('the form has no non-zero coefficient')
+                self.table_mask = [[e is not None for e in row] for row in traced]
+                self.coeff_cache_hit = self.patch.set_form_expr(full)
+                self.compiled = True
+                return
+        # (2) coefficients sampled on the Gauss grid on the host
         grid = [self.patch.gauss(k)[0] for k in range(d)]
         G = tuple(len(g) for g in grid)
         X = np.asarray(geo.grid_eval(grid))                       # shape(grid) x d, components (x, y[, z])

@@ -663,6 +663,37 @@ static int basis_orders_ok(const igx_patch *pt, int kind, const char *who)
 
 int igx_patch_set_form(igx_patch *pt, const double *const coef[16]) { return set_form_impl(pt, coef, false, "igx_patch_set_form"); }
 
+// The coefficient table of IGX_FORM as C expressions in the physical coordinates: one generated kernel evaluates all of them
+// at the resident Gauss points (rtc.hip), the arrays then take the way of igx_patch_set_form_d.
+int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cache_hit)
+{
+    if (!pt || !expr) { set_error("igx_patch_set_form_expr: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_patch_set_form_expr: the patch holds a span box"); return IGX_ERR_UNSUPPORTED; }
+    const char *list[16];
+    int n = 0;
+    for (int k = 0; k < 16; ++k)
+        if (expr[k]) list[n++] = expr[k];
+    if (n == 0) { set_error("igx_patch_set_form_expr: all coefficients are absent"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    const size_t npts = (size_t)pt->dev.npts_loc;
+    double *buf = nullptr;
+    if (hipMalloc((void **)&buf, std::max<size_t>(1, (size_t)n * npts) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %.2f GB for the form coefficients failed", n * npts * 8.0 / 1e9); return IGX_ERR_NOMEM; }
+    int rc = launch_form_exprs(pt->ctx->stream, pt, n, list, buf, cache_hit);
+    if (!rc) {
+        const double *d_coef[16];
+        int j = 0;
+        for (int k = 0; k < 16; ++k) d_coef[k] = expr[k] ? buf + (size_t)(j++) * npts : nullptr;
+        rc = set_form_impl(pt, d_coef, true, "igx_patch_set_form_expr");
+    }
+    (void)hipFree(buf);
+    return rc;
+}
+
+int igx_rtc_compile_form(int n, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit)
+{
+    return rtc_compile_form(n, expr, arch, path_out, path_len, cache_hit);
+}
+
 int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16]) { return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d"); }
 
 int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)

@@ -235,6 +235,8 @@ int launch_kron3(hipStream_t st, igx_patch *p3, const double *d_a0, const double
 // run-time compiled coefficient expressions (rtc.hip)
 int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *cache_hit);
 int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+int launch_form_exprs(hipStream_t st, igx_patch *pt, int n_expr, const char *const *expr, double *d_out /* [n_expr][npts_loc] */, int *cache_hit);
+int rtc_compile_form(int n_expr, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 // boxes of the reordered tensor X[r0][r1][r2] (r_k = index of a 1D pair (i_k, j_k) with overlapping supports): the entries

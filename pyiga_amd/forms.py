@@ -18,6 +18,25 @@ Anything else (higher derivatives, vector-valued bases, surface integrals, ``div
 import numpy as np
 
 
+def _arr(x):
+    """float array -- or the object array of a traced evaluation (pyiga_amd.symbolic), left as it is"""
+    a = np.asarray(x)
+    return a if a.dtype == object else a.astype(float)
+
+
+def _uniform_value(a):
+    """The value of an array that is the same at every grid point, else None (traced arrays: constants only)."""
+    a = np.asarray(a)
+    if a.dtype == object:
+        consts = [getattr(z, 'const', z) for z in a.reshape(-1)]
+        if any(c is None for c in consts) or any(c != consts[0] for c in consts):
+            return None
+        return float(consts[0])
+    if a.ndim == 0 or np.all(a == a.flat[0]):
+        return float(a.flat[0]) if a.ndim else float(a)
+    return None
+
+
 class _Coef:
     """A coefficient field on the grid: scalar (shape G), vector (G + (3,)) or matrix (G + (3, 3))."""
     __array_priority__ = 1000
@@ -36,7 +55,7 @@ class _Coef:
             if all(c.rank == 1 for c in comps):
                 return _Coef(np.stack([c.a for c in comps], axis=-2), 2)
             raise NotImplementedError('unsupported nested tuple in the form')
-        a = np.asarray(x, dtype=float)
+        a = _arr(x)
         if a.ndim == 0:
             return _Coef(a, 0)
         d = len(G)
@@ -231,9 +250,10 @@ def make_namespace(G, X, inputs):
             raise NotImplementedError('grad(dims=..., parametric=...): see pyiga_amd.pforms')
         if not (isinstance(e, _Lin) and not e.vector and e.w is None):
             raise NotImplementedError('grad() of anything but u or v (times a constant)')
-        if e.s.ndim and not np.all(e.s == e.s.flat[0]):
+        c = _uniform_value(e.s)
+        if c is None:
             raise NotImplementedError('grad() of a basis function times a variable coefficient')
-        return _Lin(e.who, True, M=eye * np.asarray(e.s).flat[0])
+        return _Lin(e.who, True, M=eye * c)
 
     def inner(a, b):
         if isinstance(a, _Lin) and isinstance(b, _Lin):
@@ -307,7 +327,7 @@ def make_namespace(G, X, inputs):
             if not isinstance(vals, (tuple, list)):
                 # a function that ignores some of its arguments returns fewer grid axes: broadcast like the
                 # reference does (pyiga/utils.py:17-31)
-                vals = np.asarray(vals, dtype=float)
+                vals = _arr(vals)
                 extra = vals.shape[len(G):] if vals.shape[:len(G)] == G else (vals.shape if vals.shape in ((d,), (d, d)) else ())
                 vals = np.broadcast_to(vals, G + extra)
             ns[name] = _Coef.wrap(vals, G)
@@ -316,8 +336,9 @@ def make_namespace(G, X, inputs):
     return ns
 
 
-def coefficient_table(expr, G, X, inputs):
-    """Evaluate the form string; returns the 4x4 table of coefficient arrays (shape G) or None."""
+def coefficient_table(expr, G, X, inputs, traced=False):
+    """Evaluate the form string; returns the 4x4 table of coefficient arrays (shape G) or None.  traced: the arrays are
+    object arrays of expression trees (symbolic_table)."""
     ns = make_namespace(G, X, inputs)
     try:
         res = eval(expr, {'__builtins__': {}}, ns)
@@ -331,8 +352,18 @@ def coefficient_table(expr, G, X, inputs):
         for s in range(n):
             e = res.P[r][s]
             if e is not None and np.any(e != 0.0):
-                table[r][s] = np.ascontiguousarray(np.broadcast_to(e, G), dtype=float)
+                table[r][s] = np.broadcast_to(e, G) if traced else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float)
     return table
+
+
+def symbolic_table(expr, d, inputs):
+    """The coefficient table of the form string as C expressions in the physical coordinates (x, y[, z]): the string -- and
+    every callable among the inputs -- is evaluated ONCE, on a grid of one point whose coordinates are symbols
+    (pyiga_amd.symbolic).  Raises (symbolic.NotTraceable or whatever numpy makes of the attempt) when something cannot be
+    traced; the caller then samples the coefficients on the host."""
+    from . import symbolic
+    table = coefficient_table(expr, (1,) * d, symbolic.coordinates(d), inputs, traced=True)
+    return [[None if e is None else symbolic.c_source(e) for e in row] for row in table]
 
 
 def functional_jet(expr, G, X, inputs):

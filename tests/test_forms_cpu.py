@@ -233,3 +233,64 @@ def test_pform_terms_and_passes():
                 'hess(u) * v * dx', 'hess(u)[0, 0] * hess(u)[1, 1] * dx', 'u * v'):
         with pytest.raises(NotImplementedError):
             pforms.evaluate(bad, G, X, Jac, H2, dict(c=lambda x, y: x))
+
+
+# ---------------------------------------------------------------------------------------------
+# forms compiled at run time: the tracer (pyiga_amd/symbolic.py) and the generated kernel (hiprtc cross-compiles without a GPU)
+def _eval_c(src, X):
+    ns = {k: getattr(np, k) for k in ('sin', 'cos', 'tan', 'exp', 'log', 'sqrt', 'tanh', 'sinh', 'cosh', 'fabs')}
+    ns.update(atan=np.arctan, pow=np.power, x=X[..., 0], y=X[..., 1], z=X[..., 2] if X.shape[-1] > 2 else 0.0)
+    return eval(src, {'__builtins__': {}}, ns) + 0.0 * X[..., 0]
+
+
+def test_traced_tables_equal_sampled_tables(forms):
+    """Every form string of the golden set, traced into C expressions and evaluated again with numpy, gives the table the
+    sampling front-end gives (same entries present, same values); inputs that cannot be traced are reported as such."""
+    from pyiga_amd import symbolic
+    G = (3, 4, 5)
+    X = np.random.default_rng(8).random(G + (3,)) + 0.5
+    inp = form_inputs()
+    inp['w'] = lambda x, y, z: np.exp(-((x - 0.5) ** 2 + y ** 3) / 0.7) * np.sqrt(1.0 + z * z) + np.cos(x * y) / (2.0 + np.sin(z)) + abs(x - y)
+    cases = dict(FORMS)
+    cases['transcendental'] = ('(w * inner(grad(u), grad(v)) + w**2 * u * v - inner((w, 0.0, 2.0), grad(u)) * v) * dx', ('w',))
+    for fname, (form, names) in cases.items():
+        kw = {k: inp[k] for k in names}
+        sampled = forms.coefficient_table(form, G, X, kw)
+        traced = forms.symbolic_table(form, 3, kw)
+        for r in range(4):
+            for s in range(4):
+                assert (sampled[r][s] is None) == (traced[r][s] is None), (fname, r, s)
+                if sampled[r][s] is not None:
+                    assert np.allclose(_eval_c(traced[r][s], X), sampled[r][s], rtol=1e-15, atol=1e-15), (fname, r, s, traced[r][s])
+    for bad in (lambda x, y, z: np.where(x > 0.5, 1.0, 2.0), lambda x, y, z: np.maximum(x, 0.3), lambda x, y, z: float(x.sum()),
+                lambda x, y, z: np.full(G, 2.0)):
+        with pytest.raises(Exception) as e:
+            forms.symbolic_table('c * u * v * dx', 3, dict(c=bad))
+        assert not isinstance(e.value, NotImplementedError)
+    with pytest.raises(NotImplementedError):                      # a variable coefficient inside grad(): not this front-end's
+        forms.symbolic_table('inner(grad(c * u), grad(v)) * dx', 3, dict(c=lambda x, y, z: x))
+    assert forms.symbolic_table('inner(grad(2 * u), grad(v)) * dx', 3, {})[1][1] == '2.0'
+    # constants fold, zeros vanish
+    S = symbolic.Sym
+    x = S('x')
+    assert (0.0 * x + 1.0 * x).c == 'x' and (x * 0.0).const == 0.0 and (S.lift(2.0) * 3.0 + 1.0).const == 7.0 and (-S.lift(2.0)).c == '(-2.0)'
+    assert (x ** 2).c == '(x * x)' and (x ** 0.5).c == 'pow(x, 0.5)' and (x - 0.0) is x
+
+
+def test_form_kernel_compiles_and_is_cached(forms, tmp_path, monkeypatch):
+    """The generated kernel of a traced form: compiled by hiprtc into the cache (no GPU needed), found there the second time."""
+    import ctypes
+    from pyiga_amd import _lib
+    cdll = _lib.load()
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    inp = form_inputs()
+    traced = forms.symbolic_table(FORMS['full'][0], 3, {k: inp[k] for k in FORMS['full'][1]})
+    exprs = [e.encode() for row in traced for e in row if e is not None]
+    arr = (ctypes.c_char_p * len(exprs))(*exprs)
+    buf = ctypes.create_string_buffer(1024)
+    hit = ctypes.c_int(-1)
+    assert cdll.igx_rtc_compile_form(len(exprs), arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0
+    path = buf.value.decode()
+    assert open(path, 'rb').read(4) == b'\x7fELF'
+    assert cdll.igx_rtc_compile_form(len(exprs), arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 1
+    assert cdll.igx_rtc_compile_form(len(exprs) - 1, arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0 and buf.value.decode() != path

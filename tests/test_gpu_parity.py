@@ -1960,3 +1960,50 @@ def test_basis_orders_guard(iga):
         asm.patch.set_basis_orders((1, 0), (1, 2))
     asm.patch.set_basis_orders()
     assert np.array_equal(asm.patch.assemble('mass'), M)
+
+
+def test_forms_compiled_at_run_time(iga, golden, tmp_path, monkeypatch):
+    """The coefficients of a form string -- and of the callables it names -- are traced into C, ONE kernel per form is generated,
+    compiled with hiprtc and cached on disk (igx_patch_set_form_expr; the reference: one compiled module per form,
+    pyiga/compile.py:58-73,120-132); the matrices are the reference's, the host-sampled path (IGX_FORM_RTC=0, or an input the
+    tracer cannot follow) gives the same ones; a plain callable as the convection-diffusion coefficient goes the same way."""
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    g = golden('forms')
+    inp = form_inputs()
+    kvs, gname = _form_spaces(iga)['tbox_mixed']
+    geo = _geo(iga, gname)
+    for n, (fname, (form, names)) in enumerate(FORMS.items()):
+        R = golden_csr(g, 'tbox_mixed_%s' % fname)
+        kw = dict(geo=geo, **{k: inp[k] for k in names})
+        asm = iga.assemble.instantiate_assembler(form, kvs, kw)
+        assert asm.compiled and asm.coeff_cache_hit is False
+        A = asm.assemble_csr()
+        assert rel_maxdiff(A, R) <= RTOL, (fname, rel_maxdiff(A, R))
+        again = iga.assemble.instantiate_assembler(form, kvs, kw)
+        assert again.compiled and again.coeff_cache_hit is True and np.array_equal(again.assemble_csr().data, A.data)
+        monkeypatch.setenv('IGX_FORM_RTC', '0')
+        sampled = iga.assemble.instantiate_assembler(form, kvs, kw)
+        monkeypatch.delenv('IGX_FORM_RTC')
+        assert not sampled.compiled and rel_maxdiff(sampled.assemble_csr(), A) <= 1e-13
+    assert len(os.listdir(tmp_path / 'cache')) == len(FORMS)
+    # an input the tracer cannot follow: sampled on the host, same interface
+    step = lambda x, y, z: np.where(x + y > 1.0, 2.0, 1.0)
+    asm = iga.assemble.instantiate_assembler('c * u * v * dx', kvs, dict(geo=geo, c=step))
+    assert not asm.compiled
+    M = asm.assemble_csr()
+    assert abs(M - M.T).max() <= 1e-14 * abs(M).max() and M.sum() > 0
+    # transcendental coefficients: device libm against numpy
+    w = lambda x, y, z: np.exp(-((x - 0.5) ** 2 + y ** 3) / 0.7) * np.sqrt(1.0 + z * z) + np.cos(x * y) / (2.0 + np.sin(z))
+    form = '(w * inner(grad(u), grad(v)) + w**2 * u * v) * dx'
+    a1 = iga.assemble.instantiate_assembler(form, kvs, dict(geo=geo, w=w))
+    monkeypatch.setenv('IGX_FORM_RTC', '0')
+    a0 = iga.assemble.instantiate_assembler(form, kvs, dict(geo=geo, w=w))
+    assert a1.compiled and not a0.compiled and rel_maxdiff(a1.assemble_csr(), a0.assemble_csr()) <= 1e-13
+    # convection-diffusion: a plain callable is traced and compiled like an ExprCoefficient
+    kv = iga.bspline.make_knots(3, 0.0, 1.0, 6)
+    cyl = _geo(iga, 'cylinder')
+    dc = lambda x, y, z: 2.0 + np.sin(x + z)
+    C0 = iga.assemblers.ConvDiffAssembler3D((kv, kv, kv), cyl, dc).assemble_csr()
+    monkeypatch.delenv('IGX_FORM_RTC')
+    c1 = iga.assemblers.ConvDiffAssembler3D((kv, kv, kv), cyl, dc)
+    assert getattr(c1, 'coeff_traced', False) and rel_maxdiff(c1.assemble_csr(), C0) <= 1e-13
