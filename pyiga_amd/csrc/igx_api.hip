@@ -1021,14 +1021,15 @@ int igx_load_vector_d(igx_patch *pt, const double *d_fvals, double *d_out)
     size_t n_out;
     if ((rc = lv_workspace(pt, &n_out))) return rc;
     (void)hipEventRecord(pt->ctx->ev[6], st);        // device time of the contractions, inputs resident
-    rc = launch_load_vector(st, pt, d_fvals, pt->d_fields, d_out, pt->d_lv_t1, pt->d_lv_t2);
+    int nl = pt->dim;
+    rc = launch_load_vector(st, pt, d_fvals, pt->d_fields, d_out, pt->d_lv_t1, pt->d_lv_t2, -1, 0, &nl);
     (void)hipEventRecord(pt->ctx->ev[7], st);
     if (rc) return rc;
     IGX_HIP(hipStreamSynchronize(st));
     memset(&pt->timing, 0, sizeof(pt->timing));
     (void)hipEventElapsedTime(&pt->timing.total_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
     pt->timing.algo_used = 3;                        // load vector
-    pt->timing.n_launches = pt->dim;
+    pt->timing.n_launches = nl;
     return IGX_OK;
 }
 

@@ -246,7 +246,7 @@ int launch_box_pairs(hipStream_t st, const igx_patch *pt, const PairBoxes &B, si
 int entries_pair_boxes(igx_patch *pt, int kind, const PairBoxes &B, double *out_host);   // (igx_api.hip: index pairs built on the device)
 int launch_entries_csr(hipStream_t st, const igx_patch *pt, int kind, double *d_data);
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
-                       double *d_t1, double *d_t2, int deriv_axis = -1, int accumulate = 0);
+                       double *d_t1, double *d_t2, int deriv_axis = -1, int accumulate = 0, int *n_launches = nullptr /* 2: k_lv12 + axis 0, else one per axis */);
 inline int igx_num_fields(int dim, int kind, int form_n = 0)
 {
     return kind == IGX_MASS ? 1 : (kind == IGX_CONVDIFF ? 9 : (kind == IGX_FORM ? form_n : dim * (dim + 1) / 2));

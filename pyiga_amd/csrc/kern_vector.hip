@@ -223,9 +223,10 @@ __global__ void __launch_bounds__(LV_WAVES * 64) k_lv12(const double *__restrict
 // deriv_axis: grid axis whose basis functions are differentiated (-1: none); accumulate: add to d_out;
 // d_W == nullptr: d_f already contains the weights
 int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, const double *d_W, double *d_out,
-                       double *d_t1, double *d_t2, int deriv_axis, int accumulate)
+                       double *d_t1, double *d_t2, int deriv_axis, int accumulate, int *n_launches)
 {
     const PatchDev &pd = pt->dev;
+    if (n_launches) *n_launches = pd.dim;
     const int dim = pd.dim;
     const int bs = 256;
     // the register/LDS kernel needs one thread per dof of the line, the support in VEC_MAXSUP registers and the
@@ -267,6 +268,7 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
             ax0.G = (int)G0;
             k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv_axis == 0, accumulate);
             IGX_HIP(hipGetLastError());
+            if (n_launches) *n_launches = 2;
             return IGX_OK;
         }
         // [G0,G1,G2] -> [G0,G1,N2]
