@@ -47,7 +47,7 @@ extern "C" {
 #define IGX_VERSION 101            /* 0.1.1: igx_patch_desc.box_lo / box_hi */
 #define IGX_MAX_DIM 3
 #define IGX_MAX_DEGREE 15          /* basis evaluation / entry-wise kernels */
-#define IGX_MAX_SF_DEGREE 5        /* sum-factorised fast path */
+#define IGX_MAX_SF_DEGREE 7        /* sum-factorised fast path */
 
 typedef struct igx_ctx igx_ctx;       /* one per GPU: device id + HIP stream */
 typedef struct igx_patch igx_patch;   /* device-resident state of one assembler */

@@ -2007,3 +2007,29 @@ def test_forms_compiled_at_run_time(iga, golden, tmp_path, monkeypatch):
     monkeypatch.delenv('IGX_FORM_RTC')
     c1 = iga.assemblers.ConvDiffAssembler3D((kv, kv, kv), cyl, dc)
     assert getattr(c1, 'coeff_traced', False) and rel_maxdiff(c1.assemble_csr(), C0) <= 1e-13
+
+
+@pytest.mark.parametrize('p', [6, 7])
+def test_high_degree_sum_factorisation(iga, oracle, p):
+    """Degrees 6 and 7 run through the sum-factorised stage kernels (IGX_MAX_SF_DEGREE = 7): against the oracle and the
+    entry-wise kernels, 2D and 3D, symmetric forms, convection-diffusion, unequal degrees and repeated knots."""
+    mk = iga.bspline.make_knots
+    cyl, ann = _geo(iga, 'cylinder'), _geo(iga, 'quarter_annulus')
+    for dim, kvs, geo, ogeo in ((2, (mk(p, 0.0, 1.0, 9), mk(p, 0.0, 1.0, 12)), ann, oracle.geo_quarter_annulus()),
+                                (3, (mk(p, 0.0, 1.0, 4), mk(p, 0.0, 1.0, 5), mk(p, 0.0, 1.0, 3)), cyl, oracle.geo_cylinder()),
+                                (3, (mk(p, 0.0, 1.0, 3), mk(2, 0.0, 1.0, 6, mult=2), mk(p - 1, 0.0, 1.0, 4)), cyl, oracle.geo_cylinder())):
+        okvs = tuple(oracle.KnotVector(kv.kv, kv.p) for kv in kvs)
+        for kind in ('mass', 'stiffness'):
+            asm = {('mass', 2): iga.assemblers.MassAssembler2D, ('stiffness', 2): iga.assemblers.StiffnessAssembler2D,
+                   ('mass', 3): iga.assemblers.MassAssembler3D, ('stiffness', 3): iga.assemblers.StiffnessAssembler3D}[(kind, dim)](kvs, geo)
+            A = asm.assemble_csr(algo='sumfact')
+            assert asm.patch.timing()['algo_used'] == 2
+            R = oracle.assemble(kind, okvs, ogeo, nthreads=8)
+            assert np.array_equal(A.indices, R.indices) and rel_maxdiff(A, R) <= RTOL, (p, dim, kind, rel_maxdiff(A, R))
+            assert abs(A - A.T).max() == 0.0
+            assert rel_maxdiff(asm.assemble_csr(algo='entrywise'), R) <= RTOL
+        if dim == 3:
+            coeff = lambda x, y, z: 1.0 + x * y
+            C = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff).assemble_csr(algo='sumfact')
+            R = oracle.assemble_nonsymmetric('convdiff', okvs, ogeo, coeff=coeff, nthreads=8)
+            assert rel_maxdiff(C, R) <= RTOL, (p, 'convdiff', rel_maxdiff(C, R))
