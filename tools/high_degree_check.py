@@ -24,7 +24,7 @@ for p in (5, 6, 7):
             except Exception as e:
                 print(p, dim, kind, 'sumfact FAILED:', str(e)[:150]); continue
             B = asm.assemble_csr(algo='entrywise'); ms_en = asm.patch.timing()['total_ms']
-            print('p=%d %dD %-9s sumfact %.3f ms  entrywise %.3f ms  rel diff %.2e  path %s' % (p, dim, kind, ms_sf, ms_en, rel(A, B), asm.patch.last_path))
+            print('p=%d %dD %-9s sumfact %.3f ms  entrywise %.3f ms  rel diff %.2e  path %s' % (p, dim, kind, ms_sf, ms_en, rel(A, B), asm.patch.last_path()))
         if dim == 3:
             dc = lambda x, y, z: 1.0 + x * y
             asm = assemblers.ConvDiffAssembler3D(kvs, geo, dc)
