@@ -562,11 +562,23 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
     """Load vector of the same patch.  `value` uses the device time of the contractions with the
     function values resident in HBM (igx_load_vector_d); the whole host-pointer call incl. the upload is noted."""
     from pyiga_amd import utils
+    from pyiga_amd import symbolic
     grid = tuple(patch.gauss(k)[0] for k in range(dim))
-    fvals = np.ascontiguousarray(utils.grid_eval(lambda *x: np.cos(x[0]) * np.exp(x[1]) * (np.sin(x[2]) if dim == 3 else 1.0), grid))
+    f = lambda *x: np.cos(x[0]) * np.exp(x[1]) * (np.sin(x[2]) if dim == 3 else 1.0)
+    fvals = np.ascontiguousarray(utils.grid_eval(f, grid))
     t0 = time.perf_counter()
     patch.load_vector(fvals)
     host_call_ms = 1e3 * (time.perf_counter() - t0)
+    # the same function traced into C and evaluated at the Gauss points by a run-time compiled kernel (what
+    # assemble.inner_products does with a plain callable): second call = code object from the cache
+    compiled_call_ms = None
+    src = symbolic.trace_function(f, dim)
+    if src is not None:
+        for _ in range(2):
+            t0 = time.perf_counter()
+            patch.eval_function_expr(src, parametric=True)
+            patch.load_vector_resident(to_host=True)
+            compiled_call_ms = 1e3 * (time.perf_counter() - t0)
     patch.upload_function(fvals)                      # resident from here on
     for _ in range(args.warmup):
         patch.load_vector_resident()
@@ -597,7 +609,9 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
            'config': {'workload': '%dD p=%d load vector (inner_products), %s spans' % (dim, p, 'x'.join(str(x) for x in (n0,) + (n,) * (dim - 1))),
                       'config': args.config, **({'emulated_slab': args.emulate} if args.emulate else {}), 'elements': nel_total,
                       'note': 'value = device time of the contractions, function values resident (igx_load_vector_d); whole resident call '
-                              '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms' % (wall_ms, host_call_ms)},
+                              '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms%s' % (
+                                  wall_ms, host_call_ms, '' if compiled_call_ms is None else
+                                  '; the whole call with the function compiled for the device (traced callable, igx_patch_eval_expr_d), result on the host: %.1f ms' % compiled_call_ms)},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': measured_traffic(args.config, world, 'rhs'), 'kernel': kernel_names, 'algorithmic_bytes_per_element': b_el}}
     flush_c_stdio()

@@ -176,6 +176,12 @@ int igx_patch_set_coeff_affine(igx_patch *patch, const double c[4]);
    kernels cannot express themselves. */
 int igx_patch_set_coeff_expr(igx_patch *patch, const char *expr, int *cache_hit);
 
+/* A function given as a C expression in x, y, z (same grammar), evaluated at the RESIDENT Gauss points into the device array
+   d_out (igx_patch_gauss_slab planes x G1 [x G2]) -- the input of igx_load_vector_d, without sampling the function on the
+   host and uploading it (the reference samples f on the Gauss grid: pyiga/assemble.py:283-309).  parametric = 0: x, y, z are
+   the physical coordinates (spline geometry needed); 1: the parametric coordinates of the Gauss points. */
+int igx_patch_eval_expr_d(igx_patch *patch, const char *expr, int parametric, double *d_out, int *cache_hit);
+
 /* Host only (no device, no patch): compile the coefficient kernel of `expr` for the architecture `arch` ("gfx950") into the
    cache, or find it there; path_out (may be NULL) receives the file name.  What igx_patch_set_coeff_expr does first. */
 int igx_rtc_compile(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);

@@ -70,6 +70,7 @@ SYMBOLS = [
     ('igx_patch_get_info', C.c_int, [C.c_void_p, C.POINTER(PatchInfo)]),
     ('igx_patch_set_coeff', C.c_int, [C.c_void_p, _dp]),
     ('igx_patch_set_form', C.c_int, [C.c_void_p, _dp * 16]),
+    ('igx_patch_eval_expr_d', C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     ('igx_patch_set_form_expr', C.c_int, [C.c_void_p, C.c_char_p * 16, C.POINTER(C.c_int)]),
     ('igx_rtc_compile_form', C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     ('igx_patch_set_pform', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp)]),

@@ -338,9 +338,17 @@ def inner_products(kvs, f, f_physical=False, geo=None):
     assert dim in (2, 3), 'Dimensions higher than 3 are currently not implemented.'
     g = geo if geo is not None else geometry.unit_cube(dim)     # parameter domain: |det J| = 1
     patch = assemblers.DevicePatch(kvs, g)
-    grid = tuple(patch.gauss(k)[0] for k in range(dim))
-    fvals = utils.grid_eval_transformed(f, grid, geo) if f_physical else utils.grid_eval(f, grid)
-    out = patch.load_vector(fvals)
+    # a plain scalar callable is traced into a C expression and evaluated at the Gauss points on the device
+    # (pyiga_amd.symbolic, igx_patch_eval_expr_d): no sampling on the host, no upload; anything else as in the reference
+    from . import symbolic
+    src = symbolic.trace_function(f, dim) if (not f_physical or isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc))) else None
+    if src is not None:
+        patch.eval_function_expr(src, parametric=not f_physical)
+        out = patch.load_vector_resident(to_host=True)
+    else:
+        grid = tuple(patch.gauss(k)[0] for k in range(dim))
+        fvals = utils.grid_eval_transformed(f, grid, geo) if f_physical else utils.grid_eval(f, grid)
+        out = patch.load_vector(fvals)
     patch.close()
     return out
 

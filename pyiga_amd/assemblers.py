@@ -162,6 +162,17 @@ class DevicePatch:
         ptr = self._dev_buffer('_d_f', part.nbytes)
         _lib.check(_lib.load().igx_dev_upload(self.ctx.handle, ptr, part.ctypes.data, part.nbytes), 'igx_dev_upload')
 
+    def eval_function_expr(self, c_expr, parametric=False):
+        """The function values of load_vector_resident() from a C expression in x, y, z, evaluated on the device at the resident
+        Gauss points (physical coordinates, or the parametric ones) by a kernel compiled at run time (igx_patch_eval_expr_d):
+        nothing is sampled on the host or uploaded.  Returns True if the code object came from the cache."""
+        g0_lo, g0_n = self.gauss_slab()
+        npts = g0_n * int(np.prod([self.info.ngauss[k] for k in range(1, self.dim)]))
+        ptr = self._dev_buffer('_d_f', 8 * npts)
+        hit = C.c_int(0)
+        _lib.check(_lib.load().igx_patch_eval_expr_d(self.handle, c_expr.encode(), 1 if parametric else 0, ptr, C.byref(hit)), 'igx_patch_eval_expr_d')
+        return bool(hit.value)
+
     def load_vector_resident(self, to_host=False):
         """Load vector from the function values uploaded with upload_function(); the result stays on the device unless asked for."""
         assert getattr(self, '_d_f', None), 'upload_function() first'
@@ -795,15 +806,25 @@ class _FunctionalAssembler:
         self.nqp = max(kv.p for kv in kvs0) + 1
         self.patch = DevicePatch(kvs0, geo, device=device, row0=row0)
         self.gaussgrid = tuple(self.patch.gauss(k)[0] for k in range(self._dim))
-        if self._physical:
+        self._vector = None
+        # a plain callable is traced into a C expression and evaluated on the device (pyiga_amd.symbolic); spline functions
+        # and whatever cannot be traced are sampled on the Gauss grid on the host
+        from . import symbolic
+        self._fexpr = symbolic.trace_function(f, self._dim) if (not self._physical or isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc))) else None
+        if self._fexpr is not None:
+            self._fvals = None
+        elif self._physical:
             self._fvals = utils.grid_eval_transformed(f, self.gaussgrid, geo)
         else:
             self._fvals = utils.grid_eval(f, self.gaussgrid)
-        self._vector = None
 
     def assemble_vector(self):
         if self._vector is None:
-            self._vector = self.patch.load_vector(self._fvals)
+            if self._fexpr is not None:
+                self.patch.eval_function_expr(self._fexpr, parametric=not self._physical)
+                self._vector = self.patch.load_vector_resident(to_host=True)
+            else:
+                self._vector = self.patch.load_vector(self._fvals)
         return self._vector.copy()
 
     # per-entry interface of the reference (genericasm.pxi:353-436,677-758), arity 1

@@ -549,6 +549,14 @@ int igx_patch_set_coeff_expr(igx_patch *pt, const char *expr, int *cache_hit)
     return IGX_OK;
 }
 
+// a function given as a C expression, evaluated at the resident Gauss points into a device array (input of igx_load_vector_d)
+int igx_patch_eval_expr_d(igx_patch *pt, const char *expr, int parametric, double *d_out, int *cache_hit)
+{
+    if (!pt || !expr || !d_out) { set_error("igx_patch_eval_expr_d: null argument"); return IGX_ERR_ARG; }
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    return launch_coeff_expr(pt->ctx->stream, pt, expr, d_out, cache_hit, parametric != 0);
+}
+
 int igx_rtc_compile(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit)
 {
     return rtc_compile_expr(expr, arch, path_out, path_len, cache_hit);

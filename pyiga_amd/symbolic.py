@@ -160,3 +160,19 @@ def c_source(e):
             raise NotTraceable('a traced coefficient that is not a scalar field')
         e = e.reshape(-1)[0]
     return Sym.lift(e).c
+
+
+def trace_function(f, d):
+    """C text of the scalar function `f(x, y[, z])` (a plain Python callable), or None when it cannot be traced (or is not
+    scalar-valued): the caller samples it on the host then."""
+    import os
+    if os.environ.get('IGX_FORM_RTC', '1') == '0' or not callable(f) or hasattr(f, 'grid_eval'):
+        return None
+    try:
+        X = coordinates(d)
+        val = f(*(X[..., k] for k in range(d)))
+        if isinstance(val, (tuple, list)):
+            return None
+        return c_source(np.broadcast_to(np.asarray(val, dtype=object), (1,) * d))
+    except Exception:
+        return None

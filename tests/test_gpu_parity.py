@@ -509,7 +509,13 @@ def test_load_vector_slabs_and_oracle(iga, oracle, d, p, n, G):
             fvals = iga.utils.grid_eval_transformed(f, grid, geo)
         parts.append(patch.load_vector(fvals))
         patch.close()
-    assert np.array_equal(np.concatenate(parts, axis=0), full)
+    # (inner_products evaluates a plain callable on the device -- device libm; the slabs here get the host's samples: compare
+    # them with the whole patch on the same samples, bit for bit, and the two ways of sampling to rounding)
+    whole = iga.assemblers.DevicePatch(kvs, geo)
+    full_sampled = whole.load_vector(fvals)
+    whole.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), full_sampled)
+    assert np.abs(full - full_sampled).max() <= 1e-13 * np.abs(full_sampled).max()
 
 
 @pytest.mark.parametrize('p,n1', [(2, 37), (3, 40), (4, 48), (5, 33), (5, 65), (4, 41), (3, 67)])
@@ -534,7 +540,11 @@ def test_load_vector_fused_chunks(iga, oracle, p, n1):
             fvals = iga.utils.grid_eval_transformed(_f3, tuple(patch.gauss(a)[0] for a in range(3)), geo)
         parts.append(patch.load_vector(fvals))
         patch.close()
-    assert np.array_equal(np.concatenate(parts, axis=0), full)
+    whole = iga.assemblers.DevicePatch(kvs, geo)                  # (the same host samples for the whole patch: bit for bit)
+    full_sampled = whole.load_vector(fvals)
+    whole.close()
+    assert np.array_equal(np.concatenate(parts, axis=0), full_sampled)
+    assert np.abs(full - full_sampled).max() <= 1e-13 * np.abs(full_sampled).max()
     # gradient functional (differentiated basis functions on each axis in turn): the basis is a partition of unity, so the
     # whole vector of  inner(c, grad(v)) dx  sums to zero; against the separate contractions of an unequal-degree space
     cube = iga.geometry.unit_cube()
@@ -2033,3 +2043,39 @@ def test_high_degree_sum_factorisation(iga, oracle, p):
             C = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff).assemble_csr(algo='sumfact')
             R = oracle.assemble_nonsymmetric('convdiff', okvs, ogeo, coeff=coeff, nthreads=8)
             assert rel_maxdiff(C, R) <= RTOL, (p, 'convdiff', rel_maxdiff(C, R))
+
+
+def test_load_vector_function_compiled(iga, tmp_path, monkeypatch):
+    """inner_products / the L2 functional assemblers with a plain callable: the function is traced into C and evaluated at
+    the Gauss points on the device (igx_patch_eval_expr_d) -- physical and parametric coordinates, 2D and 3D, row slabs --
+    and gives what sampling on the host gives; spline functions and untraceable callables are sampled as before."""
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    mk = iga.bspline.make_knots
+    f3 = lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z) + 0.25 * x * y * z
+    f2 = lambda x, y: np.exp(-x) * np.sin(3.0 * y) + x ** 2
+    cases = [((mk(3, 0.0, 1.0, 6), mk(2, 0.0, 1.0, 5), mk(4, 0.0, 1.0, 4)), _geo(iga, 'cylinder'), f3),
+             ((mk(3, 0.0, 1.0, 9), mk(2, 0.0, 1.0, 7, mult=2)), _geo(iga, 'quarter_annulus'), f2)]
+    for kvs, geo, f in cases:
+        for physical in (True, False):
+            got = iga.assemble.inner_products(kvs, f, f_physical=physical, geo=geo)
+            monkeypatch.setenv('IGX_FORM_RTC', '0')
+            ref = iga.assemble.inner_products(kvs, f, f_physical=physical, geo=geo)
+            monkeypatch.delenv('IGX_FORM_RTC')
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (len(kvs), physical)
+        got = iga.assemble.inner_products(kvs, f)                     # parameter domain, no geometry
+        monkeypatch.setenv('IGX_FORM_RTC', '0')
+        ref = iga.assemble.inner_products(kvs, f)
+        monkeypatch.delenv('IGX_FORM_RTC')
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    kvs, geo, f = cases[0]
+    cls = iga.assemblers.L2FunctionalAssemblerPhys3D
+    whole = cls(kvs, geo, f)
+    assert whole._fexpr is not None
+    v = whole.assemble_vector()
+    N0 = kvs[0].numdofs
+    parts = [cls(kvs, geo, f, row0=(a, b)).assemble_vector() for a, b in ((0, N0 // 2), (N0 // 2, N0))]
+    assert np.array_equal(np.concatenate(parts, axis=0), v)
+    step = lambda x, y, z: np.where(x > 1.2, 1.0, 0.5 + 0.0 * y * z)
+    assert cls(kvs, geo, step)._fexpr is None and np.isfinite(cls(kvs, geo, step).assemble_vector()).all()
+    spline = iga.bspline.BSplineFunc(kvs, np.arange(float(np.prod([kv.numdofs for kv in kvs]))))
+    assert iga.assemblers.L2FunctionalAssembler3D(kvs, geo, spline)._fexpr is None
