@@ -743,6 +743,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (int rc = basis_orders_ok(pt, kind, "igx_assemble")) return rc;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
+    const bool was_auto = algo == IGX_ALGO_AUTO;
     if (algo == IGX_ALGO_AUTO) algo = (pt->sumfact_ok && sumfact_supports_kind(pt, kind)) ? IGX_ALGO_SUMFACT : IGX_ALGO_ENTRYWISE;
     if (algo == IGX_ALGO_SUMFACT && !sumfact_supports_kind(pt, kind)) { set_error("igx_assemble: sum factorisation does not support this form yet"); return IGX_ERR_UNSUPPORTED; }
     if (algo == IGX_ALGO_SUMFACT && !pt->sumfact_ok) { set_error("igx_assemble: sum factorisation does not support this patch (degree > %d)", IGX_MAX_SF_DEGREE); return IGX_ERR_UNSUPPORTED; }
@@ -795,8 +796,17 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (staged) IGX_HIP(hipEventRecord(ev[1], st));
     if (algo == IGX_ALGO_SUMFACT) {
         rc = sumfact_assemble(pt, kind, pt->d_data);
+        if (rc == IGX_ERR_UNSUPPORTED && was_auto) {
+            // a shape the stage kernels refuse (a limit of their staging buffers): with IGX_ALGO_AUTO the entry-wise kernels take
+            // over -- same device, same matrix; an explicit IGX_ALGO_SUMFACT keeps the error
+            algo = IGX_ALGO_ENTRYWISE;
+            pt->timing.algo_used = algo;
+            pt->last_path = 0;
+            rc = ensure_fields(pt, kind);
+        }
         if (rc) return rc;
-    } else {
+    }
+    if (algo != IGX_ALGO_SUMFACT) {
         rc = launch_entries_csr(st, pt, kind, pt->d_data);
         if (rc) return rc;
         pt->timing.n_launches++;

@@ -1264,9 +1264,12 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         F.SSTR = (AL.q * AL.P * 2) | 1;
         F.KSTR = AL.q | 1;
         int ntiles = 1, tile_rows, CR, tsp_max, trow_max, nsp_max;
+        // rows per wave task: at most 64 (one lane per row), and few enough that the K window of the task -- the Gauss points
+        // under its rows: (rows + p) spans with single knots -- fits the 8 x 64 prefetch slots (degree 7 with q = 8: 56 rows)
+        const int crmax = std::max(1, std::min(64, 512 / std::max(AL.q, 1) - AL.p));
         for (;; ++ntiles) {
             const int rows_per_tile = (AL.N + ntiles - 1) / ntiles;
-            const int nch = (rows_per_tile + 63) / 64;
+            const int nch = (rows_per_tile + crmax - 1) / crmax;
             CR = (rows_per_tile + nch - 1) / nch;
             tile_rows = CR * nch;
             tsp_max = trow_max = nsp_max = 0;
@@ -1277,7 +1280,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
                 for (int cl = lo; cl < hi; cl += CR)
                     nsp_max = std::max(nsp_max, AL.mshi[std::min(cl + CR, hi) - 1] - AL.mslo[cl]);
             }
-            if ((size_t)tsp_max * F.SSTR * sizeof(double) <= 64 * 1024 || tile_rows <= 64) break;
+            if ((size_t)tsp_max * F.SSTR * sizeof(double) <= 64 * 1024 || tile_rows <= crmax) break;
         }
         ntiles = (AL.N + tile_rows - 1) / tile_rows;
         const int kpy = (nsp_max * AL.q + 63) / 64;

@@ -2079,3 +2079,19 @@ def test_load_vector_function_compiled(iga, tmp_path, monkeypatch):
     assert cls(kvs, geo, step)._fexpr is None and np.isfinite(cls(kvs, geo, step).assemble_vector()).all()
     spline = iga.bspline.BSplineFunc(kvs, np.arange(float(np.prod([kv.numdofs for kv in kvs]))))
     assert iga.assemblers.L2FunctionalAssembler3D(kvs, geo, spline)._fexpr is None
+
+
+def test_auto_falls_back_to_entry_kernels(iga):
+    """A shape the stage kernels refuse (here: more outer pairs than a launch grid has rows) is assembled by the entry-wise
+    kernels when the caller leaves the algorithm to the library; an explicit request for the sum-factorised path keeps the error."""
+    mk = iga.bspline.make_knots
+    kvs = (mk(4, 0.0, 1.0, 14000), mk(1, 0.0, 1.0, 2), mk(2, 0.0, 1.0, 2))
+    geo = iga.geometry.unit_cube()
+    asm = iga.assemblers.MassAssembler3D(kvs, geo)
+    with pytest.raises(RuntimeError):
+        asm.assemble_csr(algo='sumfact')
+    A = asm.assemble_csr()
+    assert asm.patch.timing()['algo_used'] == 1
+    E = asm.assemble_csr(algo='entrywise')
+    assert np.array_equal(A.data, E.data) and abs(A - A.T).max() == 0.0
+    assert abs(A.sum() - 1.0) <= 1e-12                    # the mass matrix of a partition of unity on the unit cube
