@@ -662,42 +662,42 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf2(cons
                 constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P;
                 int ln_ = min(lane, PPP * PL - 1);                     // (lanes past the last piece repeat its last item: nobody reads them)
                 asm volatile("" : "+v"(ln_));
-                const int ps = ln_ / PL, x = ln_ - ps * PL;              // piece slot of the pass, span of the piece
+                const int ps = ln_ / PL, x = ln_ - ps * PL;              // piece slot of the pass, span of the piece (kept across the
+                // steps in two registers instead: measured, no difference)
                 const int pid = pass * PPP + ps;
                 const int k9 = pid / NPC, pj = pid - k9 * NPC;
                 const int s1 = pj * RP + x;                            // span of the window
                 const int la = k9 <= p ? k9 : k9 - p;
                 const int row1 = k9 <= p ? dd + la : dd, col1 = k9 <= p ? dd : dd + la;
-                const bool lok = ps < PPP && pid < npieces && row1 >= rlo && row1 < rhi && col1 < A.N1;
-                const int sp = sp_lo + s1;
-                const bool eok = lok && s1 < Gm::WS && sp >= 0 && sp < A.n2;
-                const double *kl = lines + k9 * LS + s1 * P, *vl = V2s + s1 * P * P * 2;
+                const bool lok = pid < npieces && row1 >= rlo && row1 < rhi && col1 < A.N1;
+                // EVERY lane forms its element matrix -- no branch, no zero fill for the lanes without a valid item: a span outside
+                // the axis has zero basis values in V2s (the staging loop above) and finite K values (the sweepers clamp their
+                // points), so its matrix IS zero; a lane whose line is not part of the step (or whose span lies beyond the rows of
+                // the tile) computes something that is never stored -- the stored rows of a piece (x >= p) gather from lanes of the
+                // same piece only.  The LDS addresses are kept inside the image.
+                // (round 4: the branch and the zero fill of 25 registers cost the contractors 0.15 ms at C4: r04_c_c4_bf2_branch_free_ab.txt)
+                const double *kl = lines + min(k9, W - 1) * LS + min(s1, TL / P - 1) * P, *vl = V2s + min(s1, TL / P - 1) * P * P * 2;
                 // entries of row i2 = sp (the row whose function index a = 0 sits on this lane's span): entry o = b - a + p comes
                 // from the element matrix of span i2 - a, i.e. of the lane a places below
                 double out[W];
-#pragma unroll
-                for (int o = 0; o < W; ++o) out[o] = 0.0;
                 {
                     double loc[A1 - A0][P];
-                    if (eok) bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
-                    else {
-#pragma unroll
-                        for (int a = 0; a < A1 - A0; ++a)
-#pragma unroll
-                            for (int b = 0; b < P; ++b) loc[a][b] = 0.0;
-                    }
+                    bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
 #pragma unroll
                     for (int a = A0; a < A1; ++a)
 #pragma unroll
                         for (int b = 0; b < P; ++b) {
+                            // (the first addend of an entry is assigned: out[] is not cleared; entries no row of this unit
+                            // contributes to are neither written nor read)
                             if (a == 0) out[b + p] = loc[0][b];
+                            else if (a == A0 || b == 0) out[b - a + p] = bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
                             else out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
                         }
                 }
                 // (the per-lane constants of the pass are kept across the element matrix: since the store duty became an object the
                 // contractors have registers to spare -- 116 of 128 -- and working them out again cost 0.13 ms: r04_a_c4_bf2_keep_consts_ab.txt)
                 const int x2 = x, k9w = k9, s1w = s1;
-                const int law = la, row1w = row1, col1w = col1;
+                const int law = la, row1w = row1;
                 const bool lokw = lane < PPP * PL && lok;
                 const int r3 = s1w - p;                                // row of the tile
                 if (lokw && x2 >= p && r3 < nrows) {
