@@ -119,16 +119,44 @@ class Sym:
     def sinh(self): return self._fn('sinh', math.sinh)
     def cosh(self): return self._fn('cosh', math.cosh)
     def arctan(self): return self._fn('atan', math.atan)
+    def arcsin(self): return self._fn('asin', math.asin)
+    def arccos(self): return self._fn('acos', math.acos)
+    def log1p(self): return self._fn('log1p', math.log1p)
+    def expm1(self): return self._fn('expm1', math.expm1)
+    def log2(self): return self._fn('log2', math.log2)
+    def log10(self): return self._fn('log10', math.log10)
+    def cbrt(self): return self._fn('cbrt', lambda v: math.copysign(abs(v) ** (1.0 / 3.0), v))
+
+    def _fn2(self, o, cname, pyf, swap=False):
+        a, b = Sym.lift(self), Sym.lift(o)
+        if swap:
+            a, b = b, a
+        if a.const is not None and b.const is not None:
+            return Sym.lift(pyf(a.const, b.const))
+        return Sym('%s(%s, %s)' % (cname, a.c, b.c))
+
+    def arctan2(self, o): return self._fn2(o, 'atan2', math.atan2)
+    def hypot(self, o): return self._fn2(o, 'hypot', math.hypot)
     def fabs(self): return self._fn('fabs', math.fabs)
     absolute = fabs
     __abs__ = fabs
 
     # ---- what the form front-end asks of a coefficient: "is it absent", "is it the same everywhere"
+    # (only "is this coefficient identically zero" and comparisons of constants are answered; a comparison of an expression
+    # with anything else is a branch on values the trace does not have: NotTraceable, the caller samples on the host)
     def __eq__(self, o):
         if isinstance(o, Sym):
-            return self is o or (self.const is not None and self.const == o.const)
-        if isinstance(o, (int, float, np.integer, np.floating)):
-            return self.const is not None and self.const == float(o)
+            if self is o:
+                return True
+            if self.const is not None and o.const is not None:
+                return self.const == o.const
+            raise NotTraceable('comparison of traced expressions')
+        if isinstance(o, (int, float, np.integer, np.floating)) and not isinstance(o, (bool, np.bool_)):
+            if self.const is not None:
+                return self.const == float(o)
+            if float(o) == 0.0:
+                return False                      # a non-constant expression is not the absent (zero) coefficient
+            raise NotTraceable('comparison of a traced expression with a number')
         return NotImplemented
 
     def __ne__(self, o):

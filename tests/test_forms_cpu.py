@@ -239,7 +239,7 @@ def test_pform_terms_and_passes():
 # forms compiled at run time: the tracer (pyiga_amd/symbolic.py) and the generated kernel (hiprtc cross-compiles without a GPU)
 def _eval_c(src, X):
     ns = {k: getattr(np, k) for k in ('sin', 'cos', 'tan', 'exp', 'log', 'sqrt', 'tanh', 'sinh', 'cosh', 'fabs')}
-    ns.update(atan=np.arctan, pow=np.power, x=X[..., 0], y=X[..., 1], z=X[..., 2] if X.shape[-1] > 2 else 0.0)
+    ns.update(atan=np.arctan, atan2=np.arctan2, hypot=np.hypot, asin=np.arcsin, log1p=np.log1p, pow=np.power, x=X[..., 0], y=X[..., 1], z=X[..., 2] if X.shape[-1] > 2 else 0.0)
     return eval(src, {'__builtins__': {}}, ns) + 0.0 * X[..., 0]
 
 
@@ -250,7 +250,7 @@ def test_traced_tables_equal_sampled_tables(forms):
     G = (3, 4, 5)
     X = np.random.default_rng(8).random(G + (3,)) + 0.5
     inp = form_inputs()
-    inp['w'] = lambda x, y, z: np.exp(-((x - 0.5) ** 2 + y ** 3) / 0.7) * np.sqrt(1.0 + z * z) + np.cos(x * y) / (2.0 + np.sin(z)) + abs(x - y)
+    inp['w'] = lambda x, y, z: np.exp(-((x - 0.5) ** 2 + y ** 3) / 0.7) * np.sqrt(1.0 + z * z) + np.cos(x * y) / (2.0 + np.sin(z)) + abs(x - y) + np.arctan2(y, x) * np.hypot(x, z) + np.log1p(x) * np.arcsin(0.3 * y)
     cases = dict(FORMS)
     cases['transcendental'] = ('(w * inner(grad(u), grad(v)) + w**2 * u * v - inner((w, 0.0, 2.0), grad(u)) * v) * dx', ('w',))
     for fname, (form, names) in cases.items():
@@ -263,6 +263,7 @@ def test_traced_tables_equal_sampled_tables(forms):
                 if sampled[r][s] is not None:
                     assert np.allclose(_eval_c(traced[r][s], X), sampled[r][s], rtol=1e-15, atol=1e-15), (fname, r, s, traced[r][s])
     for bad in (lambda x, y, z: np.where(x > 0.5, 1.0, 2.0), lambda x, y, z: np.maximum(x, 0.3), lambda x, y, z: float(x.sum()),
+                lambda x, y, z: np.where(x == 0.5, 1.0, 2.0), lambda x, y, z: np.where(x == y, 1.0, 2.0), lambda x, y, z: x // 2, lambda x, y, z: np.sign(x),
                 lambda x, y, z: np.full(G, 2.0)):
         with pytest.raises(Exception) as e:
             forms.symbolic_table('c * u * v * dx', 3, dict(c=bad))
