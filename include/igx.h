@@ -296,6 +296,9 @@ int igx_load_vector_d(igx_patch *patch, const double *d_fvals, double *d_out);
    physical derivatives).  coef[r]: F_r on the FULL tensor Gauss grid (host) or NULL.  Arity-1 form strings such as
    'inner(b, grad(v)) * dx' (pyiga/assemble.py:837-897).  Replaces the IGX_FORM coefficients of the patch. */
 int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *out);
+/* The same functional with its coefficients given as C expressions in the physical coordinates x, y, z (expr[r] or NULL; the
+   grammar and the run-time compilation of igx_patch_set_form_expr): nothing is sampled on the host. */
+int igx_load_vector_jet_expr(igx_patch *patch, const char *const expr[4], double *out, int *cache_hit);
 
 /* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */

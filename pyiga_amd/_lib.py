@@ -91,6 +91,7 @@ SYMBOLS = [
     ('igx_patch_placement', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ('igx_load_vector', C.c_int, [C.c_void_p, _dp, _dp]),
     ('igx_load_vector_jet', C.c_int, [C.c_void_p, _dp * 4, _dp]),
+    ('igx_load_vector_jet_expr', C.c_int, [C.c_void_p, C.c_char_p * 4, _dp, C.POINTER(C.c_int)]),
     ('igx_entries_d', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('igx_load_vector_d', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('igx_fast_assemble', C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

@@ -419,6 +419,20 @@ class DevicePatch:
         _lib.check(_lib.load().igx_load_vector_jet(self.handle, ptrs, _lib.dptr(out)), 'igx_load_vector_jet')
         return out
 
+    def load_vector_jet_expr(self, exprs):
+        """The same with the coefficients as C expressions in x, y, z (strings or None), compiled for the device at run time
+        (igx_load_vector_jet_expr)."""
+        arr = (C.c_char_p * 4)()
+        for r, e in enumerate(exprs):
+            if e is not None:
+                arr[r] = e.encode()
+        lo, hi = int(self.info.row_lo), int(self.info.row_hi)
+        nd = self.ndofs
+        out = np.empty(((hi - lo) // int(np.prod(nd[1:])),) + nd[1:])
+        hit = C.c_int(0)
+        _lib.check(_lib.load().igx_load_vector_jet_expr(self.handle, arr, _lib.dptr(out), C.byref(hit)), 'igx_load_vector_jet_expr')
+        return out
+
     def gauss(self, axis):
         """Gauss nodes and weights of an axis (of its part inside the bounding box, for an on-demand patch)."""
         n = self.info.ngauss[axis]
@@ -852,13 +866,29 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
     def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
         from . import forms
         super().__init__(kvs0, geo, lambda *xyz: 0.0, device=device, row0=row0)
+        # the coefficients of v and grad(v) as generated device code when the string and its inputs can be traced (pyiga_amd.symbolic)
+        self._jet_exprs = None
+        if os.environ.get('IGX_FORM_RTC', '1') != '0' and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
+            try:
+                from . import symbolic
+                traced = forms.functional_jet(form, (1,) * self._dim, symbolic.coordinates(self._dim), dict(inputs or {}), traced=True)
+                self._jet_exprs = [None if e is None else symbolic.c_source(e) for e in traced]
+            except NotImplementedError:
+                raise
+            except Exception:
+                self._jet_exprs = None
+        if self._jet_exprs is not None:
+            self._jet = [None if e is None else True for e in self._jet_exprs]
+            return
         G = tuple(len(g) for g in self.gaussgrid)
         X = np.asarray(geo.grid_eval(list(self.gaussgrid)))
         self._jet = forms.functional_jet(form, G, X, dict(inputs or {}))
 
     def assemble_vector(self):
         if self._vector is None:
-            if all(e is None for e in self._jet):
+            if self._jet_exprs is not None and any(e is not None for e in self._jet_exprs):
+                self._vector = self.patch.load_vector_jet_expr(self._jet_exprs + [None] * (4 - len(self._jet_exprs)))
+            elif all(e is None for e in self._jet):
                 lo, hi = self.patch.row_range                # the zero functional ('0 * v * dx')
                 nd = self.patch.ndofs
                 self._vector = np.zeros(((hi - lo) // int(np.prod(nd[1:])),) + tuple(nd[1:]))

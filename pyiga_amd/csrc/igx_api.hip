@@ -161,6 +161,8 @@ static int setup_geo_axis(GeoAxis &g, const double *kv, int len, int p, const do
 
 static void free_geo_axis(GeoAxis &g) { (void)hipFree(g.d_kv); (void)hipFree(g.d_V); (void)hipFree(g.d_fa); }
 
+static int load_vector_jet_run(igx_patch *pt, double *out);
+
 static int ensure_fields(igx_patch *pt, int kind)
 {
     if (pt->fields_kind == kind) return IGX_OK;
@@ -1134,7 +1136,32 @@ int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
     if (!any) { set_error("igx_load_vector_jet: all coefficients are absent"); return IGX_ERR_ARG; }
     int rc = igx_patch_set_form(pt, table);
     if (rc) return rc;
-    rc = ensure_fields(pt, IGX_FORM);
+    return load_vector_jet_run(pt, out);
+}
+
+// the same functional with its coefficients given as C expressions in x, y, z (igx_patch_set_form_expr): nothing sampled on the host
+int igx_load_vector_jet_expr(igx_patch *pt, const char *const expr[4], double *out, int *cache_hit)
+{
+    if (!pt || !expr || !out) { set_error("igx_load_vector_jet_expr: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_load_vector_jet_expr: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
+    if (int rcb = basis_orders_ok(pt, IGX_MASS, "igx_load_vector_jet_expr")) return rcb;
+    for (int r = pt->dim + 1; r < 4; ++r)
+        if (expr[r]) { set_error("igx_load_vector_jet_expr: coefficient %d does not exist in %dD", r, pt->dim); return IGX_ERR_ARG; }
+    const char *table[16];
+    for (int k = 0; k < 16; ++k) table[k] = nullptr;
+    for (int r = 0; r < 4; ++r) table[4 * r] = expr[r];
+    int rc = igx_patch_set_form_expr(pt, table, cache_hit);
+    if (rc) return rc;
+    return load_vector_jet_run(pt, out);
+}
+
+} // extern "C"
+
+// the contractions of a jet functional whose coefficients are the column 0 of the patch's form
+static int igx::load_vector_jet_run(igx_patch *pt, double *out)
+{
+    const int dim = pt->dim;
+    int rc = ensure_fields(pt, IGX_FORM);
     if (rc) return rc;
     hipStream_t st = pt->ctx->stream;
     const PatchDev &pd = pt->dev;
@@ -1155,4 +1182,3 @@ int igx_load_vector_jet(igx_patch *pt, const double *const coef[4], double *out)
     return rc;
 }
 
-} // extern "C"

@@ -366,7 +366,7 @@ def symbolic_table(expr, d, inputs):
     return [[None if e is None else symbolic.c_source(e) for e in row] for row in table]
 
 
-def functional_jet(expr, G, X, inputs):
+def functional_jet(expr, G, X, inputs, traced=False):
     """Evaluate an arity-1 form string ``(F0 * v + inner(F, grad(v))) * dx``; returns the list
     ``[F0, F_1, ..., F_d]`` of coefficient arrays on the grid (shape G) or None."""
     ns = make_namespace(G, X, inputs)
@@ -379,7 +379,10 @@ def functional_jet(expr, G, X, inputs):
         raise NotImplementedError('the form must be a volume integral (... * dx) that is linear in v')
     out = []
     for e in _jet(res.lin):
-        out.append(None if e is None or not np.any(e != 0.0) else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float))
+        if e is None or not np.any(e != 0.0):
+            out.append(None)
+        else:
+            out.append(np.broadcast_to(e, G) if traced else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float))
     return out
 
 

@@ -2095,3 +2095,28 @@ def test_auto_falls_back_to_entry_kernels(iga):
     E = asm.assemble_csr(algo='entrywise')
     assert np.array_equal(A.data, E.data) and abs(A - A.T).max() == 0.0
     assert abs(A.sum() - 1.0) <= 1e-12                    # the mass matrix of a partition of unity on the unit cube
+
+
+def test_functional_form_strings_compiled(iga, golden, monkeypatch):
+    """Arity-1 form strings with traceable inputs: the coefficients of v and grad(v) are compiled for the device
+    (igx_load_vector_jet_expr) -- the reference's vectors, and the host-sampled path gives the same ones."""
+    g = golden('forms')
+    mk = iga.bspline.make_knots
+    kv2 = (mk(3, 0.0, 1.0, 6), mk(2, 0.0, 1.0, 5))
+    ann = _geo(iga, 'quarter_annulus')
+    b2 = lambda x, y: (y * np.ones_like(x * y), (1.0 - x) * np.ones_like(x * y))
+    form, kw = '(f * v + inner(b, grad(v))) * dx', dict(f=lambda x, y: x * y ** 2, b=b2)
+    asm = iga.assemble.instantiate_assembler(form, kv2, dict(geo=ann, **kw))
+    assert asm._jet_exprs is not None
+    got = asm.assemble_vector()
+    assert _close(got, g['funcgrad_d2'], 1e-13)
+    monkeypatch.setenv('IGX_FORM_RTC', '0')
+    ref = iga.assemble.instantiate_assembler(form, kv2, dict(geo=ann, **kw))
+    assert ref._jet_exprs is None and np.abs(ref.assemble_vector() - got).max() <= 1e-13 * np.abs(got).max()
+    monkeypatch.delenv('IGX_FORM_RTC')
+    inp = form_inputs()
+    kvs, gname = _form_spaces(iga)['tbox_mixed']
+    v3 = iga.assemble.assemble('inner(b, grad(v)) * dx', kvs, geo=_geo(iga, gname), b=inp['b'])
+    assert _close(v3, g['funcgrad_d3'], 1e-13)
+    step = iga.assemble.instantiate_assembler('c * v * dx', kv2, dict(geo=ann, c=lambda x, y: np.where(x > 1.0, 1.0, 2.0 + 0.0 * y)))
+    assert step._jet_exprs is None and np.isfinite(step.assemble_vector()).all()
