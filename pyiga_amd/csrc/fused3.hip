@@ -1,0 +1,795 @@
+// k_bf3: the fused "sweep + final" stage that writes BOTH triangles of a symmetric form -- no mirror pass.
+//
+// k_bf2 (fused.hip) forms the lower triangle only; k_mirror2 then reads it back (11.9 GB at C4, 72-byte gathers) and writes
+// the upper one (6.6 GB): 3.5 ms of a 14.7 ms chain that exist only to copy.  The transposed entries are already in the
+// registers of the contractor waves when the direct ones are, and they are complete AT THE SAME STEP:
+//
+//   A block owns an outer pair (i0, j0 <= i0) and walks the mid axis.  When dof d leaves the sweep window, the K2 lines of
+//   the pairs (d + a, d) and (d, d + a), a = 0..p, are flushed.  Direct row (i0, i1, .) needs the pairs (i1, j1) for all j1:
+//   those with j1 < i1 arrived when j1 left, the others arrive when i1 leaves.  The TRANSPOSED row -- row (j0, j1, .), columns
+//   (i0, i1, .) -- needs the pairs (i1, j1) for all i1: those with i1 < j1 arrived when i1 left, the others when j1 leaves.
+//   Same schedule with the two families of lines swapped.
+//
+// So the contractors keep TWO sets of entry rings in LDS -- direct rows and transposed rows -- and every row leaves as whole
+// (2p+1)^2 segments through the same kind of store as before.  Inside a line the transposition on the last axis needs no halo:
+// the entries of target row j2 are sums over the element matrices of the spans of supp(j2), all inside the tile's window --
+// gathered with ds_bpermute from the same registers as the direct entries, in the same order of addends, so that
+// A[I, J] and A[J, I] are the same bits (exact symmetry, as assemble_entries(symmetric=True): pyiga/assemble.py:742-752).
+// On a diagonal outer block the "transposed" entries are the upper part of the same rows (one set of rings).
+//
+// What pays for the second set (160 KB of LDS were full):
+//   * rings are allocated per LINE, not per row: the line of distance delta = i1 - j1 lives delta + 1 steps, so it gets
+//     delta + 1 rotating slots (p (p + 1) / 2 + p row-lines instead of (p + 1) p); the lines of the current row need one slot
+//     (their rows are read between the barrier that ends the contraction and the one that starts the next);
+//   * no store plan: the rings are [line][row][entry], a store slot is 64 consecutive doubles of ONE line -- its LDS address is
+//     (scalar) + lane, its target (rows of (2p+1) doubles, (2p+1)^2 apart) is one multiply-add of a per-lane row constant with
+//     a scalar of the step.  Rows next to the ends of the last axis (shorter segments) go through a small table instead.
+//
+// Semantics follow combine()/entry_impl (pyiga/assemblers.pyx:1455-1540); the values are those of k_bf2 + k_mirror2 bit for bit.
+#include "igx_internal.h"
+#include "fused_common.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace igx {
+
+// SYM: 0 non-symmetric form (one set of rings, every pair direct); 1 symmetric, every outer pair diagonal (2D: one set);
+//      2 symmetric with off-diagonal outer pairs (3D: direct + transposed set)
+template <int P, int NLG, int NRO, int NCW, int SYM> struct BF3Geom {
+    static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
+    static constexpr int NSET = SYM == 2 ? 2 : 1;
+    static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
+    static constexpr int NRING = p * (p + 1) / 2 + p;       // row-lines of the ring part: line delta = 1..p has delta + 1 slots
+    static constexpr int NRL = NRING + P;                   // ... + the P lines that complete with the row itself
+    static constexpr int T0 = p * (p + 1) / 2;              // rp2[i2] = W i2 - T0 on interior rows
+    static constexpr int NEL = 2 * p * W;                   // edge-row table: (row, entry) elements of the <= 2p edge rows
+    // LDS image (doubles): lines [W][LS] | sets [NSET][NRL][R][W] | basis values [TL][P][2] | edge table (int4) [NEL]
+    static constexpr int off_sets() { return (W * LS + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_sets() + NSET * NRL * R * W + 1) & ~1; }
+    static constexpr int off_etab(int R) { return off_v2(R) + TL * P * 2; }
+    static constexpr int lds_doubles(int R) { return off_etab(R) + NEL * 2; }
+    static constexpr int rmax()
+    {
+        int R = TL / P - p;
+        while (R > 1 && lds_doubles(R) * 8 > 160 * 1024) --R;
+        return R;
+    }
+    static constexpr int RMAX = rmax();
+    static constexpr int RW = RMAX * W;                     // doubles of one row-line block [row][entry]
+    static constexpr int SETSZ = NRL * RW;
+    static constexpr int roff(int d) { return RW * ((d - 1) * (d + 2) / 2); }   // first slot of ring line delta = d
+    static constexpr int OFF_CUR = NRING * RW;              // lines of the current row: pair (d, d + a) resp. (d + a, d) at a
+    static constexpr int OFF_SETS = off_sets(), OFF_V2 = off_v2(RMAX), OFF_ETAB = off_etab(RMAX);
+    static constexpr int LDS_BYTES = lds_doubles(RMAX) * 8;
+    static constexpr int NSUB = (RW + 63) / 64;             // store chunks of a line
+    static constexpr int NECH = (NEL + 63) / 64;            // chunks of the edge-row table
+    // contractor passes (as k_bf2): pieces of PL consecutive spans of a line, 64 / PL pieces per pass, pieces overlap by p spans
+    static constexpr int npc(int pl) { return (RMAX + pl - p - 1) / (pl - p); }
+    static constexpr int npass(int pl) { return (W * npc(pl) + 64 / pl - 1) / (64 / pl); }
+    static constexpr int pick()
+    {
+        int best = 64;
+        const int cand[4] = {64, 32, 21, 16};
+        for (int i = 1; i < 4; ++i)
+            if (cand[i] > 2 * p && npass(cand[i]) < npass(best)) best = cand[i];
+        return best;
+    }
+    static constexpr int PL = pick(), PPP = 64 / PL, NPC = npc(PL), RP = PL - p;
+};
+
+struct BF3Blk {
+    int i0, j0, diag0, c0i, c0j, cj0, ci0, rlo, rhi, row_lo, nrows, stD, stT, ne;
+    long long S12;
+};
+
+typedef int bf3_v4i __attribute__((ext_vector_type(4)));
+
+// The store duty of k_bf3, carried by the contractor waves.  Behind the barrier B2 of step t the rows d = t - 1 of both sets
+// are complete: the direct row is read into registers (and its slots cleared) and stored behind the next B1, as in k_bf2 -- the
+// LDS latency lies in the barrier wait; the transposed row is read and stored at once (the sweepers flush meanwhile; the
+// registers of the element matrices are free here).  A slot is (chunk c of 64 consecutive doubles of a line block, line l): c is
+// a compile-time constant of the slot (row constants in registers, immediate offsets), l is a scalar that depends on the wave:
+// wave cw takes the lines (cw + c) % NCW + NCW j of chunk c; the lines beyond the last full round of NCW go chunk by chunk.
+#ifndef BF3_STAGE
+#define BF3_STAGE 0                                      // 1: the direct row waits in registers from B2 to the next B1 (as in k_bf2)
+#endif
+template <class Gm, int P, int NCW, int NH, int SYM>
+struct BF3Store {
+    static constexpr int p = P - 1, W = 2 * P - 1, NSUB = Gm::NSUB, RW = Gm::RW;
+    static constexpr int JF = W / NCW, LREM0 = JF * NCW, NREM = W - LREM0, NXR = (NSUB + NCW - 1) / NCW;
+    static constexpr int NST = NSUB * JF + NREM * NXR;
+    double sv[NST];
+    int rrv[NSUB];               // W i2 - T0 of this lane's row in chunk c, or a value that takes the offset out of range
+    int lane8, lanec;            // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
+    double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
+    int nD, nT;
+    int s_sK = 0, s_soff0 = 0, s_l0 = 0, s_c1 = 0;
+    bool s_on = false;
+
+    __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int lane)
+    {
+        cip rp0 = (cip)A.rp0;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) sv[k] = 0.0;
+        lane8 = lane * 8;
+        lanec = min((NSUB - 1) * 64 + lane, RW - 1) - (NSUB - 1) * 64;
+        // descriptors: base moved by W row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W i2 - T0) (c0 c1 - 1)
+        // + (chunk element index) + W (line terms); length = the row block of the outer row (anything beyond is dropped)
+        const long long shift = (long long)W * B.row_lo - Gm::T0;
+        const long long lenD = ((long long)B.c0i * B.S12 - shift) * 8, lenT = ((long long)B.c0j * B.S12 - shift) * 8;
+        pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off + shift); nD = (int)lenD;
+        pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off + shift); nT = (int)lenT;
+        const int c0min = min(B.c0i, B.c0j);
+        const int inv = (int)(max(lenD, lenT) / (8 * (c0min * P - 1))) + 1;
+#pragma unroll
+        for (int c = 0; c < NSUB; ++c) {
+            const int q = c * 64 + lane, rr = q / W, i2 = B.row_lo + rr;
+            const bool ok = q < RW && rr < B.nrows && i2 >= p && i2 <= A.N2 - 1 - p;
+            rrv[c] = ok ? W * i2 - Gm::T0 : inv;
+        }
+    }
+    __device__ __forceinline__ static bool line_ok(const int l, const int l0, const int c1) { return l >= l0 && l - l0 < c1; }
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rs(double *ptr, const int len) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, (short)0, len, 0x00020000); }
+    // line block of line l of the row in ring slots sub1.. (doubles from the start of a set); l is a scalar
+    __device__ __forceinline__ static int line_off(const int l, const int sub1, const int sub2, const int sub3, const int sub4, const int sub5)
+    {
+        int o = Gm::OFF_CUR + (l - p) * RW;
+        o = l == p - 1 ? sub1 : o;
+        if (p >= 2) o = l == p - 2 ? sub2 : o;
+        if (p >= 3) o = l == p - 3 ? sub3 : o;
+        if (p >= 4) o = l == p - 4 ? sub4 : o;
+        if (p >= 5) o = l == p - 5 ? sub5 : o;
+        return o;
+    }
+
+    // the (chunk, line) slots of this wave: values of one row of set X out of the rings (cleared where halves add) ...
+    template <int X>
+    __device__ __forceinline__ void read_row(double (&v)[NST], double *sets, const int cw, const int lane,
+                                             const int sub1, const int sub2, const int sub3, const int sub4, const int sub5)
+    {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) v[k] = 0.0;
+        // (addresses: an opaque per-lane base + the scalar line offset, the chunk is the immediate offset of the LDS instruction)
+        int lb_ = lane, lc_ = lanec;
+        asm volatile("" : "+v"(lb_), "+v"(lc_));
+        double *bs = sets + X * Gm::SETSZ + lb_, *bc = sets + X * Gm::SETSZ + (NSUB - 1) * 64 + lc_;
+#pragma unroll
+        for (int c = 0; c < NSUB; ++c)
+#pragma unroll
+            for (int j = 0; j < JF; ++j) {
+                const int l = (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j;
+                double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(l, sub1, sub2, sub3, sub4, sub5);
+                v[c * JF + j] = *src;
+                if (NH == 2) *src = 0.0;
+            }
+#pragma unroll
+        for (int lr = LREM0; lr < W; ++lr)
+#pragma unroll
+            for (int c = 0; c < NSUB; ++c)
+                if ((c + lr) % NCW == cw) {
+                    double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(lr, sub1, sub2, sub3, sub4, sub5);
+                    v[NSUB * JF + (lr - LREM0) * NXR + c / NCW] = *src;
+                    if (NH == 2) *src = 0.0;
+                }
+    }
+    // ... and to their segments: row block `ptr` of `len` bytes (0: the row is not stored), lines [l0, l0 + c1) exist
+    __device__ __forceinline__ void write_row(const double (&v)[NST], double *ptr, const int len, const int cw, const int l0, const int c1, const int sK, const int soff0) const
+    {
+        int voff[NSUB];
+#pragma unroll
+        for (int c = 0; c < NSUB; ++c) {
+            voff[c] = (int)__umul24((unsigned)rrv[c], (unsigned)sK) + lane8;
+            asm volatile("" : "+v"(voff[c]));               // (+ c * 512 below is the store's immediate offset, not another register)
+        }
+#pragma unroll
+        for (int c = 0; c < NSUB; ++c)
+#pragma unroll
+            for (int j = 0; j < JF; ++j) {
+                const int l = (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j;
+                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * l, v[c * JF + j]);
+            }
+#pragma unroll
+        for (int lr = LREM0; lr < W; ++lr)
+#pragma unroll
+            for (int c = 0; c < NSUB; ++c)
+                if ((c + lr) % NCW == cw)
+                    bf2_buffer_store(rs(ptr, line_ok(lr, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * lr, v[NSUB * JF + (lr - LREM0) * NXR + c / NCW]);
+    }
+
+    // behind B1: the direct row read at the end of the last step goes out (BF3_STAGE)
+    __device__ __forceinline__ void issue(const int cw)
+    {
+        if (BF3_STAGE) write_row(sv, pD, s_on ? nD : 0, cw, s_l0, s_c1, s_sK, s_soff0);
+    }
+
+    // behind B2 of step t: rows d = t - 1 of both sets are complete
+    __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, const bf3_v4i *etab, const int t, const int cw, const int lane)
+    {
+        cip rp1 = (cip)A.rp1;
+        const int d = t - 1;
+        const bool on = d >= B.rlo && d < B.rhi;
+        const int dc = min(max(d, 0), A.N1 - 1);
+        const int jl1 = max(dc - p, 0), c1 = min(dc + p, A.N1 - 1) - jl1 + 1, l0 = p - (dc - jl1);
+        const int rp1d = rp1[dc];
+        // slot of row d in ring line delta (named scalars: see the contraction)
+        const int sub1 = Gm::roff(1) + (int)((unsigned)dc % 2u) * RW, sub2 = Gm::roff(2) + (int)((unsigned)dc % 3u) * RW;
+        const int sub3 = Gm::roff(3) + (int)((unsigned)dc % 4u) * RW, sub4 = Gm::roff(4) + (int)((unsigned)dc % 5u) * RW;
+        const int sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
+        // ---- FIRST (the row passes below clear whole line blocks where halves add): rows next to the ends of the last axis
+        //      (segments of fewer than 2p + 1 columns): element (row, entry) of the
+        //      table per lane, one line per slot; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift
+        //      folded into the table
+        if (B.ne > 0) {
+#pragma unroll
+            for (int X = 0; X < Gm::NSET; ++X) {
+                if (X == 0 ? !B.stD : !B.stT) continue;
+                const int c0x = X == 0 ? B.c0i : B.c0j, cx = X == 0 ? B.cj0 : B.ci0;
+                double *px = X == 0 ? pD : pT;
+                const int nx = X == 0 ? nD : nT;
+                const unsigned sA = (unsigned)(c0x * c1);
+                const int soffr = 8 * (int)((long long)c0x * A.S2) * rp1d;
+                for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W; l += NCW) {
+                    const unsigned sB = (unsigned)max(cx * c1 + l - l0, 0);
+                    const __amdgpu_buffer_rsrc_t dsc = rs(px, (on && line_ok(l, l0, c1)) ? nx : 0);
+                    double *lb = sets + X * Gm::SETSZ + line_off(l, sub1, sub2, sub3, sub4, sub5);
+                    for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
+                        const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
+                        const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
+                        double *src = lb + e.x;
+                        const double v = *src;
+                        if (NH == 2 && ok) *src = 0.0;
+                        const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
+                        bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
+                    }
+                }
+            }
+        }
+        // ---- direct row
+        if (B.stD) {
+            const int sK = 8 * (B.c0i * c1 - 1);
+            const int soff0 = 8 * ((int)((long long)B.c0i * A.S2) * rp1d + W * (B.cj0 * c1 - l0));
+            if (BF3_STAGE) {
+                s_on = on; s_l0 = l0; s_c1 = c1; s_sK = sK; s_soff0 = soff0;
+                read_row<0>(sv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
+            } else {
+                double tv[NST];
+                read_row<0>(tv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
+                write_row(tv, pD, on ? nD : 0, cw, l0, c1, sK, soff0);
+            }
+        }
+        // ---- transposed row: read and stored at once
+        if (SYM == 2 && B.stT) {
+            const int sK = 8 * (B.c0j * c1 - 1);
+            const int soff0 = 8 * ((int)((long long)B.c0j * A.S2) * rp1d + W * (B.ci0 * c1 - l0));
+            double tv[NST];
+            read_row<1>(tv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
+            write_row(tv, pT, on ? nT : 0, cw, l0, c1, sK, soff0);
+        }
+    }
+};
+
+// sweepers: as in k_bf2 (fused.hip), without the store duty
+template <int P, int MASK, int RI, int NA, int NLG>
+__device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
+                                            const int rhi, double *lines, const int LS)
+{
+    constexpr BFRole R = bf_role(MASK, RI);
+    constexpr int p = P - 1, TL = 64 * NLG;
+    BF_STAMP_DECL
+    __builtin_amdgcn_s_setprio(BF2_PRIO_S);
+    cdp V1 = (cdp)A.V1;
+    double acc[P][P];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+    __amdgpu_buffer_rsrc_t rsrc[4][NA];
+    int urs[4][NA];
+    const int voff = g2 * 8;
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            urs[t1][i] = A.rs[R.y][t1][i] * 8;
+            rsrc[t1][i] = bf2_rsrc(A.sp[R.y][t1][i] + (long long)r0 * A.ss[R.y][t1][i] - (long long)A.gmid_lo * A.rs[R.y][t1][i]);
+        }
+    auto ld = [&](const int t1, const int i, const int row) {
+        return bf2_buffer_load(rsrc[t1][i], voff, row * urs[t1][i]);
+    };
+    const int n_sw = min(A.n1, A.span_hi);
+    const int t_sw = min(n_sw, rhi);
+    double kv[P][4][NA];
+    {
+        const int s = min(s_begin, t_sw - 1);
+#pragma unroll
+        for (int l = 0; l < P; ++l)
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1)
+                if (R.has[t1])
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * P + l);
+    }
+    auto flush = [&]() {
+        double *ln = lines + RI * TL + g2l;
+#pragma unroll
+        for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
+#pragma unroll
+        for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
+#pragma unroll
+        for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+        for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
+    };
+    int t = s_begin;
+    for (; t < t_sw; ++t) {
+        bar_lds();                                       // B1
+        const int tn = min(t + 1, t_sw - 1);
+        cdp cf = V1 + (size_t)t * P * P * 2;
+        double v[P][2];
+#pragma unroll
+        for (int b = 0; b < P; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
+#pragma unroll
+        for (int l = 0; l < P; ++l) {
+            double vn[P][2];
+            const int ln_ = l + 1 < P ? l + 1 : l;
+#pragma unroll
+            for (int b = 0; b < P; ++b) { vn[b][0] = cf[(ln_ * P + b) * 2]; vn[b][1] = cf[(ln_ * P + b) * 2 + 1]; }
+            double kt[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t1 = 0; t1 < 4; ++t1)
+                if (R.has[t1]) {
+                    kt[t1] = kv[l][t1][0];
+                    if constexpr (NA == 2) kt[t1] += kv[l][t1][1];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, tn * P + l);
+                }
+            if (R.shape == 1) {
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    double w;
+                    if (R.has[2 * R.f] && R.has[2 * R.f + 1]) w = fma(v[b][1], kt[2 * R.f + 1], v[b][0] * kt[2 * R.f]);
+                    else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
+                    else w = v[b][1] * kt[2 * R.f + 1];
+#pragma unroll
+                    for (int a = 0; a < P; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
+                }
+            } else {
+#pragma unroll
+                for (int tu = 0; tu < 2; ++tu) {
+                    if (!(R.has[tu] || R.has[tu + 2])) continue;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        double c;
+                        if (R.has[tu] && R.has[tu + 2]) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
+                        else if (R.has[tu]) c = v[a][0] * kt[tu];
+                        else c = v[a][1] * kt[tu + 2];
+#pragma unroll
+                        for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+#pragma unroll
+                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+#pragma unroll
+            for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
+        }
+        bar_lds();                                       // B2: the contractors have read the previous lines
+        flush();
+    }
+    for (; t < rhi; ++t) { bar_lds(); bar_lds(); flush(); }   // spans past the end of the axis: the window only drains
+    for (; t < rhi + 1; ++t) { bar_lds(); bar_lds(); }        // the contractors finish the last row
+    BF_STAMP_END(threadIdx.x >> 6);
+}
+
+template <int P, int MASK, int NA, int NLG, int RI, bool END = (RI >= bf_nroles(MASK))>
+struct BF3SweepDispatch {
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    {
+        if (role == RI) bf3_sweeper<P, MASK, RI, NA, NLG>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
+        else BF3SweepDispatch<P, MASK, NA, NLG, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+    }
+};
+template <int P, int MASK, int NA, int NLG, int RI>
+struct BF3SweepDispatch<P, MASK, NA, NLG, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+};
+
+
+// One unit of the contraction: 64 (line, span) items -- the element matrices of a pass (H = 0) or of one half of their rows
+// (H = 1: rows 0 .. AH-1, H = 2: rows AH .. p; the halves ADD their entries into the rings) -- gathered into the entries of the
+// direct and of the transposed row of each lane.
+struct BF3Unit {
+    const double *lines, *V2s;
+    double *sets;
+    int dd, rlo, rhi, N1, row_lo, nrows, lane, npieces;
+    int diag0, stD, stT;
+    int rbs1, rbs2, rbs3, rbs4, rbs5;     // ring slot (doubles from the start of a set) of the row parked in ring line delta
+};
+template <class Gm, int P, int NY, int MASK, int SYM, int H>
+__device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
+{
+    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, LS = Gm::LS, RW = Gm::RW, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
+    constexpr int AH = (P + 1) / 2;
+    constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P;
+    const int lane = U.lane, dd = U.dd;
+    int ln_ = min(lane, PPP * PL - 1);
+    asm volatile("" : "+v"(ln_));
+    const int ps = ln_ / PL, x = ln_ - ps * PL;
+    const int pid = pass * PPP + ps;
+    const int k9 = pid / NPC, pj = pid - k9 * NPC;
+    const int s1 = pj * RP + x;
+    const bool colt = k9 <= p;                             // pair (dd + la, dd); else (dd, dd + la)
+    const int la = colt ? k9 : k9 - p;
+    const int row1 = colt ? dd + la : dd, col1 = colt ? dd : dd + la;
+    // EVERY lane forms its element matrix (a span outside the axis has zero basis values in V2s; a lane without a valid item
+    // computes something that is never stored); the LDS addresses are kept inside the image
+    const double *kl = U.lines + min(k9, W - 1) * LS + min(s1, TL / P - 1) * P, *vl = U.V2s + min(s1, TL / P - 1) * P * P * 2;
+    double loc[A1 - A0][P];
+    bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
+    const int r3 = s1 - p;                                 // row of the tile (this lane's span is the first of its support)
+    const bool item = lane < PPP * PL && pid < U.npieces && x >= p && r3 < U.nrows;
+    const int oshv = max(p - (U.row_lo + r3), 0);
+    int rb = U.rbs1;
+    if (p >= 2) rb = la == 2 ? U.rbs2 : rb;
+    if (p >= 3) rb = la == 3 ? U.rbs3 : rb;
+    if (p >= 4) rb = la == 4 ? U.rbs4 : rb;
+    if (p >= 5) rb = la == 5 ? U.rbs5 : rb;
+    const int cb = Gm::OFF_CUR + la * RW;
+    // ---- direct entries of row i2 = this lane's row: entry o = b - a + p from the element matrix of span i2 - a
+    if (U.stD) {
+        double out[W];
+#pragma unroll
+        for (int a = A0; a < A1; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) {
+                if (a == 0) out[b + p] = loc[0][b];
+                else if (a == A0 || b == 0) out[b - a + p] = bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
+                else out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
+            }
+        if (item && row1 >= U.rlo && row1 < U.rhi && col1 < U.N1) {
+            double *dste = U.sets + ((colt && la > 0) ? rb : cb) + r3 * W - oshv;
+            constexpr int OLO = H == 0 ? 0 : p - (A1 - 1), OHI = H == 0 ? 2 * p : 2 * p - A0;
+            if (SYM != 0 && U.diag0) {
+                // the diagonal line of a diagonal block: entries j2 <= i2 are direct, the others come transposed (below)
+                const int omax = la == 0 ? p : 2 * p;
+#pragma unroll
+                for (int o = OLO; o <= OHI; ++o)
+                    if (o >= oshv && o <= omax) {
+                        if (H == 0) dste[o] = out[o];
+                        else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            } else if (H == 0) {
+                if (U.row_lo >= p) {
+#pragma unroll
+                    for (int o = 0; o < W; ++o) dste[o] = out[o];
+                } else {
+#pragma unroll
+                    for (int o = 0; o < W; ++o)
+                        if (o >= oshv) dste[o] = out[o];
+                }
+            } else {
+#pragma unroll
+                for (int o = OLO; o <= OHI; ++o)
+                    if (o >= oshv) (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    // (the transposed gather starts when the direct entries are on their way to LDS: both sets of entries live at once do not
+    // fit the 128 registers of a contractor wave)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < A1 - A0; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) asm volatile("" : "+v"(loc[a][b]));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- transposed entries: target row j2 = this lane's row, entry e <-> source row i2 = j2 + e - p; the addend of span j2 - b
+    //      is loc[e - p + b][b] of the lane b places below -- the same addends in the same order as the direct entry o = 2p - e of
+    //      row i2, hence the same bits
+    if (SYM != 0 && (U.diag0 ? U.stD : U.stT)) {
+        double outT[W];
+#pragma unroll
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+            for (int a = A0; a < A1; ++a) {
+                if (b == 0) outT[a + p] = loc[a - A0][0];
+                else if (a == A0) outT[a + p - b] = bf2_from_lane(((lane - b) & 63) * 4, loc[0][b]);
+                else outT[a + p - b] += bf2_from_lane(((lane - b) & 63) * 4, loc[a - A0][b]);
+            }
+        if (item && col1 >= U.rlo && col1 < U.rhi && row1 < U.N1) {
+            constexpr int ELO = H == 0 ? 0 : A0, EHI = H == 0 ? 2 * p : A1 - 1 + p;
+            if (U.diag0) {
+                // upper part of row dd of the same block: the line of column dd + la; on the diagonal line only j2 > i2
+                double *dste = U.sets + cb + r3 * W - oshv;
+                const int emin = la == 0 ? p + 1 : oshv;
+#pragma unroll
+                for (int e = ELO; e <= EHI; ++e)
+                    if (e >= emin) {
+                        if (H == 0) dste[e] = outT[e];
+                        else (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            } else {
+                double *dste = U.sets + Gm::SETSZ + (colt ? cb : rb) + r3 * W - oshv;
+                if (H == 0) {
+                    if (U.row_lo >= p) {
+#pragma unroll
+                        for (int e = 0; e < W; ++e) dste[e] = outT[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < W; ++e)
+                            if (e >= oshv) dste[e] = outT[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = ELO; e <= EHI; ++e)
+                        if (e >= oshv) (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+}
+
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM>
+__global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(const BFArgs A)
+{
+    using Gm = BF3Geom<P, NLG, bf_nroles(MASK), NCW, SYM>;
+    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
+    constexpr int RW = Gm::RW, PPP = Gm::PPP, NPC = Gm::NPC;
+    constexpr int LS = Gm::LS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *lines = lds;                 // [W][LS]
+    double *sets = lds + Gm::OFF_SETS;   // [NSET][NRL][RMAX][W]
+    double *V2s = lds + Gm::OFF_V2;      // [TL][P][2]
+    bf3_v4i *etab = (bf3_v4i *)(lds + Gm::OFF_ETAB);   // [NEL] {ring offset of the element, 8 rp2[i2], 8 c2, 8 (entry - shift) | out of range}
+
+    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned bid = blockIdx.x;
+    const bool tail = A.tail_k > 0 && bid >= A.main_blocks;
+    {
+        const unsigned per = (A.tail_k > 0 ? A.main_blocks : gridDim.x) / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    int mch, mrows;
+    if (tail) {
+        const unsigned t = bid - A.main_blocks;
+        mch = (int)(t % (unsigned)A.tail_k); mrows = A.tail_mrows;
+        bid = A.main_blocks + t / (unsigned)A.tail_k;
+    } else { mch = (int)((bid / A.ntiles) % A.nmchunks); mrows = A.mrows; }
+    const int tile = (int)(bid % A.ntiles);
+    const int r0 = (int)(bid / ((unsigned)A.ntiles * (tail ? 1 : A.nmchunks)));
+    const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
+    const bool diag0 = SYM != 0 && i0 == j0;
+    const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
+    const int sp_lo = row_lo - p;
+    const int win0 = sp_lo * P;
+    const int rlo = A.mid_lo + mch * mrows, rhi = min(rlo + mrows, A.mid_hi);
+    const int s_begin = max(rlo - p, 0);
+
+    for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) {
+        const int gpt = win0 + idx / (2 * P);
+        V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P * 2 + idx] : 0.0;
+    }
+    if (NH == 2)
+        for (int idx = threadIdx.x; idx < Gm::OFF_V2 - Gm::OFF_SETS; idx += blockDim.x) sets[idx] = 0.0;     // the halves of a pass add onto zeros
+    // edge rows of the tile: i2 < p or i2 > N2 - 1 - p
+    const int lo_n = max(0, min(row_hi, min(p, A.N2)) - row_lo);          // low edge rows start at row_lo (tile 0 only)
+    const int hi_s = max(max(p, A.N2 - p), row_lo), hi_n = max(0, row_hi - hi_s);
+    const int ne = lo_n + hi_n;
+    if (threadIdx.x < Gm::NEL) {
+        const int k = threadIdx.x / W, e = threadIdx.x - k * W;
+        bf3_v4i v; v.x = 0; v.y = 0; v.z = 0; v.w = BF2_OOB;
+        if (k < ne) {
+            const int i2 = k < lo_n ? row_lo + k : hi_s + (k - lo_n);
+            const int jl2 = max(i2 - p, 0), c2 = min(i2 + p, A.N2 - 1) + 1 - jl2;
+            if (e < c2) {
+                const int shift = W * row_lo - Gm::T0;
+                v.x = (i2 - row_lo) * W + e; v.y = 8 * A.rp2[i2]; v.z = 8 * c2; v.w = 8 * (e - shift);
+            }
+        }
+        etab[threadIdx.x] = v;
+    }
+    // (the barrier B1 of the first iteration orders these writes before their first use)
+
+    int task = wave;
+    if (NR == 4 && NLG == 2 && NCW == 8) {
+        constexpr int tmap[16] = {0, 1, 2, 3, 6, 7, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15};
+        task = tmap[wave & 15];
+    } else if (NR == 4 && NLG == 3 && NCW == 4) {
+        // (waves w, w + 4, w + 8, w + 12 share a SIMD; tasks 0-2 role 0, 3-5 role 1, 6-8 role 2, 9-11 role 3, 12-15 contractors)
+        constexpr int tmap[16] = {12, 13, 14, 15, 9, 3, 0, 2, 10, 4, 1, 7, 11, 6, 5, 8};
+        task = tmap[wave & 15];
+    } else if (NR == 4 && NLG == 2 && NCW == 4) {
+        const int sd = wave & 3, k = wave >> 2;
+        if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
+        else task = k < 2 ? k : NSW + 3;
+    }
+    if (task < NSW) {
+        const int role = task / NLG, lg = task % NLG;
+        const int g2l = lg * 64 + lane;
+        const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
+        BF3SweepDispatch<P, MASK, NA, NLG, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        return;
+    }
+
+    // ---------------- contractors
+    const int cw = task - NSW;
+    BF3Blk B;
+    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.c0j = jhi0[j0] - jlo0[j0];
+    B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
+    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne;
+    B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
+    B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
+    BF_STAMP_DECL
+    __builtin_amdgcn_s_setprio(BF2_PRIO_C);
+    BF3Store<Gm, P, NCW, NH, SYM> store;
+    store.init(A, B, lane);
+    const int nlines = diag0 ? P : W;                     // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
+    const int npieces = nlines * NPC;
+    for (int t = s_begin; t < rhi + 1; ++t) {
+        bar_lds();                                        // B1: the lines of flush t-1 are in LDS
+        store.issue(cw);
+        const int dd = t - 1;
+        if (dd >= s_begin && dd < rhi) {
+            // ring slot of the row a line is parked for: row dd + delta of ring line delta
+            // (named scalars, not an array: the select by the lane's line must stay a chain of v_cndmask)
+            BF3Unit U;
+            U.lines = lines; U.V2s = V2s; U.sets = sets; U.dd = dd; U.rlo = rlo; U.rhi = rhi; U.N1 = A.N1; U.row_lo = row_lo; U.nrows = nrows;
+            U.lane = lane; U.npieces = npieces; U.diag0 = diag0; U.stD = B.stD; U.stT = B.stT;
+            U.rbs1 = Gm::roff(1) + (int)((unsigned)(dd + 1) % 2u) * RW; U.rbs2 = Gm::roff(2) + (int)((unsigned)(dd + 2) % 3u) * RW;
+            U.rbs3 = Gm::roff(3) + (int)((unsigned)(dd + 3) % 4u) * RW; U.rbs4 = Gm::roff(4) + (int)((unsigned)(dd + 4) % 5u) * RW;
+            U.rbs5 = Gm::roff(5) + (int)((unsigned)(dd + 5) % 6u) * RW;
+            const int npass = (npieces + PPP - 1) / PPP;
+            const int wslot = (int)((unsigned)(cw + t) % (unsigned)NCW);
+            if (NH == 1 || npass <= NCW) {
+                for (int pass = wslot; pass < npass; pass += NCW) bf3_unit<Gm, P, NY, MASK, SYM, 0>(U, pass);
+            } else {
+                bf3_unit<Gm, P, NY, MASK, SYM, 0>(U, wslot);
+                const int nsp = npass - NCW;
+                for (int u = wslot; u < 2 * nsp; u += NCW) {
+                    if (u < nsp) bf3_unit<Gm, P, NY, MASK, SYM, 2>(U, NCW + u);
+                    else bf3_unit<Gm, P, NY, MASK, SYM, 1>(U, NCW + u - nsp);
+                }
+            }
+        }
+        bar_lds();                                        // B2: lines may be overwritten, entries are visible
+        store.fetch(A, B, sets, etab, t, cw, lane);
+    }
+    store.issue(cw);                                      // the last row
+    BF_STAMP_END(wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+// k_bf3 multiplies a per-lane row constant (W i2 - T0, or an out-of-range marker) with a scalar of the step in 24 x 24 bits and
+// relies on the descriptor's range check to drop what must not be stored: the marker times the smallest scalar must pass the
+// end of a row block, times the largest one (plus the scalar offset) stay below 2^32.
+bool fused3_offsets_fit(int dim, int p0, int p, long long S_mid, long long S_last, long long N_last)
+{
+    const long long c0max = dim == 3 ? 2 * p0 + 1 : 1, c0min = dim == 3 ? p0 + 1 : 1;
+    const long long P = p + 1, W = 2 * p + 1;
+    const long long len = (c0max * S_mid * S_last + W * 64) * 8;
+    if (len > 900000000LL) return false;
+    if (c0min * P - 1 < 1) return false;
+    const long long inv = len / (8 * (c0min * P - 1)) + 1;
+    if (inv >= (1LL << 24) || W * N_last >= (1LL << 24)) return false;
+    if (inv * 8 * (c0max * W - 1) + len + 65536 >= (1LL << 32)) return false;
+    return true;
+}
+
+template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM>
+static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
+{
+    using Gm = BF3Geom<P, NLG, bf_nroles(MASK), NCW, SYM>;
+    constexpr size_t lds = (size_t)Gm::LDS_BYTES;
+    static_assert(lds <= 160 * 1024, "k_bf3: LDS");
+    static_assert(Gm::NSET * Gm::SETSZ * 8 < 65536 * 2, "k_bf3: ring sets");
+    static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf3: block size");
+    static_assert(NCW == 4 || NCW == 8, "k_bf3: contractor waves");
+    static_assert(Gm::NSUB * 512 <= 4096, "k_bf3: immediate offsets of the stores");
+    static_assert(Gm::NEL <= 1024, "k_bf3: edge table");
+    constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
+    const void *fn = (const void *)k_bf3<P, NY, MASK, NA, NLG, NCW, NH, SYM>;
+    IGX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1, ncu = ncu_ctx;
+    {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nthreads, lds) == hipSuccess && occ >= 1) per_cu = occ;
+        if (ncu < 1) ncu = 256;
+    }
+    BFArgs A = A0;
+    A.ntiles = (A.N2 + Gm::RMAX - 1) / Gm::RMAX;
+    A.R2 = (A.N2 + A.ntiles - 1) / A.ntiles;
+    bf2_choose_chunks(A, (long long)per_cu * ncu, P);
+    long long nblocks = (long long)A.npairs * A.ntiles * A.nmchunks;
+    if (A.tail_k > 0) nblocks = A.main_blocks + (nblocks - A.main_blocks) * A.tail_k;
+    if (nblocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
+    if (nblocks == 0) return IGX_OK;
+    k_bf3<P, NY, MASK, NA, NLG, NCW, NH, SYM><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
+constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
+
+// shapes (lane groups per role, contractor waves, halved passes): those of k_bf2 (fused.hip, BF2Cfg)
+template <int P, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
+template <int P> struct BF3Cfg<P, BF_MASK_MASS> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1; };
+template <int P> struct BF3Cfg<P, BF_MASK_STIFF3> {
+    static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 4 : P == 4 ? 8 : 4, NH = P == 5 ? 2 : 1;
+};
+template <int P> struct BF3Cfg<P, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
+
+template <int P, int NY, int MASK>
+static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk)
+{
+    using C = BF3Cfg<P, MASK>;
+    if (symk == 2) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2>(st, A, ncu);
+    return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1>(st, A, ncu);
+}
+template <int P>
+static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk)
+{
+    if (ny == 1 && mask == BF_MASK_MASS) return launch_bf3_c<P, 1, BF_MASK_MASS>(st, A, ncu, symk);
+    if (ny == 4 && mask == BF_MASK_STIFF3) return launch_bf3_c<P, 4, BF_MASK_STIFF3>(st, A, ncu, symk);
+    if (ny == 4 && mask == BF_MASK_STIFF2) return launch_bf3_c<P, 4, BF_MASK_STIFF2>(st, A, ncu, symk);
+    set_error("fused stage: no kernel for this set of types");
+    return IGX_ERR_UNSUPPORTED;
+}
+
+// the symmetric forms (mass, stiffness; 2D and 3D) with one input array per slot
+bool fused3_supported(const BFInputs &in)
+{
+    if (!in.sym) return false;
+    int mask = 0, ymax = 0;
+    for (int y = 0; y < 4; ++y)
+        for (int t1 = 0; t1 < 4; ++t1) {
+            if (in.slot_n[y][t1] > 1) return false;
+            if (in.slot_n[y][t1] > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }
+        }
+    return (ymax == 0 && mask == BF_MASK_MASS) || mask == BF_MASK_STIFF3 || mask == BF_MASK_STIFF2;
+}
+
+int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data)
+{
+    const Axis &AM = *in.mid, &AL = *in.last;
+    BFArgs A{};
+    int mask = 0, ymax = 0;
+    for (int y = 0; y < 4; ++y)
+        for (int t1 = 0; t1 < 4; ++t1) {
+            const int n = in.slot_n[y][t1];
+            if (n > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }
+            for (int i = 0; i < 2; ++i) {
+                if (i < n) { A.sp[y][t1][i] = in.slot_ptr[y][t1][i]; A.ss[y][t1][i] = in.slice_stride; A.rs[y][t1][i] = AL.G; }
+                else { A.sp[y][t1][i] = in.zeros; A.ss[y][t1][i] = 0; A.rs[y][t1][i] = 0; }
+            }
+        }
+    const int ny = ymax == 0 ? 1 : 4;
+    A.gmid_lo = in.gmid_lo; A.G2 = AL.G;
+    A.V1 = AM.d_V; A.V2 = AL.d_V;
+    A.n1 = AM.n; A.N1 = AM.N; A.n2 = AL.n; A.N2 = AL.N;
+    A.rp1 = AM.dev.rp; A.rp2 = AL.dev.rp;
+    A.pl0 = in.pl0; A.rp0 = in.rp0; A.jlo0 = in.jlo0; A.jhi0 = in.jhi0;
+    A.S1 = AM.S; A.S2 = AL.S; A.nnz_off = pt->nnz_off;
+    A.data = d_data; A.sym = in.sym;
+    A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
+    A.npairs = in.npairs;
+    if (pt->dim == 3) { A.own_lo = pt->r0_lo; A.own_hi = pt->r0_hi; } else { A.own_lo = 0; A.own_hi = 1; }
+    const int symk = pt->dim == 3 ? 2 : 1;
+    switch (AL.P) {
+    case 2: return launch_bf3_p<2>(st, A, ny, mask, pt->ctx->ncu, symk);
+    case 3: return launch_bf3_p<3>(st, A, ny, mask, pt->ctx->ncu, symk);
+    case 4: return launch_bf3_p<4>(st, A, ny, mask, pt->ctx->ncu, symk);
+    case 5: return launch_bf3_p<5>(st, A, ny, mask, pt->ctx->ncu, symk);
+    case 6: return launch_bf3_p<6>(st, A, ny, mask, pt->ctx->ncu, symk);
+    default: set_error("fused stage: degree %d unsupported", AL.P - 1); return IGX_ERR_UNSUPPORTED;
+    }
+}
+
+} // namespace igx

@@ -369,6 +369,7 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
         if (const char *e = getenv("IGX_FINAL")) k.final_sel = !strcmp(e, "q") ? 1 : !strcmp(e, "valu") ? 2 : !strcmp(e, "mfma") ? 3 : 1;
         if (const char *e = getenv("IGX_ENTRIES")) k.entries_thread = !strcmp(e, "thread");
         k.poison = getenv("IGX_DEBUG_POISON") != nullptr;
+        if (const char *e = getenv("IGX_BF")) k.bf = atoi(e);
         if (const char *e = getenv("IGX_PLACEMENT_TRIES")) k.placement_tries = std::max(1, std::min(16, atoi(e)));
         if (const char *e = getenv("IGX_STAGE_EVENTS")) k.stage_events = strcmp(e, "0") != 0;
     }

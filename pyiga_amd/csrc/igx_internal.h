@@ -123,6 +123,7 @@ struct igx_knobs {
     int final_sel = 0;                        // IGX_FINAL: 0 default, 1 q, 2 valu, 3 mfma (any choice implies the stage kernels)
     int entries_thread = 0;                   // IGX_ENTRIES=thread: one thread per entry (the reference's summation order)
     int poison = 0;                           // IGX_DEBUG_POISON: NaN-fill the CSR values before an assembly (tests)
+    int bf = 0;                               // IGX_BF=2: symmetric 3D forms through k_bf2 + the mirror pass (the chain of rounds 3-4) instead of k_bf3
     int placement_tries = 1;                  // IGX_PLACEMENT_TRIES=n (opt-in, 3D symmetric forms): the CSR value buffer is the fastest of n
                                               // allocations under the mirror pass, timed once at its first assembly
     int stage_events = -1;                    // IGX_STAGE_EVENTS: events between the kernels of a chain (per-kernel device times in
@@ -279,6 +280,10 @@ int fused_supported(const BFInputs &in);
 bool fused_offsets_fit(long long c0max, long long S_mid, long long S_last, long long G_mid, long long G_last);
 int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
+// k_bf3 (fused3.hip): the fused stage of the symmetric forms that writes both triangles itself (no mirror pass)
+bool fused3_supported(const BFInputs &in);
+bool fused3_offsets_fit(int dim, int p0, int p, long long S_mid, long long S_last, long long N_last);
+int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);
 int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
