@@ -80,7 +80,7 @@ template <int P, int NLG, int NRO, int NCW, int SYM> struct BF3Geom {
 };
 
 struct BF3Blk {
-    int i0, j0, diag0, c0i, c0j, cj0, ci0, rlo, rhi, row_lo, nrows, stD, stT, ne;
+    int i0, j0, diag0, c0i, c0j, cj0, ci0, rlo, rhi, row_lo, nrows, stD, stT, ne, emask;
     long long S12;
 };
 
@@ -177,6 +177,9 @@ struct BF3Store {
     // ... and to their segments: row block `ptr` of `len` bytes (0: the row is not stored), lines [l0, l0 + c1) exist
     __device__ __forceinline__ void write_row(const double (&v)[NST], double *ptr, const int len, const int cw, const int l0, const int c1, const int sK, const int soff0) const
     {
+#ifdef BF3_NOSTORE
+        return;                                              // (timing experiment: tools/buildvar.sh)
+#endif
         int voff[NSUB];
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
@@ -217,11 +220,11 @@ struct BF3Store {
         const int sub1 = Gm::roff(1) + (int)((unsigned)dc % 2u) * RW, sub2 = Gm::roff(2) + (int)((unsigned)dc % 3u) * RW;
         const int sub3 = Gm::roff(3) + (int)((unsigned)dc % 4u) * RW, sub4 = Gm::roff(4) + (int)((unsigned)dc % 5u) * RW;
         const int sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
-        // ---- FIRST (the row passes below clear whole line blocks where halves add): rows next to the ends of the last axis
-        //      (segments of fewer than 2p + 1 columns): element (row, entry) of the
-        //      table per lane, one line per slot; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift
-        //      folded into the table
-        if (B.ne > 0) {
+        // ---- FIRST: rows next to the ends of the last axis (segments of fewer than 2p + 1 columns): element (row, entry) of the
+        //      table per lane; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift folded into the table.
+        //      The elements of chunk c of line l are taken by the wave that owns the slot (c, l) of the row passes below, BEFORE its
+        //      own pass over that slot: those passes clear whole chunks where halves add, and waves are not ordered among themselves.
+        if (B.emask != 0) {
 #pragma unroll
             for (int X = 0; X < Gm::NSET; ++X) {
                 if (X == 0 ? !B.stD : !B.stT) continue;
@@ -230,18 +233,23 @@ struct BF3Store {
                 const int nx = X == 0 ? nD : nT;
                 const unsigned sA = (unsigned)(c0x * c1);
                 const int soffr = 8 * (int)((long long)c0x * A.S2) * rp1d;
-                for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W; l += NCW) {
-                    const unsigned sB = (unsigned)max(cx * c1 + l - l0, 0);
-                    const __amdgpu_buffer_rsrc_t dsc = rs(px, (on && line_ok(l, l0, c1)) ? nx : 0);
-                    double *lb = sets + X * Gm::SETSZ + line_off(l, sub1, sub2, sub3, sub4, sub5);
-                    for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
-                        const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
-                        const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
-                        double *src = lb + e.x;
-                        const double v = *src;
-                        if (NH == 2 && ok) *src = 0.0;
-                        const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
-                        bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
+                for (int c = 0; c < NSUB; ++c) {
+                    if (!((B.emask >> c) & 1)) continue;
+                    for (int j = 0; j < JF + NREM; ++j) {
+                        const int l = j < JF ? (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j : LREM0 + (j - JF);
+                        if (j >= JF && (c + l) % NCW != cw) continue;
+                        const unsigned sB = (unsigned)max(cx * c1 + l - l0, 0);
+                        const __amdgpu_buffer_rsrc_t dsc = rs(px, (on && line_ok(l, l0, c1)) ? nx : 0);
+                        double *lb = sets + X * Gm::SETSZ + line_off(l, sub1, sub2, sub3, sub4, sub5);
+                        for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
+                            const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
+                            const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB && (e.x >> 6) == c;
+                            double *src = lb + e.x;
+                            const double v = *src;
+                            if (NH == 2 && ok) *src = 0.0;
+                            const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
+                            bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
+                        }
                     }
                 }
             }
@@ -260,7 +268,11 @@ struct BF3Store {
             }
         }
         // ---- transposed row: read and stored at once
+#ifdef BF3_NOT
+        if (false) {
+#else
         if (SYM == 2 && B.stT) {
+#endif
             const int sK = 8 * (B.c0j * c1 - 1);
             const int soff0 = 8 * ((int)((long long)B.c0j * A.S2) * rp1d + W * (B.ci0 * c1 - l0));
             double tv[NST];
@@ -491,7 +503,11 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     // ---- transposed entries: target row j2 = this lane's row, entry e <-> source row i2 = j2 + e - p; the addend of span j2 - b
     //      is loc[e - p + b][b] of the lane b places below -- the same addends in the same order as the direct entry o = 2p - e of
     //      row i2, hence the same bits
+#ifdef BF3_NOT
+    if (SYM != 0 && U.diag0 && U.stD) {                     // (timing experiment: no transposed rows of off-diagonal blocks)
+#else
     if (SYM != 0 && (U.diag0 ? U.stD : U.stT)) {
+#endif
         double outT[W];
 #pragma unroll
         for (int b = 0; b < P; ++b)
@@ -623,6 +639,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.c0j = jhi0[j0] - jlo0[j0];
     B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
     B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne;
+    B.emask = 0;                                          // store chunks (64 doubles of a line block) that hold entries of edge rows
+    for (int k = 0; k < ne; ++k) {
+        const int rr = (k < lo_n ? row_lo + k : hi_s + (k - lo_n)) - row_lo;
+        B.emask |= (1 << (rr * W / 64)) | (1 << ((rr * W + W - 1) / 64));
+    }
     B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
     B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
     BF_STAMP_DECL
