@@ -96,7 +96,8 @@ TRAFFIC_FILE = 'profiles/r04_traffic.json'
 
 def measured_traffic(config, world, op='matrix'):
     """HBM bytes per assembly from the committed rocprofv3 PMC passes (TRAFFIC_FILE, tools/make_traffic.py) -- or None
-    when the kernel sources have changed since they were taken (stale numbers are not reported).  The counters need
+    when the device code of the library has changed since they were taken (stale numbers are not reported; the key is
+    the hash of the code objects inside libigx.so, so host-only changes do not invalidate it).  The counters need
     passes of their own under rocprofv3, so this is never measured by the run that prints it: `measured_in_this_run`
     says so on the line."""
     try:
@@ -106,10 +107,8 @@ def measured_traffic(config, world, op='matrix'):
         t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))[key]
         if world != 1:
             return None
-        h = hashlib.sha256()
-        for f in sorted(glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.h'))):
-            h.update(open(f, 'rb').read())
-        if h.hexdigest()[:16] != t.get('kernels_sha'):
+        from pyiga_amd import _lib
+        if _lib.device_code_sha() != t.get('kernels_sha'):     # hash of the device code objects inside libigx.so
             return None
         return {'bytes': t['chain_bytes'], 'measured_in_this_run': False, 'kernels_sha': t['kernels_sha'], 'source': TRAFFIC_FILE,
                 'kernels': {k: round(v['read_bytes'] + v['write_bytes']) for k, v in t['kernels'].items()}}
@@ -324,7 +323,7 @@ def main():
     ap.add_argument('--weak', action='store_true', help='weak scaling: axis 0 grows to N * n spans, one n-span slab per rank')
     ap.add_argument('--strong', action='store_true', help='(default) strong scaling: the patch is fixed, its rows are split')
     ap.add_argument('--emulate', default='', help='R/W: assemble the slab of rank R of a W-rank run on this one GPU (no collectives)')
-    ap.add_argument('--placement-tries', type=int, default=6,
+    ap.add_argument('--placement-tries', type=int, default=1,
                     help='candidate buffers for the CSR values, timed under the mirror pass at the FIRST assembly (outside the timed region; '
                          'IGX_PLACEMENT_TRIES: the pass follows where the driver put the buffer); 1: plain allocation')
     args = ap.parse_args()
@@ -499,12 +498,14 @@ def main():
     path = patch.last_path()
     fused = 'fused' in path
     names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_geoA' if 'geoA' in path else 'k_stageA',
-             'stage1_ms': 'k_single2d' if 'single' in path else 'k_bf2' if fused else 'k_stageB',
+             'stage1_ms': 'k_single2d' if 'single' in path else ('k_bf3' if 'both' in path else 'k_bf2') if fused else 'k_stageB',
              'final_ms': ('k_mirror2' if dim == 3 and p in (2, 3, 4) else 'k_mirror') if 'mirror' in path else 'k_final', 'entry_ms': 'k_entries_csr'}
     if 'geoA' in path or 'single' in path:
         stage_ms.pop('fields_ms', None)         # no field kernel: the geometry is evaluated inside k_geoA / k_single2d
     if 'single' in path:
         stage_ms = {k: v for k, v in stage_ms.items() if k == 'stage1_ms'}
+    if 'both' in path:
+        stage_ms.pop('final_ms', None)          # k_bf3 writes both triangles: no kernel behind it
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
     flops = algorithmic_flops(dim, p, kvs, kind) if algo_used == 2 else None

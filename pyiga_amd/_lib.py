@@ -189,3 +189,27 @@ def context(device=None):
         with _lock:
             _ctx[device] = ctx
     return ctx
+
+
+def device_code_sha(path=None):
+    """sha256 (first 16 hex digits) of the gfx950 code objects inside the library -- the ``.hip_fatbin`` section of the ELF
+    file.  Host-only changes leave it alone: what the committed counter passes (profiles/*traffic.json) were measured on is
+    identified by the device code, not by the text of the sources."""
+    import hashlib
+    import struct
+    p = path or LIB_PATH
+    with open(p, 'rb') as f:
+        eh = f.read(64)
+        if eh[:4] != b'\x7fELF' or eh[4] != 2:
+            return None
+        shoff, = struct.unpack_from('<Q', eh, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from('<HHH', eh, 0x3A)
+        f.seek(shoff)
+        sh = [struct.unpack_from('<IIQQQQIIQQ', f.read(shentsize)) for _ in range(shnum)]
+        f.seek(sh[shstrndx][4])
+        names = f.read(sh[shstrndx][5])
+        for name_off, _, _, _, off, size, *_ in sh:
+            if names[name_off:names.index(b'\0', name_off)] == b'.hip_fatbin':
+                f.seek(off)
+                return hashlib.sha256(f.read(size)).hexdigest()[:16]
+    return None

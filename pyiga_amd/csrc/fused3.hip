@@ -183,7 +183,11 @@ struct BF3Store {
         int voff[NSUB];
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
+#ifdef BF3_DENSE
+            voff[c] = (int)__umul24((unsigned)(rrv[c] & 1), (unsigned)sK) + lane8;      // (timing experiment: 512 contiguous bytes per store)
+#else
             voff[c] = (int)__umul24((unsigned)rrv[c], (unsigned)sK) + lane8;
+#endif
             asm volatile("" : "+v"(voff[c]));               // (+ c * 512 below is the store's immediate offset, not another register)
         }
 #pragma unroll
@@ -443,7 +447,17 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     // computes something that is never stored); the LDS addresses are kept inside the image
     const double *kl = U.lines + min(k9, W - 1) * LS + min(s1, TL / P - 1) * P, *vl = U.V2s + min(s1, TL / P - 1) * P * P * 2;
     double loc[A1 - A0][P];
+#ifdef BF3_NOELEM
+    {                                                      // (timing experiment: no element matrices)
+        const double k0 = kl[0], v0 = vl[0];
+#pragma unroll
+        for (int a = 0; a < A1 - A0; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) { loc[a][b] = k0 + v0 * (a + 3 * b); asm volatile("" : "+v"(loc[a][b])); }
+    }
+#else
     bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
+#endif
     const int r3 = s1 - p;                                 // row of the tile (this lane's span is the first of its support)
     const bool item = lane < PPP * PL && pid < U.npieces && x >= p && r3 < U.nrows;
     const int oshv = max(p - (U.row_lo + r3), 0);
@@ -513,11 +527,21 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
         for (int b = 0; b < P; ++b)
 #pragma unroll
             for (int a = A0; a < A1; ++a) {
+#ifdef BF3_NOTGATHER
+                if (b == 0) outT[a + p] = loc[a - A0][0];       // (timing experiment: no cross-lane traffic for the transposed entries)
+                else if (a == A0) outT[a + p - b] = loc[0][b];
+                else outT[a + p - b] += loc[a - A0][b];
+#else
                 if (b == 0) outT[a + p] = loc[a - A0][0];
                 else if (a == A0) outT[a + p - b] = bf2_from_lane(((lane - b) & 63) * 4, loc[0][b]);
                 else outT[a + p - b] += bf2_from_lane(((lane - b) & 63) * 4, loc[a - A0][b]);
+#endif
             }
+#ifdef BF3_NOTWRITE
+        if (false) {
+#else
         if (item && col1 >= U.rlo && col1 < U.rhi && row1 < U.N1) {
+#endif
             constexpr int ELO = H == 0 ? 0 : A0, EHI = H == 0 ? 2 * p : A1 - 1 + p;
             if (U.diag0) {
                 // upper part of row dd of the same block: the line of column dd + la; on the diagonal line only j2 > i2
@@ -742,8 +766,11 @@ constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0
 // shapes (lane groups per role, contractor waves, halved passes): those of k_bf2 (fused.hip, BF2Cfg)
 template <int P, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
 template <int P> struct BF3Cfg<P, BF_MASK_MASS> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1; };
+#ifndef BF3_NH
+#define BF3_NH 2
+#endif
 template <int P> struct BF3Cfg<P, BF_MASK_STIFF3> {
-    static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 4 : P == 4 ? 8 : 4, NH = P == 5 ? 2 : 1;
+    static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 4 : P == 4 ? 8 : 4, NH = P == 5 ? BF3_NH : 1;
 };
 template <int P> struct BF3Cfg<P, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
 

@@ -758,7 +758,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
         // opt-in (IGX_PLACEMENT_TRIES): keep the candidate buffer on which the mirror pass of this patch runs fastest.  The
         // candidates are alive together (the driver must not hand the same pages out again); a failed allocation or probe ends
         // the search with what there is.
-        if (pt->knobs.placement_tries > 1 && algo == IGX_ALGO_SUMFACT && igx_kind_symmetric(kind) && pt->sumfact_ok) {
+        if (pt->knobs.placement_tries > 1 && pt->knobs.bf == 2 && algo == IGX_ALGO_SUMFACT && igx_kind_symmetric(kind) && pt->sumfact_ok) {   // (only the chain with the mirror pass: IGX_BF=2)
             std::vector<double *> cand(1, pt->d_data);
             std::vector<float> ms(1, sumfact_probe_mirror(pt, pt->d_data));
             for (int k = 1; k < pt->knobs.placement_tries && ms[0] >= 0.0f; ++k) {

@@ -862,7 +862,7 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         fused3_offsets_fit(dim, dim == 3 ? A0.p : 0, in.last->p, in.mid->S, in.last->S, in.last->N)) {
         if (dim == 2) in.mid_hi = pt->r0_hi;             // (no mirror sources above the slab)
         if (int rc = launch_bf3(st, pt, in, d_data)) return rc;
-        pt->last_path |= IGX_PATH_FUSED;
+        pt->last_path |= IGX_PATH_FUSED | IGX_PATH_BOTH;
         pt->timing.n_launches++;
         stage_event(pt, 3, st);
         stage_event(pt, 4, st);

@@ -1048,6 +1048,35 @@ def test_repeatability(iga):
         assert len(hashes) == 1
 
 
+def test_both_triangles_from_the_fused_stage(iga, monkeypatch):
+    """k_bf3 (fused3.hip) writes the upper triangle of a symmetric 3D form from the same element matrices as the lower one,
+    in the same order of addends: the matrix is the one of k_bf2 + mirror pass (IGX_BF=2) BIT FOR BIT, exactly symmetric, every
+    value written (NaN poison), for every degree the fused stage is compiled for -- including axes shorter than 2p + 1 dofs
+    (every row is an edge row) and unequal sizes per axis.  (pyiga/assemble.py:742-752: assemble_entries(symmetric=True).)"""
+    mk = iga.bspline.make_knots
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    cases = [((mk(4, 0., 1., 3),) * 3, 'cylinder'), ((mk(4, 0., 1., 9),) * 3, 'cylinder'), ((mk(1, 0., 1., 5),) * 3, 'twisted_box'),
+             ((mk(2, 0., 1., 4), mk(2, 0., 1., 11), mk(2, 0., 1., 7)), 'cylinder'), ((mk(3, 0., 1., 6), mk(3, 0., 1., 5), mk(3, 0., 1., 13)), 'twisted_box'),
+             ((mk(5, 0., 1., 7), mk(5, 0., 1., 6), mk(5, 0., 1., 8)), 'cylinder'), ((mk(4, 0., 1., 5), mk(4, 0., 1., 40), mk(4, 0., 1., 36)), 'cylinder')]
+    for kvs, gname in cases:
+        for kind in ('stiffness', 'mass'):
+            out = {}
+            for bf in ('', '2'):
+                if bf:
+                    monkeypatch.setenv('IGX_BF', bf)
+                else:
+                    monkeypatch.delenv('IGX_BF', raising=False)
+                patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
+                A = patch.csr(kind, algo='sumfact')
+                assert patch.last_path() == ({'geoA', 'fused', 'mirror'} if bf else {'geoA', 'fused', 'both'}), (kind, bf, patch.last_path())
+                patch.close()
+                assert not np.isnan(A.data).any()
+                assert abs(A - A.T).max() == 0.0
+                out[bf] = A.data
+            assert np.array_equal(out[''], out['2']), (kind, [kv.numdofs for kv in kvs])
+    monkeypatch.delenv('IGX_BF', raising=False)
+
+
 def test_ablation_variables_have_no_effect(iga, monkeypatch):
     """The switches of the timing experiments (work left out: wrong matrices by construction) exist only in -DIGX_ABLATE
     builds; in the shipped library the variables change nothing, and the chain of a patch is fixed when it is created."""
@@ -1060,7 +1089,7 @@ def test_ablation_variables_have_no_effect(iga, monkeypatch):
     for var, val in (('IGX_PATH', 'unfused'), ('IGX_GEOA', '0'), ('IGX_FINAL', 'valu')):     # read at creation only
         monkeypatch.setenv(var, val)
     B = patch.csr('stiffness', algo='sumfact')
-    assert patch.last_path() == {'geoA', 'fused', 'mirror'}
+    assert patch.last_path() == {'geoA', 'fused', 'both'}
     patch.close()
     for var in ('IGX_PATH', 'IGX_GEOA', 'IGX_FINAL'):
         monkeypatch.delenv(var)
@@ -1071,10 +1100,18 @@ def test_ablation_variables_have_no_effect(iga, monkeypatch):
 
 
 def test_placement_tries_opt_in(iga, monkeypatch):
-    """IGX_PLACEMENT_TRIES (read at patch creation): the first assembly times the mirror pass on n candidate buffers for
-    the CSR values and keeps the fastest.  Same matrix, the search is reported, and without the variable it does not run."""
+    """IGX_PLACEMENT_TRIES (read at patch creation) with the chain of rounds 3-4 (IGX_BF=2: k_bf2 + mirror pass): the first
+    assembly times the mirror pass on n candidate buffers for the CSR values and keeps the fastest.  Same matrix, the search is
+    reported, and without the variable it does not run.  The default chain (k_bf3) has no mirror pass and never searches."""
     kvs = (iga.bspline.make_knots(3, 0., 1., 12),) * 3
     geo = _geo(iga, 'cylinder')
+    monkeypatch.setenv('IGX_PLACEMENT_TRIES', '3')
+    patch = iga.assemblers.DevicePatch(kvs, geo)
+    monkeypatch.delenv('IGX_PLACEMENT_TRIES')
+    patch.csr('stiffness', algo='sumfact')
+    assert patch.placement()['tried'] == 0 and 'both' in patch.last_path()
+    patch.close()
+    monkeypatch.setenv('IGX_BF', '2')
     patch = iga.assemblers.DevicePatch(kvs, geo)
     A = patch.csr('stiffness', algo='sumfact')
     assert patch.placement()['tried'] == 0

@@ -24,10 +24,10 @@ SETUP = {'k_basis_tables', 'k_pi_tables', 'k_pattern', 'k_coeff_affine', 'k_geoa
 
 
 def kernels_sha():
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'pyiga_amd', 'csrc', '*.h'))):
-        h.update(open(f, 'rb').read())
-    return h.hexdigest()[:16]
+    """hash of the device code objects inside pyiga_amd/libigx.so (the build the passes were taken on)"""
+    sys.path.insert(0, ROOT)
+    from pyiga_amd import _lib
+    return _lib.device_code_sha(os.path.join(ROOT, 'pyiga_amd', 'libigx.so'))
 
 
 def one(root, key):
