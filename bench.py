@@ -91,7 +91,7 @@ def algorithmic_flops(dim, p, kvs, kind):
     return out
 
 
-TRAFFIC_FILE = 'profiles/r04_traffic.json'
+TRAFFIC_FILE = 'profiles/r05_traffic.json'
 
 
 def measured_traffic(config, world, op='matrix'):

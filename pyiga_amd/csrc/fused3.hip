@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace igx {
 
@@ -86,43 +87,64 @@ struct BF3Blk {
 
 typedef int bf3_v4i __attribute__((ext_vector_type(4)));
 
-// The store duty of k_bf3, carried by the contractor waves.  Behind the barrier B2 of step t the rows d = t - 1 of both sets
-// are complete: the direct row is read into registers (and its slots cleared) and stored behind the next B1, as in k_bf2 -- the
-// LDS latency lies in the barrier wait; the transposed row is read and stored at once (the sweepers flush meanwhile; the
-// registers of the element matrices are free here).  A slot is (chunk c of 64 consecutive doubles of a line block, line l): c is
-// a compile-time constant of the slot (row constants in registers, immediate offsets), l is a scalar that depends on the wave:
-// wave cw takes the lines (cw + c) % NCW + NCW j of chunk c; the lines beyond the last full round of NCW go chunk by chunk.
-#ifndef BF3_STAGE
-#define BF3_STAGE 0                                      // 1: the direct row waits in registers from B2 to the next B1 (as in k_bf2)
-#endif
-template <class Gm, int P, int NCW, int NH, int SYM>
+// The store duty of k_bf3.  Behind the barrier B2 of step t the rows d = t - 1 of both sets are complete; their slots are
+// reused in step t + 1, so they are read (and cleared where halves add) before the next B1.  A slot is (set, chunk c of 64
+// consecutive doubles of a line block, line l): c is a compile-time constant (row constants in registers, immediate offsets),
+// l a scalar of the wave.  NS waves share the duty: wave sw takes, of every chunk c, the lines (sw + ROT c) % NS + NS j.
+//   * forms with several sweeper roles (stiffness): the sweepers of roles 1.. carry it, STAGED -- values read behind B2, stored
+//     behind the next B1, under the sweep.  They wait at the barriers most of a step (stamp profile: 20-50 % busy) and have the
+//     registers; on the contractor waves (90 % busy, 126 registers) the same stores sat in the B2 -> B1 window of every step,
+//     40 % of their time (profiles/r05_a_c4_bf3_stamps_contractor_stores.txt).  No branch lies around a store (a sweeper also
+//     loads: hipcc answers a store behind a branch with vmcnt(0) at the next load use): what must not be stored gets a
+//     descriptor of length 0.
+//   * the mass form has one role: the contractors carry it, at once (read -> store inside the window).
+// Rows next to the ends of the last axis (segments of fewer than 2p + 1 columns) are not part of the slots (their lanes carry an
+// out-of-range row constant and are not cleared): the contractors take them through a small table (edge()).
+template <class Gm, int P, int NS, int ROT, int NH, int SYM, bool STAGE>
 struct BF3Store {
     static constexpr int p = P - 1, W = 2 * P - 1, NSUB = Gm::NSUB, RW = Gm::RW;
-    static constexpr int JF = W / NCW, LREM0 = JF * NCW, NREM = W - LREM0, NXR = (NSUB + NCW - 1) / NCW;
-    static constexpr int NST = NSUB * JF + NREM * NXR;
-    double sv[NST];
+    static constexpr int JMAX = (W + NS - 1) / NS, NST = NSUB * JMAX, NSET = SYM == 2 ? 2 : 1;
+    double svD[STAGE ? NST : 1], svT[STAGE && NSET == 2 ? NST : 1];
     int rrv[NSUB];               // W i2 - T0 of this lane's row in chunk c, or a value that takes the offset out of range
-    int lane8, lanec;            // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
+    int lane8, lanec, inv;       // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
     double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
     int nD, nT;
-    int s_sK = 0, s_soff0 = 0, s_l0 = 0, s_c1 = 0;
-    bool s_on = false;
+    int s_l0 = 0, s_c1 = 1, s_sKD = 0, s_soffD = 0, s_sKT = 0, s_soffT = 0, s_lenD = 0, s_lenT = 0;
 
+    struct Row { int on, l0, c1, rp1d, sub1, sub2, sub3, sub4, sub5; };
+    __device__ __forceinline__ static Row row_of(const BFArgs &A, const BF3Blk &B, const int t)
+    {
+        cip rp1 = (cip)A.rp1;
+        Row r;
+        const int d = t - 1;
+        r.on = d >= B.rlo && d < B.rhi;
+        const int dc = min(max(d, 0), A.N1 - 1);
+        const int jl1 = max(dc - p, 0);
+        r.c1 = min(dc + p, A.N1 - 1) - jl1 + 1; r.l0 = p - (dc - jl1);
+        r.rp1d = rp1[dc];
+        // slot of row d in ring line delta (named scalars: a select by a lane's or a wave's line stays a chain of selects)
+        r.sub1 = Gm::roff(1) + (int)((unsigned)dc % 2u) * RW; r.sub2 = Gm::roff(2) + (int)((unsigned)dc % 3u) * RW;
+        r.sub3 = Gm::roff(3) + (int)((unsigned)dc % 4u) * RW; r.sub4 = Gm::roff(4) + (int)((unsigned)dc % 5u) * RW;
+        r.sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
+        return r;
+    }
     __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int lane)
     {
         cip rp0 = (cip)A.rp0;
 #pragma unroll
-        for (int k = 0; k < NST; ++k) sv[k] = 0.0;
+        for (int k = 0; k < (STAGE ? NST : 1); ++k) svD[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < (STAGE && NSET == 2 ? NST : 1); ++k) svT[k] = 0.0;
         lane8 = lane * 8;
         lanec = min((NSUB - 1) * 64 + lane, RW - 1) - (NSUB - 1) * 64;
         // descriptors: base moved by W row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W i2 - T0) (c0 c1 - 1)
         // + (chunk element index) + W (line terms); length = the row block of the outer row (anything beyond is dropped)
         const long long shift = (long long)W * B.row_lo - Gm::T0;
         const long long lenD = ((long long)B.c0i * B.S12 - shift) * 8, lenT = ((long long)B.c0j * B.S12 - shift) * 8;
-        pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off + shift); nD = (int)lenD;
-        pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off + shift); nT = (int)lenT;
+        pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off + shift); nD = B.stD ? (int)lenD : 0;
+        pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off + shift); nT = B.stT ? (int)lenT : 0;
         const int c0min = min(B.c0i, B.c0j);
-        const int inv = (int)(max(lenD, lenT) / (8 * (c0min * P - 1))) + 1;
+        inv = (int)(max(lenD, lenT) / (8 * (c0min * P - 1))) + 1;
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
             const int q = c * 64 + lane, rr = q / W, i2 = B.row_lo + rr;
@@ -130,27 +152,25 @@ struct BF3Store {
             rrv[c] = ok ? W * i2 - Gm::T0 : inv;
         }
     }
-    __device__ __forceinline__ static bool line_ok(const int l, const int l0, const int c1) { return l >= l0 && l - l0 < c1; }
+    __device__ __forceinline__ static bool line_ok(const int l, const int l0, const int c1) { return l < W && l >= l0 && l - l0 < c1; }
     __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rs(double *ptr, const int len) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, (short)0, len, 0x00020000); }
-    // line block of line l of the row in ring slots sub1.. (doubles from the start of a set); l is a scalar
-    __device__ __forceinline__ static int line_off(const int l, const int sub1, const int sub2, const int sub3, const int sub4, const int sub5)
+    // line block of line l of the row (doubles from the start of a set); l is a scalar
+    __device__ __forceinline__ static int line_off(const int l, const Row &r)
     {
         int o = Gm::OFF_CUR + (l - p) * RW;
-        o = l == p - 1 ? sub1 : o;
-        if (p >= 2) o = l == p - 2 ? sub2 : o;
-        if (p >= 3) o = l == p - 3 ? sub3 : o;
-        if (p >= 4) o = l == p - 4 ? sub4 : o;
-        if (p >= 5) o = l == p - 5 ? sub5 : o;
+        o = l == p - 1 ? r.sub1 : o;
+        if (p >= 2) o = l == p - 2 ? r.sub2 : o;
+        if (p >= 3) o = l == p - 3 ? r.sub3 : o;
+        if (p >= 4) o = l == p - 4 ? r.sub4 : o;
+        if (p >= 5) o = l == p - 5 ? r.sub5 : o;
         return o;
     }
+    __device__ __forceinline__ static int line_of(const int sw, const int c, const int j) { return (int)((unsigned)(sw + ROT * c) % (unsigned)NS) + NS * j; }
 
-    // the (chunk, line) slots of this wave: values of one row of set X out of the rings (cleared where halves add) ...
-    template <int X>
-    __device__ __forceinline__ void read_row(double (&v)[NST], double *sets, const int cw, const int lane,
-                                             const int sub1, const int sub2, const int sub3, const int sub4, const int sub5)
+    // the slots of this wave: values of one row of set X out of the rings (cleared where halves add) ...
+    template <int X, int N>
+    __device__ __forceinline__ void read_row(double (&v)[N], double *sets, double *dump, const int sw, const int lane, const Row &r)
     {
-#pragma unroll
-        for (int k = 0; k < NST; ++k) v[k] = 0.0;
         // (addresses: an opaque per-lane base + the scalar line offset, the chunk is the immediate offset of the LDS instruction)
         int lb_ = lane, lc_ = lanec;
         asm volatile("" : "+v"(lb_), "+v"(lc_));
@@ -158,24 +178,20 @@ struct BF3Store {
 #pragma unroll
         for (int c = 0; c < NSUB; ++c)
 #pragma unroll
-            for (int j = 0; j < JF; ++j) {
-                const int l = (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j;
-                double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(l, sub1, sub2, sub3, sub4, sub5);
-                v[c * JF + j] = *src;
-                if (NH == 2) *src = 0.0;
-            }
-#pragma unroll
-        for (int lr = LREM0; lr < W; ++lr)
-#pragma unroll
-            for (int c = 0; c < NSUB; ++c)
-                if ((c + lr) % NCW == cw) {
-                    double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(lr, sub1, sub2, sub3, sub4, sub5);
-                    v[NSUB * JF + (lr - LREM0) * NXR + c / NCW] = *src;
-                    if (NH == 2) *src = 0.0;
+            for (int j = 0; j < JMAX; ++j) {
+                const int l = line_of(sw, c, j);
+                double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(min(l, W - 1), r);
+                v[c * JMAX + j] = *src;
+                if (NH == 2) {
+                    // (edge rows belong to edge(); a wave without a line in this round clears nothing)
+                    double *cl = (rrv[c] != inv && l < W) ? src : dump;
+                    *cl = 0.0;
                 }
+            }
     }
     // ... and to their segments: row block `ptr` of `len` bytes (0: the row is not stored), lines [l0, l0 + c1) exist
-    __device__ __forceinline__ void write_row(const double (&v)[NST], double *ptr, const int len, const int cw, const int l0, const int c1, const int sK, const int soff0) const
+    template <int N>
+    __device__ __forceinline__ void write_row(const double (&v)[N], double *ptr, const int len, const int sw, const int l0, const int c1, const int sK, const int soff0) const
     {
 #ifdef BF3_NOSTORE
         return;                                              // (timing experiment: tools/buildvar.sh)
@@ -183,116 +199,101 @@ struct BF3Store {
         int voff[NSUB];
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
-#ifdef BF3_DENSE
-            voff[c] = (int)__umul24((unsigned)(rrv[c] & 1), (unsigned)sK) + lane8;      // (timing experiment: 512 contiguous bytes per store)
-#else
             voff[c] = (int)__umul24((unsigned)rrv[c], (unsigned)sK) + lane8;
-#endif
             asm volatile("" : "+v"(voff[c]));               // (+ c * 512 below is the store's immediate offset, not another register)
         }
 #pragma unroll
         for (int c = 0; c < NSUB; ++c)
 #pragma unroll
-            for (int j = 0; j < JF; ++j) {
-                const int l = (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j;
-                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * l, v[c * JF + j]);
+            for (int j = 0; j < JMAX; ++j) {
+                const int l = line_of(sw, c, j);
+                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * l, v[c * JMAX + j]);
             }
-#pragma unroll
-        for (int lr = LREM0; lr < W; ++lr)
-#pragma unroll
-            for (int c = 0; c < NSUB; ++c)
-                if ((c + lr) % NCW == cw)
-                    bf2_buffer_store(rs(ptr, line_ok(lr, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * lr, v[NSUB * JF + (lr - LREM0) * NXR + c / NCW]);
     }
 
-    // behind B1: the direct row read at the end of the last step goes out (BF3_STAGE)
-    __device__ __forceinline__ void issue(const int cw)
+    // behind B1 (STAGE): the rows read at the end of the last step go out
+    __device__ __forceinline__ void issue(const int sw)
     {
-        if (BF3_STAGE) write_row(sv, pD, s_on ? nD : 0, cw, s_l0, s_c1, s_sK, s_soff0);
+        if (!STAGE) return;
+        write_row(svD, pD, s_lenD, sw, s_l0, s_c1, s_sKD, s_soffD);
+        if (NSET == 2) write_row(svT, pT, s_lenT, sw, s_l0, s_c1, s_sKT, s_soffT);
     }
 
     // behind B2 of step t: rows d = t - 1 of both sets are complete
-    __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, const bf3_v4i *etab, const int t, const int cw, const int lane)
+    __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, double *dump, const int t, const int sw, const int lane)
     {
-        cip rp1 = (cip)A.rp1;
-        const int d = t - 1;
-        const bool on = d >= B.rlo && d < B.rhi;
-        const int dc = min(max(d, 0), A.N1 - 1);
-        const int jl1 = max(dc - p, 0), c1 = min(dc + p, A.N1 - 1) - jl1 + 1, l0 = p - (dc - jl1);
-        const int rp1d = rp1[dc];
-        // slot of row d in ring line delta (named scalars: see the contraction)
-        const int sub1 = Gm::roff(1) + (int)((unsigned)dc % 2u) * RW, sub2 = Gm::roff(2) + (int)((unsigned)dc % 3u) * RW;
-        const int sub3 = Gm::roff(3) + (int)((unsigned)dc % 4u) * RW, sub4 = Gm::roff(4) + (int)((unsigned)dc % 5u) * RW;
-        const int sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
-        // ---- FIRST: rows next to the ends of the last axis (segments of fewer than 2p + 1 columns): element (row, entry) of the
-        //      table per lane; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift folded into the table.
-        //      The elements of chunk c of line l are taken by the wave that owns the slot (c, l) of the row passes below, BEFORE its
-        //      own pass over that slot: those passes clear whole chunks where halves add, and waves are not ordered among themselves.
-        if (B.emask != 0) {
-#pragma unroll
-            for (int X = 0; X < Gm::NSET; ++X) {
-                if (X == 0 ? !B.stD : !B.stT) continue;
-                const int c0x = X == 0 ? B.c0i : B.c0j, cx = X == 0 ? B.cj0 : B.ci0;
-                double *px = X == 0 ? pD : pT;
-                const int nx = X == 0 ? nD : nT;
-                const unsigned sA = (unsigned)(c0x * c1);
-                const int soffr = 8 * (int)((long long)c0x * A.S2) * rp1d;
-                for (int c = 0; c < NSUB; ++c) {
-                    if (!((B.emask >> c) & 1)) continue;
-                    for (int j = 0; j < JF + NREM; ++j) {
-                        const int l = j < JF ? (int)((unsigned)(cw + c) % (unsigned)NCW) + NCW * j : LREM0 + (j - JF);
-                        if (j >= JF && (c + l) % NCW != cw) continue;
-                        const unsigned sB = (unsigned)max(cx * c1 + l - l0, 0);
-                        const __amdgpu_buffer_rsrc_t dsc = rs(px, (on && line_ok(l, l0, c1)) ? nx : 0);
-                        double *lb = sets + X * Gm::SETSZ + line_off(l, sub1, sub2, sub3, sub4, sub5);
-                        for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
-                            const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
-                            const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB && (e.x >> 6) == c;
-                            double *src = lb + e.x;
-                            const double v = *src;
-                            if (NH == 2 && ok) *src = 0.0;
-                            const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
-                            bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
-                        }
-                    }
-                }
-            }
-        }
-        // ---- direct row
-        if (B.stD) {
-            const int sK = 8 * (B.c0i * c1 - 1);
-            const int soff0 = 8 * ((int)((long long)B.c0i * A.S2) * rp1d + W * (B.cj0 * c1 - l0));
-            if (BF3_STAGE) {
-                s_on = on; s_l0 = l0; s_c1 = c1; s_sK = sK; s_soff0 = soff0;
-                read_row<0>(sv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
-            } else {
+        const Row r = row_of(A, B, t);
+        const int sKD = 8 * (B.c0i * r.c1 - 1), soffD = 8 * ((int)((long long)B.c0i * A.S2) * r.rp1d + W * (B.cj0 * r.c1 - r.l0));
+        const int sKT = 8 * (B.c0j * r.c1 - 1), soffT = 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W * (B.ci0 * r.c1 - r.l0));
+        if (STAGE) {
+            s_l0 = r.l0; s_c1 = r.c1; s_sKD = sKD; s_soffD = soffD; s_sKT = sKT; s_soffT = soffT;
+            s_lenD = r.on ? nD : 0; s_lenT = r.on ? nT : 0;
+            read_row<0>(svD, sets, dump, sw, lane, r);
+            if (NSET == 2) read_row<1>(svT, sets, dump, sw, lane, r);
+        } else {
+            {
                 double tv[NST];
-                read_row<0>(tv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
-                write_row(tv, pD, on ? nD : 0, cw, l0, c1, sK, soff0);
+                read_row<0>(tv, sets, dump, sw, lane, r);
+                write_row(tv, pD, r.on ? nD : 0, sw, r.l0, r.c1, sKD, soffD);
             }
-        }
-        // ---- transposed row: read and stored at once
-#ifdef BF3_NOT
-        if (false) {
-#else
-        if (SYM == 2 && B.stT) {
-#endif
-            const int sK = 8 * (B.c0j * c1 - 1);
-            const int soff0 = 8 * ((int)((long long)B.c0j * A.S2) * rp1d + W * (B.ci0 * c1 - l0));
-            double tv[NST];
-            read_row<1>(tv, sets, cw, lane, sub1, sub2, sub3, sub4, sub5);
-            write_row(tv, pT, on ? nT : 0, cw, l0, c1, sK, soff0);
+            if (NSET == 2) {
+                double tv[NST];
+                read_row<1>(tv, sets, dump, sw, lane, r);
+                write_row(tv, pT, r.on ? nT : 0, sw, r.l0, r.c1, sKT, soffT);
+            }
         }
     }
 };
 
-// sweepers: as in k_bf2 (fused.hip), without the store duty
-template <int P, int MASK, int RI, int NA, int NLG>
+// Rows next to the ends of the last axis, behind B2 of step t, on the contractor waves: element (row, entry) of the table per
+// lane, one (set, line) per round; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift folded into the
+// table.  The elements are read and cleared here and nowhere else.
+template <class Gm, int P, int NCW, int NH, int SYM>
+__device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, double *sets, const bf3_v4i *etab, const int t, const int cw, const int lane)
+{
+    using St = BF3Store<Gm, P, NCW, 1, NH, SYM, false>;
+    constexpr int W = 2 * P - 1;
+    if (B.ne == 0) return;
+    cip rp0 = (cip)A.rp0;
+    const typename St::Row r = St::row_of(A, B, t);
+    const long long shift = (long long)W * B.row_lo - Gm::T0;
+#pragma unroll
+    for (int X = 0; X < Gm::NSET; ++X) {
+        if (X == 0 ? !B.stD : !B.stT) continue;
+        const int c0x = X == 0 ? B.c0i : B.c0j, cx = X == 0 ? B.cj0 : B.ci0;
+        double *px = A.data + ((long long)rp0[X == 0 ? B.i0 : B.j0] * B.S12 - A.nnz_off + shift);
+        const int nx = (int)(((long long)c0x * B.S12 - shift) * 8);
+        const unsigned sA = (unsigned)(c0x * r.c1);
+        const int soffr = 8 * (int)((long long)c0x * A.S2) * r.rp1d;
+        for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W; l += NCW) {
+            const unsigned sB = (unsigned)max(cx * r.c1 + l - r.l0, 0);
+            const __amdgpu_buffer_rsrc_t dsc = St::rs(px, (r.on && St::line_ok(l, r.l0, r.c1)) ? nx : 0);
+            double *lb = sets + X * Gm::SETSZ + St::line_off(l, r);
+            for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
+                const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
+                const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
+                double *src = lb + e.x;
+                const double v = *src;
+                if (NH == 2 && ok) *src = 0.0;
+                const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
+                bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
+            }
+        }
+    }
+}
+
+// sweepers: as in k_bf2 (fused.hip); those of the roles 1.. carry the store duty (StoreT::NS > 0 waves, this one is number sw)
+struct BF3SweepCtx { const BF3Blk *B; double *sets, *dump; int sw; };
+template <int P, int MASK, int RI, int NA, int NLG, class StoreT, bool STW>
 __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
-                                            const int rhi, double *lines, const int LS)
+                                            const int rhi, double *lines, const int LS, const BF3SweepCtx &sc)
 {
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p = P - 1, TL = 64 * NLG;
+    constexpr bool ST = STW && RI >= 1;
+    const int slane = threadIdx.x & 63;
+    StoreT store;
+    if constexpr (ST) store.init(A, *sc.B, slane);
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_S);
     cdp V1 = (cdp)A.V1;
@@ -343,6 +344,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     int t = s_begin;
     for (; t < t_sw; ++t) {
         bar_lds();                                       // B1
+        if constexpr (ST) store.issue(sc.sw);
         const int tn = min(t + 1, t_sw - 1);
         cdp cf = V1 + (size_t)t * P * P * 2;
         double v[P][2];
@@ -397,23 +399,35 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
         }
         bar_lds();                                       // B2: the contractors have read the previous lines
         flush();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
     }
-    for (; t < rhi; ++t) { bar_lds(); bar_lds(); flush(); }   // spans past the end of the axis: the window only drains
-    for (; t < rhi + 1; ++t) { bar_lds(); bar_lds(); }        // the contractors finish the last row
+    for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
+        bar_lds();
+        if constexpr (ST) store.issue(sc.sw);
+        bar_lds(); flush();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
+    }
+    for (; t < rhi + 1; ++t) {                           // the contractors finish the last row
+        bar_lds();
+        if constexpr (ST) store.issue(sc.sw);
+        bar_lds();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
+    }
+    if constexpr (ST) store.issue(sc.sw);                // the last row
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
-template <int P, int MASK, int NA, int NLG, int RI, bool END = (RI >= bf_nroles(MASK))>
+template <int P, int MASK, int NA, int NLG, class StoreT, bool STW, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BF3SweepDispatch {
-    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS)
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS, const BF3SweepCtx &sc)
     {
-        if (role == RI) bf3_sweeper<P, MASK, RI, NA, NLG>(A, r0, g2l, g2, s_begin, rhi, lines, LS);
-        else BF3SweepDispatch<P, MASK, NA, NLG, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        if (role == RI) bf3_sweeper<P, MASK, RI, NA, NLG, StoreT, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        else BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
     }
 };
-template <int P, int MASK, int NA, int NLG, int RI>
-struct BF3SweepDispatch<P, MASK, NA, NLG, RI, true> {
-    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int) {}
+template <int P, int MASK, int NA, int NLG, class StoreT, bool STW, int RI>
+struct BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BF3SweepCtx &) {}
 };
 
 
@@ -500,9 +514,13 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
                         if (o >= oshv) dste[o] = out[o];
                 }
             } else {
+                // entries that only this half contributes to are written, the shared ones added (onto zeros, or onto the other half)
 #pragma unroll
                 for (int o = OLO; o <= OHI; ++o)
-                    if (o >= oshv) (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (o >= oshv) {
+                        if ((H == 1 && o > 2 * p - AH) || (H == 2 && o <= p - AH)) dste[o] = out[o];
+                        else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
             }
         }
     }
@@ -567,7 +585,10 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
                 } else {
 #pragma unroll
                     for (int e = ELO; e <= EHI; ++e)
-                        if (e >= oshv) (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (e >= oshv) {
+                            if ((H == 1 && e < AH) || (H == 2 && e >= p + AH)) dste[e] = outT[e];
+                            else (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                 }
             }
         }
@@ -649,37 +670,39 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
         if (sd < 3) task = k == 0 ? NSW + sd : 2 * (sd + 1) + (k - 1);
         else task = k < 2 ? k : NSW + 3;
     }
+    BF3Blk B;
+    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.c0j = jhi0[j0] - jlo0[j0];
+    B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
+    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne; B.emask = 0;
+    B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
+    B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
+    // store duty: on the sweepers of the roles 1.. where the form has them (staged), else on the contractors (at once)
+    constexpr bool STW = NR >= 2;
+    constexpr int NSTW = STW ? (NR - 1) * NLG : NCW;
+    using StoreT = BF3Store<Gm, P, NSTW, STW ? 0 : 1, NH, SYM, STW>;
+    double *dump = lines + NR * TL;                       // (the padding of line 0: target of the clears that must not happen)
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
-        BF3SweepDispatch<P, MASK, NA, NLG, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS);
+        const BF3SweepCtx sc{&B, sets, dump, (role - 1) * NLG + lg};
+        BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
         return;
     }
 
     // ---------------- contractors
     const int cw = task - NSW;
-    BF3Blk B;
-    B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.c0j = jhi0[j0] - jlo0[j0];
-    B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
-    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne;
-    B.emask = 0;                                          // store chunks (64 doubles of a line block) that hold entries of edge rows
-    for (int k = 0; k < ne; ++k) {
-        const int rr = (k < lo_n ? row_lo + k : hi_s + (k - lo_n)) - row_lo;
-        B.emask |= (1 << (rr * W / 64)) | (1 << ((rr * W + W - 1) / 64));
-    }
-    B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
-    B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_C);
-    BF3Store<Gm, P, NCW, NH, SYM> store;
-    store.init(A, B, lane);
+    StoreT store;
+    if constexpr (!STW) store.init(A, B, lane);
     const int nlines = diag0 ? P : W;                     // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
     const int npieces = nlines * NPC;
     for (int t = s_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
-        store.issue(cw);
+        if constexpr (!STW) store.issue(cw);
         const int dd = t - 1;
+        BF_SEG_BEGIN();
         if (dd >= s_begin && dd < rhi) {
             // ring slot of the row a line is parked for: row dd + delta of ring line delta
             // (named scalars, not an array: the select by the lane's line must stay a chain of v_cndmask)
@@ -702,10 +725,15 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
                 }
             }
         }
+        BF_SEG_END(1);
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
-        store.fetch(A, B, sets, etab, t, cw, lane);
+        BF_SEG_BEGIN();
+        bf3_edge_rows<Gm, P, NCW, NH, SYM>(A, B, sets, etab, t, cw, lane);
+        if constexpr (!STW) store.fetch(A, B, sets, dump, t, cw, lane);
+        BF_SEG_END(0);
     }
-    store.issue(cw);                                      // the last row
+    if constexpr (!STW) store.issue(cw);                  // the last row
+    BF_SEG_DUMP(cw & 3);
     BF_STAMP_END(wave);
 }
 
@@ -758,6 +786,24 @@ static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
     if (nblocks == 0) return IGX_OK;
     k_bf3<P, NY, MASK, NA, NLG, NCW, NH, SYM><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
+#ifdef IGX_BF_STAMP
+    {
+        static std::vector<unsigned long long> h(64 * 1024);
+        IGX_HIP(hipStreamSynchronize(st));
+        IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bf_stamp), h.size() * sizeof(unsigned long long)));
+        const int nw = bf_nroles(MASK) * NLG + NCW, nb = (int)std::min<long long>(nblocks, 2048);
+        for (int w = 0; w < nw; ++w) {
+            double wt = 0, tot = 0;
+            for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
+            fprintf(stderr, "k_bf3 stamp: wave %2d  wait %.0f  total %.0f x100ns/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
+        }
+        for (int w = 0; w < 4; ++w) {
+            double sg[3] = {0, 0, 0};
+            for (int b = 0; b < nb; ++b) for (int i = 0; i < 3; ++i) sg[i] += h[32768 + (b * 4 + w) * 3 + i];
+            fprintf(stderr, "k_bf3 stamp: contractor %d  B2->B1 window (store duty) %.0f  passes %.0f  x100ns/block\n", w, sg[0] / nb, sg[1] / nb);
+        }
+    }
+#endif
     return IGX_OK;
 }
 
