@@ -498,14 +498,14 @@ def main():
     path = patch.last_path()
     fused = 'fused' in path
     names = {'fields_ms': 'k_geo_fields', 'stage0_ms': 'k_geoA' if 'geoA' in path else 'k_stageA',
-             'stage1_ms': 'k_single2d' if 'single' in path else ('k_bf3' if 'both' in path else 'k_bf2') if fused else 'k_stageB',
+             'stage1_ms': 'k_single2d' if 'single' in path else ('k_bf3' if 'bf3' in path else 'k_bf2') if fused else 'k_stageB',
              'final_ms': ('k_mirror2' if dim == 3 and p in (2, 3, 4) else 'k_mirror') if 'mirror' in path else 'k_final', 'entry_ms': 'k_entries_csr'}
     if 'geoA' in path or 'single' in path:
         stage_ms.pop('fields_ms', None)         # no field kernel: the geometry is evaluated inside k_geoA / k_single2d
     if 'single' in path:
         stage_ms = {k: v for k, v in stage_ms.items() if k == 'stage1_ms'}
-    if 'both' in path:
-        stage_ms.pop('final_ms', None)          # k_bf3 writes both triangles: no kernel behind it
+    if 'bf3' in path or 'both' in path:
+        stage_ms.pop('final_ms', None)          # k_bf3 writes both triangles (or the form has one): no kernel behind it
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
     flops = algorithmic_flops(dim, p, kvs, kind) if algo_used == 2 else None

@@ -825,7 +825,10 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk)
 {
     using C = BF3Cfg<P, MASK>;
     if (symk == 2) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2>(st, A, ncu);
-    return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1>(st, A, ncu);
+    if (symk == 1) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1>(st, A, ncu);
+    if constexpr (MASK == BF_MASK_STIFF3) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0>(st, A, ncu);
+    set_error("fused stage: no kernel for this non-symmetric set of types");
+    return IGX_ERR_UNSUPPORTED;
 }
 template <int P>
 static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk)
@@ -837,16 +840,17 @@ static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int n
     return IGX_ERR_UNSUPPORTED;
 }
 
-// the symmetric forms (mass, stiffness; 2D and 3D) with one input array per slot
+// the symmetric forms (mass, stiffness; 2D and 3D) and the 3D convection-diffusion form (its slots merged by k_geoA), one input
+// array per slot
 bool fused3_supported(const BFInputs &in)
 {
-    if (!in.sym) return false;
     int mask = 0, ymax = 0;
     for (int y = 0; y < 4; ++y)
         for (int t1 = 0; t1 < 4; ++t1) {
             if (in.slot_n[y][t1] > 1) return false;
             if (in.slot_n[y][t1] > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }
         }
+    if (!in.sym) return mask == BF_MASK_STIFF3;
     return (ymax == 0 && mask == BF_MASK_MASS) || mask == BF_MASK_STIFF3 || mask == BF_MASK_STIFF2;
 }
 
@@ -875,7 +879,7 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
     A.npairs = in.npairs;
     if (pt->dim == 3) { A.own_lo = pt->r0_lo; A.own_hi = pt->r0_hi; } else { A.own_lo = 0; A.own_hi = 1; }
-    const int symk = pt->dim == 3 ? 2 : 1;
+    const int symk = !in.sym ? 0 : pt->dim == 3 ? 2 : 1;
     switch (AL.P) {
     case 2: return launch_bf3_p<2>(st, A, ny, mask, pt->ctx->ncu, symk);
     case 3: return launch_bf3_p<3>(st, A, ny, mask, pt->ctx->ncu, symk);

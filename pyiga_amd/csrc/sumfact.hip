@@ -858,11 +858,11 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
     }
     // symmetric forms: k_bf3 writes the upper triangle from the same registers as the lower one (fused3.hip) -- no mirror pass
-    if (sym && pt->knobs.bf != 2 && fused3_supported(in) &&
+    if (pt->knobs.bf != 2 && (sym || dim == 3) && fused3_supported(in) &&
         fused3_offsets_fit(dim, dim == 3 ? A0.p : 0, in.last->p, in.mid->S, in.last->S, in.last->N)) {
-        if (dim == 2) in.mid_hi = pt->r0_hi;             // (no mirror sources above the slab)
+        if (dim == 2 && sym) in.mid_hi = pt->r0_hi;      // (no mirror sources above the slab)
         if (int rc = launch_bf3(st, pt, in, d_data)) return rc;
-        pt->last_path |= IGX_PATH_FUSED | IGX_PATH_BOTH;
+        pt->last_path |= IGX_PATH_FUSED | IGX_PATH_BF3 | (sym ? IGX_PATH_BOTH : 0);
         pt->timing.n_launches++;
         stage_event(pt, 3, st);
         stage_event(pt, 4, st);

@@ -30,7 +30,7 @@ class DevicePatch:
         return {'total_ms': 2.0, 'fields_ms': 0.0, 'stage0_ms': 0.5, 'stage1_ms': 1.0, 'final_ms': 0.5, 'entry_ms': 0.0, 'algo_used': 2}
 
     def last_path(self):
-        return {'geoA', 'fused', 'both'}
+        return {'geoA', 'fused', 'both', 'bf3'}
 
     def close(self):
         pass

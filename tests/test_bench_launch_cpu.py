@@ -43,3 +43,14 @@ def test_single_rank_line_and_failed_rank_is_reported():
     bad = _run(['--gpus', '2', '--steps', '1', '--config', 'tiny', '--no-cpu-baseline'],
                extra_env={'BENCH_PATCH_STUB': os.path.join(ROOT, 'tests', 'does_not_exist.py')}, timeout=120)
     assert bad.returncode != 0 and 'rank' in (bad.stderr + bad.stdout)
+
+
+def test_self_launch_eight_ranks():
+    """world size 8 (what the driver launches for the scaling curve): eight ranks meet, eight slabs tile the patch."""
+    r = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--config', 'tiny', '--no-cpu-baseline'], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and len(d['slab_ms']) == 8 and len(d['setup_s_ranks']) == 8
+    N, p = 14, 2
+    S = sum(min(i + p, N - 1) + 1 - max(i - p, 0) for i in range(N))
+    assert d['config']['nnz'] == S ** 3 and 'scaling_model' in d

@@ -47,3 +47,20 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and len(d['slab_ms']) == 2
     assert d['config']['elements'] == 12 ** 3 and d['value'] > 0
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """The world size of the round-end SCALE run: bench.py --gpus 8 starts eight ranks (all on device 0, gloo rendezvous), each
+    takes its work-balanced slab of the tiny patch, and the eight slabs tile its pattern."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--config', 'tiny', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and len(d['slab_ms']) == 8 and all(x > 0 for x in d['slab_ms'])
+    N, p = 14, 2
+    S = sum(min(i + p, N - 1) + 1 - max(i - p, 0) for i in range(N))
+    assert d['config']['elements'] == 12 ** 3 and d['config']['nnz'] == S ** 3 and d['value'] > 0

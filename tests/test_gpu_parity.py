@@ -1068,7 +1068,7 @@ def test_both_triangles_from_the_fused_stage(iga, monkeypatch):
                     monkeypatch.delenv('IGX_BF', raising=False)
                 patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
                 A = patch.csr(kind, algo='sumfact')
-                assert patch.last_path() == ({'geoA', 'fused', 'mirror'} if bf else {'geoA', 'fused', 'both'}), (kind, bf, patch.last_path())
+                assert patch.last_path() == ({'geoA', 'fused', 'mirror'} if bf else {'geoA', 'fused', 'both', 'bf3'}), (kind, bf, patch.last_path())
                 patch.close()
                 assert not np.isnan(A.data).any()
                 assert abs(A - A.T).max() == 0.0
@@ -1089,7 +1089,7 @@ def test_ablation_variables_have_no_effect(iga, monkeypatch):
     for var, val in (('IGX_PATH', 'unfused'), ('IGX_GEOA', '0'), ('IGX_FINAL', 'valu')):     # read at creation only
         monkeypatch.setenv(var, val)
     B = patch.csr('stiffness', algo='sumfact')
-    assert patch.last_path() == {'geoA', 'fused', 'both'}
+    assert patch.last_path() == {'geoA', 'fused', 'both', 'bf3'}
     patch.close()
     for var in ('IGX_PATH', 'IGX_GEOA', 'IGX_FINAL'):
         monkeypatch.delenv(var)
