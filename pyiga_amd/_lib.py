@@ -111,8 +111,12 @@ _lib = None
 _lock = threading.Lock()
 
 
+IGX_OK, IGX_ERR_ARG, IGX_ERR_HIP, IGX_ERR_UNSUPPORTED, IGX_ERR_NOMEM = 0, 1, 2, 3, 4      # include/igx.h
+
+
 class IgxError(RuntimeError):
-    pass
+    """An entry point of libigx returned a status other than IGX_OK; ``code`` carries it (None: raised on the Python side)."""
+    code = None
 
 
 def load():
@@ -138,7 +142,9 @@ def last_error():
 
 def check(rc, what):
     if rc != 0:
-        raise IgxError('%s failed (code %d): %s' % (what, rc, last_error()))
+        e = IgxError('%s failed (code %d): %s' % (what, rc, last_error()))
+        e.code = rc
+        raise e
 
 
 def dptr(a):

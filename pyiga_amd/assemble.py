@@ -19,6 +19,7 @@ import scipy.sparse
 
 from . import bspline
 from . import assemblers
+from . import _lib
 from .quadrature import make_iterated_quadrature
 
 ################################################################################
@@ -143,6 +144,10 @@ def _separable_form(kind, knotvecs, geo, format):
         patch2 = assemblers.DevicePatch(knotvecs[1:], geo2, nqp=patch3.nqp)      # the Gauss rule of the 3D patch on both axes
         try:
             data = patch3.assemble_kron(kind, patch2, m0, k0)
+        except _lib.IgxError as e:
+            if e.code != _lib.IGX_ERR_UNSUPPORTED:        # degrees beyond the row buffers of the expansion kernel: the general chain
+                raise
+            return None
         finally:
             patch2.close()
         indptr, indices = patch3.pattern()
@@ -342,10 +347,14 @@ def inner_products(kvs, f, f_physical=False, geo=None):
     # (pyiga_amd.symbolic, igx_patch_eval_expr_d): no sampling on the host, no upload; anything else as in the reference
     from . import symbolic
     src = symbolic.trace_function(f, dim) if (not f_physical or isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc))) else None
+    out = None
     if src is not None:
-        patch.eval_function_expr(src, parametric=not f_physical)
-        out = patch.load_vector_resident(to_host=True)
-    else:
+        try:
+            patch.eval_function_expr(src, parametric=not f_physical)
+            out = patch.load_vector_resident(to_host=True)
+        except _lib.IgxError:                                    # (no run-time compiler on this box: sampled on the host)
+            out = None
+    if out is None:
         grid = tuple(patch.gauss(k)[0] for k in range(dim))
         fvals = utils.grid_eval_transformed(f, grid, geo) if f_physical else utils.grid_eval(f, grid)
         out = patch.load_vector(fvals)

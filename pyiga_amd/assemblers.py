@@ -632,9 +632,14 @@ class ConvDiffAssembler3D(_DeviceAssembler):
         if isinstance(diff_coeff, AffineCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
             self.patch.set_coeff_affine(diff_coeff.c)             # evaluated on the device: nothing sampled on the host
             return
+        # (run-time compilation needs libhiprtc on the box and can fail on an expression: a failure falls through to the sampled
+        # coefficient below -- same matrix, set-up on the host)
         if isinstance(diff_coeff, ExprCoefficient) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None:
-            self.coeff_cache_hit = self.patch.set_coeff_expr(diff_coeff.c_source())     # compiled for the device at run time
-            return
+            try:
+                self.coeff_cache_hit = self.patch.set_coeff_expr(diff_coeff.c_source())     # compiled for the device at run time
+                return
+            except _lib.IgxError:
+                pass
         if callable(diff_coeff) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None \
                 and os.environ.get('IGX_FORM_RTC', '1') != '0':
             # a plain Python callable: traced into a C expression (pyiga_amd.symbolic) and compiled like an ExprCoefficient;
@@ -646,9 +651,12 @@ class ConvDiffAssembler3D(_DeviceAssembler):
             except Exception:
                 src = None
             if src is not None:
-                self.coeff_cache_hit = self.patch.set_coeff_expr(src)
-                self.coeff_traced = True
-                return
+                try:
+                    self.coeff_cache_hit = self.patch.set_coeff_expr(src)
+                    self.coeff_traced = True
+                    return
+                except _lib.IgxError:
+                    pass
         # (any other geometry object: the coefficient is sampled through geo.grid_eval like a plain callable)
         grid = [self.patch.gauss(k)[0] for k in range(3)]
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
@@ -695,10 +703,13 @@ class _GeneralFormAssembler(_DeviceAssembler):
                         full[r][s] = traced[r][s]
                 if not any(e is not None for row in full for e in row):
                     raise ValueError('the form has no non-zero coefficient')
-                self.table_mask = [[e is not None for e in row] for row in traced]
-                self.coeff_cache_hit = self.patch.set_form_expr(full)
-                self.compiled = True
-                return
+                try:
+                    self.coeff_cache_hit = self.patch.set_form_expr(full)
+                    self.table_mask = [[e is not None for e in row] for row in traced]
+                    self.compiled = True
+                    return
+                except _lib.IgxError:
+                    pass                                          # no hiprtc on this box / compile error: sampled below
         # (2) coefficients sampled on the Gauss grid on the host
         grid = [self.patch.gauss(k)[0] for k in range(d)]
         G = tuple(len(g) for g in grid)
@@ -821,6 +832,7 @@ class _FunctionalAssembler:
         self.patch = DevicePatch(kvs0, geo, device=device, row0=row0)
         self.gaussgrid = tuple(self.patch.gauss(k)[0] for k in range(self._dim))
         self._vector = None
+        self._f = f
         # a plain callable is traced into a C expression and evaluated on the device (pyiga_amd.symbolic); spline functions
         # and whatever cannot be traced are sampled on the Gauss grid on the host
         from . import symbolic
@@ -835,9 +847,13 @@ class _FunctionalAssembler:
     def assemble_vector(self):
         if self._vector is None:
             if self._fexpr is not None:
-                self.patch.eval_function_expr(self._fexpr, parametric=not self._physical)
-                self._vector = self.patch.load_vector_resident(to_host=True)
-            else:
+                try:
+                    self.patch.eval_function_expr(self._fexpr, parametric=not self._physical)
+                    self._vector = self.patch.load_vector_resident(to_host=True)
+                except _lib.IgxError:                            # (no run-time compiler on this box: sampled on the host)
+                    self._fexpr = None
+                    self._fvals = utils.grid_eval_transformed(self._f, self.gaussgrid, self._geo) if self._physical else utils.grid_eval(self._f, self.gaussgrid)
+            if self._vector is None:
                 self._vector = self.patch.load_vector(self._fvals)
         return self._vector.copy()
 
@@ -866,6 +882,7 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
     def __init__(self, kvs0, geo, form, inputs=None, device=None, row0=None):
         from . import forms
         super().__init__(kvs0, geo, lambda *xyz: 0.0, device=device, row0=row0)
+        self._form, self._inputs = form, inputs
         # the coefficients of v and grad(v) as generated device code when the string and its inputs can be traced (pyiga_amd.symbolic)
         self._jet_exprs = None
         if os.environ.get('IGX_FORM_RTC', '1') != '0' and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)):
@@ -887,8 +904,15 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
     def assemble_vector(self):
         if self._vector is None:
             if self._jet_exprs is not None and any(e is not None for e in self._jet_exprs):
-                self._vector = self.patch.load_vector_jet_expr(self._jet_exprs + [None] * (4 - len(self._jet_exprs)))
-            elif all(e is None for e in self._jet):
+                try:
+                    self._vector = self.patch.load_vector_jet_expr(self._jet_exprs + [None] * (4 - len(self._jet_exprs)))
+                    return self._vector.copy()
+                except _lib.IgxError:                            # (no run-time compiler on this box: the jet is sampled on the host)
+                    from . import forms
+                    G = tuple(len(g) for g in self.gaussgrid)
+                    self._jet = forms.functional_jet(self._form, G, np.asarray(self._geo.grid_eval(list(self.gaussgrid))), dict(self._inputs or {}))
+                    self._jet_exprs = None
+            if all(e is None for e in self._jet):
                 lo, hi = self.patch.row_range                # the zero functional ('0 * v * dx')
                 nd = self.patch.ndofs
                 self._vector = np.zeros(((hi - lo) // int(np.prod(nd[1:])),) + tuple(nd[1:]))

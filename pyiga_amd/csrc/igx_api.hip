@@ -649,18 +649,27 @@ int igx_patch_set_basis_orders(igx_patch *pt, const int *slot0, const int *slot1
         if (slot0[k] < 0 || slot1[k] > 2 || slot0[k] >= slot1[k]) { set_error("igx_patch_set_basis_orders: axis %d: orders (%d, %d), expected 0 <= first < second <= 2", k, slot0[k], slot1[k]); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
-    bool def = true;
-    for (int k = 0; k < pt->dim; ++k) {
+    // On EVERY exit the flag says what the tables hold: it drops to false before the first table is touched and becomes true
+    // again only when all axes are back at (value, first derivative); an axis whose rewrite failed is marked as holding
+    // nothing usable, so that the next successful call rewrites it.
+    pt->basis_default = false;
+    int rc = IGX_OK;
+    for (int k = 0; k < pt->dim && rc == IGX_OK; ++k) {
         Axis &A = pt->ax[k];
         if (A.ord[0] != slot0[k] || A.ord[1] != slot1[k]) {
-            int rc;
-            if ((rc = launch_basis_tables(st, A.d_kv, (int)A.kv.size(), A.p, A.d_nodes, (size_t)A.G, slot1[k], nullptr, A.d_V, nullptr, nullptr, slot0[k], slot1[k]))) return rc;
-            if ((rc = launch_pi_tables(st, A.d_V, A.G, A.P, A.d_PI))) return rc;
-            A.ord[0] = slot0[k]; A.ord[1] = slot1[k];
+            A.ord[0] = A.ord[1] = -1;
+            rc = launch_basis_tables(st, A.d_kv, (int)A.kv.size(), A.p, A.d_nodes, (size_t)A.G, slot1[k], nullptr, A.d_V, nullptr, nullptr, slot0[k], slot1[k]);
+            if (rc == IGX_OK) rc = launch_pi_tables(st, A.d_V, A.G, A.P, A.d_PI);
+            if (rc == IGX_OK) { A.ord[0] = slot0[k]; A.ord[1] = slot1[k]; }
         }
-        def = def && A.ord[0] == 0 && A.ord[1] == 1;
     }
-    IGX_HIP(hipStreamSynchronize(st));
+    if (hipStreamSynchronize(st) != hipSuccess && rc == IGX_OK) { set_error("igx_patch_set_basis_orders: synchronisation failed"); rc = IGX_ERR_HIP; }
+    if (rc != IGX_OK) {
+        for (int k = 0; k < pt->dim; ++k) pt->ax[k].ord[0] = pt->ax[k].ord[1] = -1;      // (the kernels may not have run: rewrite all next time)
+        return rc;
+    }
+    bool def = true;
+    for (int k = 0; k < pt->dim; ++k) def = def && pt->ax[k].ord[0] == 0 && pt->ax[k].ord[1] == 1;
     pt->basis_default = def;
     return IGX_OK;
 }
@@ -853,6 +862,11 @@ int igx_assemble_kron3(igx_patch *p3, igx_patch *p2, int kind, const double *m0,
         if (a.N != b.N || a.P != b.P || a.q != b.q || a.S != b.S || a.kv != b.kv) { set_error("igx_assemble_kron3: axis %d of the cross-section does not match (knots, degree or Gauss points per span)", k); return IGX_ERR_ARG; }
     }
     if (p2->r0_lo != 0 || p2->r0_hi != p2->ax[0].N) { set_error("igx_assemble_kron3: the cross-section patch must be whole"); return IGX_ERR_ARG; }
+    // k_kron3 stages one 2D row (<= 128 entries) and one 1D row (<= 16 entries) per wave in LDS (kron.hip)
+    if ((2 * p3->ax[1].p + 1) * (2 * p3->ax[2].p + 1) > 128 || 2 * p3->ax[0].p + 1 > 16) {
+        set_error("igx_assemble_kron3: degrees (%d, %d, %d) beyond the row buffers of the expansion kernel", p3->ax[0].p, p3->ax[1].p, p3->ax[2].p);
+        return IGX_ERR_UNSUPPORTED;
+    }
     IGX_HIP(hipSetDevice(p3->ctx->device));
     hipStream_t st = p3->ctx->stream;
     const int C0 = 2 * p3->ax[0].p + 1, N0 = p3->ax[0].N;

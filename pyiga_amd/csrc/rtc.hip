@@ -41,10 +41,29 @@ static int rtc_api(RtcApi **out)
 {
     static RtcApi api;
     static std::once_flag once;
+    if (getenv("IGX_NO_HIPRTC")) {                           // (tests: a box without the run-time compiler)
+        set_error("run-time compilation needs libhiprtc.so (switched off: IGX_NO_HIPRTC)");
+        return IGX_ERR_UNSUPPORTED;
+    }
     std::call_once(once, [] {
-        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so.6"}) {
             api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.h) break;
+        }
+        if (!api.h) {
+            // next to the HIP runtime this library is linked against (a ROCm tree outside the loader's search path)
+            Dl_info di;
+            if (dladdr((void *)&hipGetLastError, &di) && di.dli_fname) {
+                std::string dir(di.dli_fname);
+                const size_t k = dir.rfind('/');
+                if (k != std::string::npos) {
+                    dir.resize(k + 1);
+                    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"}) {
+                        api.h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                        if (api.h) break;
+                    }
+                }
+            }
         }
         if (!api.h) return;
         api.create = (decltype(api.create))dlsym(api.h, "hiprtcCreateProgram");
@@ -78,6 +97,10 @@ static std::string cache_dir()
         }
         if (i < d.size()) cur.push_back(d[i]);
     }
+    // the cache holds code that will be LOADED: a directory this user does not own, or that others may write to, is not used
+    // (compiled in memory every time instead; rtc_code_object treats an empty directory name as "no cache")
+    struct stat sb;
+    if (stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))) return std::string();
     return d;
 }
 
@@ -107,9 +130,10 @@ static std::string coeff_source(const char *expr)
 // code object of `src` for `arch`: from the cache, or compiled and put there.  *hit = 1 when no compilation was needed.
 static int rtc_code_object(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &path, int *hit)
 {
-    path = cache_dir() + "/igx_" + source_hash(arch + "\n" + src) + ".hsaco";
+    const std::string cdir = cache_dir();                   // empty: no directory this user owns alone -- nothing is read or written
+    path = cdir.empty() ? std::string() : cdir + "/igx_" + source_hash(arch + "\n" + src) + ".hsaco";
     if (hit) *hit = 0;
-    if (FILE *f = fopen(path.c_str(), "rb")) {
+    if (FILE *f = path.empty() ? nullptr : fopen(path.c_str(), "rb")) {
         fseek(f, 0, SEEK_END);
         const long n = ftell(f);
         fseek(f, 0, SEEK_SET);
@@ -142,7 +166,7 @@ static int rtc_code_object(const std::string &src, const std::string &arch, std:
     if (grc != 0) { set_error("hiprtcGetCode failed"); return IGX_ERR_HIP; }
     // atomically into the cache (another process may compile the same source at the same time)
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    if (FILE *f = fopen(tmp.c_str(), "wb")) {
+    if (FILE *f = path.empty() ? nullptr : fopen(tmp.c_str(), "wb")) {
         const bool ok = fwrite(code.data(), 1, n, f) == n;
         fclose(f);
         if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());

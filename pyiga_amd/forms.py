@@ -17,6 +17,8 @@ Anything else (higher derivatives, vector-valued bases, surface integrals, ``div
 """
 import numpy as np
 
+from . import symbolic
+
 
 def _arr(x):
     """float array -- or the object array of a traced evaluation (pyiga_amd.symbolic), left as it is"""
@@ -351,7 +353,7 @@ def coefficient_table(expr, G, X, inputs, traced=False):
     for r in range(n):
         for s in range(n):
             e = res.P[r][s]
-            if e is not None and np.any(e != 0.0):
+            if e is not None and symbolic.any_nonzero(e):
                 table[r][s] = np.broadcast_to(e, G) if traced else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float)
     return table
 
@@ -379,7 +381,7 @@ def functional_jet(expr, G, X, inputs, traced=False):
         raise NotImplementedError('the form must be a volume integral (... * dx) that is linear in v')
     out = []
     for e in _jet(res.lin):
-        if e is None or not np.any(e != 0.0):
+        if e is None or not symbolic.any_nonzero(e):
             out.append(None)
         else:
             out.append(np.broadcast_to(e, G) if traced else np.ascontiguousarray(np.broadcast_to(e, G), dtype=float))

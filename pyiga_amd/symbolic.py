@@ -15,6 +15,21 @@ import math
 import numpy as np
 
 
+def any_nonzero(a):
+    """``np.any(a != 0.0)`` for the coefficient arrays of the form front-end: float arrays as usual; in an array of traced
+    expressions only a constant 0 counts as zero (a non-constant expression is a present coefficient)."""
+    a = np.asarray(a)
+    if a.dtype != object:
+        return bool(np.any(a != 0.0))
+    for e in a.flat:
+        if isinstance(e, Sym):
+            if e.const is None or e.const != 0.0:
+                return True
+        elif e != 0.0:
+            return True
+    return False
+
+
 class NotTraceable(TypeError):
     """The computation does something the tracer cannot express as a C expression in x, y, z."""
 
@@ -154,8 +169,8 @@ class Sym:
         if isinstance(o, (int, float, np.integer, np.floating)) and not isinstance(o, (bool, np.bool_)):
             if self.const is not None:
                 return self.const == float(o)
-            if float(o) == 0.0:
-                return False                      # a non-constant expression is not the absent (zero) coefficient
+            # (a user's ``np.where(x == 0, ...)`` or ``(x == 0) * c`` is a branch on values the trace does not have: the caller
+            # samples on the host.  The front-end's own "is this coefficient absent" test is any_nonzero() below.)
             raise NotTraceable('comparison of a traced expression with a number')
         return NotImplemented
 

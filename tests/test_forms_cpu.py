@@ -295,3 +295,18 @@ def test_form_kernel_compiles_and_is_cached(forms, tmp_path, monkeypatch):
     assert open(path, 'rb').read(4) == b'\x7fELF'
     assert cdll.igx_rtc_compile_form(len(exprs), arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 1
     assert cdll.igx_rtc_compile_form(len(exprs) - 1, arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0 and buf.value.decode() != path
+
+
+def test_equality_with_a_number_is_not_traced():
+    """a callable that branches on ``x == 0`` must not be traced with the branch silently dropped."""
+    from pyiga_amd import symbolic
+    X = symbolic.coordinates(3)
+    x = X[..., 0]
+    with pytest.raises(symbolic.NotTraceable):
+        np.where(x == 0, 1.0, np.sin(x) / x)
+    with pytest.raises(symbolic.NotTraceable):
+        (x != 0) * 2.0
+    assert symbolic.trace_function(lambda x, y, z: np.where(x == 0, 1.0, x), 3) is None
+    # the front-end's own test for an absent coefficient
+    assert symbolic.any_nonzero(x) and not symbolic.any_nonzero(np.array([symbolic.Sym('0.0', 0.0)], dtype=object))
+    assert symbolic.any_nonzero(np.array([0.0, 1e-300])) and not symbolic.any_nonzero(np.zeros(3))

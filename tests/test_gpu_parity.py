@@ -2157,3 +2157,41 @@ def test_functional_form_strings_compiled(iga, golden, monkeypatch):
     assert _close(v3, g['funcgrad_d3'], 1e-13)
     step = iga.assemble.instantiate_assembler('c * v * dx', kv2, dict(geo=ann, c=lambda x, y: np.where(x > 1.0, 1.0, 2.0 + 0.0 * y)))
     assert step._jet_exprs is None and np.isfinite(step.assemble_vector()).all()
+
+
+def test_without_the_run_time_compiler_everything_still_assembles(iga, monkeypatch, tmp_path):
+    """run-time compilation is the default for form strings, traced callables and functionals; on a box without
+    libhiprtc (IGX_NO_HIPRTC, an empty cache) every one of those calls must fall through to host sampling -- same results."""
+    mk = iga.bspline.make_knots
+    kvs = (mk(2, 0., 1., 5), mk(2, 0., 1., 4), mk(2, 0., 1., 6))
+    geo = _geo(iga, 'cylinder')
+
+    def coef(x, y, z):
+        return 1.0 + x * y + np.sin(z)
+
+    def run():
+        A = iga.assemble.assemble('(c * inner(grad(u), grad(v)) + u * v) * dx', kvs, geo=geo, c=coef)
+        b = iga.assemble.inner_products(kvs, coef, f_physical=True, geo=geo)
+        f = iga.assemble.assemble('(c * v + inner(b, grad(v))) * dx', kvs, geo=geo, c=coef, b=lambda x, y, z: (1.0 + 0 * x, x, y * z))
+        C = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coef).assemble_csr()
+        return A, b, f, C
+    ref = run()
+    monkeypatch.setenv('IGX_NO_HIPRTC', '1')
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'empty_cache'))
+    out = run()
+    for r, o in zip(ref, out):
+        r = r.toarray() if hasattr(r, 'toarray') else np.asarray(r)
+        o = o.toarray() if hasattr(o, 'toarray') else np.asarray(o)
+        assert r.shape == o.shape and np.abs(r - o).max() <= 1e-13 * np.abs(r).max()
+
+
+def test_kronecker_shortcut_refuses_degrees_beyond_its_row_buffers(iga, monkeypatch):
+    """k_kron3 stages one 2D row of at most 128 entries per wave; degree 6 on the cross-section axes (13 * 13 = 169)
+    must be refused by the library and the opt-in path must fall back to the general chain (same matrix)."""
+    mk = iga.bspline.make_knots
+    kvs = (mk(2, 0., 1., 3), mk(6, 0., 1., 2), mk(6, 0., 1., 2))
+    geo = _geo(iga, 'cylinder')
+    A = iga.assemble.stiffness(kvs, geo)
+    monkeypatch.setenv('IGX_SEPARABLE', '1')
+    B = iga.assemble.stiffness(kvs, geo)
+    assert (A != B).nnz == 0 or abs(A - B).max() <= 1e-13 * abs(A).max()
