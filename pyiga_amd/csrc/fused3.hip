@@ -313,7 +313,11 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
             rsrc[t1][i] = bf2_rsrc(A.sp[R.y][t1][i] + (long long)r0 * A.ss[R.y][t1][i] - (long long)A.gmid_lo * A.rs[R.y][t1][i]);
         }
     auto ld = [&](const int t1, const int i, const int row) {
+#ifdef BF3_NOLOAD
+        return (double)(row + t1);                           // (timing experiment: no K1 traffic)
+#else
         return bf2_buffer_load(rsrc[t1][i], voff, row * urs[t1][i]);
+#endif
     };
     const int n_sw = min(A.n1, A.span_hi);
     const int t_sw = min(n_sw, rhi);

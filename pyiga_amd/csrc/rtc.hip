@@ -114,13 +114,81 @@ static std::string source_hash(const std::string &s)
     return buf;
 }
 
+// Coordinates of the resident Gauss points are worked out INSIDE the generated kernel (round 5): the parametric ones are three
+// node tables, the physical ones the tensor-product evaluation of the control net with the geometry basis values at the Gauss
+// nodes -- the tables the assembly kernels use.  (Round 4 materialised 3 x npts doubles first -- 6.3 GB at C4 -- and read them
+// back; the reference fuses its inputs into the field loop the same way: pyiga/codegen/cython.py:673-701.)
+// The struct is part of the generated source AND of this file: keep them identical.
+struct IgxCo {
+    const double *nodes[3];        // Gauss nodes of grid axis k
+    const double *V[3];            // geometry basis values at those nodes: [G][P][2] (value, derivative)
+    const int *fa[3];              // first active control index at node g
+    int P[3], N[3];                // active functions / control points per grid axis
+    const double *ctrl;            // control net (N0, N1[, N2], nc), homogeneous for NURBS
+    int nc, dim, nurbs, parametric;
+    int g0_lo, L1, L2, b1, b2;     // resident window of the Gauss grid (PatchDev)
+};
+static const char *const RTC_PRELUDE = R"IGX(
+struct IgxCo {
+    const double *nodes[3];
+    const double *V[3];
+    const int *fa[3];
+    int P[3], N[3];
+    const double *ctrl;
+    int nc, dim, nurbs, parametric;
+    int g0_lo, L1, L2, b1, b2;
+};
+// index of this thread's resident Gauss point and its grid indices: the launch grid is (points of the last axis, mid axis,
+// axis 0) -- no integer division per point; returns -1 past the end of a line
+__device__ inline long long igx_point(const IgxCo &c, int g[3])
+{
+    const int Ll = c.dim == 3 ? c.L2 : c.L1;
+    const int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gl >= Ll) return -1;
+    g[0] = g[1] = g[2] = 0;
+    if (c.dim == 3) { g[2] = gl + c.b2; g[1] = (int)blockIdx.y + c.b1; g[0] = (int)blockIdx.z + c.g0_lo; return ((long long)blockIdx.z * c.L1 + blockIdx.y) * c.L2 + gl; }
+    g[1] = gl + c.b1; g[0] = (int)blockIdx.y + c.g0_lo;
+    return (long long)blockIdx.y * c.L1 + gl;
+}
+// (x, y, z) of the Gauss point with grid indices g: x belongs to the LAST grid axis
+__device__ inline void igx_coords(const IgxCo &c, const int g[3], double &x, double &y, double &z)
+{
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c.parametric) {
+        for (int k = 0; k < c.dim; ++k) v[k] = c.nodes[c.dim - 1 - k][g[c.dim - 1 - k]];
+    } else {
+        const int P0 = c.P[0], P1 = c.P[1], P2 = c.dim == 3 ? c.P[2] : 1;
+        const double *V0 = c.V[0] + (long long)g[0] * P0 * 2, *V1 = c.V[1] + (long long)g[1] * P1 * 2;
+        const double *V2 = c.dim == 3 ? c.V[2] + (long long)g[2] * P2 * 2 : 0;
+        const int f0 = c.fa[0][g[0]], f1 = c.fa[1][g[1]], f2 = c.dim == 3 ? c.fa[2][g[2]] : 0;
+        const int N2 = c.dim == 3 ? c.N[2] : 1;
+        for (int a0 = 0; a0 < P0; ++a0)
+            for (int a1 = 0; a1 < P1; ++a1) {
+                const double w01 = V0[2 * a0] * V1[2 * a1];
+                for (int a2 = 0; a2 < P2; ++a2) {
+                    const double w = c.dim == 3 ? w01 * V2[2 * a2] : w01;
+                    const double *cp = c.ctrl + (((long long)(f0 + a0) * c.N[1] + (f1 + a1)) * N2 + (f2 + a2)) * c.nc;
+                    for (int k = 0; k < c.nc; ++k) v[k] += w * cp[k];
+                }
+            }
+        if (c.nurbs) {
+            const double iW = 1.0 / v[c.nc - 1];
+            for (int k = 0; k < c.dim; ++k) v[k] *= iW;
+        }
+        if (c.dim == 2) v[2] = 0.0;
+    }
+    x = v[0]; y = v[1]; z = c.dim == 3 ? v[2] : 0.0;
+}
+)IGX";
+
 static std::string coeff_source(const char *expr)
 {
     std::string s;
-    s += "// generated by libigx (igx_patch_set_coeff_expr): scalar coefficient in the physical coordinates\n";
-    s += "extern \"C\" __global__ void igx_coeff_expr(const double *X, const double *Y, const double *Z, double *out, long long n)\n{\n";
-    s += "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n    if (i >= n) return;\n";
-    s += "    const double x = X[i], y = Y[i], z = Z[i];\n    const double pi = 3.14159265358979323846;\n    (void)x; (void)y; (void)z; (void)pi;\n";
+    s += "// generated by libigx (igx_patch_set_coeff_expr): scalar coefficient in the physical (or parametric) coordinates\n";
+    s += RTC_PRELUDE;
+    s += "extern \"C\" __global__ void igx_coeff_expr(const IgxCo co, double *out, long long n)\n{\n";
+    s += "    int g[3];\n    const long long i = igx_point(co, g);\n    if (i < 0 || i >= n) return;\n";
+    s += "    double x, y, z;\n    igx_coords(co, g, x, y, z);\n    const double pi = 3.14159265358979323846;\n    (void)x; (void)y; (void)z; (void)pi;\n";
     s += "    out[i] = (double)(";
     s += expr;
     s += ");\n}\n";
@@ -210,44 +278,8 @@ static int rtc_function(igx_patch *pt, const std::string &src, const char *entry
     return IGX_OK;
 }
 
-// parametric coordinates of the resident Gauss points: coordinate k (x = last grid axis) is the node of grid axis dim-1-k
-__global__ void k_param_coords(const PatchDev pd, double *xyz)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = pd.npts_loc;
-    if (i >= n) return;
-    long long r = i;
-    int g[3] = {0, 0, 0};
-    if (pd.dim == 3) { g[2] = (int)(r % pd.L2) + pd.b2; r /= pd.L2; }
-    g[1] = (int)(r % pd.L1) + pd.b1; r /= pd.L1;
-    g[0] = (int)r + pd.g0_lo;
-    for (int k = 0; k < 3; ++k) xyz[(long long)k * n + i] = k < pd.dim ? pd.ax[pd.dim - 1 - k].nodes[g[pd.dim - 1 - k]] : 0.0;
-}
-
-// physical (or parametric) coordinates of the resident Gauss points, [3][npts_loc] (absent axes: zeros): the affine-coefficient
-// kernel with unit coefficients.  The caller frees *xyz.
-static int physical_coordinates(hipStream_t st, igx_patch *pt, double **xyz, bool parametric = false)
-{
-    const long long n = pt->dev.npts_loc;
-    if (parametric) {
-        *xyz = nullptr;
-        if (hipMalloc((void **)xyz, (size_t)3 * std::max<long long>(n, 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("coefficient expression: %.2f GB for the coordinates", 24e-9 * n); return IGX_ERR_NOMEM; }
-        if (n) k_param_coords<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(pt->dev, *xyz);
-        if (hipGetLastError() != hipSuccess) { (void)hipFree(*xyz); *xyz = nullptr; set_error("parametric coordinates: launch failed"); return IGX_ERR_HIP; }
-        return IGX_OK;
-    }
-    *xyz = nullptr;
-    if (hipMalloc((void **)xyz, (size_t)3 * std::max<long long>(n, 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("coefficient expression: %.2f GB for the coordinates", 24e-9 * n); return IGX_ERR_NOMEM; }
-    int rc = IGX_OK;
-    for (int k = 0; k < 3 && !rc; ++k) {
-        double c[4] = {0, 0, 0, 0};
-        if (k < pt->dim) c[1 + k] = 1.0;
-        rc = launch_coeff_affine(st, pt, c, *xyz + (size_t)k * n);
-    }
-    if (rc) { (void)hipFree(*xyz); *xyz = nullptr; }
-    return rc;
-}
-
-// out[k][i] = expr_k(X[i], Y[i], Z[i]) for the n_expr expressions, one kernel
+// out[k][i] = expr_k(x_i, y_i, z_i) for the n_expr expressions, one kernel, coordinates evaluated in the kernel: no workspace,
+// no synchronisation -- the launch is ordered on the patch's stream like every other kernel of the library
 static int launch_exprs(hipStream_t st, igx_patch *pt, const std::string &src, const char *entry, double *d_out, int *hit, bool parametric = false)
 {
     if (!parametric && pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("a coefficient expression needs a spline geometry (physical coordinates)"); return IGX_ERR_UNSUPPORTED; }
@@ -255,20 +287,25 @@ static int launch_exprs(hipStream_t st, igx_patch *pt, const std::string &src, c
     if (int rc = rtc_function(pt, src, entry, &fn, hit)) return rc;
     const long long n = pt->dev.npts_loc;
     if (n == 0) return IGX_OK;
-    double *xyz = nullptr;
-    int rc = physical_coordinates(st, pt, &xyz, parametric);
-    if (rc) return rc;
-    {
-        const double *X = xyz, *Y = xyz + n, *Z = xyz + 2 * n;
-        long long nn = n;
-        void *args[] = {(void *)&X, (void *)&Y, (void *)&Z, (void *)&d_out, (void *)&nn};
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        if (hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr) != hipSuccess) { (void)hipGetLastError(); set_error("launch of the compiled coefficient kernel failed"); rc = IGX_ERR_HIP; }
+    IgxCo co{};
+    const int dim = pt->dim;
+    for (int k = 0; k < 3; ++k) {
+        co.nodes[k] = k < dim ? pt->ax[k].d_nodes : nullptr;
+        co.V[k] = k < dim ? pt->gax[k].d_V : nullptr;
+        co.fa[k] = k < dim ? pt->gax[k].d_fa : nullptr;
+        co.P[k] = k < dim ? pt->gax[k].P : 1;
+        co.N[k] = k < dim ? pt->gax[k].N : 1;
     }
-    const hipError_t se = hipStreamSynchronize(st);
-    (void)hipFree(xyz);
-    if (!rc && se != hipSuccess) { set_error("compiled coefficient kernel: %s", hipGetErrorString(se)); rc = IGX_ERR_HIP; }
-    return rc;
+    co.ctrl = pt->d_ctrl; co.nc = pt->ncomp; co.dim = dim; co.nurbs = pt->geo_kind == IGX_GEO_NURBS ? 1 : 0; co.parametric = parametric ? 1 : 0;
+    co.g0_lo = pt->dev.g0_lo; co.L1 = pt->dev.L1; co.L2 = dim == 3 ? pt->dev.L2 : 1; co.b1 = pt->dev.b1; co.b2 = pt->dev.b2;
+    long long nn = n;
+    void *args[] = {(void *)&co, (void *)&d_out, (void *)&nn};
+    // grid: (last axis in blocks of 256 points, mid axis, axis 0) -- the kernel takes its grid indices from the block indices
+    const int Ll = dim == 3 ? pt->dev.L2 : pt->dev.L1;
+    const unsigned gx = (unsigned)((Ll + 255) / 256), gy = (unsigned)(dim == 3 ? pt->dev.L1 : pt->dev.G0_loc), gz = (unsigned)(dim == 3 ? pt->dev.G0_loc : 1);
+    if (gy > 65535u || gz > 65535u) { set_error("coefficient expression: Gauss grid beyond the launch grid"); return IGX_ERR_UNSUPPORTED; }
+    if (hipModuleLaunchKernel(fn, gx, gy, gz, 256, 1, 1, 0, st, args, nullptr) != hipSuccess) { (void)hipGetLastError(); set_error("launch of the compiled coefficient kernel failed"); return IGX_ERR_HIP; }
+    return IGX_OK;
 }
 
 int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *hit, bool parametric)
@@ -281,9 +318,10 @@ static std::string form_source(int n_expr, const char *const *expr)
 {
     std::string s;
     s += "// generated by libigx (igx_patch_set_form_expr): coefficient fields of a form in the physical coordinates\n";
-    s += "extern \"C\" __global__ void igx_form_expr(const double *X, const double *Y, const double *Z, double *out, long long n)\n{\n";
-    s += "    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n    if (i >= n) return;\n";
-    s += "    const double x = X[i], y = Y[i], z = Z[i];\n    const double pi = 3.14159265358979323846;\n    (void)x; (void)y; (void)z; (void)pi;\n";
+    s += RTC_PRELUDE;
+    s += "extern \"C\" __global__ void igx_form_expr(const IgxCo co, double *out, long long n)\n{\n";
+    s += "    int g[3];\n    const long long i = igx_point(co, g);\n    if (i < 0 || i >= n) return;\n";
+    s += "    double x, y, z;\n    igx_coords(co, g, x, y, z);\n    const double pi = 3.14159265358979323846;\n    (void)x; (void)y; (void)z; (void)pi;\n";
     for (int k = 0; k < n_expr; ++k) {
         s += "    out[" + std::to_string(k) + " * n + i] = (double)(";
         s += expr[k];
