@@ -109,6 +109,7 @@ struct BF3Store {
     int lane8, lanec, inv;       // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
     double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
     int nD, nT;
+    int fake_tile = 0;
     int s_l0 = 0, s_c1 = 1, s_sKD = 0, s_soffD = 0, s_sKT = 0, s_soffT = 0, s_lenD = 0, s_lenT = 0;
 
     struct Row { int on, l0, c1, rp1d, sub1, sub2, sub3, sub4, sub5; };
@@ -128,7 +129,7 @@ struct BF3Store {
         r.sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
         return r;
     }
-    __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int lane)
+    __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int /*sw*/, const int lane)
     {
         cip rp0 = (cip)A.rp0;
 #pragma unroll
@@ -136,6 +137,7 @@ struct BF3Store {
 #pragma unroll
         for (int k = 0; k < (STAGE && NSET == 2 ? NST : 1); ++k) svT[k] = 0.0;
         lane8 = lane * 8;
+        fake_tile = B.row_lo / max(B.nrows, 1);
         lanec = min((NSUB - 1) * 64 + lane, RW - 1) - (NSUB - 1) * 64;
         // descriptors: base moved by W row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W i2 - T0) (c0 c1 - 1)
         // + (chunk element index) + W (line terms); length = the row block of the outer row (anything beyond is dropped)
@@ -207,11 +209,17 @@ struct BF3Store {
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int l = line_of(sw, c, j);
+#ifdef BF3_DENSEFAKE
+                // (timing experiment: the same bytes as 512 contiguous ones per store, somewhere inside the row block -- wrong matrix)
+                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), lane8 + c * 512, (soff0 / 4096) * 4096 + ((l * NSUB) * 512) % 190000 + fake_tile * 190000, v[c * JMAX + j]);
+#else
                 bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * l, v[c * JMAX + j]);
+#endif
             }
     }
 
     // behind B1 (STAGE): the rows read at the end of the last step go out
+    __device__ __forceinline__ void issue(const BFArgs &, const BF3Blk &, const int, const int sw) { issue(sw); }
     __device__ __forceinline__ void issue(const int sw)
     {
         if (!STAGE) return;
@@ -241,6 +249,109 @@ struct BF3Store {
                 read_row<1>(tv, sets, dump, sw, lane, r);
                 write_row(tv, pT, r.on ? nT : 0, sw, r.l0, r.c1, sKT, soffT);
             }
+        }
+    }
+};
+
+// The store duty on the sweeper waves, DENSE (round 5): a slot is 64 consecutive doubles of the row-major image of a tile's
+// rows -- (row, line, entry), (2p+1)^2 per row -- so a store instruction writes 512 contiguous bytes of CSR values and the
+// segments of a row leave whole within one burst (the per-line slots of BF3Store write 72-byte runs 648 bytes apart, 9 waves
+// each a ninth of every segment: 0.45 ms slower at C4 by a stand-in measurement, and 1.5 GB of read-for-ownership traffic).
+// The rings are [line][row][entry], so a lane's LDS address is (block of ITS line) + (row, entry): the line blocks of the step
+// sit in one register (lane j holds the block of line j) and come per slot through ds_bpermute.  Per lane and slot one packed
+// constant: line | (row W + entry) | row | invalid (edge rows, lanes past the tile).  NS waves take the slots s = sw + NS k.
+// The waves of one GROUP (sw = 0 .. QSTR-1) take the slots QLO + sw + QSTR k, k < K, below QHI: the sweepers of the last role
+// (one input array: registers to spare) take half as many slots again as those of the middle roles.
+template <int NR, int NLG, int NQ> struct BF3DenseSplit {
+    static constexpr int NA = (NR - 2) * NLG, NB = NLG;                        // waves of the middle roles / of the last role
+    static constexpr int ka() { if (NA == 0) return 0; int k = 1; while (NA * k + NB * ((3 * k + 1) / 2) < NQ) ++k; return k; }
+    static constexpr int KA = ka(), KB = NA == 0 ? (NQ + NB - 1) / NB : (3 * KA + 1) / 2;
+    static constexpr int QB = NA * KA < NQ ? NA * KA : NQ;                     // first slot of the last role's group
+};
+template <class Gm, int P, int NS, int NH, int SYM, int K, int QLO, int QHI, int QSTR>
+struct BF3StoreDense {
+    static constexpr int p = P - 1, W = 2 * P - 1, WW = W * W, RW = Gm::RW, NSET = SYM == 2 ? 2 : 1;
+    double svD[K], svT[NSET == 2 ? K : 1];
+    int pk[K];                   // bits 0-5: 4 line | 6-17: row W + entry | 18-25: row | 31: no element  (the same for both sets)
+    int lane8;
+    double *pD, *pT;
+    long long nD, nT;            // bytes of the row blocks of the two outer rows (0: not stored)
+    using St = BF3Store<Gm, P, NS, 0, NH, SYM, true>;
+    using Row = typename St::Row;
+
+    __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int sw, const int lane)
+    {
+        cip rp0 = (cip)A.rp0;
+        lane8 = lane * 8;
+        pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off); nD = B.stD ? (long long)B.c0i * B.S12 * 8 : 0;
+        pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off); nT = B.stT ? (long long)B.c0j * B.S12 * 8 : 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            svD[k] = 0.0;
+            if (NSET == 2) svT[k] = 0.0;
+            const int qi = QLO + sw + QSTR * k;
+            const int q = qi * 64 + lane, rr = q / WW, rem = q - rr * WW, l = rem / W, e = rem - l * W, i2 = B.row_lo + rr;
+            const bool ok = qi < QHI && q < Gm::RMAX * WW && rr < B.nrows && i2 >= p && i2 <= A.N2 - 1 - p;
+            pk[k] = ok ? (4 * l) | ((rr * W + e) << 6) | (rr << 18) : (int)0x80000000;
+        }
+    }
+
+    // behind B2 of step t: rows d = t - 1 of both sets are complete -> registers (cleared where halves add)
+    __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, double *dump, const int t, const int sw, const int lane)
+    {
+        const Row r = St::row_of(A, B, t);
+        // block (doubles from the start of a set) of line j of the row, on lane j
+        int lv = Gm::OFF_CUR + (lane - p) * RW;
+        lv = lane == p - 1 ? r.sub1 : lv;
+        if (p >= 2) lv = lane == p - 2 ? r.sub2 : lv;
+        if (p >= 3) lv = lane == p - 3 ? r.sub3 : lv;
+        if (p >= 4) lv = lane == p - 4 ? r.sub4 : lv;
+        if (p >= 5) lv = lane == p - 5 ? r.sub5 : lv;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int pkk = pk[k];
+            asm volatile("" : "+v"(pkk));                   // (decoded here, every step: kept decoded the fields of all slots cost 20 registers)
+            const int lo = __builtin_amdgcn_ds_bpermute(pkk & 60, lv) + ((pkk >> 6) & 0xfff);
+            double *src = pkk < 0 ? dump : sets + lo;        // (lanes without an element: a harmless address)
+            svD[k] = *src;
+            if (NH == 2) *src = 0.0;
+            if (NSET == 2) {
+                double *srcT = pkk < 0 ? dump : sets + Gm::SETSZ + lo;
+                svT[k] = *srcT;
+                if (NH == 2) *srcT = 0.0;
+            }
+        }
+    }
+
+    // behind B1 of step t + 1: the rows read behind B2 of step t go out, 512 contiguous bytes per instruction.  The scalars of
+    // the row are worked out again here (a handful of scalar instructions) instead of being kept across the sweep.
+    __device__ __forceinline__ void issue(const BFArgs &A, const BF3Blk &B, const int t, const int sw)
+    {
+#ifdef BF3_NOSTORE
+        return;
+#endif
+        const Row r = St::row_of(A, B, t);
+        // descriptors of the row: base moved by the row's constant part, so that an element sits at 8 (its index in the image)
+        // + row * 8 W (c0 c1 - W); what is left of the row block behind the moved base is the length
+        const int cD = B.c0i * r.c1, cT = B.c0j * r.c1;
+        const long long rowc = (long long)W * B.row_lo - Gm::T0;
+        const long long shD = (long long)B.c0i * A.S2 * r.rp1d + cD * rowc + W * (B.cj0 * r.c1 - r.l0);
+        const __amdgpu_buffer_rsrc_t dD = St::rs(pD + shD, r.on ? (int)max(nD - shD * 8, 0LL) : 0);
+        const int dlD = 8 * W * (cD - W);
+        const long long shT = (long long)B.c0j * A.S2 * r.rp1d + cT * rowc + W * (B.ci0 * r.c1 - r.l0);
+        const __amdgpu_buffer_rsrc_t dT = St::rs(pT + shT, r.on ? (int)max(nT - shT * 8, 0LL) : 0);
+        const int dlT = 8 * W * (cT - W);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int pkk = pk[k];
+            asm volatile("" : "+v"(pkk));
+            const int l = (pkk >> 2) & 15, rr = (pkk >> 18) & 0xff;
+            const bool ok = pkk >= 0 && (unsigned)(l - r.l0) < (unsigned)r.c1;
+            // (the row term is negative where a segment is shorter than W W -- 2D, first and last rows of the swept axis -- so
+            // the slot's own offset is added in the vector register: the sum is what the range check sees)
+            const int q8 = (QLO + sw + QSTR * k) * 512 + lane8;
+            bf2_buffer_store(dD, ok ? (int)__mul24(rr, dlD) + q8 : BF2_OOB, 0, svD[k]);
+            if (NSET == 2) bf2_buffer_store(dT, ok ? (int)__mul24(rr, dlT) + q8 : BF2_OOB, 0, svT[k]);
         }
     }
 };
@@ -293,7 +404,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     constexpr bool ST = STW && RI >= 1;
     const int slane = threadIdx.x & 63;
     StoreT store;
-    if constexpr (ST) store.init(A, *sc.B, slane);
+    if constexpr (ST) store.init(A, *sc.B, sc.sw, slane);
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_S);
     cdp V1 = (cdp)A.V1;
@@ -348,7 +459,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     int t = s_begin;
     for (; t < t_sw; ++t) {
         bar_lds();                                       // B1
-        if constexpr (ST) store.issue(sc.sw);
+        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
         const int tn = min(t + 1, t_sw - 1);
         cdp cf = V1 + (size_t)t * P * P * 2;
         double v[P][2];
@@ -407,30 +518,33 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     }
     for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
         bar_lds();
-        if constexpr (ST) store.issue(sc.sw);
+        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
         bar_lds(); flush();
         if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
     }
     for (; t < rhi + 1; ++t) {                           // the contractors finish the last row
         bar_lds();
-        if constexpr (ST) store.issue(sc.sw);
+        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
         bar_lds();
         if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
     }
-    if constexpr (ST) store.issue(sc.sw);                // the last row
+    if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);   // the last row
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
-template <int P, int MASK, int NA, int NLG, class StoreT, bool STW, int RI, bool END = (RI >= bf_nroles(MASK))>
+template <int P, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BF3SweepDispatch {
     __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS, const BF3SweepCtx &sc)
     {
-        if (role == RI) bf3_sweeper<P, MASK, RI, NA, NLG, StoreT, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
-        else BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        // role 0 carries no stores; the last role the larger share
+        if (role == RI) {
+            if constexpr (RI == bf_nroles(MASK) - 1) bf3_sweeper<P, MASK, RI, NA, NLG, StoreB, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+            else bf3_sweeper<P, MASK, RI, NA, NLG, StoreA, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        } else BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
     }
 };
-template <int P, int MASK, int NA, int NLG, class StoreT, bool STW, int RI>
-struct BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, RI, true> {
+template <int P, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, int RI>
+struct BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, RI, true> {
     __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BF3SweepCtx &) {}
 };
 
@@ -683,14 +797,18 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     // store duty: on the sweepers of the roles 1.. where the form has them (staged), else on the contractors (at once)
     constexpr bool STW = NR >= 2;
     constexpr int NSTW = STW ? (NR - 1) * NLG : NCW;
-    using StoreT = BF3Store<Gm, P, NSTW, STW ? 0 : 1, NH, SYM, STW>;
+    using StoreC = BF3Store<Gm, P, NCW, 1, NH, SYM, false>;                 // carried by the contractors (one-role forms)
+    constexpr int NQ = (Gm::RMAX * W * W + 63) / 64;
+    using Split = BF3DenseSplit<NR < 2 ? 2 : NR, NLG, NQ>;
+    using StoreA = BF3StoreDense<Gm, P, NSTW, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
+    using StoreB = BF3StoreDense<Gm, P, NSTW, NH, SYM, Split::KB, Split::QB, NQ, Split::NB>;                                       // last role
     double *dump = lines + NR * TL;                       // (the padding of line 0: target of the clears that must not happen)
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
-        const BF3SweepCtx sc{&B, sets, dump, (role - 1) * NLG + lg};
-        BF3SweepDispatch<P, MASK, NA, NLG, StoreT, STW, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        const BF3SweepCtx sc{&B, sets, dump, role == NR - 1 ? lg : (role - 1) * NLG + lg};
+        BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
         return;
     }
 
@@ -698,8 +816,8 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     const int cw = task - NSW;
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_C);
-    StoreT store;
-    if constexpr (!STW) store.init(A, B, lane);
+    StoreC store;
+    if constexpr (!STW) store.init(A, B, cw, lane);
     const int nlines = diag0 ? P : W;                     // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
     const int npieces = nlines * NPC;
     for (int t = s_begin; t < rhi + 1; ++t) {
