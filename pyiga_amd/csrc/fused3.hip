@@ -1,31 +1,35 @@
-// k_bf3: the fused "sweep + final" stage that writes BOTH triangles of a symmetric form -- no mirror pass.
+// k_bf3: the fused "sweep + final" stage -- second contraction (swept "mid" axis) and third contraction (last axis) of the
+// sum-factorised assembly in one kernel, CSR values out -- for every symmetric 3D patch the reference accepts with single knots
+// on the last axis, and for the convection-diffusion form.  Successor of k_bf2 + k_mirror2 (fused.hip, rounds 2-4).
 //
-// k_bf2 (fused.hip) forms the lower triangle only; k_mirror2 then reads it back (11.9 GB at C4, 72-byte gathers) and writes
-// the upper one (6.6 GB): 3.5 ms of a 14.7 ms chain that exist only to copy.  The transposed entries are already in the
-// registers of the contractor waves when the direct ones are, and they are complete AT THE SAME STEP:
+// (1) BOTH TRIANGLES, NO MIRROR PASS.  k_bf2 forms the lower triangle only; k_mirror2 then read it back (11.9 GB at C4, 72-byte
+//     gathers) and wrote the upper one (6.6 GB): 3.5 ms of a 14.7 ms chain that existed only to copy.  The transposed entries are
+//     in the registers of the contractor waves when the direct ones are, and they are complete AT THE SAME STEP:
+//       a block owns an outer pair (i0, j0 <= i0) and walks the mid axis dof by dof.  When dof d leaves the sweep window, the K2
+//       lines of the pairs (d + a, d) and (d, d + a), a = 0..p1, are flushed.  Direct row (i0, i1, .) needs the pairs (i1, j1) for
+//       all j1: those with j1 < i1 arrived when j1 left, the others arrive when i1 leaves.  The TRANSPOSED row -- row (j0, j1, .),
+//       columns (i0, i1, .) -- needs the pairs (i1, j1) for all i1: those with i1 < j1 arrived when i1 left, the others when j1
+//       leaves.  Same schedule with the two families of lines swapped.
+//     So the contractors keep TWO sets of entry rings in LDS -- direct rows and transposed rows -- and every row of both leaves as
+//     whole (2 p1 + 1) (2 p2 + 1) segments.  Inside a line the transposition on the last axis needs no halo: the entries of target
+//     row j2 are sums over the element matrices of the spans of supp(j2), all inside the tile's window -- gathered with
+//     ds_bpermute from the same registers as the direct entries, in the same order of addends, so A[I, J] and A[J, I] are the
+//     same bits (exact symmetry, as assemble_entries(symmetric=True): pyiga/assemble.py:742-752).  On a diagonal outer block the
+//     "transposed" entries are the upper part of the same rows (one set of rings).
+// (2) WHAT PAYS FOR THE SECOND SET (160 KB of LDS were full): rings are allocated per LINE, not per row -- the line of distance
+//     delta = i1 - j1 lives delta + 1 steps and gets delta + 1 rotating slots; the lines of the current row need one slot (read
+//     between the barrier that ends the contraction and the one that starts the next); no store plan in LDS.
+// (3) THE STORE DUTY IS ON THE SWEEPER WAVES of the roles 1.. (they wait at the barriers most of a step and have registers to
+//     spare), staged: read behind B2, stored behind the next B1 under the sweep, 512 contiguous bytes per instruction
+//     (BF3StoreDense).  On the contractor waves the same stores sat in the B2 -> B1 window of every step: 9.7 -> 8.4 ms at C4.
+// (4) EVERY PATCH THE REFERENCE ACCEPTS ON THE SWEPT AXIS (round 5): the degrees of the mid and the last axis are separate
+//     template parameters (P1, P2), the Gauss points per span a third (Q = nqp = max degree + 1 over all axes:
+//     pyiga/assemblers.pyx:1338), and a step is a LEAVING DOF, not a span: a span is swept when its first active dof is due
+//     (fa1[]), so a repeated knot on the mid axis just shifts the window by its multiplicity; which lines of a row exist comes
+//     from the column range of the row (jlo1 / jhi1).
 //
-//   A block owns an outer pair (i0, j0 <= i0) and walks the mid axis.  When dof d leaves the sweep window, the K2 lines of
-//   the pairs (d + a, d) and (d, d + a), a = 0..p, are flushed.  Direct row (i0, i1, .) needs the pairs (i1, j1) for all j1:
-//   those with j1 < i1 arrived when j1 left, the others arrive when i1 leaves.  The TRANSPOSED row -- row (j0, j1, .), columns
-//   (i0, i1, .) -- needs the pairs (i1, j1) for all i1: those with i1 < j1 arrived when i1 left, the others when j1 leaves.
-//   Same schedule with the two families of lines swapped.
-//
-// So the contractors keep TWO sets of entry rings in LDS -- direct rows and transposed rows -- and every row leaves as whole
-// (2p+1)^2 segments through the same kind of store as before.  Inside a line the transposition on the last axis needs no halo:
-// the entries of target row j2 are sums over the element matrices of the spans of supp(j2), all inside the tile's window --
-// gathered with ds_bpermute from the same registers as the direct entries, in the same order of addends, so that
-// A[I, J] and A[J, I] are the same bits (exact symmetry, as assemble_entries(symmetric=True): pyiga/assemble.py:742-752).
-// On a diagonal outer block the "transposed" entries are the upper part of the same rows (one set of rings).
-//
-// What pays for the second set (160 KB of LDS were full):
-//   * rings are allocated per LINE, not per row: the line of distance delta = i1 - j1 lives delta + 1 steps, so it gets
-//     delta + 1 rotating slots (p (p + 1) / 2 + p row-lines instead of (p + 1) p); the lines of the current row need one slot
-//     (their rows are read between the barrier that ends the contraction and the one that starts the next);
-//   * no store plan: the rings are [line][row][entry], a store slot is 64 consecutive doubles of ONE line -- its LDS address is
-//     (scalar) + lane, its target (rows of (2p+1) doubles, (2p+1)^2 apart) is one multiply-add of a per-lane row constant with
-//     a scalar of the step.  Rows next to the ends of the last axis (shorter segments) go through a small table instead.
-//
-// Semantics follow combine()/entry_impl (pyiga/assemblers.pyx:1455-1540); the values are those of k_bf2 + k_mirror2 bit for bit.
+// Semantics follow combine()/entry_impl (pyiga/assemblers.pyx:1455-1540); for equal degrees and single knots the values are
+// those of k_bf2 + k_mirror2 bit for bit (tests/test_gpu_parity.py::test_both_triangles_from_the_fused_stage).
 #include "igx_internal.h"
 #include "fused_common.h"
 #include <algorithm>
@@ -38,90 +42,69 @@ namespace igx {
 
 // SYM: 0 non-symmetric form (one set of rings, every pair direct); 1 symmetric, every outer pair diagonal (2D: one set);
 //      2 symmetric with off-diagonal outer pairs (3D: direct + transposed set)
-template <int P, int NLG, int NRO, int NCW, int SYM> struct BF3Geom {
-    static constexpr int p = P - 1, W = 2 * P - 1, TL = 64 * NLG;
+template <int P1, int P2, int Q, int NLG, int NRO, int NCW, int SYM> struct BF3Geom {
+    static constexpr int P1_ = P1, P2_ = P2, Q_ = Q;
+    static constexpr int p1 = P1 - 1, p2 = P2 - 1, W1 = 2 * P1 - 1, W2 = 2 * P2 - 1, TL = 64 * NLG;
     static constexpr int NSET = SYM == 2 ? 2 : 1;
     static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
-    static constexpr int NRING = p * (p + 1) / 2 + p;       // row-lines of the ring part: line delta = 1..p has delta + 1 slots
-    static constexpr int NRL = NRING + P;                   // ... + the P lines that complete with the row itself
-    static constexpr int T0 = p * (p + 1) / 2;              // rp2[i2] = W i2 - T0 on interior rows
-    static constexpr int NEL = 2 * p * W;                   // edge-row table: (row, entry) elements of the <= 2p edge rows
-    // LDS image (doubles): lines [W][LS] | sets [NSET][NRL][R][W] | basis values [TL][P][2] | edge table (int4) [NEL]
-    static constexpr int off_sets() { return (W * LS + 1) & ~1; }
-    static constexpr int off_v2(int R) { return (off_sets() + NSET * NRL * R * W + 1) & ~1; }
-    static constexpr int off_etab(int R) { return off_v2(R) + TL * P * 2; }
+    static constexpr int NRING = p1 * (p1 + 1) / 2 + p1;    // row-lines of the ring part: line delta = 1..p1 has delta + 1 slots
+    static constexpr int NRL = NRING + P1;                  // ... + the P1 lines that complete with the row itself
+    static constexpr int T0 = p2 * (p2 + 1) / 2;            // rp2[i2] = W2 i2 - T0 on interior rows of the last axis
+    static constexpr int NEL = 2 * p2 * W2;                 // edge-row table: (row, entry) elements of the <= 2 p2 edge rows
+    // LDS image (doubles): lines [W1][LS] | sets [NSET][NRL][R][W2] | basis values [TL][P2][2] | edge table (int4) [NEL]
+    static constexpr int off_sets() { return (W1 * LS + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_sets() + NSET * NRL * R * W2 + 1) & ~1; }
+    static constexpr int off_etab(int R) { return off_v2(R) + TL * P2 * 2; }
     static constexpr int lds_doubles(int R) { return off_etab(R) + NEL * 2; }
     static constexpr int rmax()
     {
-        int R = TL / P - p;
+        int R = TL / Q - p2;
         while (R > 1 && lds_doubles(R) * 8 > 160 * 1024) --R;
         return R;
     }
     static constexpr int RMAX = rmax();
-    static constexpr int RW = RMAX * W;                     // doubles of one row-line block [row][entry]
+    static constexpr int RW = RMAX * W2;                    // doubles of one row-line block [row][entry]
     static constexpr int SETSZ = NRL * RW;
     static constexpr int roff(int d) { return RW * ((d - 1) * (d + 2) / 2); }   // first slot of ring line delta = d
     static constexpr int OFF_CUR = NRING * RW;              // lines of the current row: pair (d, d + a) resp. (d + a, d) at a
     static constexpr int OFF_SETS = off_sets(), OFF_V2 = off_v2(RMAX), OFF_ETAB = off_etab(RMAX);
     static constexpr int LDS_BYTES = lds_doubles(RMAX) * 8;
-    static constexpr int NSUB = (RW + 63) / 64;             // store chunks of a line
-    static constexpr int NECH = (NEL + 63) / 64;            // chunks of the edge-row table
-    // contractor passes (as k_bf2): pieces of PL consecutive spans of a line, 64 / PL pieces per pass, pieces overlap by p spans
-    static constexpr int npc(int pl) { return (RMAX + pl - p - 1) / (pl - p); }
-    static constexpr int npass(int pl) { return (W * npc(pl) + 64 / pl - 1) / (64 / pl); }
+    static constexpr int NSUB = (RW + 63) / 64;             // store chunks of a line block
+    // contractor passes (as k_bf2): pieces of PL consecutive spans of a line, 64 / PL pieces per pass, pieces overlap by p2 spans
+    static constexpr int npc(int pl) { return (RMAX + pl - p2 - 1) / (pl - p2); }
+    static constexpr int npass(int pl) { return (W1 * npc(pl) + 64 / pl - 1) / (64 / pl); }
     static constexpr int pick()
     {
         int best = 64;
         const int cand[4] = {64, 32, 21, 16};
         for (int i = 1; i < 4; ++i)
-            if (cand[i] > 2 * p && npass(cand[i]) < npass(best)) best = cand[i];
+            if (cand[i] > 2 * p2 && npass(cand[i]) < npass(best)) best = cand[i];
         return best;
     }
-    static constexpr int PL = pick(), PPP = 64 / PL, NPC = npc(PL), RP = PL - p;
+    static constexpr int PL = pick(), PPP = 64 / PL, NPC = npc(PL), RP = PL - p2;
 };
 
 struct BF3Blk {
-    int i0, j0, diag0, c0i, c0j, cj0, ci0, rlo, rhi, row_lo, nrows, stD, stT, ne, emask;
+    int i0, j0, diag0, c0i, c0j, cj0, ci0, rlo, rhi, row_lo, nrows, stD, stT, ne;      // (rlo, rhi: rows of the mid axis)
     long long S12;
 };
 
 typedef int bf3_v4i __attribute__((ext_vector_type(4)));
 
-// The store duty of k_bf3.  Behind the barrier B2 of step t the rows d = t - 1 of both sets are complete; their slots are
-// reused in step t + 1, so they are read (and cleared where halves add) before the next B1.  A slot is (set, chunk c of 64
-// consecutive doubles of a line block, line l): c is a compile-time constant (row constants in registers, immediate offsets),
-// l a scalar of the wave.  NS waves share the duty: wave sw takes, of every chunk c, the lines (sw + ROT c) % NS + NS j.
-//   * forms with several sweeper roles (stiffness): the sweepers of roles 1.. carry it, STAGED -- values read behind B2, stored
-//     behind the next B1, under the sweep.  They wait at the barriers most of a step (stamp profile: 20-50 % busy) and have the
-//     registers; on the contractor waves (90 % busy, 126 registers) the same stores sat in the B2 -> B1 window of every step,
-//     40 % of their time (profiles/r05_a_c4_bf3_stamps_contractor_stores.txt).  No branch lies around a store (a sweeper also
-//     loads: hipcc answers a store behind a branch with vmcnt(0) at the next load use): what must not be stored gets a
-//     descriptor of length 0.
-//   * the mass form has one role: the contractors carry it, at once (read -> store inside the window).
-// Rows next to the ends of the last axis (segments of fewer than 2p + 1 columns) are not part of the slots (their lanes carry an
-// out-of-range row constant and are not cleared): the contractors take them through a small table (edge()).
-template <class Gm, int P, int NS, int ROT, int NH, int SYM, bool STAGE>
-struct BF3Store {
-    static constexpr int p = P - 1, W = 2 * P - 1, NSUB = Gm::NSUB, RW = Gm::RW;
-    static constexpr int JMAX = (W + NS - 1) / NS, NST = NSUB * JMAX, NSET = SYM == 2 ? 2 : 1;
-    double svD[STAGE ? NST : 1], svT[STAGE && NSET == 2 ? NST : 1];
-    int rrv[NSUB];               // W i2 - T0 of this lane's row in chunk c, or a value that takes the offset out of range
-    int lane8, lanec, inv;       // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
-    double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
-    int nD, nT;
-    int fake_tile = 0;
-    int s_l0 = 0, s_c1 = 1, s_sKD = 0, s_soffD = 0, s_sKT = 0, s_soffT = 0, s_lenD = 0, s_lenT = 0;
-
-    struct Row { int on, l0, c1, rp1d, sub1, sub2, sub3, sub4, sub5; };
-    __device__ __forceinline__ static Row row_of(const BFArgs &A, const BF3Blk &B, const int t)
+// scalars of row d of the mid axis (the row that completes with step d + 1): which lines of its segments exist, its place in
+// the row blocks, the ring slots it sits in
+template <class Gm> struct BF3Row {
+    int on, l0, c1, rp1d, sub1, sub2, sub3, sub4, sub5;
+    __device__ __forceinline__ static BF3Row of(const BFArgs &A, const BF3Blk &B, const int t)
     {
-        cip rp1 = (cip)A.rp1;
-        Row r;
+        cip rp1 = (cip)A.rp1, jlo1 = (cip)A.jlo1, jhi1 = (cip)A.jhi1;
+        constexpr int p1 = Gm::p1, RW = Gm::RW;
+        BF3Row r;
         const int d = t - 1;
         r.on = d >= B.rlo && d < B.rhi;
         const int dc = min(max(d, 0), A.N1 - 1);
-        const int jl1 = max(dc - p, 0);
-        r.c1 = min(dc + p, A.N1 - 1) - jl1 + 1; r.l0 = p - (dc - jl1);
+        const int jl1 = jlo1[dc];
+        r.c1 = jhi1[dc] - jl1; r.l0 = p1 - (dc - jl1);          // line l of the (2 p1 + 1) possible ones is column dc + l - p1
         r.rp1d = rp1[dc];
         // slot of row d in ring line delta (named scalars: a select by a lane's or a wave's line stays a chain of selects)
         r.sub1 = Gm::roff(1) + (int)((unsigned)dc % 2u) * RW; r.sub2 = Gm::roff(2) + (int)((unsigned)dc % 3u) * RW;
@@ -129,74 +112,84 @@ struct BF3Store {
         r.sub5 = Gm::roff(5) + (int)((unsigned)dc % 6u) * RW;
         return r;
     }
+    // line block of line l of the row (doubles from the start of a set); l is a scalar
+    __device__ __forceinline__ int line_off(const int l) const
+    {
+        constexpr int p1 = Gm::p1;
+        int o = Gm::OFF_CUR + (l - p1) * Gm::RW;
+        o = l == p1 - 1 ? sub1 : o;
+        if (p1 >= 2) o = l == p1 - 2 ? sub2 : o;
+        if (p1 >= 3) o = l == p1 - 3 ? sub3 : o;
+        if (p1 >= 4) o = l == p1 - 4 ? sub4 : o;
+        if (p1 >= 5) o = l == p1 - 5 ? sub5 : o;
+        return o;
+    }
+    __device__ __forceinline__ bool line_ok(const int l) const { return l < Gm::W1 && l >= l0 && l - l0 < c1; }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rs(double *ptr, const int len) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, (short)0, len, 0x00020000); }
+
+// The store duty of k_bf3.  Behind the barrier B2 of step t the rows d = t - 1 of both sets are complete; their slots are
+// reused in step t + 1, so they are read (and cleared where halves add) before the next B1.
+//
+// BF3Store: per-LINE slots -- (set, chunk c of 64 consecutive doubles of a line block, line l): c is a compile-time constant (row
+// constants in registers, immediate offsets), l a scalar of the wave.  NS waves share the duty: wave sw takes, of every chunk c,
+// the lines (sw + ROT c) % NS + NS j.  Used where the form has ONE sweeper role (mass): the contractors carry it, at once (read ->
+// store inside the B2 -> B1 window).  Rows next to the ends of the last axis (segments of fewer than 2 p2 + 1 columns) are not
+// part of the slots (their lanes carry an out-of-range row constant and are not cleared): bf3_edge_rows().
+template <class Gm, int NS, int ROT, int NH, int SYM>
+struct BF3Store {
+    static constexpr int P1 = Gm::P1_, W1 = Gm::W1, W2 = Gm::W2, p2 = Gm::p2, NSUB = Gm::NSUB, RW = Gm::RW;
+    static constexpr int JMAX = (W1 + NS - 1) / NS, NST = NSUB * JMAX, NSET = SYM == 2 ? 2 : 1;
+    using Row = BF3Row<Gm>;
+    int rrv[NSUB];               // W2 i2 - T0 of this lane's row in chunk c, or a value that takes the offset out of range
+    int lane8, lanec, inv;       // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
+    double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
+    int nD, nT;
+
     __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int /*sw*/, const int lane)
     {
         cip rp0 = (cip)A.rp0;
-#pragma unroll
-        for (int k = 0; k < (STAGE ? NST : 1); ++k) svD[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < (STAGE && NSET == 2 ? NST : 1); ++k) svT[k] = 0.0;
         lane8 = lane * 8;
-        fake_tile = B.row_lo / max(B.nrows, 1);
         lanec = min((NSUB - 1) * 64 + lane, RW - 1) - (NSUB - 1) * 64;
-        // descriptors: base moved by W row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W i2 - T0) (c0 c1 - 1)
-        // + (chunk element index) + W (line terms); length = the row block of the outer row (anything beyond is dropped)
-        const long long shift = (long long)W * B.row_lo - Gm::T0;
+        // descriptors: base moved by W2 row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W2 i2 - T0) (c0 c1 - 1)
+        // + (chunk element index) + W2 (line terms); length = the row block of the outer row (anything beyond is dropped)
+        const long long shift = (long long)W2 * B.row_lo - Gm::T0;
         const long long lenD = ((long long)B.c0i * B.S12 - shift) * 8, lenT = ((long long)B.c0j * B.S12 - shift) * 8;
         pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off + shift); nD = B.stD ? (int)lenD : 0;
         pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off + shift); nT = B.stT ? (int)lenT : 0;
         const int c0min = min(B.c0i, B.c0j);
-        inv = (int)(max(lenD, lenT) / (8 * (c0min * P - 1))) + 1;
+        inv = (int)(max(lenD, lenT) / (8 * max(c0min * 2 - 1, 1))) + 1;      // (a row of the mid axis has at least two columns)
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
-            const int q = c * 64 + lane, rr = q / W, i2 = B.row_lo + rr;
-            const bool ok = q < RW && rr < B.nrows && i2 >= p && i2 <= A.N2 - 1 - p;
-            rrv[c] = ok ? W * i2 - Gm::T0 : inv;
+            const int q = c * 64 + lane, rr = q / W2, i2 = B.row_lo + rr;
+            const bool ok = q < RW && rr < B.nrows && i2 >= p2 && i2 <= A.N2 - 1 - p2;
+            rrv[c] = ok ? W2 * i2 - Gm::T0 : inv;
         }
-    }
-    __device__ __forceinline__ static bool line_ok(const int l, const int l0, const int c1) { return l < W && l >= l0 && l - l0 < c1; }
-    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rs(double *ptr, const int len) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, (short)0, len, 0x00020000); }
-    // line block of line l of the row (doubles from the start of a set); l is a scalar
-    __device__ __forceinline__ static int line_off(const int l, const Row &r)
-    {
-        int o = Gm::OFF_CUR + (l - p) * RW;
-        o = l == p - 1 ? r.sub1 : o;
-        if (p >= 2) o = l == p - 2 ? r.sub2 : o;
-        if (p >= 3) o = l == p - 3 ? r.sub3 : o;
-        if (p >= 4) o = l == p - 4 ? r.sub4 : o;
-        if (p >= 5) o = l == p - 5 ? r.sub5 : o;
-        return o;
     }
     __device__ __forceinline__ static int line_of(const int sw, const int c, const int j) { return (int)((unsigned)(sw + ROT * c) % (unsigned)NS) + NS * j; }
 
-    // the slots of this wave: values of one row of set X out of the rings (cleared where halves add) ...
-    template <int X, int N>
-    __device__ __forceinline__ void read_row(double (&v)[N], double *sets, double *dump, const int sw, const int lane, const Row &r)
+    template <int X>
+    __device__ __forceinline__ void move_row(double *sets, double *dump, const int sw, const int lane, const Row &r, double *ptr, const int len, const int sK, const int soff0)
     {
         // (addresses: an opaque per-lane base + the scalar line offset, the chunk is the immediate offset of the LDS instruction)
         int lb_ = lane, lc_ = lanec;
         asm volatile("" : "+v"(lb_), "+v"(lc_));
         double *bs = sets + X * Gm::SETSZ + lb_, *bc = sets + X * Gm::SETSZ + (NSUB - 1) * 64 + lc_;
+        double v[NST];
 #pragma unroll
         for (int c = 0; c < NSUB; ++c)
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int l = line_of(sw, c, j);
-                double *src = (c == NSUB - 1 ? bc : bs + c * 64) + line_off(min(l, W - 1), r);
+                double *src = (c == NSUB - 1 ? bc : bs + c * 64) + r.line_off(min(l, W1 - 1));
                 v[c * JMAX + j] = *src;
                 if (NH == 2) {
-                    // (edge rows belong to edge(); a wave without a line in this round clears nothing)
-                    double *cl = (rrv[c] != inv && l < W) ? src : dump;
+                    double *cl = (rrv[c] != inv && l < W1) ? src : dump;      // (edge rows belong to bf3_edge_rows)
                     *cl = 0.0;
                 }
             }
-    }
-    // ... and to their segments: row block `ptr` of `len` bytes (0: the row is not stored), lines [l0, l0 + c1) exist
-    template <int N>
-    __device__ __forceinline__ void write_row(const double (&v)[N], double *ptr, const int len, const int sw, const int l0, const int c1, const int sK, const int soff0) const
-    {
 #ifdef BF3_NOSTORE
-        return;                                              // (timing experiment: tools/buildvar.sh)
+        return;
 #endif
         int voff[NSUB];
 #pragma unroll
@@ -209,57 +202,26 @@ struct BF3Store {
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int l = line_of(sw, c, j);
-#ifdef BF3_DENSEFAKE
-                // (timing experiment: the same bytes as 512 contiguous ones per store, somewhere inside the row block -- wrong matrix)
-                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), lane8 + c * 512, (soff0 / 4096) * 4096 + ((l * NSUB) * 512) % 190000 + fake_tile * 190000, v[c * JMAX + j]);
-#else
-                bf2_buffer_store(rs(ptr, line_ok(l, l0, c1) ? len : 0), voff[c] + c * 512, soff0 + 8 * W * l, v[c * JMAX + j]);
-#endif
+                bf2_buffer_store(bf3_rs(ptr, r.line_ok(l) ? len : 0), voff[c] + c * 512, soff0 + 8 * W2 * l, v[c * JMAX + j]);
             }
     }
-
-    // behind B1 (STAGE): the rows read at the end of the last step go out
-    __device__ __forceinline__ void issue(const BFArgs &, const BF3Blk &, const int, const int sw) { issue(sw); }
-    __device__ __forceinline__ void issue(const int sw)
-    {
-        if (!STAGE) return;
-        write_row(svD, pD, s_lenD, sw, s_l0, s_c1, s_sKD, s_soffD);
-        if (NSET == 2) write_row(svT, pT, s_lenT, sw, s_l0, s_c1, s_sKT, s_soffT);
-    }
-
-    // behind B2 of step t: rows d = t - 1 of both sets are complete
+    // behind B2 of step t: rows d = t - 1 of both sets are complete: out of the rings, to their segments
     __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, double *dump, const int t, const int sw, const int lane)
     {
-        const Row r = row_of(A, B, t);
-        const int sKD = 8 * (B.c0i * r.c1 - 1), soffD = 8 * ((int)((long long)B.c0i * A.S2) * r.rp1d + W * (B.cj0 * r.c1 - r.l0));
-        const int sKT = 8 * (B.c0j * r.c1 - 1), soffT = 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W * (B.ci0 * r.c1 - r.l0));
-        if (STAGE) {
-            s_l0 = r.l0; s_c1 = r.c1; s_sKD = sKD; s_soffD = soffD; s_sKT = sKT; s_soffT = soffT;
-            s_lenD = r.on ? nD : 0; s_lenT = r.on ? nT : 0;
-            read_row<0>(svD, sets, dump, sw, lane, r);
-            if (NSET == 2) read_row<1>(svT, sets, dump, sw, lane, r);
-        } else {
-            {
-                double tv[NST];
-                read_row<0>(tv, sets, dump, sw, lane, r);
-                write_row(tv, pD, r.on ? nD : 0, sw, r.l0, r.c1, sKD, soffD);
-            }
-            if (NSET == 2) {
-                double tv[NST];
-                read_row<1>(tv, sets, dump, sw, lane, r);
-                write_row(tv, pT, r.on ? nT : 0, sw, r.l0, r.c1, sKT, soffT);
-            }
-        }
+        const Row r = Row::of(A, B, t);
+        move_row<0>(sets, dump, sw, lane, r, pD, r.on ? nD : 0, 8 * (B.c0i * r.c1 - 1), 8 * ((int)((long long)B.c0i * A.S2) * r.rp1d + W2 * (B.cj0 * r.c1 - r.l0)));
+        if (NSET == 2)
+            move_row<1>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, 8 * (B.c0j * r.c1 - 1), 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W2 * (B.ci0 * r.c1 - r.l0)));
     }
 };
 
-// The store duty on the sweeper waves, DENSE (round 5): a slot is 64 consecutive doubles of the row-major image of a tile's
-// rows -- (row, line, entry), (2p+1)^2 per row -- so a store instruction writes 512 contiguous bytes of CSR values and the
-// segments of a row leave whole within one burst (the per-line slots of BF3Store write 72-byte runs 648 bytes apart, 9 waves
-// each a ninth of every segment: 0.45 ms slower at C4 by a stand-in measurement, and 1.5 GB of read-for-ownership traffic).
-// The rings are [line][row][entry], so a lane's LDS address is (block of ITS line) + (row, entry): the line blocks of the step
-// sit in one register (lane j holds the block of line j) and come per slot through ds_bpermute.  Per lane and slot one packed
-// constant: line | (row W + entry) | row | invalid (edge rows, lanes past the tile).  NS waves take the slots s = sw + NS k.
+// BF3StoreDense: the store duty on the sweeper waves of the roles 1.., staged and DENSE: a slot is 64 consecutive doubles of the
+// row-major image of a tile's rows -- (row, line, entry), W1 W2 per row -- so a store instruction writes 512 contiguous bytes of
+// CSR values and the segments of a row leave whole within one burst.  The rings are [line][row][entry], so a lane's LDS address
+// is (block of ITS line) + (row, entry): the line blocks of the step sit in one register (lane j holds the block of line j) and
+// come per slot through ds_bpermute.  Per lane and slot one packed constant: line | (row W2 + entry) | row | invalid (edge
+// rows, lanes past the tile) -- the same for both sets.  No branch lies around a store (a sweeper also loads: hipcc answers a
+// store behind a branch with vmcnt(0) at the next load use): what must not be stored gets an out-of-range offset.
 // The waves of one GROUP (sw = 0 .. QSTR-1) take the slots QLO + sw + QSTR k, k < K, below QHI: the sweepers of the last role
 // (one input array: registers to spare) take half as many slots again as those of the middle roles.
 template <int NR, int NLG, int NQ> struct BF3DenseSplit {
@@ -268,16 +230,15 @@ template <int NR, int NLG, int NQ> struct BF3DenseSplit {
     static constexpr int KA = ka(), KB = NA == 0 ? (NQ + NB - 1) / NB : (3 * KA + 1) / 2;
     static constexpr int QB = NA * KA < NQ ? NA * KA : NQ;                     // first slot of the last role's group
 };
-template <class Gm, int P, int NS, int NH, int SYM, int K, int QLO, int QHI, int QSTR>
+template <class Gm, int NH, int SYM, int K, int QLO, int QHI, int QSTR>
 struct BF3StoreDense {
-    static constexpr int p = P - 1, W = 2 * P - 1, WW = W * W, RW = Gm::RW, NSET = SYM == 2 ? 2 : 1;
+    static constexpr int p1 = Gm::p1, p2 = Gm::p2, W1 = Gm::W1, W2 = Gm::W2, WW = W1 * W2, RW = Gm::RW, NSET = SYM == 2 ? 2 : 1;
+    using Row = BF3Row<Gm>;
     double svD[K], svT[NSET == 2 ? K : 1];
-    int pk[K];                   // bits 0-5: 4 line | 6-17: row W + entry | 18-25: row | 31: no element  (the same for both sets)
+    int pk[K];                   // bits 0-5: 4 line | 6-17: row W2 + entry | 18-25: row | 31: no element
     int lane8;
     double *pD, *pT;
     long long nD, nT;            // bytes of the row blocks of the two outer rows (0: not stored)
-    using St = BF3Store<Gm, P, NS, 0, NH, SYM, true>;
-    using Row = typename St::Row;
 
     __device__ __forceinline__ void init(const BFArgs &A, const BF3Blk &B, const int sw, const int lane)
     {
@@ -290,23 +251,23 @@ struct BF3StoreDense {
             svD[k] = 0.0;
             if (NSET == 2) svT[k] = 0.0;
             const int qi = QLO + sw + QSTR * k;
-            const int q = qi * 64 + lane, rr = q / WW, rem = q - rr * WW, l = rem / W, e = rem - l * W, i2 = B.row_lo + rr;
-            const bool ok = qi < QHI && q < Gm::RMAX * WW && rr < B.nrows && i2 >= p && i2 <= A.N2 - 1 - p;
-            pk[k] = ok ? (4 * l) | ((rr * W + e) << 6) | (rr << 18) : (int)0x80000000;
+            const int q = qi * 64 + lane, rr = q / WW, rem = q - rr * WW, l = rem / W2, e = rem - l * W2, i2 = B.row_lo + rr;
+            const bool ok = qi < QHI && q < Gm::RMAX * WW && rr < B.nrows && i2 >= p2 && i2 <= A.N2 - 1 - p2;
+            pk[k] = ok ? (4 * l) | ((rr * W2 + e) << 6) | (rr << 18) : (int)0x80000000;
         }
     }
 
     // behind B2 of step t: rows d = t - 1 of both sets are complete -> registers (cleared where halves add)
     __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, double *dump, const int t, const int sw, const int lane)
     {
-        const Row r = St::row_of(A, B, t);
+        const Row r = Row::of(A, B, t);
         // block (doubles from the start of a set) of line j of the row, on lane j
-        int lv = Gm::OFF_CUR + (lane - p) * RW;
-        lv = lane == p - 1 ? r.sub1 : lv;
-        if (p >= 2) lv = lane == p - 2 ? r.sub2 : lv;
-        if (p >= 3) lv = lane == p - 3 ? r.sub3 : lv;
-        if (p >= 4) lv = lane == p - 4 ? r.sub4 : lv;
-        if (p >= 5) lv = lane == p - 5 ? r.sub5 : lv;
+        int lv = Gm::OFF_CUR + (lane - p1) * RW;
+        lv = lane == p1 - 1 ? r.sub1 : lv;
+        if (p1 >= 2) lv = lane == p1 - 2 ? r.sub2 : lv;
+        if (p1 >= 3) lv = lane == p1 - 3 ? r.sub3 : lv;
+        if (p1 >= 4) lv = lane == p1 - 4 ? r.sub4 : lv;
+        if (p1 >= 5) lv = lane == p1 - 5 ? r.sub5 : lv;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             int pkk = pk[k];
@@ -330,25 +291,25 @@ struct BF3StoreDense {
 #ifdef BF3_NOSTORE
         return;
 #endif
-        const Row r = St::row_of(A, B, t);
+        const Row r = Row::of(A, B, t);
         // descriptors of the row: base moved by the row's constant part, so that an element sits at 8 (its index in the image)
-        // + row * 8 W (c0 c1 - W); what is left of the row block behind the moved base is the length
+        // + row * 8 W2 (c0 c1 - W1); what is left of the row block behind the moved base is the length
         const int cD = B.c0i * r.c1, cT = B.c0j * r.c1;
-        const long long rowc = (long long)W * B.row_lo - Gm::T0;
-        const long long shD = (long long)B.c0i * A.S2 * r.rp1d + cD * rowc + W * (B.cj0 * r.c1 - r.l0);
-        const __amdgpu_buffer_rsrc_t dD = St::rs(pD + shD, r.on ? (int)max(nD - shD * 8, 0LL) : 0);
-        const int dlD = 8 * W * (cD - W);
-        const long long shT = (long long)B.c0j * A.S2 * r.rp1d + cT * rowc + W * (B.ci0 * r.c1 - r.l0);
-        const __amdgpu_buffer_rsrc_t dT = St::rs(pT + shT, r.on ? (int)max(nT - shT * 8, 0LL) : 0);
-        const int dlT = 8 * W * (cT - W);
+        const long long rowc = (long long)W2 * B.row_lo - Gm::T0;
+        const long long shD = (long long)B.c0i * A.S2 * r.rp1d + cD * rowc + W2 * (B.cj0 * r.c1 - r.l0);
+        const __amdgpu_buffer_rsrc_t dD = bf3_rs(pD + shD, r.on ? (int)max(nD - shD * 8, 0LL) : 0);
+        const int dlD = 8 * W2 * (cD - W1);
+        const long long shT = (long long)B.c0j * A.S2 * r.rp1d + cT * rowc + W2 * (B.ci0 * r.c1 - r.l0);
+        const __amdgpu_buffer_rsrc_t dT = bf3_rs(pT + shT, r.on ? (int)max(nT - shT * 8, 0LL) : 0);
+        const int dlT = 8 * W2 * (cT - W1);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             int pkk = pk[k];
             asm volatile("" : "+v"(pkk));
             const int l = (pkk >> 2) & 15, rr = (pkk >> 18) & 0xff;
             const bool ok = pkk >= 0 && (unsigned)(l - r.l0) < (unsigned)r.c1;
-            // (the row term is negative where a segment is shorter than W W -- 2D, first and last rows of the swept axis -- so
-            // the slot's own offset is added in the vector register: the sum is what the range check sees)
+            // (the row term is negative where a segment is shorter than W1 W2 -- 2D, rows of the swept axis with fewer columns --
+            // so the slot's own offset is added in the vector register: the sum is what the range check sees)
             const int q8 = (QLO + sw + QSTR * k) * 512 + lane8;
             bf2_buffer_store(dD, ok ? (int)__mul24(rr, dlD) + q8 : BF2_OOB, 0, svD[k]);
             if (NSET == 2) bf2_buffer_store(dT, ok ? (int)__mul24(rr, dlT) + q8 : BF2_OOB, 0, svT[k]);
@@ -359,15 +320,14 @@ struct BF3StoreDense {
 // Rows next to the ends of the last axis, behind B2 of step t, on the contractor waves: element (row, entry) of the table per
 // lane, one (set, line) per round; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift folded into the
 // table.  The elements are read and cleared here and nowhere else.
-template <class Gm, int P, int NCW, int NH, int SYM>
+template <class Gm, int NCW, int NH, int SYM>
 __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, double *sets, const bf3_v4i *etab, const int t, const int cw, const int lane)
 {
-    using St = BF3Store<Gm, P, NCW, 1, NH, SYM, false>;
-    constexpr int W = 2 * P - 1;
+    constexpr int W1 = Gm::W1, W2 = Gm::W2;
     if (B.ne == 0) return;
     cip rp0 = (cip)A.rp0;
-    const typename St::Row r = St::row_of(A, B, t);
-    const long long shift = (long long)W * B.row_lo - Gm::T0;
+    const BF3Row<Gm> r = BF3Row<Gm>::of(A, B, t);
+    const long long shift = (long long)W2 * B.row_lo - Gm::T0;
 #pragma unroll
     for (int X = 0; X < Gm::NSET; ++X) {
         if (X == 0 ? !B.stD : !B.stT) continue;
@@ -376,11 +336,11 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
         const int nx = (int)(((long long)c0x * B.S12 - shift) * 8);
         const unsigned sA = (unsigned)(c0x * r.c1);
         const int soffr = 8 * (int)((long long)c0x * A.S2) * r.rp1d;
-        for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W; l += NCW) {
+        for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W1; l += NCW) {
             const unsigned sB = (unsigned)max(cx * r.c1 + l - r.l0, 0);
-            const __amdgpu_buffer_rsrc_t dsc = St::rs(px, (r.on && St::line_ok(l, r.l0, r.c1)) ? nx : 0);
-            double *lb = sets + X * Gm::SETSZ + St::line_off(l, r);
-            for (int ch = 0; ch * 64 < B.ne * W; ++ch) {
+            const __amdgpu_buffer_rsrc_t dsc = bf3_rs(px, (r.on && r.line_ok(l)) ? nx : 0);
+            double *lb = sets + X * Gm::SETSZ + r.line_off(l);
+            for (int ch = 0; ch * 64 < B.ne * W2; ++ch) {
                 const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
                 const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
                 double *src = lb + e.x;
@@ -393,14 +353,16 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
     }
 }
 
-// sweepers: as in k_bf2 (fused.hip); those of the roles 1.. carry the store duty (StoreT::NS > 0 waves, this one is number sw)
+// sweepers: the mid-axis sweep of k_bf2 (fused.hip) with separate degree (P1) and Gauss points per span (Q), driven by LEAVING
+// DOFS: step d sweeps the next span when its first active dof is d, then flushes the lines of dof d.  Those of the roles 1..
+// carry the store duty (STW).
 struct BF3SweepCtx { const BF3Blk *B; double *sets, *dump; int sw; };
-template <int P, int MASK, int RI, int NA, int NLG, class StoreT, bool STW>
-__device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin,
+template <int P1, int Q, int MASK, int RI, int NA, int NLG, class StoreT, bool STW, bool MULT>
+__device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin, const int t_sw, const int d_begin,
                                             const int rhi, double *lines, const int LS, const BF3SweepCtx &sc)
 {
     constexpr BFRole R = bf_role(MASK, RI);
-    constexpr int p = P - 1, TL = 64 * NLG;
+    constexpr int p1 = P1 - 1, TL = 64 * NLG;
     constexpr bool ST = STW && RI >= 1;
     const int slane = threadIdx.x & 63;
     StoreT store;
@@ -408,11 +370,14 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     BF_STAMP_DECL
     __builtin_amdgcn_s_setprio(BF2_PRIO_S);
     cdp V1 = (cdp)A.V1;
-    double acc[P][P];
+    cip fa1 = (cip)A.fa1;
+    double acc[P1][P1];
 #pragma unroll
-    for (int a = 0; a < P; ++a)
+    for (int a = 0; a < P1; ++a)
 #pragma unroll
-        for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+        for (int b = 0; b < P1; ++b) acc[a][b] = 0.0;
+    // input rows through buffer descriptors: (descriptor of the slot's slice: scalar) + (scalar row offset) + (this lane's
+    // point): a load costs no vector instruction and no address registers
     __amdgpu_buffer_rsrc_t rsrc[4][NA];
     int urs[4][NA];
     const int voff = g2 * 8;
@@ -430,47 +395,43 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
         return bf2_buffer_load(rsrc[t1][i], voff, row * urs[t1][i]);
 #endif
     };
-    const int n_sw = min(A.n1, A.span_hi);
-    const int t_sw = min(n_sw, rhi);
-    double kv[P][4][NA];
+    double kv[Q][4][NA];
     {
-        const int s = min(s_begin, t_sw - 1);
+        const int s = min(s_begin, max(t_sw - 1, 0));
 #pragma unroll
-        for (int l = 0; l < P; ++l)
+        for (int l = 0; l < Q; ++l)
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1)
                 if (R.has[t1])
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * P + l);
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * Q + l);
     }
     auto flush = [&]() {
         double *ln = lines + RI * TL + g2l;
 #pragma unroll
-        for (int a = 0; a < P; ++a) ln[a * LS] = acc[a][0];
+        for (int a = 0; a < P1; ++a) ln[a * LS] = acc[a][0];
 #pragma unroll
-        for (int a = 1; a < P; ++a) ln[(p + a) * LS] = acc[0][a];
+        for (int a = 1; a < P1; ++a) ln[(p1 + a) * LS] = acc[0][a];
 #pragma unroll
-        for (int a = 0; a < P - 1; ++a)
+        for (int a = 0; a < P1 - 1; ++a)
 #pragma unroll
-            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+            for (int b = 0; b < P1 - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
 #pragma unroll
-        for (int a = 0; a < P; ++a) { acc[a][P - 1] = 0.0; acc[P - 1][a] = 0.0; }
+        for (int a = 0; a < P1; ++a) { acc[a][P1 - 1] = 0.0; acc[P1 - 1][a] = 0.0; }
     };
-    int t = s_begin;
-    for (; t < t_sw; ++t) {
-        bar_lds();                                       // B1
-        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
-        const int tn = min(t + 1, t_sw - 1);
-        cdp cf = V1 + (size_t)t * P * P * 2;
-        double v[P][2];
+    // one span of the mid axis: Q Gauss planes into the pair window, the K1 values of the next span requested meanwhile
+    auto sweep_span = [&](const int s) __attribute__((always_inline)) {
+        const int tn = min(s + 1, t_sw - 1);
+        cdp cf = V1 + (size_t)s * Q * P1 * 2;
+        double v[P1][2];
 #pragma unroll
-        for (int b = 0; b < P; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
+        for (int b = 0; b < P1; ++b) { v[b][0] = cf[2 * b]; v[b][1] = cf[2 * b + 1]; }
 #pragma unroll
-        for (int l = 0; l < P; ++l) {
-            double vn[P][2];
-            const int ln_ = l + 1 < P ? l + 1 : l;
+        for (int l = 0; l < Q; ++l) {
+            double vn[P1][2];
+            const int ln_ = l + 1 < Q ? l + 1 : l;
 #pragma unroll
-            for (int b = 0; b < P; ++b) { vn[b][0] = cf[(ln_ * P + b) * 2]; vn[b][1] = cf[(ln_ * P + b) * 2 + 1]; }
+            for (int b = 0; b < P1; ++b) { vn[b][0] = cf[(ln_ * P1 + b) * 2]; vn[b][1] = cf[(ln_ * P1 + b) * 2 + 1]; }
             double kt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1)
@@ -478,93 +439,115 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
                     kt[t1] = kv[l][t1][0];
                     if constexpr (NA == 2) kt[t1] += kv[l][t1][1];
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, tn * P + l);
+                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, tn * Q + l);
                 }
             if (R.shape == 1) {
 #pragma unroll
-                for (int b = 0; b < P; ++b) {
+                for (int b = 0; b < P1; ++b) {
                     double w;
                     if (R.has[2 * R.f] && R.has[2 * R.f + 1]) w = fma(v[b][1], kt[2 * R.f + 1], v[b][0] * kt[2 * R.f]);
                     else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
                     else w = v[b][1] * kt[2 * R.f + 1];
 #pragma unroll
-                    for (int a = 0; a < P; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
+                    for (int a = 0; a < P1; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
                 }
             } else {
 #pragma unroll
                 for (int tu = 0; tu < 2; ++tu) {
                     if (!(R.has[tu] || R.has[tu + 2])) continue;
 #pragma unroll
-                    for (int a = 0; a < P; ++a) {
+                    for (int a = 0; a < P1; ++a) {
                         double c;
                         if (R.has[tu] && R.has[tu + 2]) c = fma(v[a][1], kt[tu + 2], v[a][0] * kt[tu]);
                         else if (R.has[tu]) c = v[a][0] * kt[tu];
                         else c = v[a][1] * kt[tu + 2];
 #pragma unroll
-                        for (int b = 0; b < P; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                        for (int b = 0; b < P1; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
                     }
                 }
             }
 #pragma unroll
-            for (int a = 0; a < P; ++a)
+            for (int a = 0; a < P1; ++a)
 #pragma unroll
-                for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+                for (int b = 0; b < P1; ++b) asm volatile("" : "+v"(acc[a][b]));
 #pragma unroll
-            for (int b = 0; b < P; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
+            for (int b = 0; b < P1; ++b) { v[b][0] = vn[b][0]; v[b][1] = vn[b][1]; }
         }
-        bar_lds();                                       // B2: the contractors have read the previous lines
-        flush();
-        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
+    };
+    if constexpr (!MULT) {
+        // single knots on the swept axis: dof d is the first active one of span d -- every step below t_sw sweeps its span (no
+        // branch in the loop), the steps behind it only drain the window
+        int d = d_begin;
+        for (; d < t_sw; ++d) {
+            bar_lds();                                   // B1
+            if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
+            sweep_span(d);
+            bar_lds();                                   // B2: the contractors have read the previous lines
+            flush();
+            if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
+        }
+        for (; d < rhi; ++d) {
+            bar_lds();
+            if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
+            bar_lds(); flush();
+            if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
+        }
+    } else {
+        // repeated knots: the window moves by the multiplicity of a knot -- a span is swept when its first active dof is the
+        // next one to leave, the other steps only flush
+        int s = s_begin;                                  // next span to sweep
+        for (int d = d_begin; d < rhi; ++d) {
+            bar_lds();                                   // B1
+            if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
+            if (s < t_sw && fa1[s] == d) { sweep_span(s); ++s; }
+            bar_lds();                                   // B2
+            flush();
+            if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
+        }
     }
-    for (; t < rhi; ++t) {                               // spans past the end of the axis: the window only drains
+    {                                                    // the contractors finish the last row
         bar_lds();
-        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
-        bar_lds(); flush();
-        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
+        if constexpr (ST) store.issue(A, *sc.B, rhi - 1, sc.sw);
+        bar_lds();
+        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, rhi, sc.sw, slane);
     }
-    for (; t < rhi + 1; ++t) {                           // the contractors finish the last row
-        bar_lds();
-        if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);
-        bar_lds();
-        if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, t, sc.sw, slane);
-    }
-    if constexpr (ST) store.issue(A, *sc.B, t - 1, sc.sw);   // the last row
+    if constexpr (ST) store.issue(A, *sc.B, rhi, sc.sw);  // the last row
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
-template <int P, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, int RI, bool END = (RI >= bf_nroles(MASK))>
+template <int P1, int Q, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BF3SweepDispatch {
-    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int rhi, double *lines, int LS, const BF3SweepCtx &sc)
+    __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int t_sw, int d_begin, int rhi, double *lines, int LS, const BF3SweepCtx &sc)
     {
         // role 0 carries no stores; the last role the larger share
         if (role == RI) {
-            if constexpr (RI == bf_nroles(MASK) - 1) bf3_sweeper<P, MASK, RI, NA, NLG, StoreB, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
-            else bf3_sweeper<P, MASK, RI, NA, NLG, StoreA, STW>(A, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
-        } else BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, RI + 1>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+            if constexpr (RI == bf_nroles(MASK) - 1) bf3_sweeper<P1, Q, MASK, RI, NA, NLG, StoreB, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+            else bf3_sweeper<P1, Q, MASK, RI, NA, NLG, StoreA, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+        } else BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI + 1>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
     }
 };
-template <int P, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, int RI>
-struct BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, RI, true> {
-    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, double *, int, const BF3SweepCtx &) {}
+template <int P1, int Q, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI>
+struct BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI, true> {
+    __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, int, int, double *, int, const BF3SweepCtx &) {}
 };
 
-
 // One unit of the contraction: 64 (line, span) items -- the element matrices of a pass (H = 0) or of one half of their rows
-// (H = 1: rows 0 .. AH-1, H = 2: rows AH .. p; the halves ADD their entries into the rings) -- gathered into the entries of the
+// (H = 1: rows 0 .. AH-1, H = 2: rows AH .. p2; the halves ADD their entries into the rings) -- gathered into the entries of the
 // direct and of the transposed row of each lane.
 struct BF3Unit {
     const double *lines, *V2s;
     double *sets;
-    int dd, rlo, rhi, N1, row_lo, nrows, lane, npieces;
+    int dd, rlo, rhi, nhi, row_lo, nrows, lane, npieces;   // nhi: pairs (dd, dd + la) exist for la < nhi (column range of row dd)
     int diag0, stD, stT;
     int rbs1, rbs2, rbs3, rbs4, rbs5;     // ring slot (doubles from the start of a set) of the row parked in ring line delta
 };
-template <class Gm, int P, int NY, int MASK, int SYM, int H>
+template <class Gm, int NY, int MASK, int SYM, int H>
 __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
 {
-    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, LS = Gm::LS, RW = Gm::RW, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
-    constexpr int AH = (P + 1) / 2;
-    constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P;
+    constexpr int P2 = Gm::P2_, Q = Gm::Q_, p1 = Gm::p1, p2 = Gm::p2, W1 = Gm::W1, W2 = Gm::W2;
+    constexpr int TL = Gm::TL, LS = Gm::LS, RW = Gm::RW, PL = Gm::PL, PPP = Gm::PPP, NPC = Gm::NPC, RP = Gm::RP;
+    constexpr int AH = (P2 + 1) / 2;
+    constexpr int A0 = H == 2 ? AH : 0, A1 = H == 1 ? AH : P2;
     const int lane = U.lane, dd = U.dd;
     int ln_ = min(lane, PPP * PL - 1);
     asm volatile("" : "+v"(ln_));
@@ -572,50 +555,51 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     const int pid = pass * PPP + ps;
     const int k9 = pid / NPC, pj = pid - k9 * NPC;
     const int s1 = pj * RP + x;
-    const bool colt = k9 <= p;                             // pair (dd + la, dd); else (dd, dd + la)
-    const int la = colt ? k9 : k9 - p;
+    const bool colt = k9 <= p1;                            // pair (dd + la, dd); else (dd, dd + la)
+    const int la = colt ? k9 : k9 - p1;
     const int row1 = colt ? dd + la : dd, col1 = colt ? dd : dd + la;
     // EVERY lane forms its element matrix (a span outside the axis has zero basis values in V2s; a lane without a valid item
     // computes something that is never stored); the LDS addresses are kept inside the image
-    const double *kl = U.lines + min(k9, W - 1) * LS + min(s1, TL / P - 1) * P, *vl = U.V2s + min(s1, TL / P - 1) * P * P * 2;
-    double loc[A1 - A0][P];
+    const double *kl = U.lines + min(k9, W1 - 1) * LS + min(s1, TL / Q - 1) * Q, *vl = U.V2s + min(s1, TL / Q - 1) * Q * P2 * 2;
+    double loc[A1 - A0][P2];
 #ifdef BF3_NOELEM
     {                                                      // (timing experiment: no element matrices)
         const double k0 = kl[0], v0 = vl[0];
 #pragma unroll
         for (int a = 0; a < A1 - A0; ++a)
 #pragma unroll
-            for (int b = 0; b < P; ++b) { loc[a][b] = k0 + v0 * (a + 3 * b); asm volatile("" : "+v"(loc[a][b])); }
+            for (int b = 0; b < P2; ++b) { loc[a][b] = k0 + v0 * (a + 3 * b); asm volatile("" : "+v"(loc[a][b])); }
     }
 #else
-    bf_element<P, NY, MASK, A0, A1>(loc, kl, vl, TL);
+    bf_element<P2, NY, MASK, A0, A1, Q>(loc, kl, vl, TL);
 #endif
-    const int r3 = s1 - p;                                 // row of the tile (this lane's span is the first of its support)
-    const bool item = lane < PPP * PL && pid < U.npieces && x >= p && r3 < U.nrows;
-    const int oshv = max(p - (U.row_lo + r3), 0);
+    const int r3 = s1 - p2;                                // row of the tile (this lane's span is the first of its support)
+    // (the pair exists when the later dof lies in the column range of the earlier one: la < nhi -- single knots: dd + la < N1)
+    const bool item = lane < PPP * PL && pid < U.npieces && x >= p2 && r3 < U.nrows && la < U.nhi;
+    const int oshv = max(p2 - (U.row_lo + r3), 0);
     int rb = U.rbs1;
-    if (p >= 2) rb = la == 2 ? U.rbs2 : rb;
-    if (p >= 3) rb = la == 3 ? U.rbs3 : rb;
-    if (p >= 4) rb = la == 4 ? U.rbs4 : rb;
-    if (p >= 5) rb = la == 5 ? U.rbs5 : rb;
+    if (p1 >= 2) rb = la == 2 ? U.rbs2 : rb;
+    if (p1 >= 3) rb = la == 3 ? U.rbs3 : rb;
+    if (p1 >= 4) rb = la == 4 ? U.rbs4 : rb;
+    if (p1 >= 5) rb = la == 5 ? U.rbs5 : rb;
     const int cb = Gm::OFF_CUR + la * RW;
-    // ---- direct entries of row i2 = this lane's row: entry o = b - a + p from the element matrix of span i2 - a
+    // ---- direct entries of row i2 = this lane's row: entry o = b - a + p2 from the element matrix of span i2 - a
     if (U.stD) {
-        double out[W];
+        double out[W2];
 #pragma unroll
         for (int a = A0; a < A1; ++a)
 #pragma unroll
-            for (int b = 0; b < P; ++b) {
-                if (a == 0) out[b + p] = loc[0][b];
-                else if (a == A0 || b == 0) out[b - a + p] = bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
-                else out[b - a + p] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
+            for (int b = 0; b < P2; ++b) {
+                if (a == 0) out[b + p2] = loc[0][b];
+                else if (a == A0 || b == 0) out[b - a + p2] = bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
+                else out[b - a + p2] += bf2_from_lane(((lane - a) & 63) * 4, loc[a - A0][b]);
             }
-        if (item && row1 >= U.rlo && row1 < U.rhi && col1 < U.N1) {
-            double *dste = U.sets + ((colt && la > 0) ? rb : cb) + r3 * W - oshv;
-            constexpr int OLO = H == 0 ? 0 : p - (A1 - 1), OHI = H == 0 ? 2 * p : 2 * p - A0;
+        if (item && row1 >= U.rlo && row1 < U.rhi) {
+            double *dste = U.sets + ((colt && la > 0) ? rb : cb) + r3 * W2 - oshv;
+            constexpr int OLO = H == 0 ? 0 : p2 - (A1 - 1), OHI = H == 0 ? 2 * p2 : 2 * p2 - A0;
             if (SYM != 0 && U.diag0) {
                 // the diagonal line of a diagonal block: entries j2 <= i2 are direct, the others come transposed (below)
-                const int omax = la == 0 ? p : 2 * p;
+                const int omax = la == 0 ? p2 : 2 * p2;
 #pragma unroll
                 for (int o = OLO; o <= OHI; ++o)
                     if (o >= oshv && o <= omax) {
@@ -623,12 +607,12 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
                         else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
             } else if (H == 0) {
-                if (U.row_lo >= p) {
+                if (U.row_lo >= p2) {
 #pragma unroll
-                    for (int o = 0; o < W; ++o) dste[o] = out[o];
+                    for (int o = 0; o < W2; ++o) dste[o] = out[o];
                 } else {
 #pragma unroll
-                    for (int o = 0; o < W; ++o)
+                    for (int o = 0; o < W2; ++o)
                         if (o >= oshv) dste[o] = out[o];
                 }
             } else {
@@ -636,7 +620,7 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
 #pragma unroll
                 for (int o = OLO; o <= OHI; ++o)
                     if (o >= oshv) {
-                        if ((H == 1 && o > 2 * p - AH) || (H == 2 && o <= p - AH)) dste[o] = out[o];
+                        if ((H == 1 && o > 2 * p2 - AH) || (H == 2 && o <= p2 - AH)) dste[o] = out[o];
                         else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
             }
@@ -648,41 +632,31 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
 #pragma unroll
     for (int a = 0; a < A1 - A0; ++a)
 #pragma unroll
-        for (int b = 0; b < P; ++b) asm volatile("" : "+v"(loc[a][b]));
+        for (int b = 0; b < P2; ++b) asm volatile("" : "+v"(loc[a][b]));
     __builtin_amdgcn_sched_barrier(0);
-    // ---- transposed entries: target row j2 = this lane's row, entry e <-> source row i2 = j2 + e - p; the addend of span j2 - b
-    //      is loc[e - p + b][b] of the lane b places below -- the same addends in the same order as the direct entry o = 2p - e of
-    //      row i2, hence the same bits
+    // ---- transposed entries: target row j2 = this lane's row, entry e <-> source row i2 = j2 + e - p2; the addend of span j2 - b
+    //      is loc[e - p2 + b][b] of the lane b places below -- the same addends in the same order as the direct entry o = 2 p2 - e
+    //      of row i2, hence the same bits
 #ifdef BF3_NOT
     if (SYM != 0 && U.diag0 && U.stD) {                     // (timing experiment: no transposed rows of off-diagonal blocks)
 #else
     if (SYM != 0 && (U.diag0 ? U.stD : U.stT)) {
 #endif
-        double outT[W];
+        double outT[W2];
 #pragma unroll
-        for (int b = 0; b < P; ++b)
+        for (int b = 0; b < P2; ++b)
 #pragma unroll
             for (int a = A0; a < A1; ++a) {
-#ifdef BF3_NOTGATHER
-                if (b == 0) outT[a + p] = loc[a - A0][0];       // (timing experiment: no cross-lane traffic for the transposed entries)
-                else if (a == A0) outT[a + p - b] = loc[0][b];
-                else outT[a + p - b] += loc[a - A0][b];
-#else
-                if (b == 0) outT[a + p] = loc[a - A0][0];
-                else if (a == A0) outT[a + p - b] = bf2_from_lane(((lane - b) & 63) * 4, loc[0][b]);
-                else outT[a + p - b] += bf2_from_lane(((lane - b) & 63) * 4, loc[a - A0][b]);
-#endif
+                if (b == 0) outT[a + p2] = loc[a - A0][0];
+                else if (a == A0) outT[a + p2 - b] = bf2_from_lane(((lane - b) & 63) * 4, loc[0][b]);
+                else outT[a + p2 - b] += bf2_from_lane(((lane - b) & 63) * 4, loc[a - A0][b]);
             }
-#ifdef BF3_NOTWRITE
-        if (false) {
-#else
-        if (item && col1 >= U.rlo && col1 < U.rhi && row1 < U.N1) {
-#endif
-            constexpr int ELO = H == 0 ? 0 : A0, EHI = H == 0 ? 2 * p : A1 - 1 + p;
+        if (item && col1 >= U.rlo && col1 < U.rhi) {
+            constexpr int ELO = H == 0 ? 0 : A0, EHI = H == 0 ? 2 * p2 : A1 - 1 + p2;
             if (U.diag0) {
                 // upper part of row dd of the same block: the line of column dd + la; on the diagonal line only j2 > i2
-                double *dste = U.sets + cb + r3 * W - oshv;
-                const int emin = la == 0 ? p + 1 : oshv;
+                double *dste = U.sets + cb + r3 * W2 - oshv;
+                const int emin = la == 0 ? p2 + 1 : oshv;
 #pragma unroll
                 for (int e = ELO; e <= EHI; ++e)
                     if (e >= emin) {
@@ -690,21 +664,21 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
                         else (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
             } else {
-                double *dste = U.sets + Gm::SETSZ + (colt ? cb : rb) + r3 * W - oshv;
+                double *dste = U.sets + Gm::SETSZ + (colt ? cb : rb) + r3 * W2 - oshv;
                 if (H == 0) {
-                    if (U.row_lo >= p) {
+                    if (U.row_lo >= p2) {
 #pragma unroll
-                        for (int e = 0; e < W; ++e) dste[e] = outT[e];
+                        for (int e = 0; e < W2; ++e) dste[e] = outT[e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < W; ++e)
+                        for (int e = 0; e < W2; ++e)
                             if (e >= oshv) dste[e] = outT[e];
                     }
                 } else {
 #pragma unroll
                     for (int e = ELO; e <= EHI; ++e)
                         if (e >= oshv) {
-                            if ((H == 1 && e < AH) || (H == 2 && e >= p + AH)) dste[e] = outT[e];
+                            if ((H == 1 && e < AH) || (H == 2 && e >= p2 + AH)) dste[e] = outT[e];
                             else (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                 }
@@ -713,20 +687,20 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     }
 }
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM>
+template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT>
 __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(const BFArgs A)
 {
-    using Gm = BF3Geom<P, NLG, bf_nroles(MASK), NCW, SYM>;
-    constexpr int p = P - 1, W = 2 * P - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
+    using Gm = BF3Geom<P1, P2, Q, NLG, bf_nroles(MASK), NCW, SYM>;
+    constexpr int p2 = P2 - 1, W1 = 2 * P1 - 1, W2 = 2 * P2 - 1, TL = Gm::TL, NR = bf_nroles(MASK), NSW = NR * NLG;
     constexpr int RW = Gm::RW, PPP = Gm::PPP, NPC = Gm::NPC;
     constexpr int LS = Gm::LS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lines = lds;                 // [W][LS]
-    double *sets = lds + Gm::OFF_SETS;   // [NSET][NRL][RMAX][W]
-    double *V2s = lds + Gm::OFF_V2;      // [TL][P][2]
+    double *lines = lds;                 // [W1][LS]
+    double *sets = lds + Gm::OFF_SETS;   // [NSET][NRL][RMAX][W2]
+    double *V2s = lds + Gm::OFF_V2;      // [TL][P2][2]
     bf3_v4i *etab = (bf3_v4i *)(lds + Gm::OFF_ETAB);   // [NEL] {ring offset of the element, 8 rp2[i2], 8 c2, 8 (entry - shift) | out of range}
 
-    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0;
+    cip pl0 = (cip)A.pl0, jlo0 = (cip)A.jlo0, jhi0 = (cip)A.jhi0, fa1 = (cip)A.fa1, mslo1 = (cip)A.mslo1, jhi1 = (cip)A.jhi1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned bid = blockIdx.x;
     const bool tail = A.tail_k > 0 && bid >= A.main_blocks;
@@ -745,30 +719,38 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     const int i0 = pl0[2 * r0], j0 = pl0[2 * r0 + 1];
     const bool diag0 = SYM != 0 && i0 == j0;
     const int row_lo = tile * A.R2, row_hi = min(row_lo + A.R2, A.N2), nrows = row_hi - row_lo;
-    const int sp_lo = row_lo - p;
-    const int win0 = sp_lo * P;
+    const int sp_lo = row_lo - p2;
+    const int win0 = sp_lo * Q;
     const int rlo = A.mid_lo + mch * mrows, rhi = min(rlo + mrows, A.mid_hi);
-    const int s_begin = max(rlo - p, 0);
+    // the first span that matters is the first of supp(rlo): every pair with a dof >= rlo lies on spans from there on; the
+    // steps start with the first dof to leave after it; spans are swept while their first active dof is below rhi
+    const int s_begin = mslo1[min(rlo, A.N1 - 1)];
+    const int d_begin = fa1[s_begin];
+    int t_sw = s_begin;
+    {
+        const int n_sw = min(A.n1, A.span_hi);
+        while (t_sw < n_sw && fa1[t_sw] < rhi) ++t_sw;
+    }
 
-    for (int idx = threadIdx.x; idx < TL * P * 2; idx += blockDim.x) {
-        const int gpt = win0 + idx / (2 * P);
-        V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P * 2 + idx] : 0.0;
+    for (int idx = threadIdx.x; idx < TL * P2 * 2; idx += blockDim.x) {
+        const int gpt = win0 + idx / (2 * P2);
+        V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P2 * 2 + idx] : 0.0;
     }
     if (NH == 2)
         for (int idx = threadIdx.x; idx < Gm::OFF_V2 - Gm::OFF_SETS; idx += blockDim.x) sets[idx] = 0.0;     // the halves of a pass add onto zeros
-    // edge rows of the tile: i2 < p or i2 > N2 - 1 - p
-    const int lo_n = max(0, min(row_hi, min(p, A.N2)) - row_lo);          // low edge rows start at row_lo (tile 0 only)
-    const int hi_s = max(max(p, A.N2 - p), row_lo), hi_n = max(0, row_hi - hi_s);
+    // edge rows of the tile: i2 < p2 or i2 > N2 - 1 - p2
+    const int lo_n = max(0, min(row_hi, min(p2, A.N2)) - row_lo);          // low edge rows start at row_lo (tile 0 only)
+    const int hi_s = max(max(p2, A.N2 - p2), row_lo), hi_n = max(0, row_hi - hi_s);
     const int ne = lo_n + hi_n;
     if (threadIdx.x < Gm::NEL) {
-        const int k = threadIdx.x / W, e = threadIdx.x - k * W;
+        const int k = threadIdx.x / W2, e = threadIdx.x - k * W2;
         bf3_v4i v; v.x = 0; v.y = 0; v.z = 0; v.w = BF2_OOB;
         if (k < ne) {
             const int i2 = k < lo_n ? row_lo + k : hi_s + (k - lo_n);
-            const int jl2 = max(i2 - p, 0), c2 = min(i2 + p, A.N2 - 1) + 1 - jl2;
+            const int jl2 = max(i2 - p2, 0), c2 = min(i2 + p2, A.N2 - 1) + 1 - jl2;
             if (e < c2) {
-                const int shift = W * row_lo - Gm::T0;
-                v.x = (i2 - row_lo) * W + e; v.y = 8 * A.rp2[i2]; v.z = 8 * c2; v.w = 8 * (e - shift);
+                const int shift = W2 * row_lo - Gm::T0;
+                v.x = (i2 - row_lo) * W2 + e; v.y = 8 * A.rp2[i2]; v.z = 8 * c2; v.w = 8 * (e - shift);
             }
         }
         etab[threadIdx.x] = v;
@@ -791,24 +773,23 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     BF3Blk B;
     B.i0 = i0; B.j0 = j0; B.diag0 = diag0; B.c0i = jhi0[i0] - jlo0[i0]; B.c0j = jhi0[j0] - jlo0[j0];
     B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
-    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne; B.emask = 0;
+    B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne;
     B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
     B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
-    // store duty: on the sweepers of the roles 1.. where the form has them (staged), else on the contractors (at once)
+    // store duty: on the sweepers of the roles 1.. where the form has them (staged, dense), else on the contractors (at once)
     constexpr bool STW = NR >= 2;
-    constexpr int NSTW = STW ? (NR - 1) * NLG : NCW;
-    using StoreC = BF3Store<Gm, P, NCW, 1, NH, SYM, false>;                 // carried by the contractors (one-role forms)
-    constexpr int NQ = (Gm::RMAX * W * W + 63) / 64;
+    constexpr int NQ = (Gm::RMAX * W1 * W2 + 63) / 64;
     using Split = BF3DenseSplit<NR < 2 ? 2 : NR, NLG, NQ>;
-    using StoreA = BF3StoreDense<Gm, P, NSTW, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
-    using StoreB = BF3StoreDense<Gm, P, NSTW, NH, SYM, Split::KB, Split::QB, NQ, Split::NB>;                                       // last role
+    using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
+    using StoreB = BF3StoreDense<Gm, NH, SYM, Split::KB, Split::QB, NQ, Split::NB>;                                       // last role
+    using StoreC = BF3Store<Gm, NCW, 1, NH, SYM>;                                                                          // contractors (one-role forms)
     double *dump = lines + NR * TL;                       // (the padding of line 0: target of the clears that must not happen)
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
         const BF3SweepCtx sc{&B, sets, dump, role == NR - 1 ? lg : (role - 1) * NLG + lg};
-        BF3SweepDispatch<P, MASK, NA, NLG, StoreA, StoreB, STW, 0>::run(A, role, r0, g2l, g2, s_begin, rhi, lines, LS, sc);
+        BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, 0>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
         return;
     }
 
@@ -818,43 +799,42 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     __builtin_amdgcn_s_setprio(BF2_PRIO_C);
     StoreC store;
     if constexpr (!STW) store.init(A, B, cw, lane);
-    const int nlines = diag0 ? P : W;                     // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
+    const int nlines = diag0 ? P1 : W1;                   // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
     const int npieces = nlines * NPC;
-    for (int t = s_begin; t < rhi + 1; ++t) {
+    for (int t = d_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
-        if constexpr (!STW) store.issue(cw);
         const int dd = t - 1;
         BF_SEG_BEGIN();
-        if (dd >= s_begin && dd < rhi) {
+        if (dd >= d_begin && dd < rhi) {
+            BF3Unit U;
+            U.lines = lines; U.V2s = V2s; U.sets = sets; U.dd = dd; U.rlo = rlo; U.rhi = rhi; U.row_lo = row_lo; U.nrows = nrows;
+            U.nhi = jhi1[dd] - dd;
+            U.lane = lane; U.npieces = npieces; U.diag0 = diag0; U.stD = B.stD; U.stT = B.stT;
             // ring slot of the row a line is parked for: row dd + delta of ring line delta
             // (named scalars, not an array: the select by the lane's line must stay a chain of v_cndmask)
-            BF3Unit U;
-            U.lines = lines; U.V2s = V2s; U.sets = sets; U.dd = dd; U.rlo = rlo; U.rhi = rhi; U.N1 = A.N1; U.row_lo = row_lo; U.nrows = nrows;
-            U.lane = lane; U.npieces = npieces; U.diag0 = diag0; U.stD = B.stD; U.stT = B.stT;
             U.rbs1 = Gm::roff(1) + (int)((unsigned)(dd + 1) % 2u) * RW; U.rbs2 = Gm::roff(2) + (int)((unsigned)(dd + 2) % 3u) * RW;
             U.rbs3 = Gm::roff(3) + (int)((unsigned)(dd + 3) % 4u) * RW; U.rbs4 = Gm::roff(4) + (int)((unsigned)(dd + 4) % 5u) * RW;
             U.rbs5 = Gm::roff(5) + (int)((unsigned)(dd + 5) % 6u) * RW;
             const int npass = (npieces + PPP - 1) / PPP;
             const int wslot = (int)((unsigned)(cw + t) % (unsigned)NCW);
             if (NH == 1 || npass <= NCW) {
-                for (int pass = wslot; pass < npass; pass += NCW) bf3_unit<Gm, P, NY, MASK, SYM, 0>(U, pass);
+                for (int pass = wslot; pass < npass; pass += NCW) bf3_unit<Gm, NY, MASK, SYM, 0>(U, pass);
             } else {
-                bf3_unit<Gm, P, NY, MASK, SYM, 0>(U, wslot);
+                bf3_unit<Gm, NY, MASK, SYM, 0>(U, wslot);
                 const int nsp = npass - NCW;
                 for (int u = wslot; u < 2 * nsp; u += NCW) {
-                    if (u < nsp) bf3_unit<Gm, P, NY, MASK, SYM, 2>(U, NCW + u);
-                    else bf3_unit<Gm, P, NY, MASK, SYM, 1>(U, NCW + u - nsp);
+                    if (u < nsp) bf3_unit<Gm, NY, MASK, SYM, 2>(U, NCW + u);
+                    else bf3_unit<Gm, NY, MASK, SYM, 1>(U, NCW + u - nsp);
                 }
             }
         }
         BF_SEG_END(1);
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
         BF_SEG_BEGIN();
-        bf3_edge_rows<Gm, P, NCW, NH, SYM>(A, B, sets, etab, t, cw, lane);
+        bf3_edge_rows<Gm, NCW, NH, SYM>(A, B, sets, etab, t, cw, lane);
         if constexpr (!STW) store.fetch(A, B, sets, dump, t, cw, lane);
         BF_SEG_END(0);
     }
-    if constexpr (!STW) store.issue(cw);                  // the last row
     BF_SEG_DUMP(cw & 3);
     BF_STAMP_END(wave);
 }
@@ -862,35 +842,33 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
 // ---------------------------------------------------------------------------------------------
 // host side
 
-// k_bf3 multiplies a per-lane row constant (W i2 - T0, or an out-of-range marker) with a scalar of the step in 24 x 24 bits and
-// relies on the descriptor's range check to drop what must not be stored: the marker times the smallest scalar must pass the
-// end of a row block, times the largest one (plus the scalar offset) stay below 2^32.
-bool fused3_offsets_fit(int dim, int p0, int p, long long S_mid, long long S_last, long long N_last)
+// k_bf3 relies on the range check of the buffer descriptors to drop what must not be stored, with 32-bit offsets inside the row
+// block of an outer row and 24 x 24-bit multiplications of row constants: the patch must stay inside these.
+bool fused3_offsets_fit(int dim, int p0, int p1, int p2, long long S_mid, long long S_last, long long N_last)
 {
     const long long c0max = dim == 3 ? 2 * p0 + 1 : 1, c0min = dim == 3 ? p0 + 1 : 1;
-    const long long P = p + 1, W = 2 * p + 1;
-    const long long len = (c0max * S_mid * S_last + W * 64) * 8;
+    const long long W1 = 2 * p1 + 1, W2 = 2 * p2 + 1;
+    const long long len = (c0max * S_mid * S_last + W1 * W2 * 64) * 8;
     if (len > 900000000LL) return false;
-    if (c0min * P - 1 < 1) return false;
-    const long long inv = len / (8 * (c0min * P - 1)) + 1;
-    if (inv >= (1LL << 24) || W * N_last >= (1LL << 24)) return false;
-    if (inv * 8 * (c0max * W - 1) + len + 65536 >= (1LL << 32)) return false;
+    const long long inv = len / (8 * std::max<long long>(c0min * 2 - 1, 1)) + 1;
+    if (inv >= (1LL << 24) || W2 * N_last >= (1LL << 24)) return false;
+    if (inv * 8 * (c0max * W1 - 1) + len + 65536 >= (1LL << 32)) return false;
     return true;
 }
 
-template <int P, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM>
+template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT>
 static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
 {
-    using Gm = BF3Geom<P, NLG, bf_nroles(MASK), NCW, SYM>;
+    using Gm = BF3Geom<P1, P2, Q, NLG, bf_nroles(MASK), NCW, SYM>;
     constexpr size_t lds = (size_t)Gm::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "k_bf3: LDS");
-    static_assert(Gm::NSET * Gm::SETSZ * 8 < 65536 * 2, "k_bf3: ring sets");
+    static_assert(Gm::RMAX >= 1 && Gm::RMAX <= 255 && Gm::RW < 4096, "k_bf3: packed slot constants");
     static_assert((bf_nroles(MASK) * NLG + NCW) * 64 <= 1024, "k_bf3: block size");
     static_assert(NCW == 4 || NCW == 8, "k_bf3: contractor waves");
     static_assert(Gm::NSUB * 512 <= 4096, "k_bf3: immediate offsets of the stores");
-    static_assert(Gm::NEL <= 1024, "k_bf3: edge table");
+    static_assert(Gm::NEL <= 1024 && Gm::W1 <= 15, "k_bf3: edge table / line index");
     constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
-    const void *fn = (const void *)k_bf3<P, NY, MASK, NA, NLG, NCW, NH, SYM>;
+    const void *fn = (const void *)k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT>;
     IGX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1, ncu = ncu_ctx;
     {
@@ -901,28 +879,23 @@ static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
     BFArgs A = A0;
     A.ntiles = (A.N2 + Gm::RMAX - 1) / Gm::RMAX;
     A.R2 = (A.N2 + A.ntiles - 1) / A.ntiles;
-    bf2_choose_chunks(A, (long long)per_cu * ncu, P);
+    bf2_choose_chunks(A, (long long)per_cu * ncu, P1);
     long long nblocks = (long long)A.npairs * A.ntiles * A.nmchunks;
     if (A.tail_k > 0) nblocks = A.main_blocks + (nblocks - A.main_blocks) * A.tail_k;
     if (nblocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (nblocks == 0) return IGX_OK;
-    k_bf3<P, NY, MASK, NA, NLG, NCW, NH, SYM><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
+    k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_BF_STAMP
     {
         static std::vector<unsigned long long> h(64 * 1024);
         IGX_HIP(hipStreamSynchronize(st));
         IGX_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_bf_stamp), h.size() * sizeof(unsigned long long)));
-        const int nw = bf_nroles(MASK) * NLG + NCW, nb = (int)std::min<long long>(nblocks, 2048);
+        const int nw = bf_nroles(MASK) * NLG + NCW, nb = (int)std::min<long long>(nblocks, 1024);
         for (int w = 0; w < nw; ++w) {
             double wt = 0, tot = 0;
             for (int b = 0; b < nb; ++b) { wt += h[(b * 16 + w) * 2]; tot += h[(b * 16 + w) * 2 + 1]; }
-            fprintf(stderr, "k_bf3 stamp: wave %2d  wait %.0f  total %.0f x100ns/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
-        }
-        for (int w = 0; w < 4; ++w) {
-            double sg[3] = {0, 0, 0};
-            for (int b = 0; b < nb; ++b) for (int i = 0; i < 3; ++i) sg[i] += h[32768 + (b * 4 + w) * 3 + i];
-            fprintf(stderr, "k_bf3 stamp: contractor %d  B2->B1 window (store duty) %.0f  passes %.0f  x100ns/block\n", w, sg[0] / nb, sg[1] / nb);
+            fprintf(stderr, "k_bf3 stamp: wave %2d  wait %.0f  total %.0f x10ns/block  (busy %.1f %%)\n", w, wt / nb, tot / nb, 100.0 * (1.0 - wt / tot));
         }
     }
 #endif
@@ -931,35 +904,57 @@ static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
 
 constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0x1248;
 
-// shapes (lane groups per role, contractor waves, halved passes): those of k_bf2 (fused.hip, BF2Cfg)
-template <int P, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
-template <int P> struct BF3Cfg<P, BF_MASK_MASS> { static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 8 : 4, NH = 1; };
+// shapes (lane groups per role, contractor waves, halved passes) by the larger of the two degrees: those of k_bf2 (fused.hip,
+// BF2Cfg: chosen per degree and form from measurements)
 #ifndef BF3_NH
 #define BF3_NH 2
 #endif
-template <int P> struct BF3Cfg<P, BF_MASK_STIFF3> {
-    static constexpr int NLG = P == 5 ? 3 : 2, NCW = P == 5 ? 4 : P == 4 ? 8 : 4, NH = P == 5 ? BF3_NH : 1;
+template <int PM, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
+template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 8 : 4, NH = 1; };
+template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> {
+    static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : 1;
 };
-template <int P> struct BF3Cfg<P, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = P <= 5 ? 8 : 4, NH = 1; };
+template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = PM <= 5 ? 8 : 4, NH = 1; };
 
-template <int P, int NY, int MASK>
-static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk)
+template <int P1, int P2, int Q, int NY, int MASK>
+static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult)
 {
-    using C = BF3Cfg<P, MASK>;
-    if (symk == 2) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2>(st, A, ncu);
-    if (symk == 1) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1>(st, A, ncu);
-    if constexpr (MASK == BF_MASK_STIFF3) return launch_bf3_k<P, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0>(st, A, ncu);
-    set_error("fused stage: no kernel for this non-symmetric set of types");
+    constexpr int PM = Q > (P1 > P2 ? P1 : P2) ? Q : (P1 > P2 ? P1 : P2);   // (the registers of a sweeper follow P1 and Q)
+    using C = BF3Cfg<PM, MASK>;
+    if constexpr (P1 == P2 && P1 == Q) {                   // equal degrees: every form, 2D, repeated knots on the swept axis
+        if (symk == 2) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu)
+                                   : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
+        if (symk == 1 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1, false>(st, A, ncu);
+        if constexpr (MASK == BF_MASK_STIFF3)
+            if (symk == 0) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0, true>(st, A, ncu)
+                                       : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0, false>(st, A, ncu);
+    } else {
+        if (symk == 2 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
+    }
+    set_error("fused stage: no kernel for this form at these degrees");
     return IGX_ERR_UNSUPPORTED;
 }
-template <int P>
-static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk)
+template <int P1, int P2, int Q>
+static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk, bool mult)
 {
-    if (ny == 1 && mask == BF_MASK_MASS) return launch_bf3_c<P, 1, BF_MASK_MASS>(st, A, ncu, symk);
-    if (ny == 4 && mask == BF_MASK_STIFF3) return launch_bf3_c<P, 4, BF_MASK_STIFF3>(st, A, ncu, symk);
-    if (ny == 4 && mask == BF_MASK_STIFF2) return launch_bf3_c<P, 4, BF_MASK_STIFF2>(st, A, ncu, symk);
+    if (ny == 1 && mask == BF_MASK_MASS) return launch_bf3_c<P1, P2, Q, 1, BF_MASK_MASS>(st, A, ncu, symk, mult);
+    if (ny == 4 && mask == BF_MASK_STIFF3) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF3>(st, A, ncu, symk, mult);
+    if constexpr (P1 == P2 && P1 == Q)
+        if (ny == 4 && mask == BF_MASK_STIFF2) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF2>(st, A, ncu, symk, mult);
     set_error("fused stage: no kernel for this set of types");
     return IGX_ERR_UNSUPPORTED;
+}
+
+// Degrees the kernel is compiled for: equal degrees 1 .. 5 with Q = p + 1 (every form), and -- 3D symmetric forms -- one or
+// both of the two axes one degree below Q (the common case of the reference's nqp = max degree + 1 rule: one axis of lower
+// degree).  Anything else takes the stage kernels.
+bool fused3_degrees(int P1, int P2, int Q, bool sym3d, bool mid_simple)
+{
+    if (!mid_simple && !(P1 == P2 && P1 == Q)) return false;     // (repeated knots on the swept axis: equal degrees)
+    if (P1 < 2 || P2 < 2 || Q > 6) return false;
+    if (P1 == P2 && P1 == Q) return true;
+    if (!sym3d || Q < 3) return false;
+    return (P1 == Q || P1 == Q - 1) && (P2 == Q || P2 == Q - 1);
 }
 
 // the symmetric forms (mass, stiffness; 2D and 3D) and the 3D convection-diffusion form (its slots merged by k_geoA), one input
@@ -995,6 +990,7 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     A.V1 = AM.d_V; A.V2 = AL.d_V;
     A.n1 = AM.n; A.N1 = AM.N; A.n2 = AL.n; A.N2 = AL.N;
     A.rp1 = AM.dev.rp; A.rp2 = AL.dev.rp;
+    A.fa1 = AM.dev.fa; A.mslo1 = AM.dev.mslo; A.jlo1 = AM.dev.jlo; A.jhi1 = AM.dev.jhi;
     A.pl0 = in.pl0; A.rp0 = in.rp0; A.jlo0 = in.jlo0; A.jhi0 = in.jhi0;
     A.S1 = AM.S; A.S2 = AL.S; A.nnz_off = pt->nnz_off;
     A.data = d_data; A.sym = in.sym;
@@ -1002,14 +998,17 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     A.npairs = in.npairs;
     if (pt->dim == 3) { A.own_lo = pt->r0_lo; A.own_hi = pt->r0_hi; } else { A.own_lo = 0; A.own_hi = 1; }
     const int symk = !in.sym ? 0 : pt->dim == 3 ? 2 : 1;
-    switch (AL.P) {
-    case 2: return launch_bf3_p<2>(st, A, ny, mask, pt->ctx->ncu, symk);
-    case 3: return launch_bf3_p<3>(st, A, ny, mask, pt->ctx->ncu, symk);
-    case 4: return launch_bf3_p<4>(st, A, ny, mask, pt->ctx->ncu, symk);
-    case 5: return launch_bf3_p<5>(st, A, ny, mask, pt->ctx->ncu, symk);
-    case 6: return launch_bf3_p<6>(st, A, ny, mask, pt->ctx->ncu, symk);
-    default: set_error("fused stage: degree %d unsupported", AL.P - 1); return IGX_ERR_UNSUPPORTED;
-    }
+    const int P1 = AM.P, P2 = AL.P, Q = AL.q;
+    if (AM.q != AL.q || !fused3_degrees(P1, P2, Q, symk == 2, AM.simple) || (!AM.simple && symk == 1)) { set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q); return IGX_ERR_UNSUPPORTED; }
+#define BF3_CASE(p1, p2, q) if (P1 == p1 && P2 == p2 && Q == q) return launch_bf3_p<p1, p2, q>(st, A, ny, mask, pt->ctx->ncu, symk, !AM.simple);
+    BF3_CASE(2, 2, 2) BF3_CASE(3, 3, 3) BF3_CASE(4, 4, 4) BF3_CASE(5, 5, 5) BF3_CASE(6, 6, 6)
+    BF3_CASE(2, 3, 3) BF3_CASE(3, 2, 3) BF3_CASE(2, 2, 3)
+    BF3_CASE(3, 4, 4) BF3_CASE(4, 3, 4) BF3_CASE(3, 3, 4)
+    BF3_CASE(4, 5, 5) BF3_CASE(5, 4, 5) BF3_CASE(4, 4, 5)
+    BF3_CASE(5, 6, 6) BF3_CASE(6, 5, 6) BF3_CASE(5, 5, 6)
+#undef BF3_CASE
+    set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q);
+    return IGX_ERR_UNSUPPORTED;
 }
 
 } // namespace igx

@@ -64,6 +64,7 @@ struct BFArgs {
     int mid_lo, mid_hi;           // rows of the mid axis to produce
     int span_hi;                  // spans of the mid axis below this one are resident (2D row slabs; else n1)
     int npairs;
+    const int *fa1, *mslo1, *jlo1, *jhi1;   // mid axis (k_bf3): first active dof of a span, first span of a dof's support, column range of a row
     int own_lo, own_hi;           // owned rows of the outer axis (k_bf3: a block stores the direct rows of an owned i0, the transposed ones of an owned j0)
 };
 
@@ -93,7 +94,7 @@ __device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n
 //     loc[a][b] = sum_l sum_tu V[l][b][tu] * (sum_tv V[l][a][tv] * K[tu + 2 tv][l])        (a: test function, b: trial function)
 // -- every K and V value is read from LDS once per (line, span), not once per row.  The values of point l+1 are requested
 // before the arithmetic of point l.  One role per type: role index = position of the type among those that occur.
-template <int P, int NY, int MASK, int A0 = 0, int A1 = P>
+template <int P, int NY, int MASK, int A0 = 0, int A1 = P, int Q = P>           // Q: Gauss points per span (nqp = max degree + 1 of the patch)
 __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const double *kl, const double *vl, const int TL)
 {
     constexpr int NA_ = A1 - A0;             // rows A0 .. A1-1 of the element matrix (test functions)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
 #pragma unroll
     for (int b = 0; b < P; ++b) load_V(0, b);
 #pragma unroll
-    for (int l = 0; l < P; ++l) {
+    for (int l = 0; l < Q; ++l) {
         // every value is replaced by the one of the next point right after its last use (one register set)
         double c0[NA_], c1[NA_];
 #pragma unroll
@@ -124,7 +125,7 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
                 c1[a] = fma(V[A0 + a][1], K[3], V[A0 + a][0] * K[1]);      // types 1, 3
             }
         }
-        if (l + 1 < P) {
+        if (l + 1 < Q) {
 #pragma unroll
             for (int a = 0; a < NA_; ++a) asm volatile("" : "+v"(c0[a]), "+v"(c1[a]));     // K is dead from here
             load_K(l + 1);
@@ -140,7 +141,7 @@ __device__ __forceinline__ void bf_element(double (&loc)[A1 - A0][P], const doub
                 } else if (NY == 1) loc[a][b] = fma(V[b][0], c0[a], loc[a][b]);
                 else loc[a][b] = fma(V[b][0], c0[a], fma(V[b][1], c1[a], loc[a][b]));
             }
-            if (l + 1 < P) {
+            if (l + 1 < Q) {
 #pragma unroll
                 for (int a = 0; a < NA_; ++a) asm volatile("" : "+v"(loc[a][b]));          // V[b] is dead from here
                 load_V(l + 1, b);

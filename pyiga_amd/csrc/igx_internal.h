@@ -282,7 +282,8 @@ int launch_bf(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d
 int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, double *d_data);
 // k_bf3 (fused3.hip): the fused stage of the symmetric forms that writes both triangles itself (no mirror pass)
 bool fused3_supported(const BFInputs &in);
-bool fused3_offsets_fit(int dim, int p0, int p, long long S_mid, long long S_last, long long N_last);
+bool fused3_offsets_fit(int dim, int p0, int p1, int p2, long long S_mid, long long S_last, long long N_last);
+bool fused3_degrees(int P1, int P2, int Q, bool sym3d, bool mid_simple);
 int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);

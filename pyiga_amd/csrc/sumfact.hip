@@ -791,6 +791,7 @@ static bool geoA_wanted(const igx_patch *pt, int kind, int nslots)
     return (igx_kind_symmetric(kind) || kind == IGX_CONVDIFF) && geoA_supported(pt, kind, nslots);
 }
 static bool fused_applicable(const igx_patch *pt);
+static bool fused3_axes(const igx_patch *pt, bool sym);
 
 // The single launch beats the stage-kernel chain while its grid is one resident round of tiles of at most 6 x 6 rows
 // (a block's duration grows with its tile: 14 us at 2 x 4 rows, 27 us at 6 x 6, 39 us at 8 x 8 against 28-34 us of
@@ -815,8 +816,22 @@ bool sumfact_needs_fields(const igx_patch *pt, int kind)
     if (single2d_wanted(pt, kind)) return false;
     if (pt->dim != 3) return true;
     // the convection-diffusion form: its eight merged slots exist where the fused stage runs (sumfact_assemble)
-    if (!igx_kind_symmetric(kind)) return !(kind == IGX_CONVDIFF && fused_applicable(pt) && geoA_wanted(pt, kind, 8));
+    if (!igx_kind_symmetric(kind)) return !(kind == IGX_CONVDIFF && (fused_applicable(pt) || fused3_axes(pt, false)) && geoA_wanted(pt, kind, 8));
     return !geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 8);
+}
+
+// k_bf3 (fused3.hip): single knots on the LAST axis only; the swept axis may have repeated knots; the two degrees may differ
+// (symmetric 3D forms) and the Gauss points per span are the patch's nqp.  Decided on the whole axes: all slabs of a patch agree.
+static bool fused3_axes(const igx_patch *pt, bool sym)
+{
+    if (pt->knobs.bf == 2 || pt->knobs.path == 2 || pt->knobs.final_sel) return false;
+    const int dim = pt->dim;
+    if (dim == 2 && (pt->knobs.path != 1 || !sym)) return false;
+    const Axis &AM = pt->ax[dim - 2], &AL = pt->ax[dim - 1];
+    if (!AL.simple || AM.q != AL.q || !fused3_degrees(AM.P, AL.P, AL.q, sym && dim == 3, AM.simple)) return false;
+    if (dim == 2 && !AM.simple) return false;
+    return fused_offsets_fit(dim == 3 ? 2 * pt->ax[0].p + 1 : 1, AM.S, AL.S, AM.G, AL.G) &&
+           fused3_offsets_fit(dim, dim == 3 ? pt->ax[0].p : 0, AM.p, AL.p, AM.S, AL.S, AL.N);
 }
 
 static bool fused_applicable(const igx_patch *pt)
@@ -840,7 +855,7 @@ static bool bf_add_slot(BFInputs &in, int y, int t1, const double *ptr)
     return true;
 }
 
-static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
+static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data, bool use3)
 {
     hipStream_t st = pt->ctx->stream;
     const int dim = pt->dim;
@@ -857,9 +872,8 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data)
         i1_lo = pt->r0_lo; i1_hi = pt->r0_hi;
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
     }
-    // symmetric forms: k_bf3 writes the upper triangle from the same registers as the lower one (fused3.hip) -- no mirror pass
-    if (pt->knobs.bf != 2 && (sym || dim == 3) && fused3_supported(in) &&
-        fused3_offsets_fit(dim, dim == 3 ? A0.p : 0, in.last->p, in.mid->S, in.last->S, in.last->N)) {
+    // k_bf3 (fused3.hip): symmetric forms get their upper triangle from the same registers as the lower one -- no mirror pass
+    if (use3) {
         if (dim == 2 && sym) in.mid_hi = pt->r0_hi;      // (no mirror sources above the slab)
         if (int rc = launch_bf3(st, pt, in, d_data)) return rc;
         pt->last_path |= IGX_PATH_FUSED | IGX_PATH_BF3 | (sym ? IGX_PATH_BOTH : 0);
@@ -932,18 +946,21 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         pt->last_path |= IGX_PATH_SINGLE;
         return IGX_OK;
     }
-    const bool fused = fused_applicable(pt);
+    const bool axes3 = fused3_axes(pt, sym);
+    const bool fused = fused_applicable(pt) || axes3;
     if (fused && dim == 2) {
         // 2D: the fields ARE the sweep input (axis 0 swept, axis 1 contracted by the contractors): one kernel + mirror
         BFInputs in{};
         bool ok = true;
         for (const Term &t : terms)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : t.t[1], t.t[0], pt->d_fields + (size_t)t.f * pd.npts_loc);
-        if (ok && fused_supported(in)) {
+        in.sym = sym ? 1 : 0;
+        const bool can3 = ok && axes3 && fused3_supported(in), can2 = ok && fused_applicable(pt) && fused_supported(in);
+        if (can3 || can2) {
             in.slice_stride = 0; in.gmid_lo = pd.g0_lo;
             stage_event(pt, 1, st);
             stage_event(pt, 2, st);
-            return run_fused(pt, in, sym, d_data);
+            return run_fused(pt, in, sym, d_data, can3);
         }
     }
 
@@ -1094,9 +1111,11 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
         for (size_t i = 0; i < terms.size(); ++i)
             ok = ok && bf_add_slot(in, kind == IGX_MASS ? 0 : terms[i].t[2], terms[i].t[1],
                                    pt->d_K1 + (size_t)X[term_x[i]].slot * np0 * NPLs);
-        if (ok && fused_supported(in)) {
+        in.sym = sym ? 1 : 0;
+        const bool can3 = ok && axes3 && fused3_supported(in), can2 = ok && fused_applicable(pt) && fused_supported(in);
+        if (can3 || can2) {
             in.slice_stride = NPLs; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
-            return run_fused(pt, in, sym, d_data);
+            return run_fused(pt, in, sym, d_data, can3);
         }
     }
 
