@@ -2195,3 +2195,47 @@ def test_kronecker_shortcut_refuses_degrees_beyond_its_row_buffers(iga, monkeypa
     monkeypatch.setenv('IGX_SEPARABLE', '1')
     B = iga.assemble.stiffness(kvs, geo)
     assert (A != B).nnz == 0 or abs(A - B).max() <= 1e-13 * abs(A).max()
+
+
+def test_fused_stage_with_unequal_degrees_and_repeated_knots(iga, monkeypatch):
+    """Round 5: k_bf3 serves every symmetric 3D patch with single knots on the LAST axis -- degrees of the swept and the last
+    axis one below nqp = max degree + 1 (pyiga/assemblers.pyx:1338), repeated knots on the swept axis (equal degrees) and on
+    axis 0.  Against the entry-wise kernels (the reference's loop nest), exactly symmetric, every value written, the fused
+    stage really ran, and row slabs reproduce the patch bit for bit."""
+    mk = iga.bspline.make_knots
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+
+    def rep(p, n, m, at=None):                 # make_knots with the interior knots of index `at` repeated m times in all
+        kv = mk(p, 0., 1., n)
+        inner = np.unique(kv.kv)[1:-1]
+        extra = np.repeat(inner if at is None else inner[list(at)], m - 1)
+        return iga.bspline.KnotVector(np.sort(np.concatenate([kv.kv, extra])), p)
+    cases = [((mk(3, 0., 1., 4), mk(2, 0., 1., 9), mk(3, 0., 1., 7)), 'twisted_box', True),          # (P1, P2, Q) = (3, 4, 4)
+             ((mk(4, 0., 1., 3), mk(4, 0., 1., 6), mk(3, 0., 1., 11)), 'cylinder', True),            # (5, 4, 5)
+             ((mk(4, 0., 1., 3), mk(3, 0., 1., 8), mk(3, 0., 1., 9)), 'cylinder', True),             # (4, 4, 5)
+             ((mk(2, 0., 1., 5), mk(1, 0., 1., 6), mk(2, 0., 1., 4)), 'twisted_box', True),          # (2, 3, 3)
+             ((mk(3, 0., 1., 4), rep(3, 7, 2), mk(3, 0., 1., 9)), 'cylinder', True),                 # double knots on the swept axis
+             ((mk(4, 0., 1., 3), rep(4, 6, 3, at=(1, 3)), mk(4, 0., 1., 40)), 'cylinder', True),     # triple knots, four tiles
+             ((rep(2, 5, 2), rep(2, 6, 2, at=(0, 4)), mk(2, 0., 1., 8)), 'twisted_box', True),       # repeated knots on axes 0 and 1
+             ((mk(3, 0., 1., 4), mk(3, 0., 1., 5), rep(3, 6, 2)), 'cylinder', False),                # repeated knots on the LAST axis: stage kernels
+             ((mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 6)), 'cylinder', False)]            # two degrees below nqp: stage kernels
+    for kvs, gname, fused3 in cases:
+        for kind in ('stiffness', 'mass'):
+            patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
+            A = patch.csr(kind, algo='sumfact')
+            path = patch.last_path()
+            E = patch.csr(kind, algo='entrywise')
+            patch.close()
+            tag = (kind, [kv.p for kv in kvs], [kv.numdofs for kv in kvs], sorted(path))
+            assert ('bf3' in path and 'both' in path) == fused3, tag
+            assert not np.isnan(A.data).any(), tag
+            assert abs(A - A.T).max() == 0.0, tag
+            assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))
+            N0 = kvs[0].numdofs
+            parts = []
+            for lo, hi in ((0, N0 // 3), (N0 // 3, N0 - 1), (N0 - 1, N0)):
+                if hi > lo:
+                    sl = iga.assemblers.DevicePatch(kvs, _geo(iga, gname), row0=(lo, hi))
+                    parts.append(sl.assemble(kind, algo='sumfact', to_host=True).copy())
+                    sl.close()
+            assert np.array_equal(np.concatenate(parts), A.data), tag
