@@ -183,7 +183,7 @@ struct BF3Store {
                 const int l = line_of(sw, c, j);
                 double *src = (c == NSUB - 1 ? bc : bs + c * 64) + r.line_off(min(l, W1 - 1));
                 v[c * JMAX + j] = *src;
-                if (NH == 2) {
+                if (NH >= 2) {
                     double *cl = (rrv[c] != inv && l < W1) ? src : dump;      // (edge rows belong to bf3_edge_rows)
                     *cl = 0.0;
                 }
@@ -275,11 +275,11 @@ struct BF3StoreDense {
             const int lo = __builtin_amdgcn_ds_bpermute(pkk & 60, lv) + ((pkk >> 6) & 0xfff);
             double *src = pkk < 0 ? dump : sets + lo;        // (lanes without an element: a harmless address)
             svD[k] = *src;
-            if (NH == 2) *src = 0.0;
+            if (NH >= 2) *src = 0.0;
             if (NSET == 2) {
                 double *srcT = pkk < 0 ? dump : sets + Gm::SETSZ + lo;
                 svT[k] = *srcT;
-                if (NH == 2) *srcT = 0.0;
+                if (NH >= 2) *srcT = 0.0;
             }
         }
     }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
                 const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
                 double *src = lb + e.x;
                 const double v = *src;
-                if (NH == 2 && ok) *src = 0.0;
+                if (NH >= 2 && ok) *src = 0.0;
                 const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
                 bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
             }
@@ -357,7 +357,9 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
 // DOFS: step d sweeps the next span when its first active dof is d, then flushes the lines of dof d.  Those of the roles 1..
 // carry the store duty (STW).
 struct BF3SweepCtx { const BF3Blk *B; double *sets, *dump; int sw; };
-template <int P1, int Q, int MASK, int RI, int NA, int NLG, class StoreT, bool STW, bool MULT>
+// D: K1 rows in flight per input array (a ring: row l of a span is consumed and its register reloaded with row l + D, which lies
+// in the next span for l >= Q - D): D = Q is "one span ahead"; at P = 6 half a span (D = 3) is what 128 registers allow.
+template <int P1, int Q, int D, int MASK, int RI, int NA, int NLG, class StoreT, bool STW, bool MULT>
 __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const int g2l, const int g2, const int s_begin, const int t_sw, const int d_begin,
                                             const int rhi, double *lines, const int LS, const BF3SweepCtx &sc)
 {
@@ -395,11 +397,12 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
         return bf2_buffer_load(rsrc[t1][i], voff, row * urs[t1][i]);
 #endif
     };
-    double kv[Q][4][NA];
+    static_assert(Q % D == 0, "k_bf3: the prefetch ring must divide the span");
+    double kv[D][4][NA];
     {
         const int s = min(s_begin, max(t_sw - 1, 0));
 #pragma unroll
-        for (int l = 0; l < Q; ++l)
+        for (int l = 0; l < D; ++l)
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1)
                 if (R.has[t1])
@@ -436,10 +439,11 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
 #pragma unroll
             for (int t1 = 0; t1 < 4; ++t1)
                 if (R.has[t1]) {
-                    kt[t1] = kv[l][t1][0];
-                    if constexpr (NA == 2) kt[t1] += kv[l][t1][1];
+                    kt[t1] = kv[l % D][t1][0];
+                    if constexpr (NA == 2) kt[t1] += kv[l % D][t1][1];
+                    // the register is free: row l + D of this span, or row l + D - Q of the next one
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, tn * Q + l);
+                    for (int i = 0; i < NA; ++i) kv[l % D][t1][i] = ld(t1, i, l + D < Q ? s * Q + l + D : tn * Q + l + D - Q);
                 }
             if (R.shape == 1) {
 #pragma unroll
@@ -515,19 +519,19 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
     BF_STAMP_END(threadIdx.x >> 6);
 }
 
-template <int P1, int Q, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI, bool END = (RI >= bf_nroles(MASK))>
+template <int P1, int Q, int D, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI, bool END = (RI >= bf_nroles(MASK))>
 struct BF3SweepDispatch {
     __device__ static __forceinline__ void run(const BFArgs &A, int role, int r0, int g2l, int g2, int s_begin, int t_sw, int d_begin, int rhi, double *lines, int LS, const BF3SweepCtx &sc)
     {
         // role 0 carries no stores; the last role the larger share
         if (role == RI) {
-            if constexpr (RI == bf_nroles(MASK) - 1) bf3_sweeper<P1, Q, MASK, RI, NA, NLG, StoreB, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
-            else bf3_sweeper<P1, Q, MASK, RI, NA, NLG, StoreA, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
-        } else BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI + 1>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+            if constexpr (RI == bf_nroles(MASK) - 1) bf3_sweeper<P1, Q, D, MASK, RI, NA, NLG, StoreB, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+            else bf3_sweeper<P1, Q, D, MASK, RI, NA, NLG, StoreA, STW, MULT>(A, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+        } else BF3SweepDispatch<P1, Q, D, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI + 1>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
     }
 };
-template <int P1, int Q, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI>
-struct BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI, true> {
+template <int P1, int Q, int D, int MASK, int NA, int NLG, class StoreA, class StoreB, bool STW, bool MULT, int RI>
+struct BF3SweepDispatch<P1, Q, D, MASK, NA, NLG, StoreA, StoreB, STW, MULT, RI, true> {
     __device__ static __forceinline__ void run(const BFArgs &, int, int, int, int, int, int, int, int, double *, int, const BF3SweepCtx &) {}
 };
 
@@ -736,7 +740,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
         const int gpt = win0 + idx / (2 * P2);
         V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P2 * 2 + idx] : 0.0;
     }
-    if (NH == 2)
+    if (NH >= 2)
         for (int idx = threadIdx.x; idx < Gm::OFF_V2 - Gm::OFF_SETS; idx += blockDim.x) sets[idx] = 0.0;     // the halves of a pass add onto zeros
     // edge rows of the tile: i2 < p2 or i2 > N2 - 1 - p2
     const int lo_n = max(0, min(row_hi, min(p2, A.N2)) - row_lo);          // low edge rows start at row_lo (tile 0 only)
@@ -789,7 +793,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
         const BF3SweepCtx sc{&B, sets, dump, role == NR - 1 ? lg : (role - 1) * NLG + lg};
-        BF3SweepDispatch<P1, Q, MASK, NA, NLG, StoreA, StoreB, STW, MULT, 0>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+        BF3SweepDispatch<P1, Q, (NH == 3 ? Q / 2 : Q), MASK, NA, NLG, StoreA, StoreB, STW, MULT, 0>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
         return;
     }
 
@@ -817,7 +821,14 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
             U.rbs5 = Gm::roff(5) + (int)((unsigned)(dd + 5) % 6u) * RW;
             const int npass = (npieces + PPP - 1) / PPP;
             const int wslot = (int)((unsigned)(cw + t) % (unsigned)NCW);
-            if (NH == 1 || npass <= NCW) {
+            if constexpr (NH == 3) {
+                // every pass as two half-units (rows 0 .. AH-1 / AH .. p2 of the element matrices): a whole unit at P2 = 6 does not
+                // fit the 128 registers that sixteen waves per CU leave a wave
+                for (int u = wslot; u < 2 * npass; u += NCW) {
+                    if (u < npass) bf3_unit<Gm, NY, MASK, SYM, 2>(U, u);
+                    else bf3_unit<Gm, NY, MASK, SYM, 1>(U, u - npass);
+                }
+            } else if (NH == 1 || npass <= NCW) {
                 for (int pass = wslot; pass < npass; pass += NCW) bf3_unit<Gm, NY, MASK, SYM, 0>(U, pass);
             } else {
                 bf3_unit<Gm, NY, MASK, SYM, 0>(U, wslot);
@@ -911,16 +922,23 @@ constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0
 #endif
 template <int PM, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
 template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 8 : 4, NH = 1; };
+#ifndef BF3_P6
+#define BF3_P6 0                                         // 1: degree 5 with three lane groups, half-units only, half a span of prefetch (measured at C5: 13.4 against 13.8 ms -- not enough to give up the bit-identity with k_bf2 + mirror at p = 5; kept as an option)
+#endif
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> {
-    static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : 1;
+    static constexpr int NLG = PM == 5 || (PM == 6 && BF3_P6) ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : (PM == 6 && BF3_P6) ? 3 : 1;
 };
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = PM <= 5 ? 8 : 4, NH = 1; };
 
 template <int P1, int P2, int Q, int NY, int MASK>
-static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult)
+static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult_in)
 {
+    bool mult = mult_in;
     constexpr int PM = Q > (P1 > P2 ? P1 : P2) ? Q : (P1 > P2 ? P1 : P2);   // (the registers of a sweeper follow P1 and Q)
     using C = BF3Cfg<PM, MASK>;
+    // (degree 5 at sixteen waves per CU: the general loop -- a span swept under a branch -- happens to be the one hipcc fits into
+    // 128 registers without spills, so it also serves single knots there)
+    if (PM == 6 && BF3_P6 && P1 == 6) mult = true;
     if constexpr (P1 == P2 && P1 == Q) {                   // equal degrees: every form, 2D, repeated knots on the swept axis
         if (symk == 2) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu)
                                    : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
@@ -930,6 +948,8 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool
                                        : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0, false>(st, A, ncu);
     } else {
         if (symk == 2 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
+        if constexpr (P1 == 6)
+            if (symk == 2 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu);
     }
     set_error("fused stage: no kernel for this form at these degrees");
     return IGX_ERR_UNSUPPORTED;
