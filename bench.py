@@ -572,14 +572,14 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
     host_call_ms = 1e3 * (time.perf_counter() - t0)
     # the same function traced into C and evaluated at the Gauss points by a run-time compiled kernel (what
     # assemble.inner_products does with a plain callable): second call = code object from the cache
-    compiled_call_ms = None
+    compiled_call_ms = compiled_dev_ms = None
     src = symbolic.trace_function(f, dim)
     if src is not None:
         for _ in range(2):
             t0 = time.perf_counter()
-            patch.eval_function_expr(src, parametric=True)
-            patch.load_vector_resident(to_host=True)
+            patch.load_vector_expr(src, parametric=True)
             compiled_call_ms = 1e3 * (time.perf_counter() - t0)
+        compiled_dev_ms = patch.timing()['total_ms']
     patch.upload_function(fvals)                      # resident from here on
     for _ in range(args.warmup):
         patch.load_vector_resident()
@@ -612,7 +612,7 @@ def bench_rhs(args, patch, kvs, dim, p, n0, n, nel_total, world, rank, dist, bar
                       'note': 'value = device time of the contractions, function values resident (igx_load_vector_d); whole resident call '
                               '%.2f ms wall; a host-pointer call incl. the upload of the function values %.1f ms%s' % (
                                   wall_ms, host_call_ms, '' if compiled_call_ms is None else
-                                  '; the whole call with the function compiled for the device (traced callable, igx_patch_eval_expr_d), result on the host: %.1f ms' % compiled_call_ms)},
+                                  '; the whole call with the function compiled for the device (traced callable, igx_load_vector_expr: the function is evaluated inside a generated variant of the fused contraction kernel, no array of function values), result on the host: %.1f ms, of which on the device %.2f ms' % (compiled_call_ms, compiled_dev_ms))},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': measured_traffic(args.config, world, 'rhs'), 'kernel': kernel_names, 'algorithmic_bytes_per_element': b_el}}
     flush_c_stdio()

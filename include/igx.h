@@ -198,14 +198,22 @@ int igx_patch_set_form(igx_patch *patch, const double *const coef[16]);
 int igx_patch_set_form_d(igx_patch *patch, const double *const d_coef[16]);
 
 /* The same table given as C expressions in the physical coordinates x, y, z (and pi; the grammar of
-   igx_patch_set_coeff_expr): expr[4*r + s] or NULL.  ONE kernel that evaluates every present coefficient at the resident
-   Gauss points is generated, compiled for the device with hiprtc and cached on disk under the hash of its source -- the
-   reference compiles a module per form and caches it the same way (pyiga/compile.py:58-73,120-132,
-   pyiga/codegen/cython.py:325-387); nothing is sampled on the host.  Needs a spline geometry.  *cache_hit (may be NULL):
-   1 if the code object came from the cache. */
+   igx_patch_set_coeff_expr): expr[4*r + s] or NULL.  The FIELD kernel of the form is generated with the expressions inside
+   -- geometry map, Jacobian, coefficients and the transformation to the parametric jet coefficients in one pass over the
+   resident Gauss points; the coefficients never exist as arrays -- compiled for the device with hiprtc and cached on disk
+   under the hash of its source.  The reference generates the field loop of a form with its inputs fused in and caches the
+   compiled module the same way (pyiga/codegen/cython.py:673-701 generate_precomp, :325-387; pyiga/compile.py:58-73,
+   120-132); nothing is sampled on the host.  Needs a spline geometry.  (A geometry whose control lines exceed the LDS of a
+   block takes a generated kernel that evaluates the coefficients into arrays first.)  The call compiles; the kernel runs
+   with the next operation that needs the fields.  *cache_hit (may be NULL): 1 if the code object came from the cache. */
 int igx_patch_set_form_expr(igx_patch *patch, const char *const expr[16], int *cache_hit);
-/* Host only: compile the kernel of the n expressions for `arch` into the cache (what igx_patch_set_form_expr does first). */
+/* 1 if the patch's IGX_FORM is served by a generated field kernel (no coefficient arrays on the device), else 0. */
+int igx_patch_form_generated(const igx_patch *patch);
+/* Host only: compile the kernel that evaluates the n expressions into arrays for `arch` into the cache. */
 int igx_rtc_compile_form(int n, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+/* Host only: compile the field kernel of the form expr[16] for a dim-dimensional geometry with ncomp components
+   (ncomp = dim + 1: NURBS) for `arch` into the cache (what igx_patch_set_form_expr does). */
+int igx_rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], const char *arch, char *path_out, int path_len, int *cache_hit);
 
 /* Parametric jet form for IGX_FORM -- forms with second derivatives (hess, Dx(.., times=2)) and parametric derivatives
    (parametric=True) of the reference (pyiga/vform.py:592-625 physical Hessians from parametric ones, :1518-1586 Dx / grad /
@@ -301,6 +309,15 @@ int igx_load_vector_jet(igx_patch *patch, const double *const coef[4], double *o
 /* The same functional with its coefficients given as C expressions in the physical coordinates x, y, z (expr[r] or NULL; the
    grammar and the run-time compilation of igx_patch_set_form_expr): nothing is sampled on the host. */
 int igx_load_vector_jet_expr(igx_patch *patch, const char *const expr[4], double *out, int *cache_hit);
+/* Load vector of a scalar function given as ONE C expression in x, y, z -- the physical coordinates, or with parametric != 0
+   the parametric ones (pyiga/assemble.py:288-340, inner_products with f_physical = True / False).  3D patches that the fused
+   contraction kernel serves (equal degrees 1..5 on the last two axes, at most 640 Gauss points per line): a generated variant
+   of that kernel evaluates the function at the points of its grid line -- the function values never exist as an array; the
+   weight field of the patch is computed once and kept.  Anything else: IGX_ERR_UNSUPPORTED (igx_patch_eval_expr_d +
+   igx_load_vector_d serve it with one full-grid array).  A function of the physical coordinates needs a spline geometry. */
+int igx_load_vector_expr(igx_patch *patch, const char *expr, int parametric, double *out, int *cache_hit);
+/* Host only: compile that kernel (P = degree + 1 of the last two axes, npass = max(2, ceil(dofs of the last axis / 64)) <= 4). */
+int igx_rtc_compile_load_vector(int P, int npass, int parametric, const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
 
 /* Precomputed fields (W or upper triangle of B) of the owned Gauss slab: out has shape
    (F, G0_local, G1[, G2]) (structure-of-arrays).  For tests of precompute_fields. */

@@ -73,6 +73,10 @@ SYMBOLS = [
     ('igx_patch_eval_expr_d', C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     ('igx_patch_set_form_expr', C.c_int, [C.c_void_p, C.c_char_p * 16, C.POINTER(C.c_int)]),
     ('igx_rtc_compile_form', C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    ('igx_patch_form_generated', C.c_int, [C.c_void_p]),
+    ('igx_load_vector_expr', C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    ('igx_rtc_compile_load_vector', C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    ('igx_rtc_compile_form_fields', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     ('igx_patch_set_pform', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp)]),
     ('igx_patch_set_basis_orders', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ('igx_patch_gauss', C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),

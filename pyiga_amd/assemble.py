@@ -344,14 +344,14 @@ def inner_products(kvs, f, f_physical=False, geo=None):
     g = geo if geo is not None else geometry.unit_cube(dim)     # parameter domain: |det J| = 1
     patch = assemblers.DevicePatch(kvs, g)
     # a plain scalar callable is traced into a C expression and evaluated at the Gauss points on the device
-    # (pyiga_amd.symbolic, igx_patch_eval_expr_d): no sampling on the host, no upload; anything else as in the reference
+    # together with geometry and weight by ONE generated kernel (pyiga_amd.symbolic, igx_load_vector_expr): no sampling on the
+    # host, no upload, the products W f are the only full-grid array; anything else as in the reference
     from . import symbolic
     src = symbolic.trace_function(f, dim) if (not f_physical or isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc))) else None
     out = None
     if src is not None:
         try:
-            patch.eval_function_expr(src, parametric=not f_physical)
-            out = patch.load_vector_resident(to_host=True)
+            out = patch.load_vector_expr(src, parametric=not f_physical)
         except _lib.IgxError:                                    # (no run-time compiler on this box: sampled on the host)
             out = None
     if out is None:

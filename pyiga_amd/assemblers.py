@@ -173,6 +173,22 @@ class DevicePatch:
         _lib.check(_lib.load().igx_patch_eval_expr_d(self.handle, c_expr.encode(), 1 if parametric else 0, ptr, C.byref(hit)), 'igx_patch_eval_expr_d')
         return bool(hit.value)
 
+    def load_vector_expr(self, c_expr, parametric=False):
+        """Load vector of a scalar function given as a C expression in x, y, z (physical coordinates, or the parametric ones).  3D
+        patches the fused contraction kernel serves: a generated variant of it evaluates the function at the points of its grid
+        line (igx_load_vector_expr) -- the function values never exist as an array; anything else: the function values by a
+        generated kernel, then the contractions (igx_patch_eval_expr_d + igx_load_vector_d)."""
+        lo, hi = int(self.info.row_lo), int(self.info.row_hi)
+        nd = self.ndofs
+        out = np.empty(((hi - lo) // int(np.prod(nd[1:])),) + nd[1:])
+        hit = C.c_int(0)
+        rc = _lib.load().igx_load_vector_expr(self.handle, c_expr.encode(), 1 if parametric else 0, _lib.dptr(out), C.byref(hit))
+        if rc == _lib.IGX_ERR_UNSUPPORTED:
+            self.eval_function_expr(c_expr, parametric=parametric)
+            return self.load_vector_resident(to_host=True)
+        _lib.check(rc, 'igx_load_vector_expr')
+        return out
+
     def load_vector_resident(self, to_host=False):
         """Load vector from the function values uploaded with upload_function(); the result stays on the device unless asked for."""
         assert getattr(self, '_d_f', None), 'upload_function() first'
@@ -367,10 +383,14 @@ class DevicePatch:
             raise ValueError('the form has no non-zero coefficient')
         _lib.check(_lib.load().igx_patch_set_form(self.handle, ptrs), 'igx_patch_set_form')
 
+    def form_generated(self):
+        """True if the form set last is served by a generated field kernel: no coefficient arrays exist on the device."""
+        return bool(_lib.load().igx_patch_form_generated(self.handle))
+
     def set_form_expr(self, table):
-        """Coefficient table of IGX_FORM as C expressions in x, y, z (4x4 nested list of strings or None): ONE kernel generated,
-        compiled for the device at run time and cached on disk evaluates them at the Gauss points (igx_patch_set_form_expr).
-        Returns True if the code object came from the cache."""
+        """Coefficient table of IGX_FORM as C expressions in x, y, z (4x4 nested list of strings or None): the FIELD kernel of the
+        form is generated with the expressions inside (geometry, coefficients, jet transformation in one pass), compiled for the
+        device at run time and cached on disk (igx_patch_set_form_expr).  Returns True if the code object came from the cache."""
         exprs = (C.c_char_p * 16)()
         for r in range(4):
             for s in range(4):
@@ -848,8 +868,7 @@ class _FunctionalAssembler:
         if self._vector is None:
             if self._fexpr is not None:
                 try:
-                    self.patch.eval_function_expr(self._fexpr, parametric=not self._physical)
-                    self._vector = self.patch.load_vector_resident(to_host=True)
+                    self._vector = self.patch.load_vector_expr(self._fexpr, parametric=not self._physical)
                 except _lib.IgxError:                            # (no run-time compiler on this box: sampled on the host)
                     self._fexpr = None
                     self._fvals = utils.grid_eval_transformed(self._f, self.gaussgrid, self._geo) if self._physical else utils.grid_eval(self._f, self.gaussgrid)

@@ -46,15 +46,22 @@ template <int P1, int P2, int Q, int NLG, int NRO, int NCW, int SYM> struct BF3G
     static constexpr int P1_ = P1, P2_ = P2, Q_ = Q;
     static constexpr int p1 = P1 - 1, p2 = P2 - 1, W1 = 2 * P1 - 1, W2 = 2 * P2 - 1, TL = 64 * NLG;
     static constexpr int NSET = SYM == 2 ? 2 : 1;
-    static constexpr int LS = NRO * TL + 2;                 // doubles per line (all roles), padded against bank conflicts
+    // bank conflicts of the contractors' reads (lane = span): a line's points lie QS doubles apart per span -- an odd number, so
+    // that the 32 lanes of a ds_read_b64 group hit 32 different bank pairs (Q even: 2-way at 6, 4-way at 4) -- and the basis
+    // values VS doubles apart per span, VS / 2 odd, so that the 16 lanes of a ds_read_b128 group hit 16 different slots
+    // (Q P2 2 = 72 at degree 5: 4-way)
+    static constexpr int QS = Q + (Q % 2 == 0 ? 1 : 0), NSP = (TL + Q - 1) / Q;
+    static constexpr int TLP = TL + NSP * (QS - Q);         // doubles of one role's part of a line
+    static constexpr int VS = Q * P2 * 2 + ((Q * P2 * 2) % 4 == 2 ? 0 : 2), NV2 = NSP * VS;
+    static constexpr int LS = NRO * TLP + 2;                // doubles per line (all roles), padded against bank conflicts
     static constexpr int NRING = p1 * (p1 + 1) / 2 + p1;    // row-lines of the ring part: line delta = 1..p1 has delta + 1 slots
     static constexpr int NRL = NRING + P1;                  // ... + the P1 lines that complete with the row itself
     static constexpr int T0 = p2 * (p2 + 1) / 2;            // rp2[i2] = W2 i2 - T0 on interior rows of the last axis
     static constexpr int NEL = 2 * p2 * W2;                 // edge-row table: (row, entry) elements of the <= 2 p2 edge rows
-    // LDS image (doubles): lines [W1][LS] | sets [NSET][NRL][R][W2] | basis values [TL][P2][2] | edge table (int4) [NEL]
+    // LDS image (doubles): lines [W1][LS] | sets [NSET][NRL][R][W2] | basis values [NSP][VS] | edge table (int4) [NEL]
     static constexpr int off_sets() { return (W1 * LS + 1) & ~1; }
     static constexpr int off_v2(int R) { return (off_sets() + NSET * NRL * R * W2 + 1) & ~1; }
-    static constexpr int off_etab(int R) { return off_v2(R) + TL * P2 * 2; }
+    static constexpr int off_etab(int R) { return off_v2(R) + NV2; }
     static constexpr int lds_doubles(int R) { return off_etab(R) + NEL * 2; }
     static constexpr int rmax()
     {
@@ -275,11 +282,15 @@ struct BF3StoreDense {
             const int lo = __builtin_amdgcn_ds_bpermute(pkk & 60, lv) + ((pkk >> 6) & 0xfff);
             double *src = pkk < 0 ? dump : sets + lo;        // (lanes without an element: a harmless address)
             svD[k] = *src;
+#ifndef BF3_NOCLEAR
             if (NH >= 2) *src = 0.0;
+#endif
             if (NSET == 2) {
                 double *srcT = pkk < 0 ? dump : sets + Gm::SETSZ + lo;
                 svT[k] = *srcT;
+#ifndef BF3_NOCLEAR
                 if (NH >= 2) *srcT = 0.0;
+#endif
             }
         }
     }
@@ -356,7 +367,7 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
 // sweepers: the mid-axis sweep of k_bf2 (fused.hip) with separate degree (P1) and Gauss points per span (Q), driven by LEAVING
 // DOFS: step d sweeps the next span when its first active dof is d, then flushes the lines of dof d.  Those of the roles 1..
 // carry the store duty (STW).
-struct BF3SweepCtx { const BF3Blk *B; double *sets, *dump; int sw; };
+struct BF3SweepCtx { const BF3Blk *B; double *sets, *dump; int sw, tlp; };
 // D: K1 rows in flight per input array (a ring: row l of a span is consumed and its register reloaded with row l + D, which lies
 // in the next span for l >= Q - D): D = Q is "one span ahead"; at P = 6 half a span (D = 3) is what 128 registers allow.
 template <int P1, int Q, int D, int MASK, int RI, int NA, int NLG, class StoreT, bool STW, bool MULT>
@@ -364,7 +375,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
                                             const int rhi, double *lines, const int LS, const BF3SweepCtx &sc)
 {
     constexpr BFRole R = bf_role(MASK, RI);
-    constexpr int p1 = P1 - 1, TL = 64 * NLG;
+    constexpr int p1 = P1 - 1;
     constexpr bool ST = STW && RI >= 1;
     const int slane = threadIdx.x & 63;
     StoreT store;
@@ -410,7 +421,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
                     for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * Q + l);
     }
     auto flush = [&]() {
-        double *ln = lines + RI * TL + g2l;
+        double *ln = lines + RI * sc.tlp + g2l;             // (g2l: the point's place in the padded line)
 #pragma unroll
         for (int a = 0; a < P1; ++a) ln[a * LS] = acc[a][0];
 #pragma unroll
@@ -564,7 +575,7 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     const int row1 = colt ? dd + la : dd, col1 = colt ? dd : dd + la;
     // EVERY lane forms its element matrix (a span outside the axis has zero basis values in V2s; a lane without a valid item
     // computes something that is never stored); the LDS addresses are kept inside the image
-    const double *kl = U.lines + min(k9, W1 - 1) * LS + min(s1, TL / Q - 1) * Q, *vl = U.V2s + min(s1, TL / Q - 1) * Q * P2 * 2;
+    const double *kl = U.lines + min(k9, W1 - 1) * LS + min(s1, TL / Q - 1) * Gm::QS, *vl = U.V2s + min(s1, TL / Q - 1) * Gm::VS;
     double loc[A1 - A0][P2];
 #ifdef BF3_NOELEM
     {                                                      // (timing experiment: no element matrices)
@@ -575,7 +586,7 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
             for (int b = 0; b < P2; ++b) { loc[a][b] = k0 + v0 * (a + 3 * b); asm volatile("" : "+v"(loc[a][b])); }
     }
 #else
-    bf_element<P2, NY, MASK, A0, A1, Q>(loc, kl, vl, TL);
+    bf_element<P2, NY, MASK, A0, A1, Q>(loc, kl, vl, Gm::TLP);
 #endif
     const int r3 = s1 - p2;                                // row of the tile (this lane's span is the first of its support)
     // (the pair exists when the later dof lies in the column range of the earlier one: la < nhi -- single knots: dd + la < N1)
@@ -738,7 +749,8 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
 
     for (int idx = threadIdx.x; idx < TL * P2 * 2; idx += blockDim.x) {
         const int gpt = win0 + idx / (2 * P2);
-        V2s[idx] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P2 * 2 + idx] : 0.0;
+        const int pt = idx / (2 * P2), sp = pt / Q;
+        V2s[sp * Gm::VS + (idx - sp * (Q * P2 * 2))] = (gpt >= 0 && gpt < A.G2) ? A.V2[(long long)win0 * P2 * 2 + idx] : 0.0;
     }
     if (NH >= 2)
         for (int idx = threadIdx.x; idx < Gm::OFF_V2 - Gm::OFF_SETS; idx += blockDim.x) sets[idx] = 0.0;     // the halves of a pass add onto zeros
@@ -787,13 +799,13 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
     using StoreB = BF3StoreDense<Gm, NH, SYM, Split::KB, Split::QB, NQ, Split::NB>;                                       // last role
     using StoreC = BF3Store<Gm, NCW, 1, NH, SYM>;                                                                          // contractors (one-role forms)
-    double *dump = lines + NR * TL;                       // (the padding of line 0: target of the clears that must not happen)
+    double *dump = lines + NR * Gm::TLP;                  // (the padding of line 0: target of the clears that must not happen)
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
         const int g2l = lg * 64 + lane;
         const int g2 = min(max(win0 + g2l, 0), A.G2 - 1);
-        const BF3SweepCtx sc{&B, sets, dump, role == NR - 1 ? lg : (role - 1) * NLG + lg};
-        BF3SweepDispatch<P1, Q, (NH == 3 ? Q / 2 : Q), MASK, NA, NLG, StoreA, StoreB, STW, MULT, 0>::run(A, role, r0, g2l, g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
+        const BF3SweepCtx sc{&B, sets, dump, role == NR - 1 ? lg : (role - 1) * NLG + lg, Gm::TLP};
+        BF3SweepDispatch<P1, Q, (NH == 3 ? Q / 2 : Q), MASK, NA, NLG, StoreA, StoreB, STW, MULT, 0>::run(A, role, r0, g2l + (g2l / Q) * (Gm::QS - Q), g2, s_begin, t_sw, d_begin, rhi, lines, LS, sc);
         return;
     }
 

@@ -168,7 +168,7 @@ static int ensure_fields(igx_patch *pt, int kind)
     if (pt->fields_kind == kind) return IGX_OK;
     const int nF = igx_num_fields(pt->dim, kind, pt->dev.form_n);
     if (kind == IGX_FORM) {
-        if (!pt->d_formc || pt->dev.form_n == 0) { set_error("IGX_FORM needs igx_patch_set_form first"); return IGX_ERR_ARG; }
+        if ((!pt->d_formc && !pt->form_fn) || pt->dev.form_n == 0) { set_error("IGX_FORM needs igx_patch_set_form first"); return IGX_ERR_ARG; }
     }
     if (kind == IGX_CONVDIFF) {
         if (pt->dim != 3) { set_error("IGX_CONVDIFF is a 3D form"); return IGX_ERR_UNSUPPORTED; }
@@ -184,7 +184,9 @@ static int ensure_fields(igx_patch *pt, int kind)
         pt->fields_cap = need;
     }
     pt->fields_kind = -1;
-    int rc = launch_geo_fields(pt->ctx->stream, pt, kind, pt->d_fields);
+    // (a form given as expressions has its own generated field kernel: no coefficient arrays)
+    int rc = (kind == IGX_FORM && pt->form_fn) ? launch_form_fields(pt->ctx->stream, pt, pt->form_fn, pt->d_fields)
+                                                : launch_geo_fields(pt->ctx->stream, pt, kind, pt->d_fields);
     if (rc) return rc;
     pt->fields_kind = kind;
     return IGX_OK;
@@ -602,6 +604,7 @@ static int set_form_impl(igx_patch *pt, const double *const coef[16], bool on_de
     if (e != hipSuccess) { (void)hipFree(d_new); set_error("%s: %s", who, hipGetErrorString(e)); return IGX_ERR_HIP; }
     (void)hipFree(pt->d_formc);
     pt->d_formc = d_new;
+    pt->form_fn = nullptr;
     for (int k = 0; k < 16; ++k) { pt->form_slot[k] = slot[k]; pt->dev.form_ab[k] = k < nt ? form_ab[k] : 0; }
     pt->dev.form_n = nt;
     pt->dev.form_par = 0;
@@ -633,6 +636,7 @@ int igx_patch_set_pform(igx_patch *pt, int n, const int *masks, const double *co
     if (e != hipSuccess) { (void)hipFree(d_new); set_error("igx_patch_set_pform: %s", hipGetErrorString(e)); return IGX_ERR_HIP; }
     (void)hipFree(pt->d_formc);
     pt->d_formc = d_new;
+    pt->form_fn = nullptr;
     for (int k = 0; k < 16; ++k) { pt->form_slot[k] = k < n ? k : -1; pt->dev.form_ab[k] = k < n ? ((masks[2 * k] << 3) | masks[2 * k + 1]) : 0; }
     pt->dev.form_n = n;
     pt->dev.form_par = 1;
@@ -683,8 +687,10 @@ static int basis_orders_ok(const igx_patch *pt, int kind, const char *who)
 
 int igx_patch_set_form(igx_patch *pt, const double *const coef[16]) { return set_form_impl(pt, coef, false, "igx_patch_set_form"); }
 
-// The coefficient table of IGX_FORM as C expressions in the physical coordinates: one generated kernel evaluates all of them
-// at the resident Gauss points (rtc.hip), the arrays then take the way of igx_patch_set_form_d.
+// The coefficient table of IGX_FORM as C expressions in the physical coordinates.  Spline geometries: the expressions are
+// compiled INTO the field kernel of the form (rtc.hip, igx_form_fields) -- nothing is evaluated or stored here, the
+// coefficients never exist as arrays.  Otherwise (control lines beyond LDS): one generated kernel evaluates them at the
+// resident Gauss points and the arrays take the way of igx_patch_set_form_d.
 int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cache_hit)
 {
     if (!pt || !expr) { set_error("igx_patch_set_form_expr: null argument"); return IGX_ERR_ARG; }
@@ -694,7 +700,26 @@ int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cach
     for (int k = 0; k < 16; ++k)
         if (expr[k]) list[n++] = expr[k];
     if (n == 0) { set_error("igx_patch_set_form_expr: all coefficients are absent"); return IGX_ERR_ARG; }
+    const int nj = pt->dim + 1;
+    for (int r = 0; r < 4; ++r)
+        for (int s = 0; s < 4; ++s)
+            if (expr[4 * r + s] && (r >= nj || s >= nj)) { set_error("igx_patch_set_form_expr: coefficient (%d,%d) does not exist in %dD", r, s, pt->dim); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
+    if (form_fields_applicable(pt)) {
+        int form_ab[16];
+        const int nt = form_terms(pt->dim, expr, form_ab);
+        void *fn = nullptr;
+        if (int rc = rtc_form_fields_function(pt, expr, nt, form_ab, &fn, cache_hit)) return rc;
+        (void)hipFree(pt->d_formc);
+        pt->d_formc = nullptr;
+        pt->form_fn = fn;
+        int j = 0;
+        for (int k = 0; k < 16; ++k) { pt->form_slot[k] = expr[k] ? j++ : -1; pt->dev.form_ab[k] = k < nt ? form_ab[k] : 0; }
+        pt->dev.form_n = nt;
+        pt->dev.form_par = 0;
+        pt->fields_kind = -1;
+        return IGX_OK;
+    }
     const size_t npts = (size_t)pt->dev.npts_loc;
     double *buf = nullptr;
     if (hipMalloc((void **)&buf, std::max<size_t>(1, (size_t)n * npts) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %.2f GB for the form coefficients failed", n * npts * 8.0 / 1e9); return IGX_ERR_NOMEM; }
@@ -712,6 +737,13 @@ int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cach
 int igx_rtc_compile_form(int n, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit)
 {
     return rtc_compile_form(n, expr, arch, path_out, path_len, cache_hit);
+}
+
+int igx_patch_form_generated(const igx_patch *pt) { return pt && pt->form_fn ? 1 : 0; }
+
+int igx_rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], const char *arch, char *path_out, int path_len, int *cache_hit)
+{
+    return rtc_compile_form_fields(dim, ncomp, expr, arch, path_out, path_len, cache_hit);
 }
 
 int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16]) { return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d"); }
@@ -1168,6 +1200,35 @@ int igx_load_vector_jet_expr(igx_patch *pt, const char *const expr[4], double *o
     int rc = igx_patch_set_form_expr(pt, table, cache_hit);
     if (rc) return rc;
     return load_vector_jet_run(pt, out);
+}
+
+int igx_load_vector_expr(igx_patch *pt, const char *expr, int parametric, double *out, int *cache_hit)
+{
+    if (!pt || !expr || !out) { set_error("igx_load_vector_expr: null argument"); return IGX_ERR_ARG; }
+    if (pt->boxed) { set_error("igx_load_vector_expr: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
+    if (int rcb = basis_orders_ok(pt, IGX_MASS, "igx_load_vector_expr")) return rcb;
+    IGX_HIP(hipSetDevice(pt->ctx->device));
+    hipStream_t st = pt->ctx->stream;
+    int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab (kept between calls)
+    if (rc) return rc;
+    size_t n_out;
+    if ((rc = lv_workspace(pt, &n_out))) return rc;
+    (void)hipEventRecord(pt->ctx->ev[6], st);
+    if ((rc = launch_lv12_expr(st, pt, expr, parametric, pt->d_fields, pt->d_lv_t2, cache_hit))) return rc;
+    if ((rc = launch_lv_axis0(st, pt, pt->d_lv_t2, pt->d_lv_o, 0, 0))) return rc;
+    (void)hipEventRecord(pt->ctx->ev[7], st);
+    IGX_HIP(hipMemcpyAsync(out, pt->d_lv_o, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    IGX_HIP(hipStreamSynchronize(st));
+    memset(&pt->timing, 0, sizeof(pt->timing));
+    (void)hipEventElapsedTime(&pt->timing.total_ms, pt->ctx->ev[6], pt->ctx->ev[7]);
+    pt->timing.algo_used = 3;
+    pt->timing.n_launches = 2;
+    return IGX_OK;
+}
+
+int igx_rtc_compile_load_vector(int P, int npass, int parametric, const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit)
+{
+    return rtc_compile_lv12(P, npass, parametric, expr, arch, path_out, path_len, cache_hit);
 }
 
 } // extern "C"

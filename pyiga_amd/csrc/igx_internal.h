@@ -149,6 +149,7 @@ struct igx_patch {
     double *d_jac = nullptr;                  // IGX_GEO_JACOBIAN: resident slab of the user array
     double *d_formc = nullptr;                // IGX_FORM: physical coefficient fields [n][npts_loc]
     int form_slot[16];                        //   4*r+s -> row of d_formc or -1
+    void *form_fn = nullptr;                  // IGX_FORM given as expressions: the generated field kernel (rtc.hip); no d_formc then
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     int coef_affine = 0;                      // ... set by igx_patch_set_coeff_affine: k_geoA evaluates it from the geometry map
     double coef_c[4] = {0, 0, 0, 0};
@@ -238,6 +239,17 @@ int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d
 int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
 int launch_form_exprs(hipStream_t st, igx_patch *pt, int n_expr, const char *const *expr, double *d_out /* [n_expr][npts_loc] */, int *cache_hit);
 int rtc_compile_form(int n_expr, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+// field kernel of a form given as expressions (geometry + coefficients + jet transformation in one generated kernel)
+int rtc_form_fields_function(igx_patch *pt, const char *const expr[16], int nterms, const int *form_ab, void **fn_out, int *cache_hit, bool parametric = false);
+int launch_form_fields(hipStream_t st, const igx_patch *pt, void *fn, double *d_fields);
+bool form_fields_applicable(const igx_patch *pt);
+// 3D load vector with the function inside the first two contractions (rtc.hip) + helpers of kern_vector.hip
+int launch_lv12_expr(hipStream_t st, igx_patch *pt, const char *expr, int parametric, const double *d_W, double *d_t2, int *cache_hit);
+int rtc_compile_lv12(int P, int npass, int parametric, const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
+bool lv12_shape(const igx_patch *pt, int *clen_out, int *nch_out, size_t *lds_out);
+int launch_lv_axis0(hipStream_t st, const igx_patch *pt, const double *d_t2, double *d_out, int deriv0, int accumulate);
+int form_terms(int dim, const char *const expr[16], int form_ab[16]);
+int rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], const char *arch, char *path_out, int path_len, int *cache_hit);
 int launch_pattern(hipStream_t st, const igx_patch *pt, int32_t *d_indptr, int32_t *d_indices);
 int launch_entries_list(hipStream_t st, const igx_patch *pt, int kind, const size_t *d_ij, size_t M, double *d_out);
 // boxes of the reordered tensor X[r0][r1][r2] (r_k = index of a 1D pair (i_k, j_k) with overlapping supports): the entries

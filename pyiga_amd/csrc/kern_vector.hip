@@ -218,6 +218,43 @@ __global__ void __launch_bounds__(LV_WAVES * 64) k_lv12(const double *__restrict
     }
 }
 
+// Can k_lv12 serve the patch, and with which chunks of the mid axis?  (also the launch shape of the generated variant with the
+// function inside: rtc.hip, igx_lv12_expr)
+bool lv12_shape(const igx_patch *pt, int *clen_out, int *nch_out, size_t *lds_out)
+{
+    const PatchDev &pd = pt->dev;
+    if (pd.dim != 3) return false;
+    const AxisDev &a1 = pd.ax[1], &a2 = pd.ax[2];
+    const long long G0 = pd.G0_loc;
+    const int PQ = a2.P * a2.q;
+    const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + LV_WAVES * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
+    if (!(a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 640 && lds12 <= 64 * 1024
+          && a1.n >= a1.P)) return false;
+    // chunks of the mid axis: enough waves for the chip, never shorter than P spans (a shared dof gets two addends)
+    int nch = (int)std::min<long long>(std::max<long long>(1, (8192 + G0 - 1) / std::max<long long>(G0, 1)), std::max(1, a1.n / std::max(a1.P, 8)));
+    int clen = (a1.n + nch - 1) / nch;
+    clen = std::max(clen, a1.P);
+    nch = (a1.n + clen - 1) / clen;
+    if (nch > 1 && a1.n - (nch - 1) * clen < a1.P) { --nch; }     // a short last chunk joins its neighbour: the kernel lets
+    // the last chunk run to the end of the axis (found by tools/fuzz_rhs.py: 65 spans at p = 5 lost their last two)
+    *clen_out = clen; *nch_out = nch; *lds_out = lds12;
+    return true;
+}
+
+// the last contraction of the 3D load vector: [G0][N1][N2] -> the owned dof planes of axis 0
+int launch_lv_axis0(hipStream_t st, const igx_patch *pt, const double *d_t2, double *d_out, int deriv0, int accumulate)
+{
+    const PatchDev &pd = pt->dev;
+    const AxisDev &a0 = pd.ax[0], &a1 = pd.ax[1], &a2 = pd.ax[2];
+    const int n0 = pd.r0_hi - pd.r0_lo;
+    const long long B = (long long)a1.N * a2.N, n = (long long)n0 * B;
+    AxisDev ax0 = a0;
+    ax0.G = (int)pd.G0_loc;
+    k_contract_axis<false><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv0, accumulate);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 // d_f: function values on the RESIDENT Gauss slab (G0_loc x G1 [x G2]); d_W: mass field on the same slab;
 // d_out: (r0_hi - r0_lo) x N1 [x N2]; tmp1/tmp2: workspaces (sizes below)
 // deriv_axis: grid axis whose basis functions are differentiated (-1: none); accumulate: add to d_out;
@@ -239,17 +276,9 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
     if (dim == 3) {
         // fused first two contractions (k_lv12): single-digit degrees, even G2 <= 640 (five 16-byte pieces per lane: a longer line
         // would spill the prefetched pieces), lines and table in LDS; anything else takes the three separate contractions below
-        const int PQ = a2.P * a2.q;
-        const size_t lds12 = ((size_t)((PQ * a2.N + 1) & ~1) + LV_WAVES * (size_t)((a2.G + 1) & ~1)) * sizeof(double);
-        if (a2.P >= 2 && a2.P <= 6 && a1.P == a2.P && PQ <= VEC_MAXSUP && a2.N <= 64 * LV_MAXPASS && a2.G % 2 == 0 && a2.G <= 640 && lds12 <= 64 * 1024
-            && a1.n >= a1.P) {
-            // chunks of the mid axis: enough waves for the chip, never shorter than P spans (a shared dof gets two addends)
-            int nch = (int)std::min<long long>(std::max<long long>(1, (8192 + G0 - 1) / std::max<long long>(G0, 1)), std::max(1, a1.n / std::max(a1.P, 8)));
-            int clen = (a1.n + nch - 1) / nch;
-            clen = std::max(clen, a1.P);
-            nch = (a1.n + clen - 1) / clen;
-            if (nch > 1 && a1.n - (nch - 1) * clen < a1.P) { --nch; }     // a short last chunk joins its neighbour: the kernel lets
-            // the last chunk run to the end of the axis (found by tools/fuzz_rhs.py: 65 spans at p = 5 lost their last two)
+        int nch, clen;
+        size_t lds12;
+        if (lv12_shape(pt, &clen, &nch, &lds12)) {
             const long long units = G0 * nch;
             IGX_HIP(hipMemsetAsync(d_t2, 0, (size_t)G0 * a1.N * a2.N * sizeof(double), st));
             const dim3 grid((unsigned)((units + LV_WAVES - 1) / LV_WAVES));
@@ -263,11 +292,7 @@ int launch_load_vector(hipStream_t st, const igx_patch *pt, const double *d_f, c
 #undef LV12
 #undef LV12K
 #undef LV12P
-            const long long B = (long long)a1.N * a2.N, n = (long long)n0 * B;
-            AxisDev ax0 = a0;
-            ax0.G = (int)G0;
-            k_contract_axis<false><<<blocks(n), bs, 0, st>>>(d_t2, nullptr, d_out, ax0, 1, B, pd.r0_lo, pd.r0_hi, pd.g0_lo, deriv_axis == 0, accumulate);
-            IGX_HIP(hipGetLastError());
+            if (int rc = launch_lv_axis0(st, pt, d_t2, d_out, deriv_axis == 0, accumulate)) return rc;
             if (n_launches) *n_launches = 2;
             return IGX_OK;
         }

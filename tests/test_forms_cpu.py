@@ -297,6 +297,64 @@ def test_form_kernel_compiles_and_is_cached(forms, tmp_path, monkeypatch):
     assert cdll.igx_rtc_compile_form(len(exprs) - 1, arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 0 and buf.value.decode() != path
 
 
+def test_field_kernel_of_a_traced_form_compiles(forms, tmp_path, monkeypatch):
+    """The field kernel with the expressions inside (geometry + coefficients + jet transformation in one pass): generated for
+    2D / 3D, B-spline / NURBS geometries, compiled by hiprtc without a GPU, cached; another geometry type is another kernel."""
+    import ctypes
+    from pyiga_amd import _lib
+    cdll = _lib.load()
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    inp = form_inputs()
+    traced = forms.symbolic_table(FORMS['full'][0], 3, {k: inp[k] for k in FORMS['full'][1]})
+    table = [e.encode() if e is not None else None for row in traced for e in row]
+    assert len(table) == 16
+    arr = (ctypes.c_char_p * 16)(*table)
+    buf = ctypes.create_string_buffer(1024)
+    hit = ctypes.c_int(-1)
+    paths = set()
+    for ncomp in (3, 4):
+        assert cdll.igx_rtc_compile_form_fields(3, ncomp, arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0, _lib.last_error()
+        assert hit.value == 0 and open(buf.value.decode(), 'rb').read(4) == b'\x7fELF'
+        paths.add(buf.value.decode())
+        assert cdll.igx_rtc_compile_form_fields(3, ncomp, arr, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 1
+    # 2D: the coefficients of the third derivative direction do not exist
+    t2 = [None] * 16
+    t2[0] = b'x * y'; t2[5] = b'1.0 + x'; t2[6] = b'0.5'; t2[9] = b'0.5'; t2[10] = b'2.0 - y'; t2[1] = b'sin(pi * x)'
+    arr2 = (ctypes.c_char_p * 16)(*t2)
+    for ncomp in (2, 3):
+        assert cdll.igx_rtc_compile_form_fields(2, ncomp, arr2, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0, _lib.last_error()
+        paths.add(buf.value.decode())
+    assert len(paths) == 4
+    # a syntax error is reported with the compiler's message, bad arguments are refused
+    t2[0] = b'x +* y'
+    assert cdll.igx_rtc_compile_form_fields(2, 2, (ctypes.c_char_p * 16)(*t2), b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+    assert 'error' in _lib.last_error()
+    assert cdll.igx_rtc_compile_form_fields(2, 5, arr2, b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+    assert cdll.igx_rtc_compile_form_fields(3, 3, (ctypes.c_char_p * 16)(*([None] * 16)), b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+
+
+def test_load_vector_kernel_with_the_function_inside_compiles(tmp_path, monkeypatch):
+    """The generated variant of the fused contraction kernel (function evaluated at the points of the grid line): every degree
+    and line length class, physical and parametric coordinates, compiled by hiprtc without a GPU."""
+    import ctypes
+    from pyiga_amd import _lib, symbolic
+    import numpy as np
+    cdll = _lib.load()
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'cache'))
+    src = symbolic.trace_function(lambda x, y, z: np.cos(x) * np.exp(y) * np.sin(z) + x * y, 3).encode()
+    buf = ctypes.create_string_buffer(1024)
+    hit = ctypes.c_int(-1)
+    paths = set()
+    for P, npass, par in ((2, 2, 1), (3, 3, 0), (5, 3, 1), (5, 4, 0), (6, 2, 1)):
+        assert cdll.igx_rtc_compile_load_vector(P, npass, par, src, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0, _lib.last_error()
+        assert hit.value == 0 and open(buf.value.decode(), 'rb').read(4) == b'\x7fELF'
+        paths.add(buf.value.decode())
+    assert len(paths) == 5
+    assert cdll.igx_rtc_compile_load_vector(5, 3, 1, src, b'gfx950', buf, 1024, ctypes.byref(hit)) == 0 and hit.value == 1
+    assert cdll.igx_rtc_compile_load_vector(7, 3, 1, src, b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+    assert cdll.igx_rtc_compile_load_vector(5, 3, 1, b'x +', b'gfx950', buf, 1024, ctypes.byref(hit)) != 0
+
+
 def test_equality_with_a_number_is_not_traced():
     """a callable that branches on ``x == 0`` must not be traced with the branch silently dropped."""
     from pyiga_amd import symbolic

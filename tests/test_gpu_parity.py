@@ -2024,6 +2024,8 @@ def test_forms_compiled_at_run_time(iga, golden, tmp_path, monkeypatch):
         kw = dict(geo=geo, **{k: inp[k] for k in names})
         asm = iga.assemble.instantiate_assembler(form, kvs, kw)
         assert asm.compiled and asm.coeff_cache_hit is False
+        # the expressions live INSIDE the generated field kernel: no coefficient arrays on the device
+        assert asm.patch.form_generated()
         A = asm.assemble_csr()
         assert rel_maxdiff(A, R) <= RTOL, (fname, rel_maxdiff(A, R))
         again = iga.assemble.instantiate_assembler(form, kvs, kw)
@@ -2031,7 +2033,7 @@ def test_forms_compiled_at_run_time(iga, golden, tmp_path, monkeypatch):
         monkeypatch.setenv('IGX_FORM_RTC', '0')
         sampled = iga.assemble.instantiate_assembler(form, kvs, kw)
         monkeypatch.delenv('IGX_FORM_RTC')
-        assert not sampled.compiled and rel_maxdiff(sampled.assemble_csr(), A) <= 1e-13
+        assert not sampled.compiled and not sampled.patch.form_generated() and rel_maxdiff(sampled.assemble_csr(), A) <= 1e-13
     assert len(os.listdir(tmp_path / 'cache')) == len(FORMS)
     # an input the tracer cannot follow: sampled on the host, same interface
     step = lambda x, y, z: np.where(x + y > 1.0, 2.0, 1.0)
@@ -2104,6 +2106,20 @@ def test_load_vector_function_compiled(iga, tmp_path, monkeypatch):
         ref = iga.assemble.inner_products(kvs, f)
         monkeypatch.delenv('IGX_FORM_RTC')
         assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    # the one-kernel path (geometry + weight + function: igx_load_vector_expr) against the two-array path (function values by a
+    # generated kernel, weight field by the library, both read back: igx_patch_eval_expr_d + igx_load_vector_d), slabs included
+    for kvs, geo, f in cases:
+        from pyiga_amd import symbolic
+        src = symbolic.trace_function(f, len(kvs))
+        N0 = kvs[0].numdofs
+        for row0 in (None, (1, N0 - 2)):
+            patch = iga.assemblers.DevicePatch(kvs, geo, row0=row0)
+            for par in (False, True):
+                one = patch.load_vector_expr(src, parametric=par)
+                patch.eval_function_expr(src, parametric=par)
+                two = patch.load_vector_resident(to_host=True)
+                assert one.shape == two.shape and np.abs(one - two).max() <= 1e-13 * np.abs(two).max(), (len(kvs), row0, par)
+            patch.close()
     kvs, geo, f = cases[0]
     cls = iga.assemblers.L2FunctionalAssemblerPhys3D
     whole = cls(kvs, geo, f)

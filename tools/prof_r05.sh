@@ -49,6 +49,7 @@ sq)
   pmc c4sq tcc "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" --config c4
   pmc c4sq sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS" --config c4
   pmc c4sq sq2 "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES" --config c4
+  pmc c4sq sq3 "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" --config c4
   python3 tools/pmc_summary.py "$OUT/pmc_c4sq" | tee "$OUT/c4_pmc_summary.txt"
   ;;
 sq5)
@@ -61,6 +62,11 @@ sq5)
 slabs)
   for W in 2 4 8; do for ((r=0; r<W; r++)); do timeout 300 python3 bench.py --emulate $r/$W --no-cpu-baseline > "$OUT/c4_slab${r}of${W}_bench.json" 2>> "$OUT/bench.log"; done; done
   python3 tools/slab_table.py "$OUT" | tee "$OUT/c4_slab_table.txt"
+  ;;
+sq3)
+  pmc c4sq sq3 "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" --config c4
+  pmc c4sq sq4 "SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD" --config c4
+  python3 tools/pmc_summary.py "$OUT/pmc_c4sq" | tee "$OUT/c4_lds_summary.txt"
   ;;
 esac
 ls "$OUT"
