@@ -206,9 +206,8 @@ struct BF2Blk {
 
 // Chunks of the mid axis.  A block walks the rows of its chunk in sequence (plus p warm-up rows and a fixed set-up), the chip
 // holds `slots` blocks at a time, and a launch takes as long as its rounds: ceil(blocks / slots) x the walk of a block.  A
-// whole C4 patch (2600 blocks of 132 rows on 256 slots) is best left alone; an eighth of it (368 blocks: 2 rounds, the second
-// less than half full) finishes sooner in 2 chunks (3 rounds of 70 rows): k_bf2 of a slab of 8 1.13 -> 1.04 ms.  The entries
-// do not depend on the split.  (The mirror pass is bandwidth-bound -- its last, partly filled round is short -- and gains
+// launch is modelled two ways and the cheaper one taken: every block in m chunks, or whole blocks for some full rounds and only
+// the rest of the blocks in chunks (below).  The entries do not depend on the split.  (The mirror pass is bandwidth-bound -- its last, partly filled round is short -- and gains
 // nothing from the same model: measured.)
 inline void bf2_choose_chunks(BFArgs &A, long long slots, int P)
 {
@@ -223,16 +222,27 @@ inline void bf2_choose_chunks(BFArgs &A, long long slots, int P)
         const long long cost = rounds * (rows + (chunks > 1 ? P - 1 : 0) + SETUP_ROWS);
         if (best < 0 || cost < best) { best = cost; A.mrows = rows; A.nmchunks = chunks; }
     }
-    // one chunk per block and several rounds: split the blocks of the last round (C4: 2600 blocks = 10 rounds of 256 and
-    // 40 blocks more -- those 40 become 240 blocks of 22 rows and the launch ends a fifth of a round after the tenth)
+    // Whole blocks for `a` full rounds, the REST of the blocks cut into k chunks of the mid axis each (they follow the whole
+    // blocks in launch order): C4, 2600 blocks on 256 CUs = 10 rounds of whole blocks and 40 blocks more -- those 40 become 240
+    // blocks of 22 rows and the launch ends a fifth of a round after the tenth; an eighth of C4 (360 blocks): one round of whole
+    // blocks + 104 blocks in halves (136 + 74 row steps) instead of every block in halves (3 rounds of 74).
     A.tail_k = 0; A.main_blocks = 0; A.tail_mrows = 0;
 #ifndef BF2_NO_TAIL_SPLIT
-    if (A.nmchunks == 1 && per_chunk > slots && per_chunk % slots != 0) {
-        const long long main = (per_chunk / slots) * slots, rest = per_chunk - main;
-        const int k = (int)std::min<long long>(std::min<long long>(slots / rest, mmax), 16);
-        if (k >= 2) {
-            A.main_blocks = (unsigned)main; A.tail_mrows = (mid_rows + k - 1) / k;
-            A.tail_k = (mid_rows + A.tail_mrows - 1) / A.tail_mrows;
+    if (per_chunk > slots) {
+        const long long full = per_chunk / slots;
+        for (long long a = full; a >= 1 && a + 2 > full; --a) {
+            const long long rest = per_chunk - a * slots;
+            if (rest == 0) continue;
+            for (int k = 2; k <= mmax; ++k) {
+                const int rows = (mid_rows + k - 1) / k, chunks = (mid_rows + rows - 1) / rows;
+                const long long rounds = (rest * chunks + slots - 1) / slots;
+                const long long cost = a * (mid_rows + SETUP_ROWS) + rounds * (rows + P - 1 + SETUP_ROWS);
+                if (cost < best) {
+                    best = cost;
+                    A.mrows = mid_rows; A.nmchunks = 1;
+                    A.main_blocks = (unsigned)(a * slots); A.tail_mrows = rows; A.tail_k = chunks;
+                }
+            }
         }
     }
 #endif

@@ -23,7 +23,7 @@ trace)
   timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --op rhs --steps 10 --warmup 2 > "$OUT/c4_rhs_bench_under_rocprof.json" 2>> "$OUT/trace.log"
   find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c4_rhs_kernel_stats.csv"; rm -rf "$OUT/trace"
   timeout 600 python3 bench.py > "$OUT/c4_bench.json" 2>> "$OUT/bench.log"
-  for c in c1 c2 c3 c5; do timeout 300 python3 bench.py --config $c > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
+  for c in c1 c2 c3 c5 c4m c4k; do timeout 300 python3 bench.py --config $c > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
   timeout 300 python3 bench.py --op rhs > "$OUT/c4_rhs_bench.json" 2>> "$OUT/bench.log"
   timeout 300 python3 bench.py --op entries > "$OUT/c4_entries_bench.json" 2>> "$OUT/bench.log"
   IGX_PATH=unfused IGX_GEOA=0 timeout 300 python3 bench.py --no-cpu-baseline --no-api-call > "$OUT/c4_bench_r01_kernels.json" 2>> "$OUT/bench.log"
