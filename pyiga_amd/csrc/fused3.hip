@@ -60,7 +60,7 @@ template <int P1, int P2, int Q, int NLG, int NRO, int NCW, int SYM> struct BF3G
     static constexpr int NEL = 2 * p2 * W2;                 // edge-row table: (row, entry) elements of the <= 2 p2 edge rows
     // LDS image (doubles): lines [W1][LS] | sets [NSET][NRL][R][W2] | basis values [NSP][VS] | edge table (int4) [NEL]
     static constexpr int off_sets() { return (W1 * LS + 1) & ~1; }
-    static constexpr int off_v2(int R) { return (off_sets() + NSET * NRL * R * W2 + 1) & ~1; }
+    static constexpr int off_v2(int R) { return (off_sets() + NSET * (NRL * R * W2 + 2) + 1) & ~1; }     // (+ 2: the pad of a set)
     static constexpr int off_etab(int R) { return off_v2(R) + NV2; }
     static constexpr int lds_doubles(int R) { return off_etab(R) + NEL * 2; }
     static constexpr int rmax()
@@ -71,7 +71,8 @@ template <int P1, int P2, int Q, int NLG, int NRO, int NCW, int SYM> struct BF3G
     }
     static constexpr int RMAX = rmax();
     static constexpr int RW = RMAX * W2;                    // doubles of one row-line block [row][entry]
-    static constexpr int SETSZ = NRL * RW;
+    static constexpr int SETSZ = NRL * RW + 2;              // + a pad behind the row-lines: where lanes without an element read and clear
+    static constexpr int OFF_PAD = NRL * RW;
     static constexpr int roff(int d) { return RW * ((d - 1) * (d + 2) / 2); }   // first slot of ring line delta = d
     static constexpr int OFF_CUR = NRING * RW;              // lines of the current row: pair (d, d + a) resp. (d + a, d) at a
     static constexpr int OFF_SETS = off_sets(), OFF_V2 = off_v2(RMAX), OFF_ETAB = off_etab(RMAX);
@@ -237,12 +238,13 @@ template <int NR, int NLG, int NQ> struct BF3DenseSplit {
     static constexpr int KA = ka(), KB = NA == 0 ? (NQ + NB - 1) / NB : (3 * KA + 1) / 2;
     static constexpr int QB = NA * KA < NQ ? NA * KA : NQ;                     // first slot of the last role's group
 };
+constexpr int BF3_FAR = 0x7f000000;       // added to the offset of what must not be stored: beyond every descriptor (<= 0.9 GB, fused3_offsets_fit)
 template <class Gm, int NH, int SYM, int K, int QLO, int QHI, int QSTR>
 struct BF3StoreDense {
     static constexpr int p1 = Gm::p1, p2 = Gm::p2, W1 = Gm::W1, W2 = Gm::W2, WW = W1 * W2, RW = Gm::RW, NSET = SYM == 2 ? 2 : 1;
     using Row = BF3Row<Gm>;
     double svD[K], svT[NSET == 2 ? K : 1];
-    int pk[K];                   // bits 0-5: 4 line | 6-17: row W2 + entry | 18-25: row | 31: no element
+    int pk[K];                   // bits 0-5: 4 line | 6-17: row W2 + entry | 18-25: row | 31: no element (then line 15, row 0, entry 0)
     int lane8;
     double *pD, *pT;
     long long nD, nT;            // bytes of the row blocks of the two outer rows (0: not stored)
@@ -260,7 +262,7 @@ struct BF3StoreDense {
             const int qi = QLO + sw + QSTR * k;
             const int q = qi * 64 + lane, rr = q / WW, rem = q - rr * WW, l = rem / W2, e = rem - l * W2, i2 = B.row_lo + rr;
             const bool ok = qi < QHI && q < Gm::RMAX * WW && rr < B.nrows && i2 >= p2 && i2 <= A.N2 - 1 - p2;
-            pk[k] = ok ? (4 * l) | ((rr * W2 + e) << 6) | (rr << 18) : (int)0x80000000;
+            pk[k] = ok ? (4 * l) | ((rr * W2 + e) << 6) | (rr << 18) : (int)(0x80000000u | 60u);     // no element: "line 15" = the pad
         }
     }
 
@@ -275,24 +277,26 @@ struct BF3StoreDense {
         if (p1 >= 3) lv = lane == p1 - 3 ? r.sub3 : lv;
         if (p1 >= 4) lv = lane == p1 - 4 ? r.sub4 : lv;
         if (p1 >= 5) lv = lane == p1 - 5 ? r.sub5 : lv;
+        lv = lane == 15 ? Gm::OFF_PAD : lv;                 // "line 15": the pad of the set -- no test, no select per slot
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             int pkk = pk[k];
             asm volatile("" : "+v"(pkk));                   // (decoded here, every step: kept decoded the fields of all slots cost 20 registers)
             const int lo = __builtin_amdgcn_ds_bpermute(pkk & 60, lv) + ((pkk >> 6) & 0xfff);
-            double *src = pkk < 0 ? dump : sets + lo;        // (lanes without an element: a harmless address)
+            double *src = sets + lo;
             svD[k] = *src;
 #ifndef BF3_NOCLEAR
             if (NH >= 2) *src = 0.0;
 #endif
             if (NSET == 2) {
-                double *srcT = pkk < 0 ? dump : sets + Gm::SETSZ + lo;
+                double *srcT = src + Gm::SETSZ;
                 svT[k] = *srcT;
 #ifndef BF3_NOCLEAR
                 if (NH >= 2) *srcT = 0.0;
 #endif
             }
         }
+        (void)dump;
     }
 
     // behind B1 of step t + 1: the rows read behind B2 of step t go out, 512 contiguous bytes per instruction.  The scalars of
@@ -313,17 +317,20 @@ struct BF3StoreDense {
         const long long shT = (long long)B.c0j * A.S2 * r.rp1d + cT * rowc + W2 * (B.ci0 * r.c1 - r.l0);
         const __amdgpu_buffer_rsrc_t dT = bf3_rs(pT + shT, r.on ? (int)max(nT - shT * 8, 0LL) : 0);
         const int dlT = 8 * W2 * (cT - W1);
+        // what must not be stored -- lines outside the column range of the row, lanes without an element ("line 15") -- gets a huge
+        // offset through the SAME per-line lookup that finds the line blocks: one ds_bpermute instead of five vector instructions
+        const int lane = lane8 >> 3;
+        const int offl = (unsigned)(lane - r.l0) < (unsigned)r.c1 ? 0 : BF3_FAR;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             int pkk = pk[k];
             asm volatile("" : "+v"(pkk));
-            const int l = (pkk >> 2) & 15, rr = (pkk >> 18) & 0xff;
-            const bool ok = pkk >= 0 && (unsigned)(l - r.l0) < (unsigned)r.c1;
+            const int rr = (pkk >> 18) & 0xff;
             // (the row term is negative where a segment is shorter than W1 W2 -- 2D, rows of the swept axis with fewer columns --
             // so the slot's own offset is added in the vector register: the sum is what the range check sees)
-            const int q8 = (QLO + sw + QSTR * k) * 512 + lane8;
-            bf2_buffer_store(dD, ok ? (int)__mul24(rr, dlD) + q8 : BF2_OOB, 0, svD[k]);
-            if (NSET == 2) bf2_buffer_store(dT, ok ? (int)__mul24(rr, dlT) + q8 : BF2_OOB, 0, svT[k]);
+            const int q8 = __builtin_amdgcn_ds_bpermute(pkk & 60, offl) + ((QLO + sw + QSTR * k) * 512 + lane8);
+            bf2_buffer_store(dD, (int)__mul24(rr, dlD) + q8, 0, svD[k]);
+            if (NSET == 2) bf2_buffer_store(dT, (int)__mul24(rr, dlT) + q8, 0, svT[k]);
         }
     }
 };
@@ -420,7 +427,8 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
 #pragma unroll
                     for (int i = 0; i < NA; ++i) kv[l][t1][i] = ld(t1, i, s * Q + l);
     }
-    auto flush = [&]() {
+    // (the pairs that enter the window need no zero when a sweep follows: its first plane ASSIGNS them)
+    auto flush = [&](const bool zero) {
         double *ln = lines + RI * sc.tlp + g2l;             // (g2l: the point's place in the padded line)
 #pragma unroll
         for (int a = 0; a < P1; ++a) ln[a * LS] = acc[a][0];
@@ -430,8 +438,10 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
         for (int a = 0; a < P1 - 1; ++a)
 #pragma unroll
             for (int b = 0; b < P1 - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+        if (zero) {
 #pragma unroll
-        for (int a = 0; a < P1; ++a) { acc[a][P1 - 1] = 0.0; acc[P1 - 1][a] = 0.0; }
+            for (int a = 0; a < P1; ++a) { acc[a][P1 - 1] = 0.0; acc[P1 - 1][a] = 0.0; }
+        }
     };
     // one span of the mid axis: Q Gauss planes into the pair window, the K1 values of the next span requested meanwhile
     auto sweep_span = [&](const int s) __attribute__((always_inline)) {
@@ -464,9 +474,13 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
                     else if (R.has[2 * R.f]) w = v[b][0] * kt[2 * R.f];
                     else w = v[b][1] * kt[2 * R.f + 1];
 #pragma unroll
-                    for (int a = 0; a < P1; ++a) acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
+                    for (int a = 0; a < P1; ++a) {
+                        if (l == 0 && (a == P1 - 1 || b == P1 - 1)) acc[a][b] = v[a][R.f] * w;     // a pair new in the window
+                        else acc[a][b] = fma(v[a][R.f], w, acc[a][b]);
+                    }
                 }
             } else {
+                constexpr int tu_first = (R.has[0] || R.has[2]) ? 0 : 1;
 #pragma unroll
                 for (int tu = 0; tu < 2; ++tu) {
                     if (!(R.has[tu] || R.has[tu + 2])) continue;
@@ -477,7 +491,10 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
                         else if (R.has[tu]) c = v[a][0] * kt[tu];
                         else c = v[a][1] * kt[tu + 2];
 #pragma unroll
-                        for (int b = 0; b < P1; ++b) acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                        for (int b = 0; b < P1; ++b) {
+                            if (l == 0 && tu == tu_first && (a == P1 - 1 || b == P1 - 1)) acc[a][b] = v[b][tu] * c;
+                            else acc[a][b] = fma(v[b][tu], c, acc[a][b]);
+                        }
                     }
                 }
             }
@@ -498,13 +515,13 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
             if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
             sweep_span(d);
             bar_lds();                                   // B2: the contractors have read the previous lines
-            flush();
+            flush(d + 1 >= t_sw);
             if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
         }
         for (; d < rhi; ++d) {
             bar_lds();
             if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
-            bar_lds(); flush();
+            bar_lds(); flush(true);
             if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
         }
     } else {
@@ -516,7 +533,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
             if constexpr (ST) store.issue(A, *sc.B, d - 1, sc.sw);
             if (s < t_sw && fa1[s] == d) { sweep_span(s); ++s; }
             bar_lds();                                   // B2
-            flush();
+            flush(true);
             if constexpr (ST) store.fetch(A, *sc.B, sc.sets, sc.dump, d, sc.sw, slane);
         }
     }
@@ -631,13 +648,22 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
                         if (o >= oshv) dste[o] = out[o];
                 }
             } else {
-                // entries that only this half contributes to are written, the shared ones added (onto zeros, or onto the other half)
+                // entries that only this half contributes to are written, the shared ones added (onto zeros, or onto the other half);
+                // (a tile without low edge rows: no test per entry)
+                if (U.row_lo >= p2) {
 #pragma unroll
-                for (int o = OLO; o <= OHI; ++o)
-                    if (o >= oshv) {
+                    for (int o = OLO; o <= OHI; ++o) {
                         if ((H == 1 && o > 2 * p2 - AH) || (H == 2 && o <= p2 - AH)) dste[o] = out[o];
                         else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                } else {
+#pragma unroll
+                    for (int o = OLO; o <= OHI; ++o)
+                        if (o >= oshv) {
+                            if ((H == 1 && o > 2 * p2 - AH) || (H == 2 && o <= p2 - AH)) dste[o] = out[o];
+                            else (void)__hip_atomic_fetch_add(dste + o, out[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                }
             }
         }
     }
@@ -688,6 +714,12 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
 #pragma unroll
                         for (int e = 0; e < W2; ++e)
                             if (e >= oshv) dste[e] = outT[e];
+                    }
+                } else if (U.row_lo >= p2) {
+#pragma unroll
+                    for (int e = ELO; e <= EHI; ++e) {
+                        if ((H == 1 && e < AH) || (H == 2 && e >= p2 + AH)) dste[e] = outT[e];
+                        else (void)__hip_atomic_fetch_add(dste + e, outT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 } else {
 #pragma unroll
