@@ -918,6 +918,25 @@ def test_full_size_c4(iga, oracle, monkeypatch):
         sl.close()
 
 
+def test_full_size_c4_every_entry(iga):
+    """BASELINE config 4 at full size, EVERY one of the 1.59 G entries: the sum-factorised chain (k_geoA + k_bf3) against the
+    entry-wise kernels -- the reference's loop nest (pyiga/assemblers.pyx:1455-1540) with its own summation order, the second,
+    independent device implementation that the oracle pins at the sizes it reaches -- compared in chunks on the host."""
+    kv = iga.bspline.make_knots(4, 0., 1., 128)
+    asm = iga.assemblers.StiffnessAssembler3D((kv, kv, kv), _geo(iga, 'cylinder'))
+    data = asm.patch.assemble('stiffness', algo='sumfact', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 2 and data.size == 1593413632
+    ref = asm.patch.assemble('stiffness', algo='entrywise', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 1 and ref.size == data.size
+    scale = float(np.abs(ref[::997]).max())
+    worst = 0.0
+    step = 1 << 26
+    for a in range(0, data.size, step):
+        worst = max(worst, float(np.abs(data[a:a + step] - ref[a:a + step]).max()))
+    assert worst <= RTOL * scale, worst / scale
+    asm.patch.close()
+
+
 def test_fast_variants_match_fixtures(iga, capsys):
     """test/test_assemble.py:187-217 (test_fast_{mass,stiffness}_geo_{2,3}d): the low-rank (ACA) assemblers against the
     bundled fixtures with the reference's tolerance 1e-9; the approximation really is low-rank (few crosses, fewer entries
@@ -988,6 +1007,22 @@ def test_full_size_c5(iga, monkeypatch):
     for r in sample:
         ref = S.data[S.indptr[r]:S.indptr[r + 1]]
         assert np.abs(data[indptr[r]:indptr[r] + ref.size] - ref).max() <= RTOL * scale
+
+
+def test_full_size_c5_every_entry_of_a_slab(iga):
+    """BASELINE config 5 at full size, EVERY entry of sixteen dof planes (2.0e8 of the 1.26 G entries of the non-symmetric
+    convection-diffusion matrix; the coefficient as bench.py passes it, evaluated on the device): sum-factorised chain against
+    the entry-wise kernels.  (The whole matrix takes the entry-wise kernels 140 s at p = 5; it was compared once, in round 5,
+    with this tolerance: passed.)"""
+    kv = iga.bspline.make_knots(5, 0., 1., 96)
+    asm = iga.assemblers.ConvDiffAssembler3D((kv, kv, kv), _geo(iga, 'cylinder'), iga.assemblers.AffineCoefficient(1.0, 1.0), row0=(43, 59))
+    data = asm.patch.assemble('convdiff', algo='sumfact', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 2 and 'bf3' in asm.patch.last_path() and data.size == asm.patch.nnz > 1.9e8
+    ref = asm.patch.assemble('convdiff', algo='entrywise', to_host=True)
+    assert asm.patch.timing()['algo_used'] == 1 and ref.size == data.size
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(data - ref).max()) <= RTOL * scale
+    asm.patch.close()
 
 
 def test_full_size_c5_affine_coefficient(iga, golden, oracle, monkeypatch):
