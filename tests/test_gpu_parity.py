@@ -934,6 +934,11 @@ def test_full_size_c4_every_entry(iga):
     for a in range(0, data.size, step):
         worst = max(worst, float(np.abs(data[a:a + step] - ref[a:a + step]).max()))
     assert worst <= RTOL * scale, worst / scale
+    # ... and the chain is reproducible run to run, bit for bit (fixed summation order: the only LDS adds have two addends)
+    del ref
+    again = asm.patch.assemble('stiffness', algo='sumfact', to_host=True)
+    for a in range(0, data.size, step):
+        assert np.array_equal(data[a:a + step], again[a:a + step])
     asm.patch.close()
 
 
