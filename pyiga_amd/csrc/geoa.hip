@@ -35,6 +35,9 @@ constexpr int GA_MAXS = 8;
 #ifndef GA_READBOTH
 #define GA_READBOTH 1         // both basis rows of a plane are read from LDS even when they are the same row (no register copies)
 #endif
+#ifndef GA_DPP
+#define GA_DPP 1              // axis-0 sweep with the pair products V_a[tv] V_b[tu] of a plane in ONE register (lane m of every row of
+#endif                        // 16 lanes = pair m) and v_fmac_f64 ... row_newbcast:m -- no multiply and no broadcast reads per pair
 typedef const double __attribute__((address_space(4))) *cdp;      // uniform tables: scalar loads
 typedef const int __attribute__((address_space(4))) *cip;
 
@@ -79,6 +82,25 @@ __device__ unsigned long long g_ga_stamp[2048 * 8 * 6];
 #else
 #define GA_T(i)
 #endif
+
+// acc += pv[lane M of this lane's row of 16] * bv: the DP-ALU form of DPP (gfx90a and later: row_newbcast is the one DPP control
+// the FP64 instructions take).  All 64 lanes are active wherever this is used.
+template <int M>
+__device__ __forceinline__ void fmac_rowbc(double &acc, const double pv, const double bv)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(pv), "v"(bv), "n"(M));
+}
+// pair m = a (a + 1) / 2 + b (b <= a) of the lower triangle <-> accumulator acc[a][b]
+template <int P, int A_ = 0, int B_ = 0>
+__device__ __forceinline__ void sweep_lower_rowbc(double (&acc)[P][P], const double (&pv)[(P * (P + 1) / 2 + 15) / 16], const double bv)
+{
+    if constexpr (A_ < P) {
+        constexpr int m = A_ * (A_ + 1) / 2 + B_;
+        fmac_rowbc<(m & 15)>(acc[A_][B_], pv[m >> 4], bv);
+        if constexpr (B_ < A_) sweep_lower_rowbc<P, A_, B_ + 1>(acc, pv, bv);
+        else sweep_lower_rowbc<P, A_ + 1, 0>(acc, pv, bv);
+    }
+}
 
 // Per-plane record of axis 0 (doubles): everything wave-uniform that a Gauss plane g needs, built once per patch so that
 // the staging inside the sweep is one coalesced copy without dependent loads or branches:
@@ -185,7 +207,8 @@ k_geoA(const GeoAArgs A)
     constexpr int NF = FORM == 1 ? 9 : 6;                 // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = (NS + NGW) * 64;                   // threads
-    constexpr int NRC = NS * GA_REC;                      // doubles of a batch of plane records
+    constexpr int RECW = (MF || FORM == 1) ? GA_REC : 24; // doubles of a plane record that the kernel uses (the row tables: matrix-core / non-symmetric sweeps only)
+    constexpr int NRC = NS * RECW;                        // doubles of a batch of plane records
     constexpr int NTS = NGW ? NGW * 64 : NT;              // threads that stage them (the geometry waves where they exist)
     constexpr int KRC = (NRC + NTS - 1) / NTS;            // ... per thread
     // fields of two batches of planes, [buffer][plane][field][point]; the matrix-core sweep reads four planes with one
@@ -197,8 +220,12 @@ k_geoA(const GeoAArgs A)
     // [row mod 4][row / 4] (the four rows of a lane are neighbours), plane stride padded like the fields'
     constexpr int ATS = 4 * GA_ROWS + 16;
     __shared__ __attribute__((aligned(16))) double atb[MF ? 2 * NS * ATS : 2];
+    // pair-product sweep (GA_DPP): products of the lower pairs per plane of a batch and type, [buffer][plane][type][NPV * 16]
+    constexpr int NPR = P * (P + 1) / 2, NPV = (NPR + 15) / 16;
+    constexpr bool DPS = GA_DPP && !MF && FORM == 0 && NPV == 1;
+    __shared__ double prd_[DPS ? 2 * NS * 4 * NPV * 16 : 2];
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
-    __shared__ __attribute__((aligned(16))) double rec[3][NS][GA_REC];   // plane records of three batches: swept | evaluated | arriving
+    __shared__ __attribute__((aligned(16))) double rec[3][NS][RECW];   // plane records of three batches: swept | evaluated | arriving
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // consecutive block ids go to different XCDs: give each XCD a contiguous range of point tiles
@@ -224,8 +251,8 @@ k_geoA(const GeoAArgs A)
     auto stage_load = [&](const int gb) {
 #pragma unroll
         for (int k = 0; k < KRC; ++k) {
-            const int i = tid - (NT - NTS) + k * NTS, j = i / GA_REC;
-            if (i >= 0 && i < NRC) rc_reg[k] = A.tab[(size_t)min(gb + j, g_last) * GA_REC + (i - j * GA_REC)];
+            const int i = tid - (NT - NTS) + k * NTS, j = i / RECW;
+            if (i >= 0 && i < NRC) rc_reg[k] = A.tab[(size_t)min(gb + j, g_last) * GA_REC + (i - j * RECW)];
         }
     };
     auto stage_store = [&](const int slot) {
@@ -650,6 +677,105 @@ k_geoA(const GeoAArgs A)
             rs = rn;
             __syncthreads();
         }
+        return;
+    }
+    // ---- pair-product sweep (GA_DPP; symmetric forms, at most 16 lower pairs: p <= 4): the products V_a[tv](g0) V_b[tu](g0) of a
+    // plane are functions of the plane alone -- one thread computes one of them per batch (plane, type, pair) -> LDS; a sweep
+    // wave reads ITS type's 16 products of a plane into one register (lane m of each row of 16 = pair m) and the field value of
+    // its point, and updates the pair window with P (P + 1) / 2 row-broadcast multiply-adds: per plane and wave 15 FP64
+    // instructions and 2 LDS reads at p = 4 instead of 5 + 15 and 7.  (acc += (V_a V_b) f instead of acc += V_b (V_a f): the
+    // same roundings per (plane, pair) wherever the batches cut, so slabs and chunks still reproduce the patch bit for bit.)
+    if constexpr (DPS) {
+        const int t = A.type[w], fi = A.field[w];
+        double *const out = A.out[w] + pt;
+        const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
+        double acc[P][P];
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+        auto products = [&](const int rsl, const int bufn) {
+            for (int i = tid; i < NS * 64; i += NT) {
+                const int jp = i >> 6, ty = (i >> 4) & 3, m = i & 15;
+                const int a = m >= 10 ? 4 : m >= 6 ? 3 : m >= 3 ? 2 : m >= 1 ? 1 : 0, b = m - a * (a + 1) / 2;
+                const double x = rec[rsl][jp][6 * (ty >> 1) + a] * rec[rsl][jp][6 * (ty & 1) + b];
+                prd_[((bufn * NS + jp) * 4 + ty) * 16 + m] = m < NPR ? x : 0.0;
+            }
+        };
+        const double *const pw = &prd_[t * 16 + (lane & 15)];
+#ifdef IGX_GA_STAMP
+        unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
+        stage_load(g_begin); stage_store(0);
+        stage_load(g_begin + NS); stage_store(1);
+        __syncthreads();
+        next_batch(g_begin, 0, 0);
+        products(0, 0);
+        __syncthreads();
+        GA_T(0);
+        int it = 0, l = 0, sp = s_begin, rs = 0;
+        for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+            const int buf = it & 1;
+            const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
+            stage_load(gb + 2 * NS);
+            double pv[1] = {pw[(buf * NS) * 64]};
+            double bv = FLD(buf, 0, fi, lane);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (gb + j >= g_end) break;
+                // the operands of the next plane are requested before this plane's arithmetic
+                const int jn = j + 1 < NS ? j + 1 : j;
+                const double pvn = pw[(buf * NS + jn) * 64], bvn = FLD(buf, jn, fi, lane);
+                asm volatile("" ::: "memory");
+                if (!GA_OFF(4)) sweep_lower_rowbc<P>(acc, pv, bv);
+                else acc[0][0] += pv[0] + bv;
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) asm volatile("" : "+v"(acc[a][b]));
+                asm volatile("" ::: "memory");
+                pv[0] = pvn; bv = bvn;
+                GA_T(1);
+                if (++l < q) continue;
+                const bool write = sp >= own_lo && !GA_OFF(2);
+                const int *fr = (const int *)&rec[rs][j][20];
+                const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
+                for (int st = st0; st < st0 + nst; ++st) {
+                    int pr[P];
+                    if (st == st0) {
+#pragma unroll
+                        for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(fr[2 + a]);
+                    } else {                              // (several dofs leave at the end of the axis)
+                        const int8v rec8 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 8);
+#pragma unroll
+                        for (int a = 0; a < P; ++a) pr[a] = rec8[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < P; ++a)
+                        if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);
+#pragma unroll
+                    for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+                    for (int b = 0; b < P; ++b) acc[P - 1][b] = 0.0;
+                }
+                l = 0; ++sp;
+                GA_T(2);
+            }
+            GA_T(1);
+            next_batch(gb + NS, rn, buf ^ 1);
+            products(rn, buf ^ 1);
+            GA_T(0);
+            stage_store(ra);
+            rs = rn;
+            __syncthreads();
+            GA_T(3);
+        }
+#ifdef IGX_GA_STAMP
+        if (lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0)
+            for (int i = 0; i < 4; ++i) g_ga_stamp[(blockIdx.x * 8 + (w & 7)) * 6 + i] = st_[i];
+#endif
         return;
     }
     // ---- sweep state of this wave

@@ -67,6 +67,11 @@ KERNEL(k_fmac_sv_ldsr4, ACC16_X4("v_fmac_f64", "s[22:23], v[42:43]", "ds_read_b6
 KERNEL(k_fmac_sv_ldsr128_4, ACC16_X4("v_fmac_f64", "s[22:23], v[42:43]", "ds_read_b128 v[52:55], v48\n"))
 KERNEL(k_fmac_sv_ldsw4, ACC16_X4("v_fmac_f64", "s[22:23], v[42:43]", "ds_write_b64 v48, v[50:51]\n"))
 
+// round 6: the DP-ALU form of DPP (row_newbcast: lane N of each row of 16 lanes as the first multiplicand)
+#define DPPSRC "v[40:41], v[42:43] row_newbcast:3 row_mask:0xf bank_mask:0xf"
+KERNEL(k_fmac_dpp, ACC16("v_fmac_f64_dpp", DPPSRC))
+KERNEL(k_fmac_dpp_ldsr4, ACC16_X4("v_fmac_f64_dpp", DPPSRC, "ds_read_b64 v[52:53], v48\n"))
+
 // integer-only and mixed reference loops written separately (32-bit destinations)
 #define INT16(X) X X X X X X X X X X X X X X X X
 __global__ void __launch_bounds__(1024) k_vint(float *out, int iters)
@@ -111,6 +116,7 @@ int main()
         {"fmac s,v + 1 v_add_u32 per 2 fmac", k_fmac_sv_vint2, 32}, {"fmac s,v + 1 v_add_u32 per 4 fmac", k_fmac_sv_vint4, 32},
         {"fmac s,v + 1 v_mov_b64 per 2 fmac", k_fmac_sv_mov64_2, 32}, {"fmac s,v + 1 ds_read_b64 per 4 fmac", k_fmac_sv_ldsr4, 32},
         {"fmac s,v + 1 ds_read_b128 per 4 fmac", k_fmac_sv_ldsr128_4, 32}, {"fmac s,v + 1 ds_write_b64 per 4 fmac", k_fmac_sv_ldsw4, 32},
+        {"v_fmac_f64_dpp v, v, v row_newbcast", k_fmac_dpp, 32}, {"fmac_dpp + 1 ds_read_b64 per 4 fmac", k_fmac_dpp_ldsr4, 32},
         {"v_add_u32 only (32 per iteration)", k_vint, 32},
     };
     const int iters = 4000;
