@@ -38,6 +38,10 @@
 #include <cstring>
 #include <vector>
 
+#ifndef BF3_FIXED_PASS
+#define BF3_FIXED_PASS 1      // the contractor waves keep their passes from step to step (no rotation)
+#endif
+
 namespace igx {
 
 // SYM: 0 non-symmetric form (one set of rings, every pair direct); 1 symmetric, every outer pair diagonal (2D: one set);
@@ -873,7 +877,14 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
                     else bf3_unit<Gm, NY, MASK, SYM, 1>(U, u - npass);
                 }
             } else if (NH == 1 || npass <= NCW) {
-                for (int pass = wslot; pass < npass; pass += NCW) bf3_unit<Gm, NY, MASK, SYM, 0>(U, pass);
+                for (int pass = BF3_FIXED_PASS ? cw : wslot; pass < npass; pass += NCW) bf3_unit<Gm, NY, MASK, SYM, 0>(U, pass);
+            } else if (BF3_FIXED_PASS && 2 * (npass - NCW) == NCW) {
+                // as many halves as waves: every wave keeps ITS passes for the whole walk -- the whole pass cw and one half of pass
+                // NCW + cw / 2 -- so that what a lane derives from (lane, pass) does not change from step to step; the two waves that
+                // share a pass swap halves every step (the halves cost 3 : 2)
+                bf3_unit<Gm, NY, MASK, SYM, 0>(U, cw);
+                if ((cw ^ t) & 1) bf3_unit<Gm, NY, MASK, SYM, 1>(U, NCW + (cw >> 1));
+                else bf3_unit<Gm, NY, MASK, SYM, 2>(U, NCW + (cw >> 1));
             } else {
                 bf3_unit<Gm, NY, MASK, SYM, 0>(U, wslot);
                 const int nsp = npass - NCW;
@@ -963,6 +974,9 @@ constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0
 // BF2Cfg: chosen per degree and form from measurements)
 #ifndef BF3_NH
 #define BF3_NH 2
+#endif
+#ifndef BF3_FIXED_PASS
+#define BF3_FIXED_PASS 1      // the contractor waves keep their passes from step to step (no rotation)
 #endif
 template <int PM, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
 template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 8 : 4, NH = 1; };
