@@ -102,6 +102,16 @@ __device__ __forceinline__ void sweep_lower_rowbc(double (&acc)[P][P], const dou
     }
 }
 
+// the full window of a non-symmetric form: pair m = a P + b <-> acc[a][b], products in NPV registers of 16 pairs each
+template <int P, int M = 0>
+__device__ __forceinline__ void sweep_full_rowbc(double (&acc)[P][P], const double (&pv)[(P * P + 15) / 16], const double bv)
+{
+    if constexpr (M < P * P) {
+        fmac_rowbc<(M & 15)>(acc[M / P][M % P], pv[M >> 4], bv);
+        sweep_full_rowbc<P, M + 1>(acc, pv, bv);
+    }
+}
+
 // Per-plane record of axis 0 (doubles): everything wave-uniform that a Gauss plane g needs, built once per patch so that
 // the staging inside the sweep is one coalesced copy without dependent loads or branches:
 //   [0, 12)   basis of the SPACE at the plane: [value | derivative][active function a < P <= 6]
@@ -223,7 +233,9 @@ k_geoA(const GeoAArgs A)
     // pair-product sweep (GA_DPP): products of the lower pairs per plane of a batch and type, [buffer][plane][type][NPV * 16]
     constexpr int NPR = P * (P + 1) / 2, NPV = (NPR + 15) / 16;
     constexpr bool DPS = GA_DPP && !MF && FORM == 0 && NPV == 1;
-    __shared__ double prd_[DPS ? 2 * NS * 4 * NPV * 16 : 2];
+    constexpr int NPVF = (P * P + 15) / 16;               // ... of the full window (non-symmetric forms)
+    constexpr bool DPF = GA_DPP && FORM == 1;
+    __shared__ double prd_[DPS ? 2 * NS * 4 * NPV * 16 : DPF ? 2 * NS * 4 * NPVF * 16 : 2];
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
     __shared__ __attribute__((aligned(16))) double rec[3][NS][RECW];   // plane records of three batches: swept | evaluated | arriving
     const int tid = threadIdx.x, lane = tid & 63;
@@ -413,7 +425,7 @@ k_geoA(const GeoAArgs A)
                 if (w <= jl && __builtin_amdgcn_readfirstlane((int)rec[gbuf][w][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, w, gn + w);
             } else if (w >= NS) {
                 for (int jp = w - NS; jp <= jl; jp += NGW)
-                    if (__builtin_amdgcn_readfirstlane((int)rec[gbuf][jp][19]) == cur) evaluate(gbuf, buf, jp, gn + jp);
+                    if (__builtin_amdgcn_readfirstlane((int)rec[gbuf][jp][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, jp, gn + jp);
             }
             if (cur == last) break;
             int nxt = last;
@@ -570,17 +582,31 @@ k_geoA(const GeoAArgs A)
         // The geometry waves stage the plane records and evaluate the next batch; the sweep waves sweep: two loops that meet
         // only at the barriers, so that no value of one role is live in the other (the pair window of a sweep wave alone is 72
         // registers at p = 5; anything spilled around it is reloaded behind a vmcnt(0), i.e. behind the K1 stores).
+        // pair products of a batch (GA_DPP): V_a[tv] V_b[tu] per (plane, type, pair m = a P + b), by the geometry waves
+        auto products_full = [&](const int rsl, const int bufn) {
+            if constexpr (DPF) {
+                constexpr int PW = NPVF * 16;
+                for (int i = tid - NS * 64; i < NS * 4 * PW; i += NGW * 64) {
+                    const int jp = i / (4 * PW), r = i - jp * (4 * PW), ty = r / PW, m = r - ty * PW;
+                    const int a = min(m / P, P - 1), b = m - (m / P) * P;
+                    const double x = rec[rsl][jp][6 * (ty >> 1) + a] * rec[rsl][jp][6 * (ty & 1) + b];
+                    prd_[(bufn * NS + jp) * (4 * PW) + r] = m < P * P ? x : 0.0;
+                }
+            }
+        };
         if (w >= NS) {
             stage_load(g_begin); stage_store(0);
             stage_load(g_begin + NS); stage_store(1);
             __syncthreads();
             next_batch(g_begin, 0, 0);
+            products_full(0, 0);
             __syncthreads();
             int it = 0, rs = 0;
             for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
                 const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
                 stage_load(gb + 2 * NS);
                 next_batch(gb + NS, rn, (it & 1) ^ 1);
+                products_full(rn, (it & 1) ^ 1);
                 stage_store(ra);
                 rs = rn;
                 __syncthreads();
@@ -589,6 +615,9 @@ k_geoA(const GeoAArgs A)
         }
         typedef double d2 __attribute__((ext_vector_type(2)));
         const int t = A.type[w], fi = A.field[w], xt = A.xtype[w], xf = A.xfield[w];
+#ifdef GA_PRIO2
+        if (xf >= 0) __builtin_amdgcn_s_setprio(GA_PRIO2);  // (experiment) the waves with two sources close every batch
+#endif
         double *const out = A.out[w] + pt;
         const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
         double acc[P][P];
@@ -635,11 +664,44 @@ k_geoA(const GeoAArgs A)
         for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
             const int buf = it & 1;
             const int rn = rs == 2 ? 0 : rs + 1;
+            // (GA_DPP: the operands of a plane -- the products of the slot's one or two types and the field values -- are requested
+            // one plane ahead; a source is P P row-broadcast multiply-adds)
+            double pv1[NPVF], pv2[NPVF], bv1 = 0.0, bv2 = 0.0;
+            auto operands = [&](double (&pv)[NPVF], double &bv, const int j, const int ty, const int ff) {
+                const double *pr_ = &prd_[((buf * NS + j) * 4 + ty) * (NPVF * 16) + (lane & 15)];
+#pragma unroll
+                for (int k = 0; k < NPVF; ++k) pv[k] = pr_[16 * k];
+                bv = FLD(buf, j, ff, lane);
+            };
+            if constexpr (DPF) {
+                operands(pv1, bv1, 0, t, fi);
+                if (xf >= 0) operands(pv2, bv2, 0, xt, xf);
+            }
 #pragma unroll 1
             for (int j = 0; j < NS; ++j) {
                 if (gb + j >= g_end) break;
-                source(rs, buf, j, t, fi);
-                if (xf >= 0) source(rs, buf, j, xt, xf);
+                if constexpr (DPF) {
+                    double pn1[NPVF], pn2[NPVF], bn1, bn2 = 0.0;
+                    const int jn = j + 1 < NS ? j + 1 : j;
+                    operands(pn1, bn1, jn, t, fi);
+                    if (xf >= 0) operands(pn2, bn2, jn, xt, xf);
+                    asm volatile("" ::: "memory");
+                    if (!GA_OFF(4)) {
+                        sweep_full_rowbc<P>(acc, pv1, bv1);
+                        if (xf >= 0) sweep_full_rowbc<P>(acc, pv2, bv2);
+                    } else acc[0][0] += (pv1[0] + bv1) + (pv2[0] + bv2);
+#pragma unroll
+                    for (int a = 0; a < P; ++a)
+#pragma unroll
+                        for (int b = 0; b < P; ++b) asm volatile("" : "+v"(acc[a][b]));
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < NPVF; ++k) { pv1[k] = pn1[k]; pv2[k] = pn2[k]; }
+                    bv1 = bn1; bv2 = bn2;
+                } else {
+                    source(rs, buf, j, t, fi);
+                    if (xf >= 0) source(rs, buf, j, xt, xf);
+                }
                 if (++l < q) continue;
                 const bool write = sp >= own_lo && !GA_OFF(2);
                 const int *fr = (const int *)&rec[rs][j][20];
@@ -979,7 +1041,7 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
 {
     const bool nonsym = kind == IGX_CONVDIFF;
     if (nonsym) {
-        if (!pt->d_coeff) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
+        if (!pt->coef_affine && !pt->coeff_sampled) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
         if (!pt->d_stepsn) { set_error("internal: flush records of the non-symmetric form are missing"); return IGX_ERR_UNSUPPORTED; }
         if (!pt->d_geoa_tabn) {                          // per-plane records with the 16-int flush steps of the non-symmetric sweep
             double *tab = nullptr;

@@ -163,6 +163,24 @@ static void free_geo_axis(GeoAxis &g) { (void)hipFree(g.d_kv); (void)hipFree(g.d
 
 static int load_vector_jet_run(igx_patch *pt, double *out);
 
+// the sampled scalar coefficient of IGX_CONVDIFF: an affine coefficient is evaluated inside k_geoA and sampled into d_coeff only for the
+// kernels that read the array (field kernels of the stage / entry-wise paths) -- 1.5 GB and a 17 ms launch at C5 that the fast
+// chain never reads
+static int ensure_coeff(igx_patch *pt)
+{
+    if (pt->coeff_sampled) return IGX_OK;
+    if (!pt->coef_affine) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
+    const size_t n = (size_t)pt->dev.npts_loc;
+    if (!pt->d_coeff && hipMalloc((void **)&pt->d_coeff, std::max<size_t>(1, n) * sizeof(double)) != hipSuccess) {
+        pt->d_coeff = nullptr;
+        set_error("hipMalloc of %.2f GB for the sampled coefficient failed", n * 8.0 / 1e9);
+        return IGX_ERR_NOMEM;
+    }
+    if (int rc = launch_coeff_affine(pt->ctx->stream, pt, pt->coef_c, pt->d_coeff)) return rc;
+    pt->coeff_sampled = true;
+    return IGX_OK;
+}
+
 static int ensure_fields(igx_patch *pt, int kind)
 {
     if (pt->fields_kind == kind) return IGX_OK;
@@ -172,8 +190,8 @@ static int ensure_fields(igx_patch *pt, int kind)
     }
     if (kind == IGX_CONVDIFF) {
         if (pt->dim != 3) { set_error("IGX_CONVDIFF is a 3D form"); return IGX_ERR_UNSUPPORTED; }
-        if (!pt->d_coeff) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
         if (pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("IGX_CONVDIFF needs a spline geometry (physical coordinates)"); return IGX_ERR_UNSUPPORTED; }
+        if (int rc = ensure_coeff(pt)) return rc;
     }
     const size_t need = (size_t)nF * pt->dev.npts_loc;
     if (pt->fields_cap < need) {
@@ -518,6 +536,7 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     pt->fields_kind = -1;
     pt->coef_affine = 0;
+    pt->coeff_sampled = true;
     return IGX_OK;
 }
 
@@ -526,14 +545,11 @@ int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
     if (!pt || !c) { set_error("igx_patch_set_coeff_affine: null argument"); return IGX_ERR_ARG; }
     if (pt->dim != 3) { set_error("igx_patch_set_coeff_affine: the coefficient belongs to the 3D convection-diffusion form"); return IGX_ERR_UNSUPPORTED; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
-    const size_t n = (size_t)pt->dev.npts_loc;
-    if (!pt->d_coeff) IGX_HIP(hipMalloc((void **)&pt->d_coeff, std::max<size_t>(1, n) * sizeof(double)));
-    if (int rc = launch_coeff_affine(pt->ctx->stream, pt, c, pt->d_coeff)) return rc;
-    IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
     pt->fields_kind = -1;
-    // (the sampled values stay for the kernels that read them -- entry-wise, stage kernels; the fused geometry + axis-0 sweep
-    // evaluates the coefficient itself from the physical coordinates it has at hand)
+    // (the fused geometry + axis-0 sweep evaluates the coefficient itself from the physical coordinates it has at hand; the
+    // kernels that read sampled values -- entry-wise, stage kernels -- get them through ensure_coeff when they run)
     pt->coef_affine = 1;
+    pt->coeff_sampled = false;
     for (int k = 0; k < 4; ++k) pt->coef_c[k] = c[k];
     return IGX_OK;
 }
@@ -551,6 +567,7 @@ int igx_patch_set_coeff_expr(igx_patch *pt, const char *expr, int *cache_hit)
     pt->d_coeff = buf;
     pt->fields_kind = -1;
     pt->coef_affine = 0;
+    pt->coeff_sampled = true;
     return IGX_OK;
 }
 

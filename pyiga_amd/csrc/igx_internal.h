@@ -152,6 +152,7 @@ struct igx_patch {
     void *form_fn = nullptr;                  // IGX_FORM given as expressions: the generated field kernel (rtc.hip); no d_formc then
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     int coef_affine = 0;                      // ... set by igx_patch_set_coeff_affine: k_geoA evaluates it from the geometry map
+    bool coeff_sampled = false;               // d_coeff holds the values of the current coefficient (an affine one is sampled only when a kernel that reads the array runs: ensure_coeff)
     double coef_c[4] = {0, 0, 0, 0};
     // slab
     int r0_lo = 0, r0_hi = 0, s0_lo = 0, s0_hi = 0;

@@ -172,6 +172,18 @@ def golden_matrices():
     put_matrix(out, 'd3_mult_cyl_mass_lower', lower_csr(assemble.mass(kvs3m, cyl)))
     for k, kvx in enumerate(kvs3m):
         out['d3_mult_kv%d' % k] = kvx.kv
+    # -- round 6: the shapes the fused second kernel (k_bf3) was generalised to, pinned to the reference itself: repeated knots on
+    #    the MID axis (equal degrees), one or both of the mid / last axes one degree below nqp = max degree + 1
+    #    (pyiga/assemblers.pyx:1338); and the two shapes round 6 moves onto it: repeated knots on the LAST axis, a degree gap of two
+    mk = bspline.make_knots
+    r6 = {'d3_midmult_cyl': (mk(3, 0.0, 1.0, 3), mk(3, 0.0, 1.0, 5, mult=2), mk(3, 0.0, 1.0, 4)),
+          'd3_p443_cyl': (mk(4, 0.0, 1.0, 3), mk(4, 0.0, 1.0, 4), mk(3, 0.0, 1.0, 5)),
+          'd3_p433_cyl': (mk(4, 0.0, 1.0, 3), mk(3, 0.0, 1.0, 5), mk(3, 0.0, 1.0, 5)),
+          'd3_lastmult_cyl': (mk(3, 0.0, 1.0, 3), mk(3, 0.0, 1.0, 4), mk(3, 0.0, 1.0, 5, mult=2)),
+          'd3_p424_cyl': (mk(4, 0.0, 1.0, 3), mk(2, 0.0, 1.0, 5), mk(4, 0.0, 1.0, 4))}
+    for name, kvs in r6.items():
+        put_matrix(out, name + '_stiff_lower', lower_csr(assemble.stiffness(kvs, cyl)))
+        put_matrix(out, name + '_mass_lower', lower_csr(assemble.mass(kvs, cyl)))
     save('matrices', **out)
 
     # -- single entries via the assembler object (genericasm.pxi:677-758)

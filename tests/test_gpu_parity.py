@@ -190,7 +190,19 @@ def _matrix_cases(iga):
         ('d3_p323_n342_tbox_stiff_lower', 'stiffness', (mk(3, 0., 1., 3), mk(2, 0., 1., 4), mk(3, 0., 1., 2)), 'twisted_box', True),
         ('d3_mult_cyl_stiff_lower', 'stiffness', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), 'cylinder', True),
         ('d3_mult_cyl_mass_lower', 'mass', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), 'cylinder', True),
-    ]
+    ] + [(name + sfx, kind, kvs, 'cylinder', True) for name, kvs in _r6_shapes(iga).items()
+         for sfx, kind in (('_stiff_lower', 'stiffness'), ('_mass_lower', 'mass'))]
+
+
+def _r6_shapes(iga):
+    """Round 6: the shapes k_bf3 was generalised to (round 5: repeated knots on the mid axis, mid / last axis one degree below
+    nqp) and is being generalised to (repeated knots on the last axis, a degree gap of two), as reference-made matrices."""
+    mk = iga.bspline.make_knots
+    return {'d3_midmult_cyl': (mk(3, 0., 1., 3), mk(3, 0., 1., 5, mult=2), mk(3, 0., 1., 4)),
+            'd3_p443_cyl': (mk(4, 0., 1., 3), mk(4, 0., 1., 4), mk(3, 0., 1., 5)),
+            'd3_p433_cyl': (mk(4, 0., 1., 3), mk(3, 0., 1., 5), mk(3, 0., 1., 5)),
+            'd3_lastmult_cyl': (mk(3, 0., 1., 3), mk(3, 0., 1., 4), mk(3, 0., 1., 5, mult=2)),
+            'd3_p424_cyl': (mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 4))}
 
 
 @pytest.mark.parametrize('algo', ['sumfact', 'entrywise'])
@@ -2287,6 +2299,12 @@ def test_fused_stage_with_unequal_degrees_and_repeated_knots(iga, monkeypatch):
             assert not np.isnan(A.data).any(), tag
             assert abs(A - A.T).max() == 0.0, tag
             assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))
+            # ... and against the CPU oracle (the reference's loop nest restated, pinned to reference-made matrices of these very
+            # shapes: golden_matrices.npz d3_midmult / d3_p443 / d3_p433 / d3_lastmult / d3_p424), not only HIP against HIP
+            from oracle import iga_oracle as orc
+            okvs = tuple(orc.KnotVector(np.asarray(kv.kv), kv.p) for kv in kvs)
+            R = orc.assemble(kind, okvs, orc.geo_cylinder() if gname == 'cylinder' else orc.geo_twisted_box())
+            assert A.nnz == R.nnz and rel_maxdiff(A, R) <= RTOL, (tag, rel_maxdiff(A, R))
             N0 = kvs[0].numdofs
             parts = []
             for lo, hi in ((0, N0 // 3), (N0 // 3, N0 - 1), (N0 - 1, N0)):

@@ -132,6 +132,15 @@ def test_golden_matrices(oracle, golden):
         ('d3_mult_cyl_stiff_lower', 'stiffness', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), oracle.geo_cylinder(), True),
         ('d3_mult_cyl_mass_lower', 'mass', (mk(2, 0., 1., 3, mult=2), mk(2, 0., 1., 3), mk(3, 0., 1., 2)), oracle.geo_cylinder(), True),
     ]
+    # round 6: repeated knots on the mid / the last axis, one or two degrees below nqp on the mid and last axes
+    r6 = {'d3_midmult_cyl': (mk(3, 0., 1., 3), mk(3, 0., 1., 5, mult=2), mk(3, 0., 1., 4)),
+          'd3_p443_cyl': (mk(4, 0., 1., 3), mk(4, 0., 1., 4), mk(3, 0., 1., 5)),
+          'd3_p433_cyl': (mk(4, 0., 1., 3), mk(3, 0., 1., 5), mk(3, 0., 1., 5)),
+          'd3_lastmult_cyl': (mk(3, 0., 1., 3), mk(3, 0., 1., 4), mk(3, 0., 1., 5, mult=2)),
+          'd3_p424_cyl': (mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 4))}
+    for name, kvs in r6.items():
+        cases.append((name + '_stiff_lower', 'stiffness', kvs, oracle.geo_cylinder(), True))
+        cases.append((name + '_mass_lower', 'mass', kvs, oracle.geo_cylinder(), True))
     for name, kind, kvs, geo, lower in cases:
         A = oracle.assemble(kind, kvs, geo)
         if lower:
