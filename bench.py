@@ -41,6 +41,10 @@ CONFIGS = {
     # there) -- the stage kernels with 64-bit addresses; and C4 at degree 4 x 3 x 4 (unequal degrees on the mid / last axis)
     'c4k': (3, 4, 128, 'stiffness', 'cylinder'),
     'c4m': (3, 4, 128, 'stiffness', 'cylinder'),
+    # round 6: C4 with double interior knots on the LAST axis, C4 at degree 4 x 2 x 4 (a degree gap of two), the symmetric form at C5's size
+    'c4l': (3, 4, 128, 'stiffness', 'cylinder'),
+    'c4g': (3, 4, 128, 'stiffness', 'cylinder'),
+    'c5s': (3, 5, 96, 'stiffness', 'cylinder'),
     # BASELINE config 5: the run-time compiled (vform) convection-diffusion form, non-symmetric
     'c5': (3, 5, 96, 'convdiff', 'cylinder'),
 }
@@ -394,6 +398,10 @@ def main():
         kvs = (kv0, bspline.make_knots(p, 0.0, 1.0, n // 2, mult=2), kv)
     elif args.config == 'c4m':
         kvs = (kv0, bspline.make_knots(p - 1, 0.0, 1.0, n), kv)
+    elif args.config == 'c4l':
+        kvs = (kv0, kv, bspline.make_knots(p, 0.0, 1.0, n // 2, mult=2))
+    elif args.config == 'c4g':
+        kvs = (kv0, bspline.make_knots(p - 2, 0.0, 1.0, n), kv)
     row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world, p if dim == 3 else None)      # balanced by work
     if kind == 'convdiff':
         patch = assemblers.ConvDiffAssembler3D(kvs, geo, assemblers.AffineCoefficient(1.0, 1.0), device=local_rank, row0=row0 if part_world > 1 else None).patch
@@ -527,7 +535,7 @@ def main():
         'config': {'workload': '%dD p=%s %s, %s spans, NURBS quarter-annulus %s, %s'
                                % (dim, p if len({k.p for k in kvs}) == 1 else 'x'.join(str(k.p) for k in kvs), kind,
                                   'x'.join(str(k.numspans) for k in kvs), 'cylinder' if dim == 3 else gname,
-                                  'double interior knots on the mid axis' if args.config == 'c4k' else 'uniform open knots'),
+                                  'double interior knots on the mid axis' if args.config == 'c4k' else 'double interior knots on the last axis' if args.config == 'c4l' else 'uniform open knots'),
                    'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
                    'path': ' + '.join(parts),

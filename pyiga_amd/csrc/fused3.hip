@@ -980,34 +980,41 @@ constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0
 #endif
 template <int PM, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
 template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 8 : 4, NH = 1; };
+// Degree 5 (PM = 6) of the NON-SYMMETRIC form (SYM = 0, BASELINE config 5): sixteen waves per CU -- three lane groups, 27-row
+// tiles, half-units only, half a span of K1 prefetch to fit 128 registers -- against twelve waves of 150 registers: 13.25 against
+// 14.1-14.4 ms at C5 (profiles/r06_a_c5_geoa_variants.txt).  The SYMMETRIC form at the same size keeps the twelve-wave shape:
+// 8.9 against 12.3 ms (profiles/r06_a_c5s_p6_ab.txt) -- its contractors also gather the transposed rows.
 #ifndef BF3_P6
-#define BF3_P6 0                                         // 1: degree 5 with three lane groups, half-units only, half a span of prefetch (measured at C5: 13.4 against 13.8 ms -- not enough to give up the bit-identity with k_bf2 + mirror at p = 5; kept as an option)
+#define BF3_P6 1
 #endif
-template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> {
-    static constexpr int NLG = PM == 5 || (PM == 6 && BF3_P6) ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : (PM == 6 && BF3_P6) ? 3 : 1;
+template <int PM, int SYMK = 2> struct BF3CfgS3 {
+    static constexpr bool P6 = PM == 6 && BF3_P6 && SYMK == 0;
+    static constexpr int NLG = PM == 5 || P6 ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : P6 ? 3 : 1;
 };
+template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> : BF3CfgS3<PM, 2> {};
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = PM <= 5 ? 8 : 4, NH = 1; };
 
 template <int P1, int P2, int Q, int NY, int MASK>
 static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult_in)
 {
-    bool mult = mult_in;
+    const bool mult = mult_in;
     constexpr int PM = Q > (P1 > P2 ? P1 : P2) ? Q : (P1 > P2 ? P1 : P2);   // (the registers of a sweeper follow P1 and Q)
     using C = BF3Cfg<PM, MASK>;
-    // (degree 5 at sixteen waves per CU: the general loop -- a span swept under a branch -- happens to be the one hipcc fits into
-    // 128 registers without spills, so it also serves single knots there)
-    if (PM == 6 && BF3_P6 && P1 == 6) mult = true;
+    // (degree 5 at sixteen waves per CU, the non-symmetric form: the general loop -- a span swept under a branch -- happens to be
+    // the one hipcc fits into 128 registers without spills, so it also serves single knots there)
+    using C0 = BF3CfgS3<PM, 0>;
     if constexpr (P1 == P2 && P1 == Q) {                   // equal degrees: every form, 2D, repeated knots on the swept axis
         if (symk == 2) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu)
                                    : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
         if (symk == 1 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1, false>(st, A, ncu);
         if constexpr (MASK == BF_MASK_STIFF3)
-            if (symk == 0) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0, true>(st, A, ncu)
-                                       : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 0, false>(st, A, ncu);
+            if (symk == 0) {
+                if constexpr (C0::P6) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C0::NLG, C0::NCW, C0::NH, 0, true>(st, A, ncu);
+                else return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C0::NLG, C0::NCW, C0::NH, 0, true>(st, A, ncu)
+                                 : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C0::NLG, C0::NCW, C0::NH, 0, false>(st, A, ncu);
+            }
     } else {
         if (symk == 2 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
-        if constexpr (P1 == 6)
-            if (symk == 2 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu);
     }
     set_error("fused stage: no kernel for this form at these degrees");
     return IGX_ERR_UNSUPPORTED;
@@ -1024,15 +1031,16 @@ static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int n
 }
 
 // Degrees the kernel is compiled for: equal degrees 1 .. 5 with Q = p + 1 (every form), and -- 3D symmetric forms -- one or
-// both of the two axes one degree below Q (the common case of the reference's nqp = max degree + 1 rule: one axis of lower
-// degree).  Anything else takes the stage kernels.
+// both of the two axes one or two degrees below Q (the reference's nqp = max degree + 1 rule, pyiga/assemblers.pyx:1338: an
+// axis of lower degree is integrated with the points of the highest one).  Anything else takes the stage kernels.
 bool fused3_degrees(int P1, int P2, int Q, bool sym3d, bool mid_simple)
 {
     if (!mid_simple && !(P1 == P2 && P1 == Q)) return false;     // (repeated knots on the swept axis: equal degrees)
     if (P1 < 2 || P2 < 2 || Q > 6) return false;
     if (P1 == P2 && P1 == Q) return true;
     if (!sym3d || Q < 3) return false;
-    return (P1 == Q || P1 == Q - 1) && (P2 == Q || P2 == Q - 1);
+    const int gap = Q <= 5 ? 2 : 1;                            // two degrees below nqp up to nqp = 5 (round 6), one at nqp = 6
+    return P1 >= Q - gap && P2 >= Q - gap;
 }
 
 // the symmetric forms (mass, stiffness; 2D and 3D) and the 3D convection-diffusion form (its slots merged by k_geoA), one input
@@ -1084,6 +1092,8 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     BF3_CASE(3, 4, 4) BF3_CASE(4, 3, 4) BF3_CASE(3, 3, 4)
     BF3_CASE(4, 5, 5) BF3_CASE(5, 4, 5) BF3_CASE(4, 4, 5)
     BF3_CASE(5, 6, 6) BF3_CASE(6, 5, 6) BF3_CASE(5, 5, 6)
+    BF3_CASE(2, 4, 4) BF3_CASE(4, 2, 4) BF3_CASE(2, 3, 4) BF3_CASE(3, 2, 4) BF3_CASE(2, 2, 4)
+    BF3_CASE(3, 5, 5) BF3_CASE(5, 3, 5) BF3_CASE(3, 4, 5) BF3_CASE(4, 3, 5) BF3_CASE(3, 3, 5)
 #undef BF3_CASE
     set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q);
     return IGX_ERR_UNSUPPORTED;

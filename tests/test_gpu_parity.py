@@ -2286,7 +2286,9 @@ def test_fused_stage_with_unequal_degrees_and_repeated_knots(iga, monkeypatch):
              ((mk(4, 0., 1., 3), rep(4, 6, 3, at=(1, 3)), mk(4, 0., 1., 40)), 'cylinder', True),     # triple knots, four tiles
              ((rep(2, 5, 2), rep(2, 6, 2, at=(0, 4)), mk(2, 0., 1., 8)), 'twisted_box', True),       # repeated knots on axes 0 and 1
              ((mk(3, 0., 1., 4), mk(3, 0., 1., 5), rep(3, 6, 2)), 'cylinder', False),                # repeated knots on the LAST axis: stage kernels
-             ((mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 6)), 'cylinder', False)]            # two degrees below nqp: stage kernels
+             ((mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 6)), 'cylinder', True),             # two degrees below nqp on the swept axis (round 6): (3, 5, 5)
+             ((mk(4, 0., 1., 3), mk(4, 0., 1., 5), mk(2, 0., 1., 14)), 'cylinder', True),            # ... on the last axis: (5, 3, 5)
+             ((mk(3, 0., 1., 4), mk(1, 0., 1., 6), mk(2, 0., 1., 9)), 'twisted_box', True)]          # (2, 3, 4)
     for kvs, gname, fused3 in cases:
         for kind in ('stiffness', 'mass'):
             patch = iga.assemblers.DevicePatch(kvs, _geo(iga, gname))
