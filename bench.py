@@ -95,13 +95,14 @@ def algorithmic_flops(dim, p, kvs, kind):
     return out
 
 
-TRAFFIC_FILE = 'profiles/r05_traffic.json'
+TRAFFIC_FILE = 'profiles/r06_traffic.json'
 
 
-def measured_traffic(config, world, op='matrix'):
+def measured_traffic(config, world, op='matrix', kernels_now=None):
     """HBM bytes per assembly from the committed rocprofv3 PMC passes (TRAFFIC_FILE, tools/make_traffic.py) -- or None
-    when the device code of the library has changed since they were taken (stale numbers are not reported; the key is
-    the hash of the code objects inside libigx.so, so host-only changes do not invalidate it).  The counters need
+    when the device code of the library has changed since they were taken, or when this run launched other kernels than the
+    profiled one (stale numbers are not reported; the key is the hash of the code objects inside libigx.so plus the set of kernel
+    names of the chain).  The counters need
     passes of their own under rocprofv3, so this is never measured by the run that prints it: `measured_in_this_run`
     says so on the line."""
     try:
@@ -114,10 +115,47 @@ def measured_traffic(config, world, op='matrix'):
         from pyiga_amd import _lib
         if _lib.device_code_sha() != t.get('kernels_sha'):     # hash of the device code objects inside libigx.so
             return None
+        # ... and the CHAIN that ran must be the one that was profiled: the host side picks the kernels (path knobs, shapes), and a
+        # host-only change that sends the config down another chain leaves the device code -- and the hash -- untouched
+        if kernels_now is not None and set(kernels_now) != set(t['kernels']):
+            return None
         return {'bytes': t['chain_bytes'], 'measured_in_this_run': False, 'kernels_sha': t['kernels_sha'], 'source': TRAFFIC_FILE,
                 'kernels': {k: round(v['read_bytes'] + v['write_bytes']) for k, v in t['kernels'].items()}}
     except Exception:
         return None
+
+
+MIXED_STREAM_GBS = 5300.0      # what a stream of reads and writes side by side reaches on this part (a copy: 6.3 TB/s)
+ISSUE_CYCLES, N_SIMD, CLOCK_GHZ = 5.0, 1024, 2.0   # a wave64 FP64 instruction holds its SIMD 5 cycles (profiles/r03_ubench_valu_f64.txt); the chain clocks 1.8-2.0 GHz
+
+
+def design_floor(config, dim, kvs, kind, nnz_total, alg_bytes, world):
+    """Where the TWO-KERNEL design stops, printed beside the measured fraction so that the gap to north_star's 0.70 is stated where
+    the number is: the chain must write the axis-0 intermediate K1 once, read it once and write the CSR values once (`floor_bytes`);
+    at the rate a mixed stream reaches that is `floor_ms`, i.e. `ceiling_frac` of the HBM roof in ALGORITHMIC bytes -- and the
+    vector instructions the two kernels issue (SQ_INSTS_VALU of the committed PMC pass) take `issue_ms` on 1024 SIMDs by themselves."""
+    if dim != 3 or world != 1 or kind not in ('stiffness', 'mass', 'convdiff'):
+        return None
+    p0, N0 = kvs[0].p, kvs[0].numdofs
+    sym = kind != 'convdiff'
+    pairs0 = N0 * (p0 + 1) - p0 * (p0 + 1) // 2 if sym else N0 * (2 * p0 + 1) - p0 * (p0 + 1)     # single interior knots on axis 0
+    nq = max(k.p for k in kvs) + 1
+    npl = (kvs[1].numspans * nq) * (kvs[2].numspans * nq)
+    k1 = 8.0 * (1 if kind == 'mass' else 8) * pairs0 * npl
+    floor_bytes = 2 * k1 + 8.0 * nnz_total
+    floor_ms = floor_bytes / (MIXED_STREAM_GBS * 1e9) * 1e3
+    out = {'floor_bytes': floor_bytes, 'floor_ms': round(floor_ms, 3), 'ceiling_frac': round(alg_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           'target_frac': 0.70, 'issue_ms': None,
+           'note': 'two-kernel global sum factorisation: K1 written + read once, CSR values written once, at %.1f TB/s (mixed stream); '
+                   'north_star asks 0.70 -- not reachable by this design' % (MIXED_STREAM_GBS / 1e3)}
+    try:
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))[config]
+        insts = sum(k['valu_insts'] for k in t['kernels'].values())
+        out['issue_ms'] = round(insts * ISSUE_CYCLES / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3, 3)
+        out['valu_insts'] = insts
+    except Exception:
+        pass
+    return out
 
 
 def COEFF(x, y, z):
@@ -553,7 +591,8 @@ def main():
         'api_call_s': api_call_s,                                              # assemble.stiffness() end to end: + pattern, D2H of values and indices, scipy
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': measured_traffic(args.config, world),
+            'traffic': measured_traffic(args.config, world, kernels_now=list(parts)),
+            'design': design_floor(args.config, dim, kvs, kind, nnz_total, b_el * nel_total, world),
             'kernel': 'assembly chain (' + ' + '.join(parts) + '), HIP events on the igx stream; median step',
             'algorithmic_bytes_per_element': b_el, 'algorithmic_bytes_def': ALGORITHMIC_BYTES_DEF, 'chain_ms': chain_ms, 'kernel_ms': parts, 'kernel_ms_source': kernel_ms_source, 'dominant_kernel': dominant,
             'fp64': fp64,

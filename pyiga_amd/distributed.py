@@ -2,12 +2,13 @@
 
 The path shards without any exchange ("zero-communication
 alternative"): rank r owns a slab of dof planes of axis 0 (``slab_range``: balanced by work), i.e. a
-contiguous block of CSR rows, and computes every entry of those rows itself -- the lower
-triangle directly and the upper triangle as the mirror of lower entries it (re)computes for
-the p planes above its slab.  Each rank evaluates the quadrature fields only on the spans its
-rows touch, straight from the control net, so no input has to be communicated either.  The
-result is bit-for-bit the row block of the single-GPU matrix (tests/test_gpu_parity.py::
-test_row_slabs_equal_full), independent of the number of ranks.
+contiguous block of CSR rows, and computes every entry of those rows itself.  The second kernel
+(k_bf3) processes the outer pairs (i0, j0 <= i0) with the row OR the column owned and stores the
+direct rows of a block if it owns i0, the transposed rows if it owns j0 -- both triangles come from
+the same element matrices, there is no mirror pass.  Each rank evaluates the quadrature fields only
+on the spans its rows touch, straight from the control net, so no input has to be communicated
+either.  The result is bit-for-bit the row block of the single-GPU matrix
+(tests/test_gpu_parity.py::test_row_slabs_equal_full), independent of the number of ranks.
 
 ``torch.distributed`` (RCCL when the backend is "nccl") is used only to gather results or
 timings; there is no collective on the data path.
@@ -16,10 +17,11 @@ import numpy as np
 import scipy.sparse
 
 
-# Cost model of one slab of the default 3D chain (microseconds; MI355X, C4 kernels of round 3 -- only the RATIOS matter):
-# the fused stage works per processed outer pair (i0, j0 <= i0) with the row or the column owned, the mirror per target
-# pair (i0 owned, j0 >= i0), the geometry + axis-0 sweep per resident span (own spans + p warm-up spans).
-_COST_PAIR, _COST_TARGET, _COST_SPAN = 10.8, 5.7, 39.0
+# Cost model of one slab of the default 3D chain k_geoA + k_bf3 (microseconds on MI355X, C4 kernels of round 6 -- whole patch:
+# 8.2 ms of k_bf3 over 650 processed outer pairs, 3.7 ms of k_geoA over 128 swept spans; only the RATIO matters for the split):
+# the second kernel works per processed outer pair (i0, j0 <= i0) with the row or the column owned, the geometry + axis-0 sweep
+# per resident span (own spans + p warm-up spans).  There is no per-target term any more (round 5 removed the mirror pass).
+_COST_PAIR, _COST_SPAN = 12.6, 28.9
 
 
 def slab_cost(ndofs0, p, lo, hi):
@@ -27,9 +29,8 @@ def slab_cost(ndofs0, p, lo, hi):
     own = np.arange(lo, hi)
     halo = np.arange(hi, min(hi + p, ndofs0))                 # rows above the slab whose lower pairs have an owned column
     pairs = int(np.sum(np.minimum(own, p) + 1) + np.sum(np.maximum(hi - np.maximum(halo - p, lo), 0)))
-    targets = int(np.sum(np.minimum(own + p, ndofs0 - 1) + 1 - own))
     spans = min(hi - 1, ndofs0 - p - 1) - max(lo - p, 0) + 1     # spans the rows lo .. hi-1 touch
-    return _COST_PAIR * pairs + _COST_TARGET * targets + _COST_SPAN * spans
+    return _COST_PAIR * pairs + _COST_SPAN * spans
 
 
 def balanced_slabs(ndofs0, world, p):

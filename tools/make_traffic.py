@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/r05_traffic.json from the PMC passes of tools/prof_r05.sh pmc (gpurun_out/r05/pmc_<key>/{fetch,write}): memory-side
+"""profiles/r06_traffic.json from the PMC passes of tools/prof_r06.sh pmc (gpurun_out/r06/pmc_<key>/{fetch,write}): memory-side
 bytes per kernel of ONE pass of the timed operation -- keys c2, c3, c4, c5 (one assembly), c4_rhs (one load vector),
 c4_entries (one batched multi_entries request) -- with the hash of the kernel sources they were measured on (bench.py drops
-the figure when the sources have changed since).  usage: python3 tools/make_traffic.py gpurun_out/r05
+the figure when the sources have changed since).  usage: python3 tools/make_traffic.py gpurun_out/r06
+The vector-instruction counts of the SQ passes (tools/prof_r06.sh sq -> pmc_<key>sq/sq1: SQ_INSTS_VALU) are added per kernel where
+present: bench.py turns them into the issue-time floor it prints beside the roofline (roofline.design.issue_ms).
 
 Reads: 2 * FETCH_SIZE * 1024 for EVERY kernel -- a read request is a whole 128-byte line and the counter tallies it at 64
 bytes, for coalesced streams and for the 72-byte gathers of the mirror pass alike (profiles/r03_fetch_calibration.txt,
@@ -49,8 +51,15 @@ def one(root, key):
         total += write + 2 * fetch
     if not kernels:
         return None
+    # vector instructions per kernel (wave-level) from the SQ pass of the same configuration, if it was taken
+    for f in glob.glob(os.path.join(root, 'pmc_' + key + 'sq') + '/**/*counter_collection.csv', recursive=True):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
+        for row in rows:
+            name = re.sub(r'[<(].*', '', row['Kernel_Name']).replace('void igx::', '').replace('igx::', '')
+            if name in kernels and row['Counter_Name'] == 'SQ_INSTS_VALU':
+                kernels[name]['valu_insts'] = float(row['Counter_Value'])
     return {'config': key,
-            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r05.sh pmc), plain buffer allocation',
+            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/prof_r06.sh pmc), plain buffer allocation',
             'correction': 'read bytes = 2 * FETCH_SIZE * 1024 (128-byte requests tallied at 64 bytes; calibrated for streams and '
                           'for 72-byte gathers: profiles/r03_fetch_calibration.txt), write bytes = WRITE_SIZE * 1024',
             'kernels': kernels, 'chain_bytes': total, 'kernels_sha': kernels_sha()}
@@ -63,7 +72,7 @@ def main():
         r = one(root, key)
         if r:
             out[key] = r
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r05_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r06_traffic.json'), 'w'), indent=1)
     print(json.dumps({k: {'chain_GB': round(v['chain_bytes'] / 1e9, 3), 'kernels': {n: [round(x['read_bytes'] / 1e9, 3), round(x['write_bytes'] / 1e9, 3)] for n, x in v['kernels'].items()}}
                       for k, v in out.items()}, indent=1))
 
