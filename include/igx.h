@@ -69,7 +69,9 @@ enum { IGX_ALGO_AUTO = 0,      /* sum-factorised when the patch supports it, els
        IGX_ALGO_ENTRYWISE = 1, /* one thread per matrix entry, the reference's own summation order */
        IGX_ALGO_SUMFACT = 2 }; /* global sum factorisation (stage kernels) */
 
-enum { IGX_OK = 0, IGX_ERR_ARG = 1, IGX_ERR_HIP = 2, IGX_ERR_UNSUPPORTED = 3, IGX_ERR_NOMEM = 4 };
+enum { IGX_OK = 0, IGX_ERR_ARG = 1, IGX_ERR_HIP = 2, IGX_ERR_UNSUPPORTED = 3, IGX_ERR_NOMEM = 4,
+       IGX_ERR_NORTC = 5,      /* an entry point that compiles at run time, on a box without libhiprtc: take the sampled-array path */
+       IGX_ERR_COMPILE = 6 };  /* the expression handed to the run-time compiler did not compile (igx_last_error has the log) */
 
 /* Knot vectors are in the reference's (z, y, x) order: axis 0 is the slowest dof index. */
 typedef struct {

@@ -115,7 +115,24 @@ _lib = None
 _lock = threading.Lock()
 
 
-IGX_OK, IGX_ERR_ARG, IGX_ERR_HIP, IGX_ERR_UNSUPPORTED, IGX_ERR_NOMEM = 0, 1, 2, 3, 4      # include/igx.h
+IGX_OK, IGX_ERR_ARG, IGX_ERR_HIP, IGX_ERR_UNSUPPORTED, IGX_ERR_NOMEM, IGX_ERR_NORTC, IGX_ERR_COMPILE = 0, 1, 2, 3, 4, 5, 6      # include/igx.h
+_warned = set()
+
+
+def sampled_fallback(e, what):
+    """May a call that hands an EXPRESSION to the run-time compiler fall back to sampling on the host after error `e`?  Only when
+    the device path is not available for this input -- no libhiprtc on the box, the expression does not compile, the kernel does
+    not serve the patch -- never after a device failure (IGX_ERR_HIP: failed launch, sticky error) or an allocation failure
+    (IGX_ERR_NOMEM): those are re-raised.  The reason is reported once per kind, so that a missing libhiprtc is visible."""
+    code = getattr(e, 'code', None)
+    if code not in (IGX_ERR_NORTC, IGX_ERR_COMPILE, IGX_ERR_UNSUPPORTED):
+        return False
+    key = (what, code)
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn('pyiga_amd: %s is sampled on the host (%s)' % (what, str(e).split(': ', 1)[-1][:200]), RuntimeWarning, stacklevel=3)
+    return True
 
 
 class IgxError(RuntimeError):

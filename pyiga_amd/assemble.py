@@ -352,7 +352,9 @@ def inner_products(kvs, f, f_physical=False, geo=None):
     if src is not None:
         try:
             out = patch.load_vector_expr(src, parametric=not f_physical)
-        except _lib.IgxError:                                    # (no run-time compiler on this box: sampled on the host)
+        except _lib.IgxError as e:                               # (no run-time compiler on this box / not traceable into a kernel: sampled on the host)
+            if not _lib.sampled_fallback(e, 'the function of a load vector'):
+                raise
             out = None
     if out is None:
         grid = tuple(patch.gauss(k)[0] for k in range(dim))

@@ -658,8 +658,9 @@ class ConvDiffAssembler3D(_DeviceAssembler):
             try:
                 self.coeff_cache_hit = self.patch.set_coeff_expr(diff_coeff.c_source())     # compiled for the device at run time
                 return
-            except _lib.IgxError:
-                pass
+            except _lib.IgxError as e:
+                if not _lib.sampled_fallback(e, 'the coefficient of the convection-diffusion form'):
+                    raise
         if callable(diff_coeff) and isinstance(geo, (bspline.BSplineFunc, geometry.NurbsFunc)) and bbox is None \
                 and os.environ.get('IGX_FORM_RTC', '1') != '0':
             # a plain Python callable: traced into a C expression (pyiga_amd.symbolic) and compiled like an ExprCoefficient;
@@ -675,8 +676,9 @@ class ConvDiffAssembler3D(_DeviceAssembler):
                     self.coeff_cache_hit = self.patch.set_coeff_expr(src)
                     self.coeff_traced = True
                     return
-                except _lib.IgxError:
-                    pass
+                except _lib.IgxError as e:
+                    if not _lib.sampled_fallback(e, 'the coefficient of the convection-diffusion form'):
+                        raise
         # (any other geometry object: the coefficient is sampled through geo.grid_eval like a plain callable)
         grid = [self.patch.gauss(k)[0] for k in range(3)]
         X = geo.grid_eval(grid)                                   # shape(grid) x 3, components (x, y, z)
@@ -728,8 +730,9 @@ class _GeneralFormAssembler(_DeviceAssembler):
                     self.table_mask = [[e is not None for e in row] for row in traced]
                     self.compiled = True
                     return
-                except _lib.IgxError:
-                    pass                                          # no hiprtc on this box / compile error: sampled below
+                except _lib.IgxError as e:                        # no hiprtc on this box / compile error: sampled below
+                    if not _lib.sampled_fallback(e, 'the coefficient table of a form'):
+                        raise
         # (2) coefficients sampled on the Gauss grid on the host
         grid = [self.patch.gauss(k)[0] for k in range(d)]
         G = tuple(len(g) for g in grid)
@@ -869,7 +872,9 @@ class _FunctionalAssembler:
             if self._fexpr is not None:
                 try:
                     self._vector = self.patch.load_vector_expr(self._fexpr, parametric=not self._physical)
-                except _lib.IgxError:                            # (no run-time compiler on this box: sampled on the host)
+                except _lib.IgxError as e:                       # (no run-time compiler on this box: sampled on the host)
+                    if not _lib.sampled_fallback(e, 'the function of a load vector'):
+                        raise
                     self._fexpr = None
                     self._fvals = utils.grid_eval_transformed(self._f, self.gaussgrid, self._geo) if self._physical else utils.grid_eval(self._f, self.gaussgrid)
             if self._vector is None:
@@ -926,7 +931,9 @@ class _FormFunctionalAssembler(_FunctionalAssembler):
                 try:
                     self._vector = self.patch.load_vector_jet_expr(self._jet_exprs + [None] * (4 - len(self._jet_exprs)))
                     return self._vector.copy()
-                except _lib.IgxError:                            # (no run-time compiler on this box: the jet is sampled on the host)
+                except _lib.IgxError as e:                       # (no run-time compiler on this box: the jet is sampled on the host)
+                    if not _lib.sampled_fallback(e, 'the jet of a functional'):
+                        raise
                     from . import forms
                     G = tuple(len(g) for g in self.gaussgrid)
                     self._jet = forms.functional_jet(self._form, G, np.asarray(self._geo.grid_eval(list(self.gaussgrid))), dict(self._inputs or {}))

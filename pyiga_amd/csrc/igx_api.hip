@@ -1224,6 +1224,10 @@ int igx_load_vector_expr(igx_patch *pt, const char *expr, int parametric, double
     if (!pt || !expr || !out) { set_error("igx_load_vector_expr: null argument"); return IGX_ERR_ARG; }
     if (pt->boxed) { set_error("igx_load_vector_expr: the patch holds a span box (batched entries only)"); return IGX_ERR_UNSUPPORTED; }
     if (int rcb = basis_orders_ok(pt, IGX_MASS, "igx_load_vector_expr")) return rcb;
+    // does the fused contraction kernel serve this patch, and is there a run-time compiler?  Asked BEFORE the weight field and
+    // the workspaces are touched: IGX_ERR_UNSUPPORTED = shape not served (the caller takes igx_patch_eval_expr_d +
+    // igx_load_vector_d), IGX_ERR_NORTC = no libhiprtc on this box (the caller samples the function itself)
+    if (int rca = lv12_expr_applicable(pt, parametric)) return rca;
     IGX_HIP(hipSetDevice(pt->ctx->device));
     hipStream_t st = pt->ctx->stream;
     int rc = ensure_fields(pt, IGX_MASS);           // W = gw0*gw1*gw2*|det J| on the resident Gauss slab (kept between calls)

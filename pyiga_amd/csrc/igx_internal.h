@@ -237,6 +237,7 @@ int launch_coeff_affine(hipStream_t st, const igx_patch *pt, const double c[4], 
 int launch_kron3(hipStream_t st, igx_patch *p3, const double *d_a0, const double *d_b0, int C0, const double *d_A2, const double *d_B2);
 // run-time compiled coefficient expressions (rtc.hip)
 int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *cache_hit, bool parametric = false /* x, y, z = parametric coordinates */);
+int lv12_expr_applicable(const igx_patch *pt, int parametric);   // IGX_OK | IGX_ERR_UNSUPPORTED (shape) | IGX_ERR_NORTC (no libhiprtc)
 int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int path_len, int *cache_hit);
 int launch_form_exprs(hipStream_t st, igx_patch *pt, int n_expr, const char *const *expr, double *d_out /* [n_expr][npts_loc] */, int *cache_hit);
 int rtc_compile_form(int n_expr, const char *const *expr, const char *arch, char *path_out, int path_len, int *cache_hit);

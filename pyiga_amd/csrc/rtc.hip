@@ -43,7 +43,7 @@ static int rtc_api(RtcApi **out)
     static std::once_flag once;
     if (getenv("IGX_NO_HIPRTC")) {                           // (tests: a box without the run-time compiler)
         set_error("run-time compilation needs libhiprtc.so (switched off: IGX_NO_HIPRTC)");
-        return IGX_ERR_UNSUPPORTED;
+        return IGX_ERR_NORTC;
     }
     std::call_once(once, [] {
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so.6"}) {
@@ -76,7 +76,7 @@ static int rtc_api(RtcApi **out)
     });
     if (!api.h || !api.create || !api.compile || !api.code_size || !api.code || !api.destroy) {
         set_error("run-time compilation needs libhiprtc.so (not found or incomplete)");
-        return IGX_ERR_UNSUPPORTED;
+        return IGX_ERR_NORTC;
     }
     *out = &api;
     return IGX_OK;
@@ -181,6 +181,17 @@ __device__ inline void igx_coords(const IgxCo &c, const int g[3], double &x, dou
 }
 )IGX";
 
+static bool expr_is_plain(const char *expr);
+static int exprs_ok(int n, const char *const *expr, const char *what)
+{
+    for (int k = 0; k < n; ++k)
+        if (expr[k] && !expr_is_plain(expr[k])) {
+            set_error("%s: the expression may not contain line breaks, backslashes, comments, '#', ';' or braces", what);
+            return IGX_ERR_ARG;
+        }
+    return IGX_OK;
+}
+
 static std::string coeff_source(const char *expr)
 {
     std::string s;
@@ -224,7 +235,7 @@ static int rtc_code_object(const std::string &src, const std::string &arch, std:
         if (api->log_size && api->log && api->log_size(prog, &ls) == 0 && ls > 1) { log.resize(ls); api->log(prog, &log[0]); }
         api->destroy(&prog);
         set_error("run-time compilation of the coefficient expression failed: %.900s", log.c_str());
-        return IGX_ERR_ARG;
+        return IGX_ERR_COMPILE;
     }
     size_t n = 0;
     if (api->code_size(prog, &n) != 0 || n == 0) { api->destroy(&prog); set_error("hiprtc returned no code"); return IGX_ERR_HIP; }
@@ -247,6 +258,7 @@ int rtc_compile_expr(const char *expr, const char *arch, char *path_out, int pat
     if (!expr || !arch) { set_error("igx_rtc_compile: null argument"); return IGX_ERR_ARG; }
     std::vector<char> code;
     std::string path;
+    if (int rc = exprs_ok(1, &expr, "igx_rtc_compile")) return rc;
     if (int rc = rtc_code_object(coeff_source(expr), arch, code, path, hit)) return rc;
     if (path_out && path_len > 0) { strncpy(path_out, path.c_str(), (size_t)path_len - 1); path_out[path_len - 1] = 0; }
     return IGX_OK;
@@ -313,6 +325,7 @@ static int launch_exprs(hipStream_t st, igx_patch *pt, const std::string &src, c
 
 int launch_coeff_expr(hipStream_t st, igx_patch *pt, const char *expr, double *d_coeff, int *hit, bool parametric)
 {
+    if (int rc = exprs_ok(1, &expr, "coefficient expression")) return rc;
     return launch_exprs(st, pt, coeff_source(expr), "igx_coeff_expr", d_coeff, hit, parametric);
 }
 
@@ -336,6 +349,7 @@ static std::string form_source(int n_expr, const char *const *expr)
 
 int launch_form_exprs(hipStream_t st, igx_patch *pt, int n_expr, const char *const *expr, double *d_out, int *hit)
 {
+    if (int rc = exprs_ok(n_expr, expr, "form coefficients")) return rc;
     return launch_exprs(st, pt, form_source(n_expr, expr), "igx_form_expr", d_out, hit);
 }
 
@@ -552,6 +566,7 @@ int rtc_form_fields_function(igx_patch *pt, const char *const expr[16], int nter
     if (pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("a coefficient expression needs a spline geometry (physical coordinates)"); return IGX_ERR_UNSUPPORTED; }
     if (pt->boxed) { set_error("a form given as expressions needs the whole Gauss grid of the slab (no span box)"); return IGX_ERR_UNSUPPORTED; }
     hipFunction_t fn;
+    if (int rc = exprs_ok(16, expr, "form given as expressions")) return rc;
     const std::string src = form_fields_source(pt->dim, pt->ncomp, pt->geo_kind == IGX_GEO_NURBS, expr, nterms, form_ab, parametric);
     if (int rc = rtc_function(pt, src, "igx_form_fields", &fn, hit)) return rc;
     *fn_out = (void *)fn;
@@ -582,6 +597,7 @@ int rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], cons
     if (nt == 0) { set_error("igx_rtc_compile_form_fields: all coefficients are absent"); return IGX_ERR_ARG; }
     std::vector<char> code;
     std::string path;
+    if (int rc = exprs_ok(16, expr, "igx_rtc_compile_form_fields")) return rc;
     if (int rc = rtc_code_object(form_fields_source(dim, ncomp, ncomp == dim + 1, expr, nt, form_ab), arch, code, path, hit)) return rc;
     if (path_out && path_len > 0) { strncpy(path_out, path.c_str(), (size_t)path_len - 1); path_out[path_len - 1] = 0; }
     return IGX_OK;
@@ -765,15 +781,29 @@ extern "C" __global__ void __launch_bounds__(256) igx_lv12_expr(const IgxCo co, 
 }
 )IGX";
 
+// An expression is pasted into generated source: one that could end the construct it is pasted into -- a line break, a line
+// continuation, a comment opener, a preprocessor line -- is refused before anything is generated (expressions traced in Python are
+// single-line arithmetic; this guards the public C entry points).
+static bool expr_is_plain(const char *expr)
+{
+    for (const char *c = expr; *c; ++c) {
+        if (*c == '\n' || *c == '\r' || *c == '\\' || *c == '#' || *c == ';' || *c == '{' || *c == '}') return false;
+        if (c[0] == '/' && (c[1] == '/' || c[1] == '*')) return false;
+    }
+    return true;
+}
+
 static std::string lv12_source(int P, int npass, bool parametric, const char *expr)
 {
     std::string s;
     s += "// generated by libigx (igx_load_vector_expr): first two contractions of the 3D load vector with the function inside\n";
     s += "#define IGX_P " + std::to_string(P) + "\n#define IGX_NPASS " + std::to_string(npass) + "\n#define IGX_PARAMETRIC " + std::to_string(parametric ? 1 : 0) + "\n";
-    s += "#define IGX_F ";
-    s += expr;
-    s += "\n";
     s += RTC_PRELUDE;
+    // (the function as a FUNCTION behind the prelude, like the coefficient kernels: not a macro in front of it, whose body the
+    // names of the prelude could capture)
+    s += "__device__ inline double igx_f(const double x, const double y, const double z, const double pi)\n{\n    return (double)(";
+    s += expr;
+    s += ");\n}\n#define IGX_F igx_f(x, y, z, pi)\n";
     s += RTC_LV12_BODY;
     return s;
 }
@@ -794,6 +824,16 @@ static void fill_co(const igx_patch *pt, bool parametric, IgxCo &co)
 
 // [G0][G1][G2] weight field x f(expr) -> [G0][N1][N2] (d_t2), by the generated kernel; IGX_ERR_UNSUPPORTED where k_lv12 does not
 // apply (2D, long lines, unequal degrees of the last two axes): the caller takes the two-array path
+int lv12_expr_applicable(const igx_patch *pt, int parametric)
+{
+    int clen, nch;
+    size_t lds12;
+    if (pt->boxed || !lv12_shape(pt, &clen, &nch, &lds12)) { set_error("load vector of an expression: the fused contraction kernel does not serve this patch"); return IGX_ERR_UNSUPPORTED; }
+    if (!parametric && pt->geo_kind == IGX_GEO_JACOBIAN) { set_error("a function of the physical coordinates needs a spline geometry"); return IGX_ERR_UNSUPPORTED; }
+    RtcApi *api;
+    return rtc_api(&api);
+}
+
 int launch_lv12_expr(hipStream_t st, igx_patch *pt, const char *expr, int parametric, const double *d_W, double *d_t2, int *hit)
 {
     int clen, nch;
@@ -804,6 +844,7 @@ int launch_lv12_expr(hipStream_t st, igx_patch *pt, const char *expr, int parame
     const AxisDev a1 = pd.ax[1], a2 = pd.ax[2];
     const int npass = std::max(2, (a2.N + 63) / 64);
     hipFunction_t fn;
+    if (int rc = exprs_ok(1, &expr, "igx_load_vector_expr")) return rc;
     if (int rc = rtc_function(pt, lv12_source(a2.P, npass, parametric != 0, expr), "igx_lv12_expr", &fn, hit)) return rc;
     IgxCo co{};
     fill_co(pt, parametric != 0, co);
@@ -822,6 +863,7 @@ int rtc_compile_lv12(int P, int npass, int parametric, const char *expr, const c
     if (!expr || !arch || P < 2 || P > 6 || npass < 2 || npass > 4) { set_error("igx_rtc_compile_load_vector: bad argument"); return IGX_ERR_ARG; }
     std::vector<char> code;
     std::string path;
+    if (int rc = exprs_ok(1, &expr, "igx_rtc_compile_load_vector")) return rc;
     if (int rc = rtc_code_object(lv12_source(P, npass, parametric != 0, expr), arch, code, path, hit)) return rc;
     if (path_out && path_len > 0) { strncpy(path_out, path.c_str(), (size_t)path_len - 1); path_out[path_len - 1] = 0; }
     return IGX_OK;
@@ -832,6 +874,7 @@ int rtc_compile_form(int n_expr, const char *const *expr, const char *arch, char
     if (!expr || !arch || n_expr < 1) { set_error("igx_rtc_compile_form: bad argument"); return IGX_ERR_ARG; }
     std::vector<char> code;
     std::string path;
+    if (int rc = exprs_ok(n_expr, expr, "igx_rtc_compile_form")) return rc;
     if (int rc = rtc_code_object(form_source(n_expr, expr), arch, code, path, hit)) return rc;
     if (path_out && path_len > 0) { strncpy(path_out, path.c_str(), (size_t)path_len - 1); path_out[path_len - 1] = 0; }
     return IGX_OK;

@@ -2253,6 +2253,46 @@ def test_without_the_run_time_compiler_everything_still_assembles(iga, monkeypat
         assert r.shape == o.shape and np.abs(r - o).max() <= 1e-13 * np.abs(r).max()
 
 
+def test_run_time_compiler_errors_are_told_apart(iga, monkeypatch, tmp_path):
+    """(1) 'no run-time compiler' (IGX_ERR_NORTC), 'the expression does not compile' (IGX_ERR_COMPILE) and 'the kernel
+    does not serve this patch' (IGX_ERR_UNSUPPORTED) are different codes -- the Python side falls back to host sampling for these
+    and for nothing else (a device failure must surface); (2) igx_load_vector_expr asks whether it applies BEFORE it touches the
+    weight field; (3) an expression that could end the construct it is pasted into is refused (IGX_ERR_ARG) before anything is
+    generated."""
+    from pyiga_amd import _lib
+    mk = iga.bspline.make_knots
+    kvs = (mk(2, 0., 1., 5), mk(2, 0., 1., 4), mk(2, 0., 1., 6))
+    patch = iga.assemblers.DevicePatch(kvs, _geo(iga, 'cylinder'))
+    good = patch.load_vector_expr('x + y * z')
+    for bad in ('x + y\n+ z', 'x // y', 'x + \\\ny', 'x; y', 'x /* y */', '1) ; } void f() { (0'):
+        with pytest.raises(_lib.IgxError) as ei:
+            patch.load_vector_expr(bad)
+        assert ei.value.code == _lib.IGX_ERR_ARG, (bad, ei.value.code)
+        with pytest.raises(_lib.IgxError) as ei:
+            patch.set_coeff_expr(bad)
+        assert ei.value.code == _lib.IGX_ERR_ARG, (bad, ei.value.code)
+    with pytest.raises(_lib.IgxError) as ei:
+        patch.load_vector_expr('x + undefined_name')
+    assert ei.value.code == _lib.IGX_ERR_COMPILE
+    assert np.array_equal(patch.load_vector_expr('x + y * z'), good)           # the patch is intact after the refusals
+    patch.close()
+    monkeypatch.setenv('IGX_NO_HIPRTC', '1')
+    monkeypatch.setenv('IGX_CACHE_DIR', str(tmp_path / 'empty_cache'))
+    patch = iga.assemblers.DevicePatch(kvs, _geo(iga, 'cylinder'))
+    with pytest.raises(_lib.IgxError) as ei:
+        patch.load_vector_expr('x + y * z + 1')
+    assert ei.value.code == _lib.IGX_ERR_NORTC
+    patch.close()
+    # what may fall back and what may not
+    ok, dev = _lib.IgxError('x'), _lib.IgxError('y')
+    ok.code, dev.code = _lib.IGX_ERR_NORTC, _lib.IGX_ERR_HIP
+    with pytest.warns(RuntimeWarning):
+        assert _lib.sampled_fallback(ok, 'test input %d' % id(ok))
+    assert not _lib.sampled_fallback(dev, 'test input')
+    dev.code = _lib.IGX_ERR_NOMEM
+    assert not _lib.sampled_fallback(dev, 'test input')
+
+
 def test_kronecker_shortcut_refuses_degrees_beyond_its_row_buffers(iga, monkeypatch):
     """k_kron3 stages one 2D row of at most 128 entries per wave; degree 6 on the cross-section axes (13 * 13 = 169)
     must be refused by the library and the opt-in path must fall back to the general chain (same matrix)."""
