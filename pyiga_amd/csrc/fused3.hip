@@ -1053,6 +1053,10 @@ bool fused3_supported(const BFInputs &in)
             if (in.slot_n[y][t1] > 1) return false;
             if (in.slot_n[y][t1] > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }
         }
+    if (in.pad_stiff3) {                                   // general first-order forms: a subset of the stiffness slots, the rest zero rows
+        if (mask & ~BF_MASK_STIFF3) return false;
+        mask = BF_MASK_STIFF3; ymax = 3;
+    }
     if (!in.sym) return mask == BF_MASK_STIFF3;
     return (ymax == 0 && mask == BF_MASK_MASS) || mask == BF_MASK_STIFF3 || mask == BF_MASK_STIFF2;
 }
@@ -1066,6 +1070,7 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
         for (int t1 = 0; t1 < 4; ++t1) {
             const int n = in.slot_n[y][t1];
             if (n > 0) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }
+            if (in.pad_stiff3 && ((BF_MASK_STIFF3 >> (4 * y + t1)) & 1)) { mask |= 1 << (4 * y + t1); ymax = std::max(ymax, y); }   // (absent: the zero row)
             for (int i = 0; i < 2; ++i) {
                 if (i < n) { A.sp[y][t1][i] = in.slot_ptr[y][t1][i]; A.ss[y][t1][i] = in.slice_stride; A.rs[y][t1][i] = AL.G; }
                 else { A.sp[y][t1][i] = in.zeros; A.ss[y][t1][i] = 0; A.rs[y][t1][i] = 0; }

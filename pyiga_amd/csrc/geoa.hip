@@ -64,7 +64,20 @@ struct GeoAArgs {
     int g0_lo, coef_affine;
     double cf[4];
     int soff_ok;                // every K1 slice offset (pairs x stride x 8 bytes) fits 32 bits: scalar-offset stores
+    // general first-order forms (FORM = 2 non-symmetric, 3 symmetric; IGX_FORM given as a coefficient table, igx_patch_set_form_expr):
+    // a(u, v) = int sum_{r,s} P_rs D_r v D_s u, D_0 = id, D_1.. = d/dx, d/dy, d/dz.  Entry 4 r + s of the PHYSICAL table is a
+    // constant (pc), an array sampled on the resident Gauss slab (pa, plane g0_lo first) or absent (bit of pmask clear); the
+    // kernel transforms it at every point, F = W T P T^T with T = diag(1, J^-1) (fields_form, geo_device.h), keeps the entries the
+    // form needs -- fslot[4 a + b]: place of F_ab among the fields of a point in LDS, or -1 -- and array x sums up to four sources
+    // (axis-0 type, field) per plane.
+    double pc[16];
+    const double *pa[16];
+    int pmask, amask, fmask;    // bits 4 r + s: entry present | entry is an array;  bits 4 a + b: F_ab is kept (fslot >= 0)
+    int fslot[16];
+    int nsrc[GA_MAXS], sfield[GA_MAXS][4], stype[GA_MAXS][4];
+    int nslots;                 // arrays the form has (<= 8): the sweep waves beyond them sweep nothing and store nothing
 };
+constexpr int GA_NFT = 10;      // fields of a point a table form may keep in LDS (ten: a symmetric table with every entry)
 
 typedef int int8v __attribute__((ext_vector_type(8)));
 
@@ -206,18 +219,19 @@ struct K1Store {
 #define GA_NGW_N 4
 #endif
 constexpr int GA_NGW = GA_NGW_N;
-constexpr int geoa_threads(int NS, int FORM) { return (NS + (FORM == 1 ? GA_NGW : 0)) * 64; }
+constexpr int geoa_threads(int NS, int FORM) { return (NS + (FORM >= 1 ? GA_NGW : 0)) * 64; }
 template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
-__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? (GA_NGW > 4 ? 4 : 3) : NS >= 8 ? 4 : 1, FORM == 1 ? (GA_NGW > 4 ? 4 : 3) : 4)))
+__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM >= 1 ? (GA_NGW > 4 ? 4 : 3) : NS >= 8 ? 4 : 1, FORM >= 1 ? (GA_NGW > 4 ? 4 : 3) : 4)))
 k_geoA(const GeoAArgs A)
 {
-    constexpr int NGW = FORM == 1 ? GA_NGW : 0;           // geometry waves (0: every sweep wave evaluates the plane of its own number)
+    constexpr int NGW = FORM >= 1 ? GA_NGW : 0;           // geometry waves (0: every sweep wave evaluates the plane of its own number)
+    constexpr bool SYMW = FORM == 0 || FORM == 3;         // lower triangle of the pair window (symmetric forms)
     static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
     static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
-    constexpr int NF = FORM == 1 ? 9 : 6;                 // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
+    constexpr int NF = FORM == 1 ? 9 : FORM >= 2 ? GA_NFT : 6;   // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = (NS + NGW) * 64;                   // threads
-    constexpr int RECW = (MF || FORM == 1) ? GA_REC : 24; // doubles of a plane record that the kernel uses (the row tables: matrix-core / non-symmetric sweeps only)
+    constexpr int RECW = (MF || FORM >= 1) ? GA_REC : 24; // doubles of a plane record that the kernel uses (the row tables: matrix-core / non-symmetric sweeps only)
     constexpr int NRC = NS * RECW;                        // doubles of a batch of plane records
     constexpr int NTS = NGW ? NGW * 64 : NT;              // threads that stage them (the geometry waves where they exist)
     constexpr int KRC = (NRC + NTS - 1) / NTS;            // ... per thread
@@ -234,12 +248,21 @@ k_geoA(const GeoAArgs A)
     constexpr int NPR = P * (P + 1) / 2, NPV = (NPR + 15) / 16;
     constexpr bool DPS = GA_DPP && !MF && FORM == 0 && NPV == 1;
     constexpr int NPVF = (P * P + 15) / 16;               // ... of the full window (non-symmetric forms)
-    constexpr bool DPF = GA_DPP && FORM == 1;
-    __shared__ double prd_[DPS ? 2 * NS * 4 * NPV * 16 : DPF ? 2 * NS * 4 * NPVF * 16 : 2];
+    constexpr bool DPF = GA_DPP && FORM >= 1;
+    constexpr int NPW = FORM == 3 ? NPV : NPVF;           // product registers of a (plane, type): lower triangle or full window
+    __shared__ double prd_[DPS ? 2 * NS * 4 * NPV * 16 : DPF ? 2 * NS * 4 * NPW * 16 : 2];
     __shared__ double Cs[P0G * NC][3][64];                // column coefficients of the block's points, geometry span f0_blk
     __shared__ __attribute__((aligned(16))) double rec[3][NS][RECW];   // plane records of three batches: swept | evaluated | arriving
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // table forms: the 16 constants / array pointers / field slots are read from LDS where they are used (as kernel arguments in
+    // scalar registers they are 80 of the 102 a wave has, hoisted out of every loop: spills)
+    __shared__ double tabc[FORM >= 2 ? 16 : 1];
+    __shared__ const double *tabp[FORM >= 2 ? 16 : 1];
+    __shared__ int tabf[FORM >= 2 ? 16 : 1];
+    if constexpr (FORM >= 2) {
+        if (tid < 16) { tabc[tid] = A.pc[tid]; tabp[tid] = A.pa[tid]; tabf[tid] = A.fslot[tid]; }
+    }
     // consecutive block ids go to different XCDs: give each XCD a contiguous range of point tiles
     const int per_xcd = gridDim.x >> 3;                   // the grid is padded to a multiple of 8 blocks
     int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -363,6 +386,61 @@ k_geoA(const GeoAArgs A)
             FLD(buf, jp, 8, lane) = bs * ((a[6] * Y - a[7] * X) + a[8] * wh);
             return;
         }
+        if constexpr (FORM >= 2) {
+            // general first-order form: physical Jacobian and point, T = diag(1, J^-1), F = W T P T^T (fields_form, geo_device.h)
+            double t[9];                                   // J[r][c] = d G_r / d xi_c, c = 0 the LAST grid axis; NURBS: quotient rule, one reciprocal
+            if constexpr (NC == 4) {
+                const double iW = 1.0 / val[3], iW2 = iW * iW;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) t[r * 3 + c] = (jac[r][2 - c] * val[3] - val[r] * jac[3][2 - c]) * iW2;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) t[r * 3 + c] = jac[r][2 - c];
+            }
+            const double t3 = t[4] * t[8] - t[5] * t[7], t4 = t[3] * t[8] - t[5] * t[6], t5 = t[3] * t[7] - t[4] * t[6];
+            const double det = (t[0] * t3 - t[1] * t4) + t[2] * t5;
+            const double inv = 1.0 / det;
+            double T[4][4];
+            T[1][1] = inv * t3; T[1][2] = inv * -(t[1] * t[8] - t[2] * t[7]); T[1][3] = inv * (t[1] * t[5] - t[2] * t[4]);
+            T[2][1] = inv * -t4; T[2][2] = inv * (t[0] * t[8] - t[2] * t[6]); T[2][3] = inv * -(t[0] * t[5] - t[2] * t[3]);
+            T[3][1] = inv * t5; T[3][2] = inv * -(t[0] * t[7] - t[1] * t[6]); T[3][3] = inv * (t[0] * t[4] - t[1] * t[3]);
+            const double W = GW * fabs(det);
+            // the physical table at this point: wave-uniform choices (constant | sampled array | absent)
+            const long long ip = (long long)(gpl - A.g0_lo) * A.NPL + pt;
+            // (the constants without a test -- an absent entry is the constant 0 -- so that the sixteen LDS reads are in flight
+            // together; the sampled entries, where the form has any, requested one after the other before the first is used)
+            double Pm[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Pm[r][c] = tabc[4 * r + c];
+            if (A.amask) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if ((A.amask >> (4 * r + c)) & 1) Pm[r][c] = tabp[4 * r + c][ip];
+            }
+            // row by row of T P (rows of T act on the test index): few values live at a time
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double TPa[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    TPa[c] = a == 0 ? Pm[0][c] : fma(T[a][3], Pm[3][c], fma(T[a][2], Pm[2][c], T[a][1] * Pm[1][c]));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (!((A.fmask >> (4 * a + b)) & 1)) continue;
+                    const double v = b == 0 ? TPa[0] : fma(TPa[3], T[b][3], fma(TPa[2], T[b][2], TPa[1] * T[b][1]));
+                    FLD(buf, jp, tabf[4 * a + b], lane) = W * v;
+                }
+            }
+            return;
+        }
         if (GA_ONEDIV && NS == 8) {
             // stiffness fields with ONE division (an f64 division is 12 vector instructions).  With the unscaled quotient-rule
             // matrix M = V'W - V W' (J = M / W^2; M = J for a polynomial geometry):
@@ -423,6 +501,11 @@ k_geoA(const GeoAArgs A)
             }
             if (NGW == 0) {
                 if (w <= jl && __builtin_amdgcn_readfirstlane((int)rec[gbuf][w][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, w, gn + w);
+            } else if (FORM >= 2) {
+                // table forms: the evaluation is twice the stiffness form's -- the geometry waves take the planes 0 .. NGW-1 of a
+                // batch, the sweep waves NGW .. NS-1 (the arrays with the fewest sources) the plane of their own number
+                const int jp = w >= NS ? w - NS : (w >= NGW ? w : -1);
+                if (jp >= 0 && jp <= jl && __builtin_amdgcn_readfirstlane((int)rec[gbuf][jp][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, jp, gn + jp);
             } else if (w >= NS) {
                 for (int jp = w - NS; jp <= jl; jp += NGW)
                     if (__builtin_amdgcn_readfirstlane((int)rec[gbuf][jp][19]) == cur && !GA_OFF(1)) evaluate(gbuf, buf, jp, gn + jp);
@@ -572,6 +655,156 @@ k_geoA(const GeoAArgs A)
             next_batch(gb + NS, rn, buf ^ 1);
             products(gb + NS, rn, buf ^ 1);
             stage_store(ra);
+            rs = rn;
+            __syncthreads();
+        }
+        return;
+    }
+    // ---- general first-order forms (coefficient table; FORM = 2: full pair window, FORM = 3: symmetric table, lower triangle): the
+    // block structure of the convection-diffusion form below -- geometry waves evaluate the next batch beside eight sweep waves --
+    // with up to four sources per array and the symmetric flush where the table is symmetric
+    if constexpr (FORM >= 2) {
+        static_assert(DPF, "the table forms sweep with row-broadcast multiply-adds");
+        constexpr int PW = NPW * 16;
+        auto products_tab = [&](const int rsl, const int bufn) {
+            for (int i = tid - NS * 64; i < NS * 4 * PW; i += NGW * 64) {
+                const int jp = i / (4 * PW), r = i - jp * (4 * PW), ty = r / PW, m = r - ty * PW;
+                int a, b;
+                bool ok;
+                if (SYMW) {                               // m = a (a + 1) / 2 + b, b <= a
+                    a = 0;
+                    while ((a + 1) * (a + 2) / 2 <= m) ++a;
+                    b = m - a * (a + 1) / 2; ok = a < P;
+                    a = min(a, P - 1); b = min(b, P - 1);
+                } else { a = min(m / P, P - 1); b = m - (m / P) * P; ok = m < P * P; }
+                const double x = rec[rsl][jp][6 * (ty >> 1) + a] * rec[rsl][jp][6 * (ty & 1) + b];
+                prd_[(bufn * NS + jp) * (4 * PW) + r] = ok ? x : 0.0;
+            }
+        };
+        if (w >= NS) {
+            stage_load(g_begin); stage_store(0);
+            stage_load(g_begin + NS); stage_store(1);
+            __syncthreads();
+            next_batch(g_begin, 0, 0);
+            products_tab(0, 0);
+            __syncthreads();
+            int it = 0, rs = 0;
+            for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+                const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
+                stage_load(gb + 2 * NS);
+                next_batch(gb + NS, rn, (it & 1) ^ 1);
+                products_tab(rn, (it & 1) ^ 1);
+                stage_store(ra);
+                rs = rn;
+                __syncthreads();
+            }
+            return;
+        }
+        const bool live = w < A.nslots;
+        const int nsrc = live ? A.nsrc[w] : 1;
+        double *const out = A.out[w] + pt;
+        const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
+        double acc[P][P];
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) acc[a][b] = 0.0;
+        __syncthreads();
+        next_batch(g_begin, 0, 0);                        // (the planes NGW .. NS-1 of a batch are evaluated here: see next_batch)
+        __syncthreads();
+        int it = 0, l = 0, sp = s_begin, rs = 0;
+        for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
+            const int buf = it & 1;
+            const int rn = rs == 2 ? 0 : rs + 1;
+            auto operands = [&](double (&pv)[NPW], double &bv, const int j, const int k) {
+                const int ty = A.stype[w][k], ff = A.sfield[w][k];       // (uniform: scalar loads of the kernel arguments)
+                const double *pr_ = &prd_[((buf * NS + j) * 4 + ty) * PW + (lane & 15)];
+#pragma unroll
+                for (int e = 0; e < NPW; ++e) pv[e] = pr_[16 * e];
+                bv = FLD(buf, j, ff, lane);
+            };
+            double pv0[NPW], bv0;
+            operands(pv0, bv0, 0, 0);
+#pragma unroll 1
+            for (int j = 0; j < NS; ++j) {
+                if (gb + j >= g_end) break;
+                // the first source of the next plane is requested before this plane's arithmetic; further sources as they come
+                double pn[NPW], bn;
+                operands(pn, bn, j + 1 < NS ? j + 1 : j, 0);
+                // (the further sources of this plane: all requested before the first multiply-add)
+                double pv1[NPW], pv2[NPW], pv3[NPW], bv1 = 0.0, bv2 = 0.0, bv3 = 0.0;
+                if (nsrc > 1) operands(pv1, bv1, j, 1);
+                if (nsrc > 2) operands(pv2, bv2, j, 2);
+                if (nsrc > 3) operands(pv3, bv3, j, 3);
+                asm volatile("" ::: "memory");
+                if constexpr (SYMW) sweep_lower_rowbc<P>(acc, pv0, bv0);
+                else sweep_full_rowbc<P>(acc, pv0, bv0);
+                if (nsrc > 1) { if constexpr (SYMW) sweep_lower_rowbc<P>(acc, pv1, bv1); else sweep_full_rowbc<P>(acc, pv1, bv1); }
+                if (nsrc > 2) { if constexpr (SYMW) sweep_lower_rowbc<P>(acc, pv2, bv2); else sweep_full_rowbc<P>(acc, pv2, bv2); }
+                if (nsrc > 3) { if constexpr (SYMW) sweep_lower_rowbc<P>(acc, pv3, bv3); else sweep_full_rowbc<P>(acc, pv3, bv3); }
+#pragma unroll
+                for (int a = 0; a < P; ++a)
+#pragma unroll
+                    for (int b = 0; b < (SYMW ? a + 1 : P); ++b) asm volatile("" : "+v"(acc[a][b]));
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < NPW; ++e) pv0[e] = pn[e];
+                bv0 = bn;
+                if (++l < q) continue;
+                const bool write = sp >= own_lo && live && !GA_OFF(2);
+                const int *fr = (const int *)&rec[rs][j][20];
+                const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
+                for (int st = st0; st < st0 + nst; ++st) {
+                    if constexpr (SYMW) {
+                        int pr[P];
+                        if (st == st0) {
+#pragma unroll
+                            for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(fr[2 + a]);
+                        } else {
+                            const int8v rec8 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 8);
+#pragma unroll
+                            for (int a = 0; a < P; ++a) pr[a] = rec8[a];
+                        }
+#pragma unroll
+                        for (int a = 0; a < P; ++a)
+                            if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);
+#pragma unroll
+                        for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                            for (int b = 0; b <= a; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+                        for (int b = 0; b < P; ++b) acc[P - 1][b] = 0.0;
+                    } else {
+                        int pr[16];
+                        if (st == st0) {
+                            const int *f16 = (const int *)&rec[rs][j][24];
+#pragma unroll
+                            for (int a = 0; a < P; ++a) pr[a] = __builtin_amdgcn_readfirstlane(f16[a]);
+#pragma unroll
+                            for (int a = 1; a < P; ++a) pr[8 + a] = __builtin_amdgcn_readfirstlane(f16[8 + a]);
+                        } else {
+                            const int8v r0 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 16);
+                            const int8v r1 = *(const int8v __attribute__((address_space(4))) *)((cip)A.steps + (size_t)st * 16 + 8);
+#pragma unroll
+                            for (int a = 0; a < P; ++a) { pr[a] = r0[a]; pr[8 + a] = r1[a]; }
+                        }
+#pragma unroll
+                        for (int a = 0; a < P; ++a)
+                            if (pr[a] >= 0 && write) k1s.store(out, pr[a], A.stride, acc[a][0]);
+#pragma unroll
+                        for (int a = 1; a < P; ++a)
+                            if (pr[8 + a] >= 0 && write) k1s.store(out, pr[8 + a], A.stride, acc[0][a]);
+#pragma unroll
+                        for (int a = 0; a < P - 1; ++a)
+#pragma unroll
+                            for (int b = 0; b < P - 1; ++b) acc[a][b] = acc[a + 1][b + 1];
+#pragma unroll
+                        for (int b = 0; b < P; ++b) { acc[P - 1][b] = 0.0; acc[b][P - 1] = 0.0; }
+                    }
+                }
+                l = 0; ++sp;
+            }
+            next_batch(gb + NS, rn, buf ^ 1);
             rs = rn;
             __syncthreads();
         }
@@ -1036,12 +1269,24 @@ bool geoA_supported(const igx_patch *pt, int kind, int nslots)
     return 2 * gspans <= (long long)pt->ax[0].G;
 }
 
-int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
-                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield, const int *slot_xtype)
+// general first-order forms (coefficient table): 3D spline geometries, degrees 2 .. 5 on axis 0, the whole Gauss slab resident
+bool geoA_form_supported(const igx_patch *pt)
 {
-    const bool nonsym = kind == IGX_CONVDIFF;
+    if (pt->dim != 3 || pt->boxed || !pt->knobs.geoa) return false;
+    if (pt->geo_kind != IGX_GEO_BSPLINE && pt->geo_kind != IGX_GEO_NURBS) return false;
+    const int P = pt->ax[0].P, p0g = pt->gax[0].P;
+    if (P < 3 || P > 6 || p0g < 2 || p0g > 3) return false;
+    const long long gspans = pt->gax[0].N - pt->gax[0].P + 1;
+    return 2 * gspans <= (long long)pt->ax[0].G;
+}
+
+int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield, const int *slot_xtype,
+                const GeoAForm *form)
+{
+    const bool nonsym = kind == IGX_CONVDIFF || (form && !form->sym);
     if (nonsym) {
-        if (!pt->coef_affine && !pt->coeff_sampled) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
+        if (kind == IGX_CONVDIFF && !pt->coef_affine && !pt->coeff_sampled) { set_error("IGX_CONVDIFF needs igx_patch_set_coeff first"); return IGX_ERR_ARG; }
         if (!pt->d_stepsn) { set_error("internal: flush records of the non-symmetric form are missing"); return IGX_ERR_UNSUPPORTED; }
         if (!pt->d_geoa_tabn) {                          // per-plane records with the 16-int flush steps of the non-symmetric sweep
             double *tab = nullptr;
@@ -1129,12 +1374,28 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     { const char *e = getenv("IGX_GEOA_DBG"); A.dbg = e ? atoi(e) : 0; }
 #endif
     for (int x = 0; x < nslots; ++x) {
-        A.field[x] = slot_field[x]; A.type[x] = slot_type[x]; A.out[x] = slot_out[x];
+        A.field[x] = slot_field ? slot_field[x] : 0; A.type[x] = slot_type ? slot_type[x] : 0; A.out[x] = slot_out[x];
         A.xfield[x] = slot_xfield ? slot_xfield[x] : -1; A.xtype[x] = slot_xtype ? slot_xtype[x] : 0;
     }
     A.ntiles = (int)((A.NPL + 63) / 64);
     dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs
     const int nc = pt->ncomp, p0g = pt->gax[0].P;
+    if (form) {
+        for (int k = 0; k < 16; ++k) { A.pc[k] = form->pc[k]; A.pa[k] = form->pa[k]; A.fslot[k] = form->fslot[k]; }
+        A.pmask = form->pmask; A.nslots = nslots; A.amask = 0; A.fmask = 0;
+        for (int k = 0; k < 16; ++k) { if (form->pa[k]) A.amask |= 1 << k; if (form->fslot[k] >= 0) A.fmask |= 1 << k; }
+        for (int x = 0; x < GA_MAXS; ++x) {
+            A.nsrc[x] = x < nslots ? form->nsrc[x] : 1;
+            for (int k = 0; k < 4; ++k) { A.sfield[x][k] = x < nslots ? form->sfield[x][k] : 0; A.stype[x][k] = x < nslots ? form->stype[x][k] : 0; }
+            if (x >= nslots) A.out[x] = A.out[0];
+        }
+#define GEOA_T(PV, FV) case PV: return p0g == 2 ? launch_geoA_k<PV, 8, 2, false, FV>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<PV, 8, 3, false, FV>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED
+        if (form->sym) switch (A0.P) { GEOA_T(3, 3); GEOA_T(4, 3); GEOA_T(5, 3); GEOA_T(6, 3); }
+        else switch (A0.P) { GEOA_T(3, 2); GEOA_T(4, 2); GEOA_T(5, 2); GEOA_T(6, 2); }
+#undef GEOA_T
+        set_error("fused geometry + stage A (general form): unsupported degree %d", A0.p);
+        return IGX_ERR_UNSUPPORTED;
+    }
     if (nonsym) {
 #define GEOA_N(PV) case PV: return p0g == 2 ? launch_geoA_k<PV, 8, 2, false, 1>(st, A, nc, grid) : p0g == 3 ? launch_geoA_k<PV, 8, 3, false, 1>(st, A, nc, grid) : IGX_ERR_UNSUPPORTED
         switch (A0.P) {

@@ -366,6 +366,7 @@ void igx_patch_destroy(igx_patch *pt)
     (void)hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
     (void)hipFree(pt->d_ctrl); (void)hipFree(pt->d_jac); (void)hipFree(pt->d_coeff); (void)hipFree(pt->d_formc); (void)hipFree(pt->d_fields); (void)hipFree(pt->d_data);
+    (void)hipFree(pt->ftab_arr);
     (void)hipFree(pt->d_indices); (void)hipFree(pt->d_indptr); (void)hipFree(pt->d_pl0); (void)hipFree(pt->d_rl0_of); (void)hipFree(pt->d_steps); (void)hipFree(pt->d_ldesc);
     (void)hipFree(pt->d_pl0n); (void)hipFree(pt->d_stepsn); (void)hipFree(pt->d_qdesc); (void)hipFree(pt->d_qdescn);
     (void)hipFree(pt->d_K1); (void)hipFree(pt->d_K2);
@@ -657,6 +658,7 @@ int igx_patch_set_pform(igx_patch *pt, int n, const int *masks, const double *co
     for (int k = 0; k < 16; ++k) { pt->form_slot[k] = k < n ? k : -1; pt->dev.form_ab[k] = k < n ? ((masks[2 * k] << 3) | masks[2 * k + 1]) : 0; }
     pt->dev.form_n = n;
     pt->dev.form_par = 1;
+    pt->ftab.valid = false;
     pt->fields_kind = -1;
     return IGX_OK;
 }
@@ -702,12 +704,69 @@ static int basis_orders_ok(const igx_patch *pt, int kind, const char *who)
     return IGX_ERR_ARG;
 }
 
-int igx_patch_set_form(igx_patch *pt, const double *const coef[16]) { return set_form_impl(pt, coef, false, "igx_patch_set_form"); }
+int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
+{
+    if (pt) pt->ftab.valid = false;                      // (sampled coefficients: the stage kernels over the field arrays)
+    return set_form_impl(pt, coef, false, "igx_patch_set_form");
+}
 
 // The coefficient table of IGX_FORM as C expressions in the physical coordinates.  Spline geometries: the expressions are
 // compiled INTO the field kernel of the form (rtc.hip, igx_form_fields) -- nothing is evaluated or stored here, the
 // coefficients never exist as arrays.  Otherwise (control lines beyond LDS): one generated kernel evaluates them at the
 // resident Gauss points and the arrays take the way of igx_patch_set_form_d.
+// The physical coefficient table of a form given as expressions, as the fast chain wants it: constants told from expressions
+// (a constant is a number, possibly in parentheses: pyiga_amd.symbolic writes them so), equal entries found by their text.
+static void capture_form_table(igx_patch *pt, const char *const expr[16])
+{
+    igx_patch::FormTable &T = pt->ftab;
+    T = igx_patch::FormTable();
+    (void)hipFree(pt->ftab_arr); pt->ftab_arr = nullptr; pt->ftab_ready = false;
+    for (int k = 0; k < 16; ++k) {
+        T.arr_of[k] = -1;
+        if (!expr[k]) continue;
+        T.present |= 1 << k;
+        std::string e(expr[k]);
+        // strip blanks and balanced outer parentheses
+        auto strip = [](std::string x) {
+            for (;;) {
+                while (!x.empty() && isspace((unsigned char)x.front())) x.erase(x.begin());
+                while (!x.empty() && isspace((unsigned char)x.back())) x.pop_back();
+                if (x.size() >= 2 && x.front() == '(' && x.back() == ')') {
+                    int depth = 0; bool outer = true;
+                    for (size_t i = 0; i + 1 < x.size(); ++i) { depth += x[i] == '(' ? 1 : x[i] == ')' ? -1 : 0; if (depth == 0) { outer = false; break; } }
+                    if (outer) { x = x.substr(1, x.size() - 2); continue; }
+                }
+                return x;
+            }
+        };
+        const std::string b = strip(e);
+        char *end = nullptr;
+        const double v = b.empty() ? 0.0 : strtod(b.c_str(), &end);
+        if (!b.empty() && end && *end == 0) { T.is_const |= 1 << k; T.cval[k] = v; }
+        else T.expr[k] = e;
+    }
+    auto same = [&](int i, int j) {
+        const bool pi = (T.present >> i) & 1, pj = (T.present >> j) & 1;
+        if (pi != pj) return false;
+        if (!pi) return true;
+        const bool ci = (T.is_const >> i) & 1, cj = (T.is_const >> j) & 1;
+        if (ci != cj) return false;
+        return ci ? T.cval[i] == T.cval[j] : T.expr[i] == T.expr[j];
+    };
+    T.sym = true; T.blocksym = true;
+    for (int r = 0; r < 4; ++r)
+        for (int c = r + 1; c < 4; ++c)
+            if (!same(4 * r + c, 4 * c + r)) { T.sym = false; if (r >= 1) T.blocksym = false; }
+    // arrays: one per distinct expression text
+    for (int k = 0; k < 16; ++k) {
+        if (!((T.present >> k) & 1) || ((T.is_const >> k) & 1)) continue;
+        for (int j = 0; j < k; ++j)
+            if (T.arr_of[j] >= 0 && T.expr[j] == T.expr[k]) { T.arr_of[k] = T.arr_of[j]; break; }
+        if (T.arr_of[k] < 0) T.arr_of[k] = T.narr++;
+    }
+    T.valid = true;
+}
+
 int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cache_hit)
 {
     if (!pt || !expr) { set_error("igx_patch_set_form_expr: null argument"); return IGX_ERR_ARG; }
@@ -722,6 +781,7 @@ int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cach
         for (int s = 0; s < 4; ++s)
             if (expr[4 * r + s] && (r >= nj || s >= nj)) { set_error("igx_patch_set_form_expr: coefficient (%d,%d) does not exist in %dD", r, s, pt->dim); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
+    capture_form_table(pt, expr);
     if (form_fields_applicable(pt)) {
         int form_ab[16];
         const int nt = form_terms(pt->dim, expr, form_ab);
@@ -763,7 +823,11 @@ int igx_rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], 
     return rtc_compile_form_fields(dim, ncomp, expr, arch, path_out, path_len, cache_hit);
 }
 
-int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16]) { return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d"); }
+int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16])
+{
+    if (pt) pt->ftab.valid = false;                      // (sampled coefficients: the stage kernels over the field arrays)
+    return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d");
+}
 
 int igx_patch_gauss(const igx_patch *pt, int axis, double *nodes, double *weights)
 {

@@ -150,6 +150,19 @@ struct igx_patch {
     double *d_formc = nullptr;                // IGX_FORM: physical coefficient fields [n][npts_loc]
     int form_slot[16];                        //   4*r+s -> row of d_formc or -1
     void *form_fn = nullptr;                  // IGX_FORM given as expressions: the generated field kernel (rtc.hip); no d_formc then
+    // ... and its PHYSICAL coefficient table as the fast chain reads it (k_geoA<FORM = 2 | 3> evaluates the fields inside the sweep;
+    // sumfact.hip: form_table_plan): entry 4 r + s is a constant, an expression (sampled into ftab_arr when the chain first runs),
+    // or absent
+    struct FormTable {
+        bool valid = false, sym = false, blocksym = false;    // sym: P_rs == P_sr for all r, s; blocksym: for r, s >= 1
+        int present = 0, is_const = 0;                        // bit masks over 4 r + s
+        double cval[16] = {0};
+        std::string expr[16];
+        int arr_of[16];                                       // index of the entry's array in ftab_arr, or -1
+        int narr = 0;
+    } ftab;
+    double *ftab_arr = nullptr;                               // [narr][npts_loc] sampled non-constant entries (lazily)
+    bool ftab_ready = false;
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     int coef_affine = 0;                      // ... set by igx_patch_set_coeff_affine: k_geoA evaluates it from the geometry map
     bool coeff_sampled = false;               // d_coeff holds the values of the current coefficient (an affine one is sampled only when a kernel that reads the array runs: ensure_coeff)
@@ -270,6 +283,7 @@ constexpr size_t IGX_DUMP_PAD = 1024 * 16 + 16;   // doubles behind the CSR valu
 inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF && kind != IGX_FORM; }
 // fused sweep + final stage and mirror pass (fused.hip)
 struct BFInputs {
+    int pad_stiff3 = 0;                       // treat the slot set as the full first-order set (absent slots read the zero row): general forms
     const Axis *mid, *last;                   // swept axis, last (contiguous) axis
     int slot_n[4][4];                         // [last-axis type y][mid-axis type t1]: number of input arrays (<= 2)
     const double *slot_ptr[4][4][2];          // their device pointers: array[slice][g_mid - gmid_lo][g_last]
@@ -301,8 +315,19 @@ bool fused3_degrees(int P1, int P2, int Q, bool sym3d, bool mid_simple);
 int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);
+// table of a general first-order form for k_geoA (FORM = 2 | 3): see GeoAArgs (geoa.hip)
+struct GeoAForm {
+    int sym;                                  // symmetric table: lower pairs of axis 0, symmetric flush
+    double pc[16];
+    const double *pa[16];
+    int pmask;
+    int fslot[16];
+    int nsrc[8], sfield[8][4], stype[8][4];
+};
 int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *slot_field, const int *slot_type,
-                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield = nullptr, const int *slot_xtype = nullptr);
+                double *const *slot_out, long long slice_stride, int chunk_len, int nchunks, const int *slot_xfield = nullptr, const int *slot_xtype = nullptr,
+                const GeoAForm *form = nullptr);
+bool geoA_form_supported(const igx_patch *pt);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
 // device time of the mirror pass of this patch on `buf` (access pattern only: the values are whatever the buffer holds);
 // < 0 when the patch has no such pass

@@ -811,9 +811,11 @@ static bool single2d_wanted(const igx_patch *pt, int kind)
     return nb >= 0 && nb <= SINGLE2D_MAX_BLOCKS && rows <= SINGLE2D_MAX_TILE;
 }
 
+bool form_on_fast_chain(const igx_patch *pt);
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
     if (single2d_wanted(pt, kind)) return false;
+    if (kind == IGX_FORM && pt->dim == 3 && form_on_fast_chain(pt)) return false;
     if (pt->dim != 3) return true;
     // the convection-diffusion form: its eight merged slots exist where the fused stage runs (sumfact_assemble)
     if (!igx_kind_symmetric(kind)) return !(kind == IGX_CONVDIFF && (fused_applicable(pt) || fused3_axes(pt, false)) && geoA_wanted(pt, kind, 8));
@@ -926,11 +928,155 @@ float sumfact_probe_mirror(igx_patch *pt, double *buf)
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// General first-order forms on the fast chain (round 6).  A form given as a coefficient table (igx_patch_set_form_expr: constants
+// and expressions in the physical coordinates) needs no field arrays: k_geoA<FORM = 2 | 3> evaluates F = W T P T^T at every point
+// inside the axis-0 sweep -- the constants ride in the kernel arguments, an expression is sampled once into an array of its own
+// (the generated coefficient kernel of rtc.hip) -- and sums the up to four (axis-0 type, field) sources of every (mid, last)-type
+// slot into ONE K1 array, which is what k_bf3 wants.  A symmetric table takes the symmetric chain: lower pairs of axis 0, both
+// triangles from k_bf3<SYM = 2>, exactly symmetric result -- half the work of the reference's default for such a form.
+// Reference: pyiga/vform.py:705-731 (finalize), pyiga/codegen/cython.py:325-387 (the generated combine), assemble.py:837-897.
+struct FormPlan {
+    bool ok = false, sym = false;
+    GeoAForm g;
+    int narr = 0;
+    int slot_arr[4][4];                                  // (last-axis type y, mid-axis type t1) -> K1 array, or -1
+    bool mass_only = false;
+};
+
+static FormPlan form_table_plan(const igx_patch *pt)
+{
+    FormPlan fp;
+    const igx_patch::FormTable &T = pt->ftab;
+    if (!T.valid || pt->dim != 3 || pt->dev.form_par || !geoA_form_supported(pt) || pt->knobs.path == 2 || pt->knobs.final_sel) return fp;
+    fp.sym = T.sym;
+    if (!fused3_axes(pt, fp.sym)) return fp;
+    memset(&fp.g, 0, sizeof(fp.g));
+    fp.g.sym = fp.sym ? 1 : 0;
+    for (int y = 0; y < 4; ++y) for (int t1 = 0; t1 < 4; ++t1) fp.slot_arr[y][t1] = -1;
+    for (int k = 0; k < 16; ++k) { fp.g.fslot[k] = -1; fp.g.pc[k] = ((T.is_const >> k) & 1) ? T.cval[k] : 0.0; fp.g.pa[k] = nullptr; }
+    fp.g.pmask = T.present;
+    // parametric entries F_ab that do not vanish identically, their canonical representative and its place among the fields
+    auto has = [&](int r, int c) { return ((T.present >> (4 * r + c)) & 1) != 0; };
+    bool any00 = has(0, 0), any0s = false, anyr0 = false, anyrs = false;
+    for (int k = 1; k < 4; ++k) {
+        any0s = any0s || has(0, k); anyr0 = anyr0 || has(k, 0);
+        for (int c = 1; c < 4; ++c) anyrs = anyrs || has(k, c);
+    }
+    int nf = 0;
+    struct Src { int t0, f; bool operator<(const Src &o) const { return t0 != o.t0 ? t0 < o.t0 : f < o.f; } bool operator==(const Src &o) const { return t0 == o.t0 && f == o.f; } };
+    std::vector<Src> slot_src[4][4];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const bool nz = a == 0 ? (b == 0 ? any00 : any0s) : (b == 0 ? anyr0 : anyrs);
+            if (!nz) continue;
+            int ca = a, cb = b;                              // canonical entry: F_ab = F_ba where the table says so
+            if (a > b && (T.sym || (T.blocksym && b >= 1))) { ca = b; cb = a; }
+            if (fp.g.fslot[4 * ca + cb] < 0) {
+                if (nf >= 10) return fp;                     // (GA_NFT fields of a point in LDS)
+                fp.g.fslot[4 * ca + cb] = nf++;
+            }
+            // a: test function v, b: trial function u; jet index c >= 1 differentiates grid axis 3 - c (form_terms)
+            int t[3];
+            for (int ax = 0; ax < 3; ++ax) t[ax] = ((b >= 1 && ax == 3 - b) ? 1 : 0) + 2 * ((a >= 1 && ax == 3 - a) ? 1 : 0);
+            slot_src[t[2]][t[1]].push_back(Src{t[0], fp.g.fslot[4 * ca + cb]});
+        }
+    // (the entries that are only representatives of others must still be evaluated: fslot is set for canonical ones only)
+    std::vector<std::vector<Src>> arrs;
+    int mask = 0;
+    for (int y = 0; y < 4; ++y)
+        for (int t1 = 0; t1 < 4; ++t1) {
+            std::vector<Src> &v = slot_src[y][t1];
+            if (v.empty()) continue;
+            if (v.size() > 4) return fp;
+            std::sort(v.begin(), v.end());
+            mask |= 1 << (4 * y + t1);
+            int found = -1;
+            for (size_t x = 0; x < arrs.size(); ++x)
+                if (arrs[x] == v) found = (int)x;
+            if (found < 0) { found = (int)arrs.size(); arrs.push_back(v); }
+            fp.slot_arr[y][t1] = found;
+        }
+    if (arrs.empty() || arrs.size() > 8) return fp;
+    // arrays with more sources first: array x is swept by wave x, the waves of a workgroup go to the four SIMDs cyclically
+    std::vector<int> order(arrs.size());
+    for (size_t x = 0; x < arrs.size(); ++x) order[x] = (int)x;
+    std::stable_sort(order.begin(), order.end(), [&](int i, int j) { return arrs[i].size() > arrs[j].size(); });
+    std::vector<int> newidx(arrs.size());
+    for (size_t x = 0; x < arrs.size(); ++x) newidx[order[x]] = (int)x;
+    for (int y = 0; y < 4; ++y) for (int t1 = 0; t1 < 4; ++t1) if (fp.slot_arr[y][t1] >= 0) fp.slot_arr[y][t1] = newidx[fp.slot_arr[y][t1]];
+    for (size_t x = 0; x < arrs.size(); ++x) {
+        const std::vector<Src> &v = arrs[order[x]];
+        fp.g.nsrc[x] = (int)v.size();
+        for (size_t k = 0; k < v.size(); ++k) { fp.g.stype[x][k] = v[k].t0; fp.g.sfield[x][k] = v[k].f; }
+    }
+    fp.narr = (int)arrs.size();
+    fp.mass_only = mask == 1;
+    if (!fp.sym && fp.mass_only) return fp;                  // (u v alone is symmetric; a non-symmetric table cannot get here)
+    fp.ok = true;
+    return fp;
+}
+
+bool form_on_fast_chain(const igx_patch *pt) { return form_table_plan(pt).ok; }
+
+static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data, bool use3);
+static int assemble_form_table(igx_patch *pt, FormPlan &fp, double *d_data)
+{
+    hipStream_t st = pt->ctx->stream;
+    const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
+    const long long NPL = (long long)A1.G * A2.G;
+    const bool sym = fp.sym;
+    if (!sym && prepare_nonsym(pt)) return IGX_ERR_HIP;
+    const int np0 = sym ? pt->npairs0 : pt->npairs0n;
+    const int *d_pl0 = sym ? pt->d_pl0 : pt->d_pl0n;
+    if (np0 == 0) return IGX_OK;
+    // the entries of the table that are functions: sampled once per patch by the generated coefficient kernel
+    igx_patch::FormTable &T = pt->ftab;
+    const size_t npts = (size_t)pt->dev.npts_loc;
+    if (T.narr > 0 && !pt->ftab_ready) {
+        std::vector<const char *> list((size_t)T.narr, nullptr);
+        for (int k = 0; k < 16; ++k)
+            if (T.arr_of[k] >= 0 && !list[(size_t)T.arr_of[k]]) list[(size_t)T.arr_of[k]] = T.expr[k].c_str();
+        if (!pt->ftab_arr && hipMalloc((void **)&pt->ftab_arr, std::max<size_t>(1, (size_t)T.narr * npts) * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError(); pt->ftab_arr = nullptr;
+            set_error("hipMalloc of %.2f GB for the sampled coefficients of the form failed", T.narr * npts * 8.0 / 1e9);
+            return IGX_ERR_NOMEM;
+        }
+        int hit = 0;
+        if (int rc = launch_form_exprs(st, pt, T.narr, list.data(), pt->ftab_arr, &hit)) return rc;
+        pt->ftab_ready = true;
+    }
+    for (int k = 0; k < 16; ++k) fp.g.pa[k] = T.arr_of[k] >= 0 ? pt->ftab_arr + (size_t)T.arr_of[k] * npts : nullptr;
+    if (ensure(st, &pt->d_K1, &pt->K1_cap, (size_t)fp.narr * np0 * NPL)) return IGX_ERR_NOMEM;
+    stage_event(pt, 1, st);
+    double *so[8];
+    for (int x = 0; x < fp.narr; ++x) so[x] = pt->d_K1 + (size_t)x * np0 * NPL;
+    const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P);
+    if (int rc = launch_geoA(st, pt, IGX_FORM, fp.narr, nullptr, nullptr, so, NPL, ch.len, ch.nchunks, nullptr, nullptr, &fp.g)) return rc;
+    pt->last_path |= IGX_PATH_GEOA;
+    pt->timing.n_launches++;
+    stage_event(pt, 2, st);
+    BFInputs in{};
+    bool ok = true;
+    for (int y = 0; y < 4; ++y)
+        for (int t1 = 0; t1 < 4; ++t1)
+            if (fp.slot_arr[y][t1] >= 0) ok = ok && bf_add_slot(in, y, t1, pt->d_K1 + (size_t)fp.slot_arr[y][t1] * np0 * NPL);
+    in.sym = sym ? 1 : 0;
+    in.pad_stiff3 = fp.mass_only ? 0 : 1;
+    if (!ok || !fused3_supported(in)) { set_error("internal: the slots of the form do not fit the fused stage"); return IGX_ERR_UNSUPPORTED; }
+    in.slice_stride = NPL; in.gmid_lo = 0; in.pl0 = d_pl0; in.npairs = np0;
+    return run_fused(pt, in, sym, d_data, true);
+}
+
 int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
 {
     hipStream_t st = pt->ctx->stream;
     const int dim = pt->dim;
     const PatchDev &pd = pt->dev;
+    if (kind == IGX_FORM && dim == 3) {                   // a coefficient table on the fast chain: no field arrays
+        FormPlan fp = form_table_plan(pt);
+        if (fp.ok) return assemble_form_table(pt, fp, d_data);
+    }
     std::vector<Term> terms = form_terms(dim, kind, &pd);
     const Axis &A0 = pt->ax[0], &A1 = pt->ax[1], &A2 = pt->ax[2];
     const long long NPL = (long long)A1.G * (dim == 3 ? A2.G : 1);
