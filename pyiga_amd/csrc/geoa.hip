@@ -219,12 +219,20 @@ struct K1Store {
 #define GA_NGW_N 4
 #endif
 constexpr int GA_NGW = GA_NGW_N;
-constexpr int geoa_threads(int NS, int FORM) { return (NS + (FORM >= 1 ? GA_NGW : 0)) * 64; }
+// geometry waves of a block: none (FORM = 0: every sweep wave evaluates the plane of its number), GA_NGW beside the eight sweep waves
+// of the convection-diffusion form (two planes each), eight for the table forms (their evaluation is twice as long: one plane each,
+// sixteen waves of 128 registers)
+#ifndef GA_NGW_T
+#define GA_NGW_T 8
+#endif
+constexpr int geoa_ngw(int FORM) { return FORM >= 2 ? GA_NGW_T : FORM == 1 ? GA_NGW : 0; }
+constexpr int geoa_wpe(int NS, int FORM) { return FORM >= 1 ? (geoa_ngw(FORM) > 4 ? 4 : 3) : NS >= 8 ? 4 : 1; }
+constexpr int geoa_threads(int NS, int FORM) { return (NS + geoa_ngw(FORM)) * 64; }
 template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
-__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(FORM >= 1 ? (GA_NGW > 4 ? 4 : 3) : NS >= 8 ? 4 : 1, FORM >= 1 ? (GA_NGW > 4 ? 4 : 3) : 4)))
+__global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(geoa_wpe(NS, FORM), FORM >= 1 ? geoa_wpe(NS, FORM) : 4)))
 k_geoA(const GeoAArgs A)
 {
-    constexpr int NGW = FORM >= 1 ? GA_NGW : 0;           // geometry waves (0: every sweep wave evaluates the plane of its own number)
+    constexpr int NGW = geoa_ngw(FORM);                   // geometry waves (0: every sweep wave evaluates the plane of its own number)
     constexpr bool SYMW = FORM == 0 || FORM == 3;         // lower triangle of the pair window (symmetric forms)
     static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
     static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
@@ -682,8 +690,11 @@ k_geoA(const GeoAArgs A)
             }
         };
         if (w >= NS) {
+            // (the plane records of batch it + 2 are REQUESTED an iteration before they are written to LDS: the round trip of the
+            // request lies beside a whole iteration, not inside one -- with one block per CU nothing else hides it)
             stage_load(g_begin); stage_store(0);
             stage_load(g_begin + NS); stage_store(1);
+            stage_load(g_begin + 2 * NS);
             __syncthreads();
             next_batch(g_begin, 0, 0);
             products_tab(0, 0);
@@ -691,10 +702,10 @@ k_geoA(const GeoAArgs A)
             int it = 0, rs = 0;
             for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
                 const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
-                stage_load(gb + 2 * NS);
+                stage_store(ra);
+                stage_load(gb + 3 * NS);
                 next_batch(gb + NS, rn, (it & 1) ^ 1);
                 products_tab(rn, (it & 1) ^ 1);
-                stage_store(ra);
                 rs = rn;
                 __syncthreads();
             }
@@ -702,6 +713,11 @@ k_geoA(const GeoAArgs A)
         }
         const bool live = w < A.nslots;
         const int nsrc = live ? A.nsrc[w] : 1;
+        // (types and fields of the sources in scalar registers, read ONCE: a scalar load inside the plane loop waits on the
+        // counter the LDS reads use and drains them; every use below names its source by a constant)
+        int sty[4], sfl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sty[k] = __builtin_amdgcn_readfirstlane(A.stype[w][k]); sfl[k] = __builtin_amdgcn_readfirstlane(A.sfield[w][k]); }
         double *const out = A.out[w] + pt;
         const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
         double acc[P][P];
@@ -716,26 +732,26 @@ k_geoA(const GeoAArgs A)
         for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
             const int buf = it & 1;
             const int rn = rs == 2 ? 0 : rs + 1;
-            auto operands = [&](double (&pv)[NPW], double &bv, const int j, const int k) {
-                const int ty = A.stype[w][k], ff = A.sfield[w][k];       // (uniform: scalar loads of the kernel arguments)
+            auto operands = [&](double (&pv)[NPW], double &bv, const int j, const int ty, const int ff) {
                 const double *pr_ = &prd_[((buf * NS + j) * 4 + ty) * PW + (lane & 15)];
 #pragma unroll
                 for (int e = 0; e < NPW; ++e) pv[e] = pr_[16 * e];
                 bv = FLD(buf, j, ff, lane);
             };
             double pv0[NPW], bv0;
-            operands(pv0, bv0, 0, 0);
-#pragma unroll 1
-            for (int j = 0; j < NS; ++j) {
-                if (gb + j >= g_end) break;
+            operands(pv0, bv0, 0, sty[0], sfl[0]);
+            // (the symmetric window is 15 registers at p = 4: the planes of a batch unrolled, so that the waits for the LDS reads
+            // are counted and the operands of the next plane stay in flight under this plane's arithmetic)
+            auto plane = [&](const int j) __attribute__((always_inline)) -> bool {
+                if (gb + j >= g_end) return false;
                 // the first source of the next plane is requested before this plane's arithmetic; further sources as they come
                 double pn[NPW], bn;
-                operands(pn, bn, j + 1 < NS ? j + 1 : j, 0);
+                operands(pn, bn, j + 1 < NS ? j + 1 : j, sty[0], sfl[0]);
                 // (the further sources of this plane: all requested before the first multiply-add)
                 double pv1[NPW], pv2[NPW], pv3[NPW], bv1 = 0.0, bv2 = 0.0, bv3 = 0.0;
-                if (nsrc > 1) operands(pv1, bv1, j, 1);
-                if (nsrc > 2) operands(pv2, bv2, j, 2);
-                if (nsrc > 3) operands(pv3, bv3, j, 3);
+                if (nsrc > 1) operands(pv1, bv1, j, sty[1], sfl[1]);
+                if (nsrc > 2) operands(pv2, bv2, j, sty[2], sfl[2]);
+                if (nsrc > 3) operands(pv3, bv3, j, sty[3], sfl[3]);
                 asm volatile("" ::: "memory");
                 if constexpr (SYMW) sweep_lower_rowbc<P>(acc, pv0, bv0);
                 else sweep_full_rowbc<P>(acc, pv0, bv0);
@@ -750,7 +766,7 @@ k_geoA(const GeoAArgs A)
 #pragma unroll
                 for (int e = 0; e < NPW; ++e) pv0[e] = pn[e];
                 bv0 = bn;
-                if (++l < q) continue;
+                if (++l < q) return true;
                 const bool write = sp >= own_lo && live && !GA_OFF(2);
                 const int *fr = (const int *)&rec[rs][j][20];
                 const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
@@ -803,6 +819,16 @@ k_geoA(const GeoAArgs A)
                     }
                 }
                 l = 0; ++sp;
+                return true;
+            };
+            if constexpr (SYMW && P <= 5) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (!plane(j)) break;
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < NS; ++j)
+                    if (!plane(j)) break;
             }
             next_batch(gb + NS, rn, buf ^ 1);
             rs = rn;
@@ -828,8 +854,10 @@ k_geoA(const GeoAArgs A)
             }
         };
         if (w >= NS) {
+            // (records of batch it + 2 requested an iteration before they are written to LDS: see the table forms above)
             stage_load(g_begin); stage_store(0);
             stage_load(g_begin + NS); stage_store(1);
+            stage_load(g_begin + 2 * NS);
             __syncthreads();
             next_batch(g_begin, 0, 0);
             products_full(0, 0);
@@ -837,10 +865,10 @@ k_geoA(const GeoAArgs A)
             int it = 0, rs = 0;
             for (int gb = g_begin; gb < g_end; gb += NS, ++it) {
                 const int rn = rs == 2 ? 0 : rs + 1, ra = rn == 2 ? 0 : rn + 1;
-                stage_load(gb + 2 * NS);
+                stage_store(ra);
+                stage_load(gb + 3 * NS);
                 next_batch(gb + NS, rn, (it & 1) ^ 1);
                 products_full(rn, (it & 1) ^ 1);
-                stage_store(ra);
                 rs = rn;
                 __syncthreads();
             }
