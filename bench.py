@@ -134,7 +134,7 @@ def design_floor(config, dim, kvs, kind, nnz_total, alg_bytes, world):
     the number is: the chain must write the axis-0 intermediate K1 once, read it once and write the CSR values once (`floor_bytes`);
     at the rate a mixed stream reaches that is `floor_ms`, i.e. `ceiling_frac` of the HBM roof in ALGORITHMIC bytes -- and the
     vector instructions the two kernels issue (SQ_INSTS_VALU of the committed PMC pass) take `issue_ms` on 1024 SIMDs by themselves."""
-    if dim != 3 or world != 1 or kind not in ('stiffness', 'mass', 'convdiff'):
+    if dim != 3 or world != 1 or kind not in ('stiffness', 'mass', 'convdiff', 'form'):
         return None
     p0, N0 = kvs[0].p, kvs[0].numdofs
     sym = kind != 'convdiff'
@@ -156,6 +156,9 @@ def design_floor(config, dim, kvs, kind, nnz_total, alg_bytes, world):
     except Exception:
         pass
     return out
+
+
+FORM_STRING = '(inner(grad(u), grad(v)) + u * v) * dx'
 
 
 def COEFF(x, y, z):
@@ -358,7 +361,7 @@ def main():
     ap.add_argument('--algo', default='auto', choices=['auto', 'sumfact', 'entrywise'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api-call', action='store_true', help='skip the end-to-end assemble.stiffness() call (host copy of the matrix)')
-    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries', 'fast', 'structured'],
+    ap.add_argument('--op', default='matrix', choices=['matrix', 'rhs', 'entries', 'fast', 'structured', 'form'],
                     help='rhs: the load vector (inner_products) of the same patch; entries: batched multi_entries on random in-pattern pairs; '
                          'fast: the low-rank (ACA) assembler against the exact assembly (use --config c2 / c3: the reordered tensor lives on the host); '
                          'structured: the opt-in Kronecker expansion for geometries that are separable along axis 0 (the cylinder of the 3D configs)')
@@ -441,7 +444,13 @@ def main():
     elif args.config == 'c4g':
         kvs = (kv0, bspline.make_knots(p - 2, 0.0, 1.0, n), kv)
     row0 = distributed.slab_range(kv0.numdofs, part_rank, part_world, p if dim == 3 else None)      # balanced by work
-    if kind == 'convdiff':
+    if args.op == 'form':
+        # the matrix of the config's patch from a FORM STRING through the front-end (pyiga.assemble.assemble: one generated kernel per
+        # form in the reference, pyiga/codegen/cython.py:325-387): stiffness + mass, a symmetric table of constants
+        assert dim == 3 and kind == 'stiffness' and not stub, '--op form: the 3D stiffness configs'
+        kind = 'form'
+        patch = assemblers.GeneralFormAssembler3D(kvs, geo, FORM_STRING, device=local_rank, row0=row0 if part_world > 1 else None).patch
+    elif kind == 'convdiff':
         patch = assemblers.ConvDiffAssembler3D(kvs, geo, assemblers.AffineCoefficient(1.0, 1.0), device=local_rank, row0=row0 if part_world > 1 else None).patch
     else:
         patch = assemblers.DevicePatch(kvs, geo, device=local_rank, row0=row0 if part_world > 1 else None)
@@ -538,7 +547,8 @@ def main():
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
     # roofline on rank 0's slab: algorithmic bytes of one assembly / device time of the kernel chain (median step)
     nel_rank = nel_total / world
-    b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total, kind)
+    mkind = 'stiffness' if kind == 'form' else kind          # (the form of --op form is stiffness + mass: the stiffness models)
+    b_el = algorithmic_bytes_per_element(dim, p, nnz_total, nel_total, mkind)
     chain_ms = float(np.median(steps_ms))
     achieved = b_el * nel_rank / (chain_ms * 1e-3) / 1e9
     path = patch.last_path()
@@ -554,7 +564,7 @@ def main():
         stage_ms.pop('final_ms', None)          # k_bf3 writes both triangles (or the form has one): no kernel behind it
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
-    flops = algorithmic_flops(dim, p, kvs, kind) if algo_used == 2 else None
+    flops = algorithmic_flops(dim, p, kvs, mkind) if algo_used == 2 else None
     fp64 = None
     if flops:
         share = part_world if emu is not None else world    # flops of ONE slab (approximately: halo planes not counted)
@@ -565,13 +575,13 @@ def main():
                 'frac': tot / (chain_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 'algorithm': 'global sum factorisation, useful flops only'}
     out = {
         'metric': 'assembled elements/sec (3D p=4, 128^3 spans) + HBM-roofline %; 1/2/4/8 GPU'
-                  if args.config == 'c4' else 'assembled elements/sec',
+                  if args.config == 'c4' and args.op == 'matrix' else 'assembled elements/sec',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak' if weak else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (launcher test, no device work)',
         'config': {'workload': '%dD p=%s %s, %s spans, NURBS quarter-annulus %s, %s'
-                               % (dim, p if len({k.p for k in kvs}) == 1 else 'x'.join(str(k.p) for k in kvs), kind,
+                               % (dim, p if len({k.p for k in kvs}) == 1 else 'x'.join(str(k.p) for k in kvs), kind if kind != 'form' else 'form string %r' % FORM_STRING,
                                   'x'.join(str(k.numspans) for k in kvs), 'cylinder' if dim == 3 else gname,
                                   'double interior knots on the mid axis' if args.config == 'c4k' else 'double interior knots on the last axis' if args.config == 'c4l' else 'uniform open knots'),
                    'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
@@ -591,8 +601,8 @@ def main():
         'api_call_s': api_call_s,                                              # assemble.stiffness() end to end: + pattern, D2H of values and indices, scipy
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': measured_traffic(args.config, world, kernels_now=list(parts)),
-            'design': design_floor(args.config, dim, kvs, kind, nnz_total, b_el * nel_total, world),
+            'traffic': measured_traffic(args.config, world, op=args.op, kernels_now=list(parts)),
+            'design': design_floor(args.config if args.op == 'matrix' else '%s_%s' % (args.config, args.op), dim, kvs, mkind, nnz_total, b_el * nel_total, world),
             'kernel': 'assembly chain (' + ' + '.join(parts) + '), HIP events on the igx stream; median step',
             'algorithmic_bytes_per_element': b_el, 'algorithmic_bytes_def': ALGORITHMIC_BYTES_DEF, 'chain_ms': chain_ms, 'kernel_ms': parts, 'kernel_ms_source': kernel_ms_source, 'dominant_kernel': dominant,
             'fp64': fp64,

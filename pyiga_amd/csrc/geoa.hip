@@ -77,7 +77,8 @@ struct GeoAArgs {
     int nsrc[GA_MAXS], sfield[GA_MAXS][4], stype[GA_MAXS][4];
     int nslots;                 // arrays the form has (<= 8): the sweep waves beyond them sweep nothing and store nothing
 };
-constexpr int GA_NFT = 10;      // fields of a point a table form may keep in LDS (ten: a symmetric table with every entry)
+constexpr int GA_NFT = 13;      // fields of a point a table form may keep in LDS: ten for a symmetric table with every entry, thirteen for
+                                // reaction + convection both ways + a symmetric diffusion block (sumfact.hip: form_table_plan)
 
 typedef int int8v __attribute__((ext_vector_type(8)));
 
@@ -236,7 +237,7 @@ k_geoA(const GeoAArgs A)
     constexpr bool SYMW = FORM == 0 || FORM == 3;         // lower triangle of the pair window (symmetric forms)
     static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
     static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
-    constexpr int NF = FORM == 1 ? 9 : FORM >= 2 ? GA_NFT : 6;   // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
+    constexpr int NF = FORM == 1 ? 9 : FORM == 2 ? GA_NFT : FORM == 3 ? 10 : 6;   // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = (NS + NGW) * 64;                   // threads
     constexpr int RECW = (MF || FORM >= 1) ? GA_REC : 24; // doubles of a plane record that the kernel uses (the row tables: matrix-core / non-symmetric sweeps only)

@@ -973,7 +973,7 @@ static FormPlan form_table_plan(const igx_patch *pt)
             int ca = a, cb = b;                              // canonical entry: F_ab = F_ba where the table says so
             if (a > b && (T.sym || (T.blocksym && b >= 1))) { ca = b; cb = a; }
             if (fp.g.fslot[4 * ca + cb] < 0) {
-                if (nf >= 10) return fp;                     // (GA_NFT fields of a point in LDS)
+                if (nf >= (fp.sym ? 10 : 13)) return fp;     // (fields of a point in LDS: GA_NFT, geoa.hip)
                 fp.g.fslot[4 * ca + cb] = nf++;
             }
             // a: test function v, b: trial function u; jet index c >= 1 differentiates grid axis 3 - c (form_terms)

@@ -674,6 +674,65 @@ def test_general_form_consistency_and_slabs(iga, oracle):
     assert np.array_equal(S.indices, A.indices) and np.array_equal(S.data, A.data)
 
 
+def test_form_tables_on_the_fast_chain(iga, monkeypatch):
+    """Round 6: a first-order form given as a string is a coefficient TABLE (constants and expressions) that k_geoA<FORM = 2 | 3>
+    evaluates inside the axis-0 sweep -- no field arrays -- and k_bf3 finishes: `geoA` and `bf3` in last_path().  A symmetric
+    table takes the symmetric chain (both triangles from the same element matrices: exactly symmetric, `both`).  Checked against
+    the entry-wise kernel (the reference's loop nest over fields written by the generated field kernel), against
+    a * stiffness + c * mass where the form is that, every value written (NaN poison), row slabs bit for bit; degrees 2 .. 5,
+    NURBS and B-spline maps, a map of degree 2 along axis 0, repeated knots on axis 0 and the mid axis.
+    (pyiga/vform.py:705-731, pyiga/codegen/cython.py:325-387: the reference generates one kernel per form.)"""
+    mk = iga.bspline.make_knots
+    g = iga.geometry
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    G = iga.assemblers.GeneralFormAssembler3D
+    geos = {'cylinder': _geo(iga, 'cylinder'), 'twisted_box': _geo(iga, 'twisted_box'),
+            'annulus_x_line': g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0)),        # degree 2 (NURBS) along axis 0
+            'bannulus_x_line': g.tensor_product(g.bspline_quarter_annulus(), g.line_segment(0.0, 1.5, intervals=2))}
+    c = lambda x, y, z: 1.0 + x * y + 0.5 * z
+    forms = [('(2 * inner(grad(u), grad(v)) + 3 * u * v) * dx', {}, True),
+             ('(c * inner(grad(u), grad(v)) + u * v) * dx', {'c': c}, True),
+             ('(inner(grad(u), grad(v)) + inner((x[1], -x[0], 1.0), grad(u)) * v) * dx', {}, False),
+             ('(c * inner(grad(u), grad(v)) + inner((1.0, c, 2.0), grad(u)) * v + u * inner((0.5, 1.0, c), grad(v)) + 2 * c * u * v) * dx', {'c': c}, False),
+             ('(inner(dot(((2.0, 0.5, 0.0), (0.5, 3.0, 0.25), (0.0, 0.25, 1.0)), grad(u)), grad(v))) * dx', {}, True),
+             ('c * u * v * dx', {'c': c}, True)]
+    cases = [((mk(2, 0., 1., 5), mk(2, 0., 1., 4), mk(2, 0., 1., 6)), 'cylinder'),
+             ((mk(3, 0., 1., 4), mk(3, 0., 1., 9), mk(3, 0., 1., 5)), 'annulus_x_line'),
+             ((mk(4, 0., 1., 3), mk(4, 0., 1., 4), mk(4, 0., 1., 40)), 'cylinder'),
+             ((mk(5, 0., 1., 3), mk(5, 0., 1., 3), mk(5, 0., 1., 4)), 'twisted_box'),
+             ((mk(3, 0., 1., 4, mult=2), mk(3, 0., 1., 6, mult=2), mk(3, 0., 1., 7)), 'bannulus_x_line'),
+             ((mk(4, 0., 1., 3), mk(3, 0., 1., 6), mk(4, 0., 1., 5)), 'twisted_box')]                  # mid axis one degree below nqp: symmetric tables only
+    for kvs, gname in cases:
+        geo = geos[gname]
+        for form, inputs, sym in forms:
+            asm = G(kvs, geo, form, inputs=inputs)
+            assert asm.compiled
+            A = asm.assemble_csr(algo='sumfact')
+            path = asm.patch.last_path()
+            E = asm.assemble_csr(algo='entrywise')
+            tag = (form, [kv.p for kv in kvs], gname, sorted(path))
+            equal_degrees = len({kv.p for kv in kvs[1:]}) == 1 and kvs[1].p + 1 == max(kv.p for kv in kvs) + 1
+            if sym or equal_degrees:
+                assert 'geoA' in path and 'bf3' in path, tag
+                assert ('both' in path) == sym, tag
+            assert not np.isnan(A.data).any(), tag
+            assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))
+            if sym:
+                assert abs(A - A.T).max() == 0.0, tag
+            N0 = kvs[0].numdofs
+            parts = []
+            for lo, hi in ((0, N0 // 2), (N0 // 2, N0)):
+                sl = G(kvs, geo, form, inputs=inputs, row0=(lo, hi))
+                parts.append(sl.assemble_csr(algo='sumfact'))
+                sl.patch.close()
+            S = scipy.sparse.vstack(parts).tocsr()
+            assert np.array_equal(S.indices, A.indices) and np.array_equal(S.data, A.data), tag
+            asm.patch.close()
+        K, M = iga.assemble.stiffness(kvs, geo), iga.assemble.mass(kvs, geo)
+        A = G(kvs, geo, forms[0][0]).assemble_csr()
+        assert rel_maxdiff(A, 2 * K + 3 * M) <= RTOL, (gname, rel_maxdiff(A, 2 * K + 3 * M))
+
+
 def test_arity1_form_strings(iga, golden):
     """Form strings that only contain v assemble a load vector (pyiga/assemble.py:837-897, arity 1;
     test/test_assemble.py:426-429), against vectors from the reference."""
