@@ -226,6 +226,9 @@ constexpr int GA_NGW = GA_NGW_N;
 #ifndef GA_NGW_T
 #define GA_NGW_T 8
 #endif
+#ifndef GA_F1_UNROLL
+#define GA_F1_UNROLL 1        // planes of a batch unrolled in the sweep of the convection-diffusion form
+#endif
 constexpr int geoa_ngw(int FORM) { return FORM >= 2 ? GA_NGW_T : FORM == 1 ? GA_NGW : 0; }
 constexpr int geoa_wpe(int NS, int FORM) { return FORM >= 1 ? (geoa_ngw(FORM) > 4 ? 4 : 3) : NS >= 8 ? 4 : 1; }
 constexpr int geoa_threads(int NS, int FORM) { return (NS + geoa_ngw(FORM)) * 64; }
@@ -939,7 +942,7 @@ k_geoA(const GeoAArgs A)
                 operands(pv1, bv1, 0, t, fi);
                 if (xf >= 0) operands(pv2, bv2, 0, xt, xf);
             }
-#pragma unroll 1
+#pragma unroll GA_F1_UNROLL
             for (int j = 0; j < NS; ++j) {
                 if (gb + j >= g_end) break;
                 if constexpr (DPF) {

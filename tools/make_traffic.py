@@ -52,7 +52,7 @@ def one(root, key):
     if not kernels:
         return None
     # vector instructions per kernel (wave-level) from the SQ pass of the same configuration, if it was taken
-    for f in glob.glob(os.path.join(root, 'pmc_' + key + 'sq') + '/**/*counter_collection.csv', recursive=True):
+    for f in glob.glob(os.path.join(root, 'pmc_' + key.split('_')[0] + 'sq') + '/**/*counter_collection.csv', recursive=True) if '_' not in key else []:
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
         for row in rows:
             name = re.sub(r'[<(].*', '', row['Kernel_Name']).replace('void igx::', '').replace('igx::', '')
@@ -68,7 +68,7 @@ def one(root, key):
 def main():
     root = sys.argv[1]
     out = {}
-    for key in ('c4', 'c5', 'c3', 'c2', 'c4_rhs', 'c4_entries'):
+    for key in ('c4', 'c5', 'c3', 'c2', 'c4_rhs', 'c4_entries', 'c4_form'):
         r = one(root, key)
         if r:
             out[key] = r

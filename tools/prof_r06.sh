@@ -26,6 +26,7 @@ trace)
   for c in c1 c2 c3 c5 c4m c4k c4g c4l c5s; do timeout 300 python3 bench.py --config $c > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
   timeout 300 python3 bench.py --op rhs > "$OUT/c4_rhs_bench.json" 2>> "$OUT/bench.log"
   timeout 300 python3 bench.py --op entries > "$OUT/c4_entries_bench.json" 2>> "$OUT/bench.log"
+  timeout 300 python3 bench.py --op form --no-cpu-baseline > "$OUT/c4_form_bench.json" 2>> "$OUT/bench.log"
   IGX_PATH=unfused IGX_GEOA=0 timeout 300 python3 bench.py --no-cpu-baseline --no-api-call > "$OUT/c4_bench_r01_kernels.json" 2>> "$OUT/bench.log"
   IGX_BF=2 timeout 300 python3 bench.py --no-cpu-baseline --no-api-call > "$OUT/c4_bench_bf2_mirror.json" 2>> "$OUT/bench.log"
   IGX_GEOA=0 timeout 300 python3 bench.py --config c5 --no-cpu-baseline --no-api-call > "$OUT/c5_bench_r03_kernels.json" 2>> "$OUT/bench.log"
@@ -43,6 +44,7 @@ pmc)
   done
   pmc c4_rhs fetch FETCH_SIZE --op rhs; pmc c4_rhs write WRITE_SIZE --op rhs
   pmc c4_entries fetch FETCH_SIZE --op entries; pmc c4_entries write WRITE_SIZE --op entries
+  pmc c4_form fetch FETCH_SIZE --op form; pmc c4_form write WRITE_SIZE --op form
   python3 tools/make_traffic.py "$OUT" | tail -40
   ;;
 sq)
@@ -58,6 +60,9 @@ sq5)
   pmc c5sq sq2 "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES" --config c5
   pmc c5sq sq3 "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" --config c5
   python3 tools/pmc_summary.py "$OUT/pmc_c5sq" | tee "$OUT/c5_pmc_summary.txt"
+  ;;
+all)
+  bash "$0" trace "$OUT"; bash "$0" sq "$OUT"; bash "$0" sq5 "$OUT"; bash "$0" pmc "$OUT"; bash "$0" slabs "$OUT"
   ;;
 slabs)
   for W in 2 4 8; do for ((r=0; r<W; r++)); do timeout 300 python3 bench.py --emulate $r/$W --no-cpu-baseline > "$OUT/c4_slab${r}of${W}_bench.json" 2>> "$OUT/bench.log"; done; done
