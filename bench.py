@@ -45,6 +45,9 @@ CONFIGS = {
     'c4l': (3, 4, 128, 'stiffness', 'cylinder'),
     'c4g': (3, 4, 128, 'stiffness', 'cylinder'),
     'c5s': (3, 5, 96, 'stiffness', 'cylinder'),
+    # the mass form of BASELINE config 3 ("3D p=2 n=64 mass+stiffness"), and at C4's size
+    'c3mass': (3, 2, 64, 'mass', 'cylinder'),
+    'c4mass': (3, 4, 128, 'mass', 'cylinder'),
     # BASELINE config 5: the run-time compiled (vform) convection-diffusion form, non-symmetric
     'c5': (3, 5, 96, 'convdiff', 'cylinder'),
 }

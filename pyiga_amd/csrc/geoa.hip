@@ -232,15 +232,19 @@ constexpr int GA_NGW = GA_NGW_N;
 constexpr int geoa_ngw(int FORM) { return FORM >= 2 ? GA_NGW_T : FORM == 1 ? GA_NGW : 0; }
 constexpr int geoa_wpe(int NS, int FORM) { return FORM >= 1 ? (geoa_ngw(FORM) > 4 ? 4 : 3) : NS >= 8 ? 4 : 1; }
 constexpr int geoa_threads(int NS, int FORM) { return (NS + geoa_ngw(FORM)) * 64; }
-template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0>
+// D2 (round 6): the same kernel for 2D patches -- a "plane" is the line of Gauss points of axis 1, a block's 64 points lie on it,
+// NS = 4 arrays (2D stiffness: (axis-0 type, field) = (0, B00) (2, B01) (1, B01) (3, B11)) or 1 (mass), NC = 2 | 3 components.
+// Replaces the field kernel + k_stageA of the 2D chain (two launches and 50 MB of field traffic at BASELINE config 2).
+template <int P, int NS, int P0G, int NC, bool MF, int FORM = 0, bool D2 = false>
 __global__ void __launch_bounds__(geoa_threads(NS, FORM)) __attribute__((amdgpu_waves_per_eu(geoa_wpe(NS, FORM), FORM >= 1 ? geoa_wpe(NS, FORM) : 4)))
 k_geoA(const GeoAArgs A)
 {
+    static_assert(!D2 || (FORM == 0 && !MF), "2D: the symmetric fixed forms, vector sweep");
     constexpr int NGW = geoa_ngw(FORM);                   // geometry waves (0: every sweep wave evaluates the plane of its own number)
     constexpr bool SYMW = FORM == 0 || FORM == 3;         // lower triangle of the pair window (symmetric forms)
     static_assert(!MF || (NS == 8 && P * (P + 1) / 2 <= GA_ROWS), "matrix-core sweep: eight slots, at most 16 live pairs");
     static_assert(!(MF && FORM), "the matrix-core sweep serves the symmetric forms");
-    constexpr int NF = FORM == 1 ? 9 : FORM == 2 ? GA_NFT : FORM == 3 ? 10 : 6;   // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
+    constexpr int NF = D2 ? 3 : FORM == 1 ? 9 : FORM == 2 ? GA_NFT : FORM == 3 ? 10 : 6;   // fields of a point in LDS (convection-diffusion: c B (6) + beta (3))
     constexpr int PV = (P + 1) & ~1;                      // basis row in registers, padded to an even length
     constexpr int NT = (NS + NGW) * 64;                   // threads
     constexpr int RECW = (MF || FORM >= 1) ? GA_REC : 24; // doubles of a plane record that the kernel uses (the row tables: matrix-core / non-symmetric sweeps only)
@@ -284,7 +288,7 @@ k_geoA(const GeoAArgs A)
     if (tile >= A.ntiles) tile = A.ntiles - 1;            // surplus blocks redo the last tile (same values again: harmless)
     long long pt = (long long)tile * 64 + lane;
     if (pt >= A.NPL) pt = A.NPL - 1;                      // lanes past the end redo the last point (and store it again: harmless)
-    const int g1 = (int)(pt / A.G2), g2 = (int)(pt - (long long)g1 * A.G2);
+    const int g1 = D2 ? (int)pt : (int)(pt / A.G2), g2 = D2 ? 0 : (int)(pt - (long long)g1 * A.G2);
     const int q = A.q;
     const int own_lo = A.s_lo + blockIdx.y * A.chunk_len;
     const int own_hi = min(own_lo + A.chunk_len, A.s_hi);
@@ -311,12 +315,27 @@ k_geoA(const GeoAArgs A)
     };
 
     // ---- geometry
-    const double GW1 = A.w1[g1], GW2 = A.w2[g2];
+    const double GW1 = A.w1[g1], GW2 = D2 ? 1.0 : A.w2[g2];
     // the prologue loads are complete before the loop: a wait for them inside it would also drain the K1 stores
     asm volatile("" :: "v"(GW1), "v"(GW2));
     int f0_blk = -1;
     // the block's waves share the work: wave w contracts the control net along axes 1, 2 for its (a0, component) pairs
     auto columns = [&](const int f0) {
+        if constexpr (D2) {                               // 2D: the control net contracted along axis 1 (value, d/d1)
+            const double *V1 = gv.V[1] + (size_t)g1 * gv.P[1] * 2;
+            const int f1 = gv.fa[1][g1];
+            for (int e = w; e < P0G * NC; e += NS) {
+                const int a0 = e / NC, c = e - a0 * NC;
+                double sv = 0.0, s1 = 0.0;
+                for (int a1 = 0; a1 < gv.P[1]; ++a1) {
+                    const double cf = gv.ctrl[((size_t)(f0 + a0) * gv.N[1] + (f1 + a1)) * NC + c];
+                    sv = fma(V1[a1 * 2], cf, sv);
+                    s1 = fma(V1[a1 * 2 + 1], cf, s1);
+                }
+                Cs[e][0][lane] = sv; Cs[e][1][lane] = s1;
+            }
+            return;
+        }
         const double *V1 = gv.V[1] + (size_t)g1 * gv.P[1] * 2, *V2 = gv.V[2] + (size_t)g2 * gv.P[2] * 2;
         const int f1 = gv.fa[1][g1], f2 = gv.fa[2][g2];
         for (int e = NGW ? w - NS : w; e >= 0 && e < P0G * NC; e += NGW ? NGW : NS) {
@@ -347,15 +366,29 @@ k_geoA(const GeoAArgs A)
             const double n = V0[a0 * 2], d = V0[a0 * 2 + 1];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const double c0 = Cs[a0 * NC + c][0][lane], c1 = Cs[a0 * NC + c][1][lane], c2 = Cs[a0 * NC + c][2][lane];
+                const double c0 = Cs[a0 * NC + c][0][lane], c1 = Cs[a0 * NC + c][1][lane];
                 val[c] = fma(n, c0, val[c]);
                 jac[c][0] = fma(d, c0, jac[c][0]);
                 jac[c][1] = fma(n, c1, jac[c][1]);
-                jac[c][2] = fma(n, c2, jac[c][2]);
+                if constexpr (!D2) jac[c][2] = fma(n, Cs[a0 * NC + c][2][lane], jac[c][2]);
             }
         }
         double GW = gw0 * GW1;
         GW = GW * GW2;
+        if constexpr (D2) {
+            // 2D: Jacobian (quotient rule for a NURBS map), W or the upper triangle of W J^-1 J^-T (pyiga/assemblers.pyx:86-110, 234-275)
+            double Jm2[MAX_COMP][3], ev2[MAX_COMP];
+            finish_jacobian<2>(val, jac, NC == 3, 2, NC, Jm2, ev2);
+            double tt2[9] = {Jm2[0][0], Jm2[0][1], Jm2[1][0], Jm2[1][1], 0.0, 0.0, 0.0, 0.0, 0.0};
+            double f2[6];
+            fields_values<2>(tt2, GW, A.kind, f2);
+            if (A.kind == IGX_MASS) FLD(buf, jp, 0, lane) = f2[0];
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) FLD(buf, jp, k, lane) = f2[k];
+            }
+            return;
+        }
         if constexpr (FORM == 1) {
             // convection-diffusion form: c W JacInv JacInv^T (upper triangle) and beta_a = W sum_r JacInv[a][r] b_r, b = (y, -x, 1)
             // (fields_convdiff, geo_device.h), with ONE division: M = quotient-rule numerator (J = M / w^2; M = J, w = 1 for a
@@ -1251,6 +1284,15 @@ k_geoA(const GeoAArgs A)
 #endif
 }
 
+template <int P, int NS, int P0G>
+static int launch_geoA_2d(hipStream_t st, const GeoAArgs &A, int nc, dim3 grid)
+{
+    if (nc == 3) k_geoA<P, NS, P0G, 3, false, 0, true><<<grid, dim3(geoa_threads(NS, 0)), 0, st>>>(A);
+    else k_geoA<P, NS, P0G, 2, false, 0, true><<<grid, dim3(geoa_threads(NS, 0)), 0, st>>>(A);
+    IGX_HIP(hipGetLastError());
+    return IGX_OK;
+}
+
 template <int P, int NS, int P0G, bool MF = false, int FORM = 0>
 static int launch_geoA_k(hipStream_t st, const GeoAArgs &A, int nc, dim3 grid)
 {
@@ -1285,6 +1327,17 @@ static int launch_geoA_g(hipStream_t st, const GeoAArgs &A, int nc, int p0g, dim
 
 bool geoA_supported(const igx_patch *pt, int kind, int nslots)
 {
+    if (pt->dim == 2) {
+        // 2D (round 6): mass (one array) and stiffness (four), spline maps of degree 1 or 2 along axis 0, degrees 1 .. 4 (the
+        // pair products of a plane in one register); a resident row slab is a span range of axis 0 like in 3D
+        if ((kind != IGX_STIFFNESS && kind != IGX_MASS) || pt->boxed) return false;
+        if (pt->geo_kind != IGX_GEO_BSPLINE && pt->geo_kind != IGX_GEO_NURBS) return false;
+        if (nslots != (kind == IGX_MASS ? 1 : 4)) return false;
+        const int P = pt->ax[0].P, p0g = pt->gax[0].P;
+        if (P < 2 || P > 5 || p0g < 2 || p0g > 3) return false;
+        const long long gspans = pt->gax[0].N - pt->gax[0].P + 1;
+        return 2 * gspans <= (long long)pt->ax[0].G;
+    }
     if (pt->dim != 3 || (kind != IGX_STIFFNESS && kind != IGX_MASS && kind != IGX_CONVDIFF)) return false;
     if (pt->geo_kind != IGX_GEO_BSPLINE && pt->geo_kind != IGX_GEO_NURBS) return false;
     if (nslots != (kind == IGX_MASS ? 1 : 8)) return false;
@@ -1337,7 +1390,7 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
         // row tables of the matrix-core sweep, per span: [16] row -> a | b << 4 | 256, [16] row -> K1 slot of the pair when
         // it is complete after the span (-2: complete, not processed by this slab; -1: not complete), [2] smallest slot
         std::vector<int> rows;
-        bool mf_ok = A0.P >= 2 && A0.P * (A0.P + 1) / 2 <= GA_ROWS;
+        bool mf_ok = pt->dim == 3 && A0.P >= 2 && A0.P * (A0.P + 1) / 2 <= GA_ROWS;
         if (mf_ok) {
             const int P = A0.P, W = 2 * GA_ROWS + 2;
             std::vector<int> slot_of(A0.S, -1);
@@ -1389,10 +1442,11 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
         pt->geoa_mf = mf_ok ? 1 : 0;
     }
     GeoAArgs A{};
-    A.gv = make_view(3, pt->gax, pt->d_ctrl, pt->ncomp);
-    A.w0 = pd.ax[0].w; A.w1 = pd.ax[1].w; A.w2 = pd.ax[2].w;
+    const bool d2 = pt->dim == 2;
+    A.gv = make_view(pt->dim, pt->gax, pt->d_ctrl, pt->ncomp);
+    A.w0 = pd.ax[0].w; A.w1 = pd.ax[1].w; A.w2 = d2 ? nullptr : pd.ax[2].w;
     A.nurbs = pt->geo_kind == IGX_GEO_NURBS; A.kind = kind;
-    A.G1 = pd.ax[1].G; A.G2 = pd.ax[2].G;
+    A.G1 = pd.ax[1].G; A.G2 = d2 ? 1 : pd.ax[2].G;
     A.NPL = (long long)A.G1 * A.G2; A.stride = slice_stride;
     // (the hardware's range check adds the scalar offset to the lane offset before it compares with the length of the
     // descriptor: a slice offset at or above 2^31 - 16 would have its stores DROPPED -- found in round 4 by the WRITE_SIZE counter
@@ -1412,6 +1466,14 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
     A.ntiles = (int)((A.NPL + 63) / 64);
     dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs
     const int nc = pt->ncomp, p0g = pt->gax[0].P;
+    if (d2) {
+#define GEOA_2D(PV) case PV: return nslots == 1 ? (p0g == 2 ? launch_geoA_2d<PV, 1, 2>(st, A, nc, grid) : launch_geoA_2d<PV, 1, 3>(st, A, nc, grid)) \
+                                                : (p0g == 2 ? launch_geoA_2d<PV, 4, 2>(st, A, nc, grid) : launch_geoA_2d<PV, 4, 3>(st, A, nc, grid))
+        switch (A0.P) { GEOA_2D(2); GEOA_2D(3); GEOA_2D(4); GEOA_2D(5); }
+#undef GEOA_2D
+        set_error("fused geometry + stage A (2D): unsupported degree %d", A0.p);
+        return IGX_ERR_UNSUPPORTED;
+    }
     if (form) {
         for (int k = 0; k < 16; ++k) { A.pc[k] = form->pc[k]; A.pa[k] = form->pa[k]; A.fslot[k] = form->fslot[k]; }
         A.pmask = form->pmask; A.nslots = nslots; A.amask = 0; A.fmask = 0;

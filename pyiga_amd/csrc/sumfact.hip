@@ -771,6 +771,15 @@ static SweepChunks sweep_chunks(long long blocks_without, int nspans, int P, int
     return c;
 }
 
+// 2D k_geoA: a line of Gauss points gives few blocks (16 at C2), the walk along axis 0 is what takes the time -- chunks of a few
+// spans each (every chunk re-walks P - 1 warm-up spans)
+static int geoa2d_min_chunk(int P)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("IGX_GEOA2D_CHUNK"); v = e ? atoi(e) : 0; }
+    return v > 0 ? v : 2 * P;
+}
+
 #define DISPATCH_P(Pv, CALL)                                   \
     switch (Pv) {                                              \
     case 2: { constexpr int PP = 2; CALL; } break;             \
@@ -816,6 +825,7 @@ bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
     if (single2d_wanted(pt, kind)) return false;
     if (kind == IGX_FORM && pt->dim == 3 && form_on_fast_chain(pt)) return false;
+    if (pt->dim == 2) return !(igx_kind_symmetric(kind) && pt->knobs.path != 1 && geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 4));
     if (pt->dim != 3) return true;
     // the convection-diffusion form: its eight merged slots exist where the fused stage runs (sumfact_assemble)
     if (!igx_kind_symmetric(kind)) return !(kind == IGX_CONVDIFF && (fused_applicable(pt) || fused3_axes(pt, false)) && geoA_wanted(pt, kind, 8));
@@ -1198,7 +1208,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             sf[x] = xa.f; stp[x] = xa.t0; sxf[x] = xa.xf; sxt[x] = xa.xt0 < 0 ? 0 : xa.xt0;
             so[x] = pt->d_K1 + (size_t)xa.slot * np0 * NPLs;
         }
-        const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P);
+        const SweepChunks ch = sweep_chunks((NPL + 63) / 64, pt->s0_hi - pt->s0_lo, A0.P, dim == 2 ? geoa2d_min_chunk(A0.P) : 0);
         int rc = launch_geoA(st, pt, kind, nX, sf, stp, so, NPLs, ch.len, ch.nchunks, sxf, sxt);
         if (rc) return rc;
         pt->last_path |= IGX_PATH_GEOA;

@@ -1304,6 +1304,46 @@ def test_fullsize_vs_reference_c2(iga, golden, path, monkeypatch):
     assert abs(A - A.T).max() == 0.0
 
 
+def test_2d_geometry_inside_the_axis0_sweep(iga, oracle, monkeypatch):
+    """Round 6: above the single-launch crossover a 2D mass / stiffness patch over a spline map takes TWO launches -- k_geoA (2D
+    instantiation: control net -> Jacobian -> fields -> axis-0 sweep -> K1, no field arrays) and the final stage -- instead of field
+    kernel + k_stageA + final stage.  `geoA` in last_path(); against the oracle, the entry-wise kernel, row slabs bit for bit;
+    degrees 1 .. 4, NURBS / B-spline maps (degree 2 and 1 along axis 0), repeated knots on either axis, unequal degrees.
+    (pyiga/assemblers.pyx:86-135, 234-349.)"""
+    mk = iga.bspline.make_knots
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+    cases = [((mk(3, 0., 1., 110), mk(3, 0., 1., 120)), 'quarter_annulus'),                         # (above the single-launch crossover: > 9216 rows)
+             ((mk(2, 0., 1., 130), mk(2, 0., 1., 100)), 'bspline_quarter_annulus'),
+             ((mk(1, 0., 1., 120), mk(1, 0., 1., 130)), 'quarter_annulus'),
+             ((mk(4, 0., 1., 100), mk(4, 0., 1., 110)), 'unit_square'),
+             ((mk(3, 0., 1., 60, mult=2), mk(2, 0., 1., 70, mult=2)), 'quarter_annulus'),
+             ((mk(2, 0., 1., 128), mk(4, 0., 1., 100)), 'bspline_quarter_annulus')]
+    ogeo = {'quarter_annulus': oracle.geo_quarter_annulus, 'bspline_quarter_annulus': oracle.geo_bspline_quarter_annulus,
+            'unit_square': lambda: oracle.geo_unit_cube(2)}
+    for kvs, gname in cases:
+        geo = _geo(iga, gname)
+        okvs = tuple(oracle.KnotVector(kv.kv, kv.p) for kv in kvs)
+        for kind in ('stiffness', 'mass'):
+            patch = iga.assemblers.DevicePatch(kvs, geo)
+            A = patch.csr(kind, algo='sumfact')
+            path = patch.last_path()
+            E = patch.csr(kind, algo='entrywise')
+            patch.close()
+            tag = (kind, [kv.p for kv in kvs], [kv.numdofs for kv in kvs], gname, sorted(path))
+            assert 'geoA' in path and 'single' not in path, tag
+            assert not np.isnan(A.data).any() and abs(A - A.T).max() == 0.0, tag
+            assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))
+            R = oracle.assemble(kind, okvs, ogeo[gname](), nthreads=8)
+            assert A.nnz == R.nnz and rel_maxdiff(A, R) <= RTOL, (tag, rel_maxdiff(A, R))
+            N0 = kvs[0].numdofs
+            parts = []
+            for lo, hi in ((0, N0 // 3), (N0 // 3, N0 - 2), (N0 - 2, N0)):
+                sl = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+                parts.append(sl.assemble(kind, algo='sumfact', to_host=True).copy())
+                sl.close()
+            assert np.array_equal(np.concatenate(parts), A.data), tag
+
+
 @pytest.mark.parametrize('path', ['fused', 'unfused'])
 def test_fullsize_vs_reference_3d(iga, golden, path, monkeypatch):
     """BASELINE config 3 at full size (3D p=2 n=64, mass + stiffness) and the config-4 / config-5 degrees at the largest
