@@ -41,11 +41,22 @@
 #ifndef BF3_FIXED_PASS
 #define BF3_FIXED_PASS 1      // the contractor waves keep their passes from step to step (no rotation)
 #endif
+#ifndef BF3_MASS_AXSYM
+#define BF3_MASS_AXSYM 1      // the 3D mass form through its per-axis symmetry (SYM = 3)
+#endif
+#ifndef BF3_MASS_STW
+#define BF3_MASS_STW 1        // ... with the store duty on its sweeper waves (dense slots) at low degree; 0: always on the contractors
+#endif
 
 namespace igx {
 
 // SYM: 0 non-symmetric form (one set of rings, every pair direct); 1 symmetric, every outer pair diagonal (2D: one set);
-//      2 symmetric with off-diagonal outer pairs (3D: direct + transposed set)
+//      2 symmetric with off-diagonal outer pairs (3D: direct + transposed set);
+//      3 (round 6) symmetric PER AXIS -- the 3D mass form: A[(i0,i1,i2),(j0,j1,j2)] = sum_g W N_i0 N_j0 N_i1 N_j1 N_i2 N_j2 does not
+//        change when the indices of ONE axis are exchanged, so the block of ANY outer pair (i0, j0) is symmetric under
+//        (i1, i2) <-> (j1, j2): every block contracts like a diagonal one (lower lines only, the upper part of a row from the same
+//        element matrices, one set of rings) and a finished row is STORED TWICE -- to row block i0 and, with the same values, to
+//        row block j0 (A[(j0,i1,i2),(i0,j1,j2)] is the same number)
 template <int P1, int P2, int Q, int NLG, int NRO, int NCW, int SYM> struct BF3Geom {
     static constexpr int P1_ = P1, P2_ = P2, Q_ = Q;
     static constexpr int p1 = P1 - 1, p2 = P2 - 1, W1 = 2 * P1 - 1, W2 = 2 * P2 - 1, TL = 64 * NLG;
@@ -224,6 +235,8 @@ struct BF3Store {
         move_row<0>(sets, dump, sw, lane, r, pD, r.on ? nD : 0, 8 * (B.c0i * r.c1 - 1), 8 * ((int)((long long)B.c0i * A.S2) * r.rp1d + W2 * (B.cj0 * r.c1 - r.l0)));
         if (NSET == 2)
             move_row<1>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, 8 * (B.c0j * r.c1 - 1), 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W2 * (B.ci0 * r.c1 - r.l0)));
+        if (SYM == 3)       // per-axis symmetry: the same row once more, to the row block of j0 (read again: whole passes only, nothing is cleared)
+            move_row<0>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, 8 * (B.c0j * r.c1 - 1), 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W2 * (B.ci0 * r.c1 - r.l0)));
     }
 };
 
@@ -335,6 +348,7 @@ struct BF3StoreDense {
             const int q8 = __builtin_amdgcn_ds_bpermute(pkk & 60, offl) + ((QLO + sw + QSTR * k) * 512 + lane8);
             bf2_buffer_store(dD, (int)__mul24(rr, dlD) + q8, 0, svD[k]);
             if (NSET == 2) bf2_buffer_store(dT, (int)__mul24(rr, dlT) + q8, 0, svT[k]);
+            if (SYM == 3) bf2_buffer_store(dT, (int)__mul24(rr, dlT) + q8, 0, svD[k]);      // per-axis symmetry: the same values to row block j0
         }
     }
 };
@@ -350,8 +364,9 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
     cip rp0 = (cip)A.rp0;
     const BF3Row<Gm> r = BF3Row<Gm>::of(A, B, t);
     const long long shift = (long long)W2 * B.row_lo - Gm::T0;
+    static_assert(SYM != 3 || NH == 1, "per-axis symmetry: the second store reads the rows again (no halves, no clears)");
 #pragma unroll
-    for (int X = 0; X < Gm::NSET; ++X) {
+    for (int X = 0; X < (SYM == 3 ? 2 : Gm::NSET); ++X) {
         if (X == 0 ? !B.stD : !B.stT) continue;
         const int c0x = X == 0 ? B.c0i : B.c0j, cx = X == 0 ? B.cj0 : B.ci0;
         double *px = A.data + ((long long)rp0[X == 0 ? B.i0 : B.j0] * B.S12 - A.nnz_off + shift);
@@ -361,7 +376,7 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
         for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W1; l += NCW) {
             const unsigned sB = (unsigned)max(cx * r.c1 + l - r.l0, 0);
             const __amdgpu_buffer_rsrc_t dsc = bf3_rs(px, (r.on && r.line_ok(l)) ? nx : 0);
-            double *lb = sets + X * Gm::SETSZ + r.line_off(l);
+            double *lb = sets + (SYM == 3 ? 0 : X) * Gm::SETSZ + r.line_off(l);
             for (int ch = 0; ch * 64 < B.ne * W2; ++ch) {
                 const bf3_v4i e = etab[min(ch * 64 + lane, Gm::NEL - 1)];
                 const bool ok = ch * 64 + lane < Gm::NEL && e.w != BF2_OOB;
@@ -387,7 +402,7 @@ __device__ __forceinline__ void bf3_sweeper(const BFArgs &A, const int r0, const
 {
     constexpr BFRole R = bf_role(MASK, RI);
     constexpr int p1 = P1 - 1;
-    constexpr bool ST = STW && RI >= 1;
+    constexpr bool ST = STW && (RI >= 1 || bf_nroles(MASK) == 1);      // (a form with ONE role -- mass -- and the duty on its sweepers)
     const int slane = threadIdx.x & 63;
     StoreT store;
     if constexpr (ST) store.init(A, *sc.B, sc.sw, slane);
@@ -827,9 +842,11 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     B.cj0 = j0 - jlo0[i0]; B.ci0 = i0 - jlo0[j0]; B.rlo = rlo; B.rhi = rhi;
     B.row_lo = row_lo; B.nrows = nrows; B.S12 = A.S1 * A.S2; B.ne = ne;
     B.stD = (i0 >= A.own_lo && i0 < A.own_hi) ? 1 : 0;
-    B.stT = (SYM == 2 && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
+    B.stT = ((SYM == 2 || SYM == 3) && !diag0 && j0 >= A.own_lo && j0 < A.own_hi) ? 1 : 0;
     // store duty: on the sweepers of the roles 1.. where the form has them (staged, dense), else on the contractors (at once)
-    constexpr bool STW = NR >= 2;
+    // (mass: on the sweepers at degree <= 2 -- 0.157 against 0.178 ms at BASELINE config 3 --, on the contractors above: the fifteen
+    // staged slots of a sweeper at degree 4 cost 154 registers and 6.5-7.1 against 6.3 ms at C4's size)
+    constexpr bool STW = NR >= 2 || (SYM == 3 && BF3_MASS_STW && Q <= 3);
     constexpr int NQ = (Gm::RMAX * W1 * W2 + 63) / 64;
     using Split = BF3DenseSplit<NR < 2 ? 2 : NR, NLG, NQ>;
     using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
@@ -851,7 +868,8 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     __builtin_amdgcn_s_setprio(BF2_PRIO_C);
     StoreC store;
     if constexpr (!STW) store.init(A, B, cw, lane);
-    const int nlines = diag0 ? P1 : W1;                   // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
+    const bool cdiag = diag0 || SYM == 3;                 // the block is contracted like a diagonal one
+    const int nlines = cdiag ? P1 : W1;                   // a diagonal outer block: the pairs (d + a, d) give both halves of its rows
     const int npieces = nlines * NPC;
     for (int t = d_begin; t < rhi + 1; ++t) {
         bar_lds();                                        // B1: the lines of flush t-1 are in LDS
@@ -861,7 +879,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
             BF3Unit U;
             U.lines = lines; U.V2s = V2s; U.sets = sets; U.dd = dd; U.rlo = rlo; U.rhi = rhi; U.row_lo = row_lo; U.nrows = nrows;
             U.nhi = jhi1[dd] - dd;
-            U.lane = lane; U.npieces = npieces; U.diag0 = diag0; U.stD = B.stD; U.stT = B.stT;
+            U.lane = lane; U.npieces = npieces; U.diag0 = cdiag; U.stD = SYM == 3 ? (B.stD | B.stT) : B.stD; U.stT = B.stT;
             // ring slot of the row a line is parked for: row dd + delta of ring line delta
             // (named scalars, not an array: the select by the lane's line must stay a chain of v_cndmask)
             U.rbs1 = Gm::roff(1) + (int)((unsigned)(dd + 1) % 2u) * RW; U.rbs2 = Gm::roff(2) + (int)((unsigned)(dd + 2) % 3u) * RW;
@@ -1003,9 +1021,17 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool
     // (degree 5 at sixteen waves per CU, the non-symmetric form: the general loop -- a span swept under a branch -- happens to be
     // the one hipcc fits into 128 registers without spills, so it also serves single knots there)
     using C0 = BF3CfgS3<PM, 0>;
+    if constexpr (MASK == BF_MASK_MASS) {
+        if constexpr (P1 == P2 && P1 == Q) {
+            if (symk == 3 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 3, true>(st, A, ncu);
+        }
+        if (symk == 3 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 3, false>(st, A, ncu);
+    }
+    constexpr bool S2 = !(MASK == BF_MASK_MASS && BF3_MASS_AXSYM);     // (the 3D mass form never takes SYM = 2: not compiled)
     if constexpr (P1 == P2 && P1 == Q) {                   // equal degrees: every form, 2D, repeated knots on the swept axis
-        if (symk == 2) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu)
-                                   : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
+        if constexpr (S2)
+            if (symk == 2) return mult ? launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, true>(st, A, ncu)
+                                       : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
         if (symk == 1 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 1, false>(st, A, ncu);
         if constexpr (MASK == BF_MASK_STIFF3)
             if (symk == 0) {
@@ -1014,7 +1040,8 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool
                                  : launch_bf3_k<P1, P2, Q, NY, MASK, 1, C0::NLG, C0::NCW, C0::NH, 0, false>(st, A, ncu);
             }
     } else {
-        if (symk == 2 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
+        if constexpr (S2)
+            if (symk == 2 && !mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C::NLG, C::NCW, C::NH, 2, false>(st, A, ncu);
     }
     set_error("fused stage: no kernel for this form at these degrees");
     return IGX_ERR_UNSUPPORTED;
@@ -1088,9 +1115,11 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     A.mid_lo = in.mid_lo; A.mid_hi = in.mid_hi; A.span_hi = in.span_hi;
     A.npairs = in.npairs;
     if (pt->dim == 3) { A.own_lo = pt->r0_lo; A.own_hi = pt->r0_hi; } else { A.own_lo = 0; A.own_hi = 1; }
-    const int symk = !in.sym ? 0 : pt->dim == 3 ? 2 : 1;
+    // (the 3D mass form is symmetric per axis: SYM = 3 -- unless the rows of the mid axis are cut by repeated knots with unequal
+    // degrees, which k_bf3 does not serve at all)
+    const int symk = !in.sym ? 0 : pt->dim == 3 ? ((BF3_MASS_AXSYM && mask == BF_MASK_MASS && ny == 1) ? 3 : 2) : 1;
     const int P1 = AM.P, P2 = AL.P, Q = AL.q;
-    if (AM.q != AL.q || !fused3_degrees(P1, P2, Q, symk == 2, AM.simple) || (!AM.simple && symk == 1)) { set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q); return IGX_ERR_UNSUPPORTED; }
+    if (AM.q != AL.q || !fused3_degrees(P1, P2, Q, symk >= 2, AM.simple) || (!AM.simple && symk == 1)) { set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q); return IGX_ERR_UNSUPPORTED; }
 #define BF3_CASE(p1, p2, q) if (P1 == p1 && P2 == p2 && Q == q) return launch_bf3_p<p1, p2, q>(st, A, ny, mask, pt->ctx->ncu, symk, !AM.simple);
     BF3_CASE(2, 2, 2) BF3_CASE(3, 3, 3) BF3_CASE(4, 4, 4) BF3_CASE(5, 5, 5) BF3_CASE(6, 6, 6)
     BF3_CASE(2, 3, 3) BF3_CASE(3, 2, 3) BF3_CASE(2, 2, 3)

@@ -916,7 +916,7 @@ int igx_assemble(igx_patch *pt, int kind, int algo, double *data_out)
     if (rc) return rc;
     pt->timing.n_launches = 1;
     // k_single2d: first and last event only (one launch); a chain without stage events likewise
-    const bool one_launch = algo == IGX_ALGO_SUMFACT && !sumfact_needs_fields(pt, kind) && pt->dim == 2;
+    const bool one_launch = algo == IGX_ALGO_SUMFACT && pt->dim == 2 && sumfact_single_launch(pt, kind);
     const bool staged = !one_launch && pt->knobs.stage_events;
     if (staged) IGX_HIP(hipEventRecord(ev[1], st));
     if (algo == IGX_ALGO_SUMFACT) {

@@ -329,6 +329,7 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
                 const GeoAForm *form = nullptr);
 bool geoA_form_supported(const igx_patch *pt);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
+bool sumfact_single_launch(const igx_patch *pt, int kind);     // the 2D single-launch kernel will run (no stage events inside)
 // device time of the mirror pass of this patch on `buf` (access pattern only: the values are whatever the buffer holds);
 // < 0 when the patch has no such pass
 float sumfact_probe_mirror(igx_patch *pt, double *buf);

@@ -821,6 +821,7 @@ static bool single2d_wanted(const igx_patch *pt, int kind)
 }
 
 bool form_on_fast_chain(const igx_patch *pt);
+bool sumfact_single_launch(const igx_patch *pt, int kind) { return single2d_wanted(pt, kind); }
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
     if (single2d_wanted(pt, kind)) return false;

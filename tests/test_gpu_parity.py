@@ -1184,7 +1184,13 @@ def test_both_triangles_from_the_fused_stage(iga, monkeypatch):
                 assert not np.isnan(A.data).any()
                 assert abs(A - A.T).max() == 0.0
                 out[bf] = A.data
-            assert np.array_equal(out[''], out['2']), (kind, [kv.numdofs for kv in kvs])
+            if kind == 'stiffness':
+                assert np.array_equal(out[''], out['2']), (kind, [kv.numdofs for kv in kvs])
+            else:
+                # round 6: the mass form goes through its per-axis symmetry (k_bf3<SYM = 3>: every block contracted like a diagonal
+                # one, a finished row stored to both row blocks) -- the upper lines of an off-diagonal block are no longer swept
+                # separately, so the two chains agree to rounding, not bit for bit
+                assert np.abs(out[''] - out['2']).max() <= 1e-14 * np.abs(out['2']).max(), (kind, [kv.numdofs for kv in kvs])
     monkeypatch.delenv('IGX_BF', raising=False)
 
 
