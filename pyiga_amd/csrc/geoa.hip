@@ -226,6 +226,9 @@ constexpr int GA_NGW = GA_NGW_N;
 #ifndef GA_NGW_T
 #define GA_NGW_T 8
 #endif
+#ifndef GA_MASS8
+#define GA_MASS8 1            // the mass form (one array) on the eight-wave block
+#endif
 #ifndef GA_F1_UNROLL
 #define GA_F1_UNROLL 1        // planes of a batch unrolled in the sweep of the convection-diffusion form
 #endif
@@ -486,7 +489,7 @@ k_geoA(const GeoAArgs A)
             }
             return;
         }
-        if (GA_ONEDIV && NS == 8) {
+        if (GA_ONEDIV && NS == 8 && A.kind != IGX_MASS) {
             // stiffness fields with ONE division (an f64 division is 12 vector instructions).  With the unscaled quotient-rule
             // matrix M = V'W - V W' (J = M / W^2; M = J for a polynomial geometry):
             //   GW |det J| J^-1 J^-T = GW adj(J) adj(J)^T / |det J| = GW / (W^2 |det M|) * adj(M) adj(M)^T
@@ -1046,6 +1049,9 @@ k_geoA(const GeoAArgs A)
     // instructions and 2 LDS reads at p = 4 instead of 5 + 15 and 7.  (acc += (V_a V_b) f instead of acc += V_b (V_a f): the
     // same roundings per (plane, pair) wherever the batches cut, so slabs and chunks still reproduce the patch bit for bit.)
     if constexpr (DPS) {
+        // (a form with fewer arrays than waves -- mass: one -- runs on the same block: every wave evaluates its plane of the batch,
+        // the waves without an array sweep and store nothing.  Mass at C4's size: 2.27 ms on one-wave blocks -> see DESIGN 3.1)
+        const bool live = w < A.nslots;
         const int t = A.type[w], fi = A.field[w];
         double *const out = A.out[w] + pt;
         const K1Store k1s(A.out[w], pt, tile, A.soff_ok);
@@ -1082,7 +1088,7 @@ k_geoA(const GeoAArgs A)
             double bv = FLD(buf, 0, fi, lane);
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                if (gb + j >= g_end) break;
+                if (gb + j >= g_end || !live) break;
                 // the operands of the next plane are requested before this plane's arithmetic
                 const int jn = j + 1 < NS ? j + 1 : j;
                 const double pvn = pw[(buf * NS + jn) * 64], bvn = FLD(buf, jn, fi, lane);
@@ -1463,6 +1469,8 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
         A.field[x] = slot_field ? slot_field[x] : 0; A.type[x] = slot_type ? slot_type[x] : 0; A.out[x] = slot_out[x];
         A.xfield[x] = slot_xfield ? slot_xfield[x] : -1; A.xtype[x] = slot_xtype ? slot_xtype[x] : 0;
     }
+    A.nslots = nslots;
+    for (int x = nslots; x < GA_MAXS; ++x) A.out[x] = A.out[0];  // (waves without an array: never stored through)
     A.ntiles = (int)((A.NPL + 63) / 64);
     dim3 grid((unsigned)((A.ntiles + 7) / 8 * 8), nchunks);     // the kernel permutes the tiles over the XCDs
     const int nc = pt->ncomp, p0g = pt->gax[0].P;
@@ -1507,7 +1515,9 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
         if (A0.P == 5) return launch_geoA_k<5, 8, 2, true>(st, A, nc, grid);
         return launch_geoA_k<4, 8, 2, true>(st, A, nc, grid);
     }
-#define GEOA_P(PV) case PV: return nslots == 1 ? launch_geoA_g<PV, 1>(st, A, nc, p0g, grid) : launch_geoA_g<PV, 8>(st, A, nc, p0g, grid)
+    // (mass -- one array -- on the eight-wave block where the pair-product sweep applies (p <= 4): the geometry of eight planes in
+    // parallel; the one-wave block of rounds 2-5 above that)
+#define GEOA_P(PV) case PV: return (nslots == 1 && !(GA_MASS8 && PV <= 5)) ? launch_geoA_g<PV, 1>(st, A, nc, p0g, grid) : launch_geoA_g<PV, 8>(st, A, nc, p0g, grid)
     switch (A0.P) {
         GEOA_P(2); GEOA_P(3); GEOA_P(4); GEOA_P(5); GEOA_P(6);
     }
