@@ -22,8 +22,10 @@ trace)
   find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c5_kernel_stats.csv"; rm -rf "$OUT/trace"
   timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --op rhs --steps 10 --warmup 2 > "$OUT/c4_rhs_bench_under_rocprof.json" 2>> "$OUT/trace.log"
   find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c4_rhs_kernel_stats.csv"; rm -rf "$OUT/trace"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --config c2 --steps 50 --warmup 5 --no-cpu-baseline --no-api-call > "$OUT/c2_bench_under_rocprof.json" 2>> "$OUT/trace.log"
+  find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c2_kernel_stats.csv"; rm -rf "$OUT/trace"
   timeout 600 python3 bench.py > "$OUT/c4_bench.json" 2>> "$OUT/bench.log"
-  for c in c1 c2 c3 c5 c4m c4k c4g c4l c5s; do timeout 300 python3 bench.py --config $c > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
+  for c in c1 c2 c3 c5 c4m c4k c4g c4l c5s c3mass c4mass; do timeout 300 python3 bench.py --config $c > "$OUT/${c}_bench.json" 2>> "$OUT/bench.log"; done
   timeout 300 python3 bench.py --op rhs > "$OUT/c4_rhs_bench.json" 2>> "$OUT/bench.log"
   timeout 300 python3 bench.py --op entries > "$OUT/c4_entries_bench.json" 2>> "$OUT/bench.log"
   timeout 300 python3 bench.py --op form --no-cpu-baseline > "$OUT/c4_form_bench.json" 2>> "$OUT/bench.log"
