@@ -1005,9 +1005,15 @@ template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = P
 #ifndef BF3_P6
 #define BF3_P6 1
 #endif
+#ifndef BF3_PM3_NLG
+#define BF3_PM3_NLG 2         // shape of the degree-2 stiffness kernel (BASELINE config 3): lane groups, contractor waves, halved passes
+#define BF3_PM3_NCW 4
+#define BF3_PM3_NH 1
+#endif
 template <int PM, int SYMK = 2> struct BF3CfgS3 {
     static constexpr bool P6 = PM == 6 && BF3_P6 && SYMK == 0;
-    static constexpr int NLG = PM == 5 || P6 ? 3 : 2, NCW = PM == 5 ? 4 : PM == 4 ? 8 : 4, NH = PM == 5 ? BF3_NH : P6 ? 3 : 1;
+    static constexpr int NLG = PM == 3 ? BF3_PM3_NLG : PM == 5 || P6 ? 3 : 2, NCW = PM == 3 ? BF3_PM3_NCW : PM == 5 ? 4 : PM == 4 ? 8 : 4,
+                         NH = PM == 3 ? BF3_PM3_NH : PM == 5 ? BF3_NH : P6 ? 3 : 1;
 };
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> : BF3CfgS3<PM, 2> {};
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = PM <= 5 ? 8 : 4, NH = 1; };
