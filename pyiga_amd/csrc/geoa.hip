@@ -714,19 +714,26 @@ k_geoA(const GeoAArgs A)
     if constexpr (FORM >= 2) {
         static_assert(DPF, "the table forms sweep with row-broadcast multiply-adds");
         constexpr int PW = NPW * 16;
+        // (one (type, pair) per geometry thread, worked out once; the planes of the batch in turn)
+        static_assert(4 * PW <= NGW * 64, "one product per geometry thread and plane");
+        const int pr_r = tid - NS * 64, pr_ty = pr_r / PW, pr_m = pr_r - pr_ty * PW;
+        int pr_a, pr_b;
+        bool pr_ok;
+        if (SYMW) {                                       // m = a (a + 1) / 2 + b, b <= a
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= pr_m) ++a;
+            pr_ok = a < P;
+            pr_b = min(pr_m - a * (a + 1) / 2, P - 1); pr_a = min(a, P - 1);
+        } else { pr_a = min(pr_m / P, P - 1); pr_b = pr_m - (pr_m / P) * P; pr_ok = pr_m < P * P; }
+        pr_a += 6 * (pr_ty >> 1); pr_b += 6 * (pr_ty & 1);
+        const bool pr_on = pr_r >= 0 && pr_r < 4 * PW;
         auto products_tab = [&](const int rsl, const int bufn) {
-            for (int i = tid - NS * 64; i < NS * 4 * PW; i += NGW * 64) {
-                const int jp = i / (4 * PW), r = i - jp * (4 * PW), ty = r / PW, m = r - ty * PW;
-                int a, b;
-                bool ok;
-                if (SYMW) {                               // m = a (a + 1) / 2 + b, b <= a
-                    a = 0;
-                    while ((a + 1) * (a + 2) / 2 <= m) ++a;
-                    b = m - a * (a + 1) / 2; ok = a < P;
-                    a = min(a, P - 1); b = min(b, P - 1);
-                } else { a = min(m / P, P - 1); b = m - (m / P) * P; ok = m < P * P; }
-                const double x = rec[rsl][jp][6 * (ty >> 1) + a] * rec[rsl][jp][6 * (ty & 1) + b];
-                prd_[(bufn * NS + jp) * (4 * PW) + r] = ok ? x : 0.0;
+            if (pr_on) {
+#pragma unroll
+                for (int jp = 0; jp < NS; ++jp) {
+                    const double x = rec[rsl][jp][pr_a] * rec[rsl][jp][pr_b];
+                    prd_[(bufn * NS + jp) * (4 * PW) + pr_r] = pr_ok ? x : 0.0;
+                }
             }
         };
         if (w >= NS) {
@@ -882,14 +889,21 @@ k_geoA(const GeoAArgs A)
         // only at the barriers, so that no value of one role is live in the other (the pair window of a sweep wave alone is 72
         // registers at p = 5; anything spilled around it is reloaded behind a vmcnt(0), i.e. behind the K1 stores).
         // pair products of a batch (GA_DPP): V_a[tv] V_b[tu] per (plane, type, pair m = a P + b), by the geometry waves
+        // (one (type, pair) per thread, its place in the record and in the product image worked out ONCE; the planes of the batch in
+        // turn -- the index arithmetic of six products per thread and batch was as long as the evaluation of a plane)
+        constexpr int PWF = NPVF * 16;
+        static_assert(!DPF || 4 * PWF <= NGW * 64, "one product per geometry thread and plane");
+        const int pr_r = tid - NS * 64, pr_ty = pr_r / PWF, pr_m = pr_r - pr_ty * PWF;
+        const int pr_a = 6 * (pr_ty >> 1) + min(pr_m / P, P - 1), pr_b = 6 * (pr_ty & 1) + (pr_m - (pr_m / P) * P);
+        const bool pr_on = pr_r >= 0 && pr_r < 4 * PWF, pr_ok = pr_m < P * P;
         auto products_full = [&](const int rsl, const int bufn) {
             if constexpr (DPF) {
-                constexpr int PW = NPVF * 16;
-                for (int i = tid - NS * 64; i < NS * 4 * PW; i += NGW * 64) {
-                    const int jp = i / (4 * PW), r = i - jp * (4 * PW), ty = r / PW, m = r - ty * PW;
-                    const int a = min(m / P, P - 1), b = m - (m / P) * P;
-                    const double x = rec[rsl][jp][6 * (ty >> 1) + a] * rec[rsl][jp][6 * (ty & 1) + b];
-                    prd_[(bufn * NS + jp) * (4 * PW) + r] = m < P * P ? x : 0.0;
+                if (pr_on) {
+#pragma unroll
+                    for (int jp = 0; jp < NS; ++jp) {
+                        const double x = rec[rsl][jp][pr_a] * rec[rsl][jp][pr_b];
+                        prd_[(bufn * NS + jp) * (4 * PWF) + pr_r] = pr_ok ? x : 0.0;
+                    }
                 }
             }
         };
