@@ -226,6 +226,9 @@ constexpr int GA_NGW = GA_NGW_N;
 #ifndef GA_NGW_T
 #define GA_NGW_T 8
 #endif
+#ifndef GA_T2_UNROLL_P
+#define GA_T2_UNROLL_P 5      // non-symmetric table forms: the planes of a batch unrolled up to this P (functions per span): 10.3-10.7 -> 9.8-10.3 ms at C4 size
+#endif
 #ifndef GA_MASS8
 #define GA_MASS8 1            // the mass form (one array) on the eight-wave block
 #endif
@@ -868,7 +871,7 @@ k_geoA(const GeoAArgs A)
                 l = 0; ++sp;
                 return true;
             };
-            if constexpr (SYMW && P <= 5) {
+            if constexpr ((SYMW && P <= 5) || (!SYMW && P <= GA_T2_UNROLL_P)) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
                     if (!plane(j)) break;
