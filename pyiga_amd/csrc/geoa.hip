@@ -232,8 +232,8 @@ constexpr int GA_NGW = GA_NGW_N;
 #ifndef GA_MASS8
 #define GA_MASS8 1            // the mass form (one array) on the eight-wave block
 #endif
-#ifndef GA_F1_UNROLL
-#define GA_F1_UNROLL 1        // planes of a batch unrolled in the sweep of the convection-diffusion form
+#ifndef GA_F1_UNROLL_P
+#define GA_F1_UNROLL_P 6      // convection-diffusion form: the planes of a batch unrolled up to this P (functions per span): 6.81 -> 6.37 ms at C5
 #endif
 constexpr int geoa_ngw(int FORM) { return FORM >= 2 ? GA_NGW_T : FORM == 1 ? GA_NGW : 0; }
 constexpr int geoa_wpe(int NS, int FORM) { return FORM >= 1 ? (geoa_ngw(FORM) > 4 ? 4 : 3) : NS >= 8 ? 4 : 1; }
@@ -995,9 +995,8 @@ k_geoA(const GeoAArgs A)
                 operands(pv1, bv1, 0, t, fi);
                 if (xf >= 0) operands(pv2, bv2, 0, xt, xf);
             }
-#pragma unroll GA_F1_UNROLL
-            for (int j = 0; j < NS; ++j) {
-                if (gb + j >= g_end) break;
+            auto plane = [&](const int j) __attribute__((always_inline)) -> bool {
+                if (gb + j >= g_end) return false;
                 if constexpr (DPF) {
                     double pn1[NPVF], pn2[NPVF], bn1, bn2 = 0.0;
                     const int jn = j + 1 < NS ? j + 1 : j;
@@ -1020,7 +1019,7 @@ k_geoA(const GeoAArgs A)
                     source(rs, buf, j, t, fi);
                     if (xf >= 0) source(rs, buf, j, xt, xf);
                 }
-                if (++l < q) continue;
+                if (++l < q) return true;
                 const bool write = sp >= own_lo && !GA_OFF(2);
                 const int *fr = (const int *)&rec[rs][j][20];
                 const int nst = __builtin_amdgcn_readfirstlane(fr[0]), st0 = __builtin_amdgcn_readfirstlane(fr[1]);
@@ -1052,6 +1051,18 @@ k_geoA(const GeoAArgs A)
                     for (int b = 0; b < P; ++b) { acc[P - 1][b] = 0.0; acc[b][P - 1] = 0.0; }
                 }
                 l = 0; ++sp;
+                return true;
+            };
+            // (the planes of a batch unrolled where the registers allow it: the waits for the LDS reads are counted then and the
+            // next plane's operands stay in flight under this plane's arithmetic)
+            if constexpr (DPF && P <= GA_F1_UNROLL_P) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (!plane(j)) break;
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < NS; ++j)
+                    if (!plane(j)) break;
             }
             next_batch_barriers(gb + NS, rn);
             rs = rn;
