@@ -133,6 +133,7 @@ typedef struct {
 #define IGX_PATH_SINGLE  8   /* 2D mass / stiffness in ONE launch (k_single2d: fields, sweep and contraction in LDS): timing.stage1_ms */
 #define IGX_PATH_BOTH   32   /* the fused stage wrote both triangles of a symmetric form itself (k_bf3): no mirror pass; timing.stage1_ms = k_bf3 */
 #define IGX_PATH_BF3    64   /* the fused stage ran as k_bf3 (fused3.hip: entry rings per line, store duty on the sweeper waves) */
+#define IGX_PATH_TWIN  128   /* repeated knots on the last axis: the chain ran on the patch with mid and last axis exchanged, k_bf3 stored to this patch's layout */
 #define IGX_PATH_KRON   16   /* separable geometry: 2D matrices of the cross-section expanded by k_kron3 (igx_assemble_kron3): timing.final_ms */
 
 int         igx_version(void);

@@ -295,9 +295,9 @@ class DevicePatch:
         return scipy.sparse.csr_matrix((data, indices, indptr), shape=self.shape)
 
     def last_path(self):
-        """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'both' (the fused stage wrote both triangles), 'bf3' (the fused stage ran as k_bf3), 'mirror', 'single' (include/igx.h IGX_PATH_*)."""
+        """Kernels of the last sum-factorised assembly: set of 'geoA', 'fused', 'both' (the fused stage wrote both triangles), 'bf3' (the fused stage ran as k_bf3), 'mirror', 'single', 'twin' (the chain ran on the patch with mid and last axis exchanged) (include/igx.h IGX_PATH_*)."""
         bits = _lib.load().igx_patch_last_path(self.handle)
-        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single'), (16, 'kron'), (32, 'both'), (64, 'bf3')) if bits & bit}
+        return {name for bit, name in ((1, 'geoA'), (2, 'fused'), (4, 'mirror'), (8, 'single'), (16, 'kron'), (32, 'both'), (64, 'bf3'), (128, 'twin')) if bits & bit}
 
     def placement(self):
         """Outcome of the opt-in buffer placement search (IGX_PLACEMENT_TRIES, include/igx.h igx_patch_placement):

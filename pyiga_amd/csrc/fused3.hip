@@ -159,12 +159,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf3_rs(double *ptr, const int 
 // the lines (sw + ROT c) % NS + NS j.  Used where the form has ONE sweeper role (mass): the contractors carry it, at once (read ->
 // store inside the B2 -> B1 window).  Rows next to the ends of the last axis (segments of fewer than 2 p2 + 1 columns) are not
 // part of the slots (their lanes carry an out-of-range row constant and are not cleared): bf3_edge_rows().
-template <class Gm, int NS, int ROT, int NH, int SYM>
+//
+// TR (round 6, every store path of the kernel): the patch is one whose MID AND LAST AXIS WERE EXCHANGED by the host (repeated knots on
+// the last axis of the caller's patch: sumfact.hip, swap_route) and the values go to the CSR layout of the CALLER's patch -- row
+// (i0, i2, d), and inside the segment of an outer column the entry of (line l, entry e) at (cx c2 + e) c1 + (l - l0) instead of
+// (cx c1 + l - l0) c2 + e: with rp2 / c2 the row table of the last axis here (the caller's mid axis) and rp1d / c1 those of row d
+//     offset = c0 (rp2[i2] S1 + c2 rp1d) + (cx c2 + e) c1 + (l - l0)        (non-TR: c0 (rp1d S2 + c1 rp2[i2]) + (cx c1 + l - l0) c2 + e)
+// Only the offsets change: what a lane reads from the rings, and when, is the same.
+template <class Gm, int NS, int ROT, int NH, int SYM, bool TR>
 struct BF3Store {
     static constexpr int P1 = Gm::P1_, W1 = Gm::W1, W2 = Gm::W2, p2 = Gm::p2, NSUB = Gm::NSUB, RW = Gm::RW;
     static constexpr int JMAX = (W1 + NS - 1) / NS, NST = NSUB * JMAX, NSET = SYM == 2 ? 2 : 1;
     using Row = BF3Row<Gm>;
     int rrv[NSUB];               // W2 i2 - T0 of this lane's row in chunk c, or a value that takes the offset out of range
+    int ev[TR ? NSUB : 1];       // TR: 8 x the lane's entry index in chunk c
     int lane8, lanec, inv;       // 8 lane | offset (doubles) of this lane in the last chunk, kept inside the line
     double *pD, *pT;             // descriptor bases (an absent row or line gets length 0: every lane out of range)
     int nD, nT;
@@ -174,6 +182,20 @@ struct BF3Store {
         cip rp0 = (cip)A.rp0;
         lane8 = lane * 8;
         lanec = min((NSUB - 1) * 64 + lane, RW - 1) - (NSUB - 1) * 64;
+        if constexpr (TR) {
+            // whole row blocks of the two outer rows; a lane without a row gets a row constant beyond both (c0max < 2 c0min)
+            pD = A.data + ((long long)rp0[B.i0] * B.S12 - A.nnz_off); nD = B.stD ? (int)((long long)B.c0i * B.S12 * 8) : 0;
+            pT = A.data + ((long long)rp0[B.j0] * B.S12 - A.nnz_off); nT = B.stT ? (int)((long long)B.c0j * B.S12 * 8) : 0;
+            inv = 2 * (int)A.S2 + 1;
+#pragma unroll
+            for (int c = 0; c < NSUB; ++c) {
+                const int q = c * 64 + lane, rr = q / W2, i2 = B.row_lo + rr;
+                const bool ok = q < RW && rr < B.nrows && i2 >= p2 && i2 <= A.N2 - 1 - p2;
+                rrv[c] = ok ? W2 * i2 - Gm::T0 : inv;
+                ev[c] = 8 * (q - rr * W2);
+            }
+            return;
+        }
         // descriptors: base moved by W2 row_lo - T0 doubles, so that an interior row i2 of the tile sits at (W2 i2 - T0) (c0 c1 - 1)
         // + (chunk element index) + W2 (line terms); length = the row block of the outer row (anything beyond is dropped)
         const long long shift = (long long)W2 * B.row_lo - Gm::T0;
@@ -191,6 +213,7 @@ struct BF3Store {
     }
     __device__ __forceinline__ static int line_of(const int sw, const int c, const int j) { return (int)((unsigned)(sw + ROT * c) % (unsigned)NS) + NS * j; }
 
+    // (TR: sK = 8 c0 S1, soff0 = 8 (c0 W2 rp1d + cx W2 c1 - l0), a line adds 8)
     template <int X>
     __device__ __forceinline__ void move_row(double *sets, double *dump, const int sw, const int lane, const Row &r, double *ptr, const int len, const int sK, const int soff0)
     {
@@ -217,7 +240,8 @@ struct BF3Store {
         int voff[NSUB];
 #pragma unroll
         for (int c = 0; c < NSUB; ++c) {
-            voff[c] = (int)__umul24((unsigned)rrv[c], (unsigned)sK) + lane8;
+            if constexpr (TR) voff[c] = (int)(__umul24((unsigned)rrv[c], (unsigned)sK) + __umul24((unsigned)ev[c], (unsigned)r.c1));
+            else voff[c] = (int)__umul24((unsigned)rrv[c], (unsigned)sK) + lane8;
             asm volatile("" : "+v"(voff[c]));               // (+ c * 512 below is the store's immediate offset, not another register)
         }
 #pragma unroll
@@ -225,13 +249,22 @@ struct BF3Store {
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int l = line_of(sw, c, j);
-                bf2_buffer_store(bf3_rs(ptr, r.line_ok(l) ? len : 0), voff[c] + c * 512, soff0 + 8 * W2 * l, v[c * JMAX + j]);
+                if constexpr (TR) bf2_buffer_store(bf3_rs(ptr, r.line_ok(l) ? len : 0), voff[c], soff0 + 8 * l, v[c * JMAX + j]);
+                else bf2_buffer_store(bf3_rs(ptr, r.line_ok(l) ? len : 0), voff[c] + c * 512, soff0 + 8 * W2 * l, v[c * JMAX + j]);
             }
     }
     // behind B2 of step t: rows d = t - 1 of both sets are complete: out of the rings, to their segments
     __device__ __forceinline__ void fetch(const BFArgs &A, const BF3Blk &B, double *sets, double *dump, const int t, const int sw, const int lane)
     {
         const Row r = Row::of(A, B, t);
+        if constexpr (TR) {
+            const int sD = 8 * B.c0i * (int)A.S1, sT = 8 * B.c0j * (int)A.S1;
+            const int oD = 8 * (W2 * (B.c0i * r.rp1d + B.cj0 * r.c1) - r.l0), oT = 8 * (W2 * (B.c0j * r.rp1d + B.ci0 * r.c1) - r.l0);
+            move_row<0>(sets, dump, sw, lane, r, pD, r.on ? nD : 0, sD, oD);
+            if (NSET == 2) move_row<1>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, sT, oT);
+            if (SYM == 3) move_row<0>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, sT, oT);
+            return;
+        }
         move_row<0>(sets, dump, sw, lane, r, pD, r.on ? nD : 0, 8 * (B.c0i * r.c1 - 1), 8 * ((int)((long long)B.c0i * A.S2) * r.rp1d + W2 * (B.cj0 * r.c1 - r.l0)));
         if (NSET == 2)
             move_row<1>(sets, dump, sw, lane, r, pT, r.on ? nT : 0, 8 * (B.c0j * r.c1 - 1), 8 * ((int)((long long)B.c0j * A.S2) * r.rp1d + W2 * (B.ci0 * r.c1 - r.l0)));
@@ -256,7 +289,7 @@ template <int NR, int NLG, int NQ> struct BF3DenseSplit {
     static constexpr int QB = NA * KA < NQ ? NA * KA : NQ;                     // first slot of the last role's group
 };
 constexpr int BF3_FAR = 0x7f000000;       // added to the offset of what must not be stored: beyond every descriptor (<= 0.9 GB, fused3_offsets_fit)
-template <class Gm, int NH, int SYM, int K, int QLO, int QHI, int QSTR>
+template <class Gm, int NH, int SYM, int K, int QLO, int QHI, int QSTR, bool TR>
 struct BF3StoreDense {
     static constexpr int p1 = Gm::p1, p2 = Gm::p2, W1 = Gm::W1, W2 = Gm::W2, WW = W1 * W2, RW = Gm::RW, NSET = SYM == 2 ? 2 : 1;
     using Row = BF3Row<Gm>;
@@ -326,6 +359,29 @@ struct BF3StoreDense {
         const Row r = Row::of(A, B, t);
         // descriptors of the row: base moved by the row's constant part, so that an element sits at 8 (its index in the image)
         // + row * 8 W2 (c0 c1 - W1); what is left of the row block behind the moved base is the length
+        if constexpr (TR) {
+            // offset of (row rr, line l, entry e) = c0 S1 (W2 (row_lo + rr) - T0) + c0 W2 rp1d + (cx W2 + e) c1 + l - l0
+            //                                     = [row constant part: the descriptor's base] + (rr W2 + e) c1 + rr W2 (c0 S1 - c1) + l
+            const long long rowc = (long long)W2 * B.row_lo - Gm::T0;
+            const long long shD = (long long)B.c0i * A.S1 * rowc + (long long)W2 * (B.c0i * r.rp1d + B.cj0 * r.c1) - r.l0;
+            const long long shT = (long long)B.c0j * A.S1 * rowc + (long long)W2 * (B.c0j * r.rp1d + B.ci0 * r.c1) - r.l0;
+            const __amdgpu_buffer_rsrc_t dD = bf3_rs(pD + shD, r.on ? (int)max(nD - shD * 8, 0LL) : 0);
+            const __amdgpu_buffer_rsrc_t dT = bf3_rs(pT + shT, r.on ? (int)max(nT - shT * 8, 0LL) : 0);
+            const int dlD = 8 * W2 * (B.c0i * (int)A.S1 - r.c1), dlT = 8 * W2 * (B.c0j * (int)A.S1 - r.c1), c18 = 8 * r.c1;
+            const int lane = lane8 >> 3;
+            const int offl = (unsigned)(lane - r.l0) < (unsigned)r.c1 ? lane8 : BF3_FAR;      // lane j: 8 x line j, or far away
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                int pkk = pk[k];
+                asm volatile("" : "+v"(pkk));
+                const int rr = (pkk >> 18) & 0xff;
+                const int q8 = __builtin_amdgcn_ds_bpermute(pkk & 60, offl) + (int)__mul24((pkk >> 6) & 0xfff, c18);
+                bf2_buffer_store(dD, (int)__mul24(rr, dlD) + q8, 0, svD[k]);
+                if (NSET == 2) bf2_buffer_store(dT, (int)__mul24(rr, dlT) + q8, 0, svT[k]);
+                if (SYM == 3) bf2_buffer_store(dT, (int)__mul24(rr, dlT) + q8, 0, svD[k]);
+            }
+            return;
+        }
         const int cD = B.c0i * r.c1, cT = B.c0j * r.c1;
         const long long rowc = (long long)W2 * B.row_lo - Gm::T0;
         const long long shD = (long long)B.c0i * A.S2 * r.rp1d + cD * rowc + W2 * (B.cj0 * r.c1 - r.l0);
@@ -356,7 +412,7 @@ struct BF3StoreDense {
 // Rows next to the ends of the last axis, behind B2 of step t, on the contractor waves: element (row, entry) of the table per
 // lane, one (set, line) per round; offset = 8 (c0 c1 rp2[i2] + (cX c1 + m) c2 + o) with the descriptor's shift folded into the
 // table.  The elements are read and cleared here and nowhere else.
-template <class Gm, int NCW, int NH, int SYM>
+template <class Gm, int NCW, int NH, int SYM, bool TR>
 __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, double *sets, const bf3_v4i *etab, const int t, const int cw, const int lane)
 {
     constexpr int W1 = Gm::W1, W2 = Gm::W2;
@@ -369,12 +425,14 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
     for (int X = 0; X < (SYM == 3 ? 2 : Gm::NSET); ++X) {
         if (X == 0 ? !B.stD : !B.stT) continue;
         const int c0x = X == 0 ? B.c0i : B.c0j, cx = X == 0 ? B.cj0 : B.ci0;
-        double *px = A.data + ((long long)rp0[X == 0 ? B.i0 : B.j0] * B.S12 - A.nnz_off + shift);
-        const int nx = (int)(((long long)c0x * B.S12 - shift) * 8);
-        const unsigned sA = (unsigned)(c0x * r.c1);
-        const int soffr = 8 * (int)((long long)c0x * A.S2) * r.rp1d;
+        // TR (table: {ring offset, 8 c2, 8 e, rp2[i2]}): offset = 8 c0 S1 rp2[i2] + 8 c2 (c0 rp1d + cx c1) + 8 e c1 + 8 (l - l0)
+        double *px = A.data + ((long long)rp0[X == 0 ? B.i0 : B.j0] * B.S12 - A.nnz_off + (TR ? 0 : shift));
+        const int nx = (int)(((long long)c0x * B.S12 - (TR ? 0 : shift)) * 8);
+        const unsigned sA = TR ? (unsigned)(c0x * r.rp1d + cx * r.c1) : (unsigned)(c0x * r.c1);
+        const unsigned sC = (unsigned)(8 * c0x * (int)A.S1);
+        const int soffr = TR ? 0 : 8 * (int)((long long)c0x * A.S2) * r.rp1d;
         for (int l = (int)((unsigned)(cw + NCW - X) % (unsigned)NCW); l < W1; l += NCW) {
-            const unsigned sB = (unsigned)max(cx * r.c1 + l - r.l0, 0);
+            const unsigned sB = TR ? (unsigned)r.c1 : (unsigned)max(cx * r.c1 + l - r.l0, 0);
             const __amdgpu_buffer_rsrc_t dsc = bf3_rs(px, (r.on && r.line_ok(l)) ? nx : 0);
             double *lb = sets + (SYM == 3 ? 0 : X) * Gm::SETSZ + r.line_off(l);
             for (int ch = 0; ch * 64 < B.ne * W2; ++ch) {
@@ -383,7 +441,9 @@ __device__ __forceinline__ void bf3_edge_rows(const BFArgs &A, const BF3Blk &B, 
                 double *src = lb + e.x;
                 const double v = *src;
                 if (NH >= 2 && ok) *src = 0.0;
-                const int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z)) + e.w;
+                int off = (int)(__umul24(sA, (unsigned)e.y) + __umul24(sB, (unsigned)e.z));
+                if constexpr (TR) off += (int)__umul24(sC, (unsigned)e.w) + 8 * (l - r.l0);
+                else off += e.w;
                 bf2_buffer_store(dsc, ok ? off : BF2_OOB, soffr, v);
             }
         }
@@ -753,7 +813,7 @@ __device__ __forceinline__ void bf3_unit(const BF3Unit U, const int pass)
     }
 }
 
-template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT>
+template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT, bool TR = false>
 __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(const BFArgs A)
 {
     using Gm = BF3Geom<P1, P2, Q, NLG, bf_nroles(MASK), NCW, SYM>;
@@ -818,6 +878,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
             if (e < c2) {
                 const int shift = W2 * row_lo - Gm::T0;
                 v.x = (i2 - row_lo) * W2 + e; v.y = 8 * A.rp2[i2]; v.z = 8 * c2; v.w = 8 * (e - shift);
+                if constexpr (TR) { v.y = 8 * c2; v.z = 8 * e; v.w = A.rp2[i2]; }
             }
         }
         etab[threadIdx.x] = v;
@@ -849,9 +910,9 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     constexpr bool STW = NR >= 2 || (SYM == 3 && BF3_MASS_STW && Q <= 3);
     constexpr int NQ = (Gm::RMAX * W1 * W2 + 63) / 64;
     using Split = BF3DenseSplit<NR < 2 ? 2 : NR, NLG, NQ>;
-    using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA>;   // middle roles
-    using StoreB = BF3StoreDense<Gm, NH, SYM, Split::KB, Split::QB, NQ, Split::NB>;                                       // last role
-    using StoreC = BF3Store<Gm, NCW, 1, NH, SYM>;                                                                          // contractors (one-role forms)
+    using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA, TR>;   // middle roles
+    using StoreB = BF3StoreDense<Gm, NH, SYM, Split::KB, Split::QB, NQ, Split::NB, TR>;                                       // last role
+    using StoreC = BF3Store<Gm, NCW, 1, NH, SYM, TR>;                                                                          // contractors (one-role forms)
     double *dump = lines + NR * Gm::TLP;                  // (the padding of line 0: target of the clears that must not happen)
     if (task < NSW) {
         const int role = task / NLG, lg = task % NLG;
@@ -915,7 +976,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
         BF_SEG_END(1);
         bar_lds();                                        // B2: lines may be overwritten, entries are visible
         BF_SEG_BEGIN();
-        bf3_edge_rows<Gm, NCW, NH, SYM>(A, B, sets, etab, t, cw, lane);
+        bf3_edge_rows<Gm, NCW, NH, SYM, TR>(A, B, sets, etab, t, cw, lane);
         if constexpr (!STW) store.fetch(A, B, sets, dump, t, cw, lane);
         BF_SEG_END(0);
     }
@@ -940,7 +1001,15 @@ bool fused3_offsets_fit(int dim, int p0, int p1, int p2, long long S_mid, long l
     return true;
 }
 
-template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT>
+// ... and the exchanged-axes store (TR) multiplies a row of the tile by 8 W2 c0 S_mid and a row constant by 8 c0 S_mid (24-bit)
+bool fused3_tr_fits(int p0, int p1, int p2, long long S_mid, long long S_last)
+{
+    const long long c0max = 2 * p0 + 1, W2 = 2 * p2 + 1;
+    (void)p1;
+    return 8 * W2 * c0max * S_mid < (1LL << 23) && 2 * S_last + 1 < (1LL << 24) && (2 * S_last + 1) * 8 * c0max * S_mid + 8 * W2 * 16 < (1LL << 32);
+}
+
+template <int P1, int P2, int Q, int NY, int MASK, int NA, int NLG, int NCW, int NH, int SYM, bool MULT, bool TR = false>
 static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
 {
     using Gm = BF3Geom<P1, P2, Q, NLG, bf_nroles(MASK), NCW, SYM>;
@@ -952,7 +1021,7 @@ static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
     static_assert(Gm::NSUB * 512 <= 4096, "k_bf3: immediate offsets of the stores");
     static_assert(Gm::NEL <= 1024 && Gm::W1 <= 15, "k_bf3: edge table / line index");
     constexpr int nthreads = (bf_nroles(MASK) * NLG + NCW) * 64;
-    const void *fn = (const void *)k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT>;
+    const void *fn = (const void *)k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT, TR>;
     IGX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1, ncu = ncu_ctx;
     {
@@ -968,7 +1037,7 @@ static int launch_bf3_k(hipStream_t st, const BFArgs &A0, int ncu_ctx)
     if (A.tail_k > 0) nblocks = A.main_blocks + (nblocks - A.main_blocks) * A.tail_k;
     if (nblocks > 0x7fffffffLL) { set_error("fused stage: too many blocks"); return IGX_ERR_UNSUPPORTED; }
     if (nblocks == 0) return IGX_OK;
-    k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
+    k_bf3<P1, P2, Q, NY, MASK, NA, NLG, NCW, NH, SYM, MULT, TR><<<dim3((unsigned)nblocks), dim3(nthreads), lds, st>>>(A);
     IGX_HIP(hipGetLastError());
 #ifdef IGX_BF_STAMP
     {
@@ -1019,9 +1088,25 @@ template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF3> : BF3CfgS3<PM, 2> {};
 template <int PM> struct BF3Cfg<PM, BF_MASK_STIFF2> { static constexpr int NLG = 2, NCW = PM <= 5 ? 8 : 4, NH = 1; };
 
 template <int P1, int P2, int Q, int NY, int MASK>
-static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult_in)
+static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool mult_in, bool tr)
 {
     const bool mult = mult_in;
+    if (tr) {
+        // values to the layout of the caller's patch, whose mid and last axis the host exchanged (BF3Store, TR): equal degrees,
+        // repeated knots on the swept axis (that is why they were exchanged), the three 3D forms
+        if constexpr (P1 == P2 && P1 == Q && P1 <= 5) {
+            if constexpr (MASK == BF_MASK_MASS)
+                if (symk == 3 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, BF3Cfg<P1, MASK>::NLG, BF3Cfg<P1, MASK>::NCW, BF3Cfg<P1, MASK>::NH, 3, true, true>(st, A, ncu);
+            if constexpr (MASK == BF_MASK_STIFF3) {
+                using C2 = BF3Cfg<P1, MASK>;
+                using C0 = BF3CfgS3<P1, 0>;
+                if (symk == 2 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C2::NLG, C2::NCW, C2::NH, 2, true, true>(st, A, ncu);
+                if (symk == 0 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, C0::NLG, C0::NCW, C0::NH, 0, true, true>(st, A, ncu);
+            }
+        }
+        set_error("fused stage: no kernel with exchanged axes for this form at these degrees");
+        return IGX_ERR_UNSUPPORTED;
+    }
     constexpr int PM = Q > (P1 > P2 ? P1 : P2) ? Q : (P1 > P2 ? P1 : P2);   // (the registers of a sweeper follow P1 and Q)
     using C = BF3Cfg<PM, MASK>;
     // (degree 5 at sixteen waves per CU, the non-symmetric form: the general loop -- a span swept under a branch -- happens to be
@@ -1053,12 +1138,12 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool
     return IGX_ERR_UNSUPPORTED;
 }
 template <int P1, int P2, int Q>
-static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk, bool mult)
+static int launch_bf3_p(hipStream_t st, const BFArgs &A, int ny, int mask, int ncu, int symk, bool mult, bool tr)
 {
-    if (ny == 1 && mask == BF_MASK_MASS) return launch_bf3_c<P1, P2, Q, 1, BF_MASK_MASS>(st, A, ncu, symk, mult);
-    if (ny == 4 && mask == BF_MASK_STIFF3) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF3>(st, A, ncu, symk, mult);
+    if (ny == 1 && mask == BF_MASK_MASS) return launch_bf3_c<P1, P2, Q, 1, BF_MASK_MASS>(st, A, ncu, symk, mult, tr);
+    if (ny == 4 && mask == BF_MASK_STIFF3) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF3>(st, A, ncu, symk, mult, tr);
     if constexpr (P1 == P2 && P1 == Q)
-        if (ny == 4 && mask == BF_MASK_STIFF2) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF2>(st, A, ncu, symk, mult);
+        if (ny == 4 && mask == BF_MASK_STIFF2) return launch_bf3_c<P1, P2, Q, 4, BF_MASK_STIFF2>(st, A, ncu, symk, mult, tr);
     set_error("fused stage: no kernel for this set of types");
     return IGX_ERR_UNSUPPORTED;
 }
@@ -1126,7 +1211,8 @@ int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *
     const int symk = !in.sym ? 0 : pt->dim == 3 ? ((BF3_MASS_AXSYM && mask == BF_MASK_MASS && ny == 1) ? 3 : 2) : 1;
     const int P1 = AM.P, P2 = AL.P, Q = AL.q;
     if (AM.q != AL.q || !fused3_degrees(P1, P2, Q, symk >= 2, AM.simple) || (!AM.simple && symk == 1)) { set_error("fused stage: degrees (%d, %d) with %d Gauss points per span", P1 - 1, P2 - 1, Q); return IGX_ERR_UNSUPPORTED; }
-#define BF3_CASE(p1, p2, q) if (P1 == p1 && P2 == p2 && Q == q) return launch_bf3_p<p1, p2, q>(st, A, ny, mask, pt->ctx->ncu, symk, !AM.simple);
+    if (in.tr && !fused3_tr_fits(pt->ax[0].p, AM.p, AL.p, AM.S, AL.S)) { set_error("fused stage: patch too large for the exchanged-axes store"); return IGX_ERR_UNSUPPORTED; }
+#define BF3_CASE(p1, p2, q) if (P1 == p1 && P2 == p2 && Q == q) return launch_bf3_p<p1, p2, q>(st, A, ny, mask, pt->ctx->ncu, symk, !AM.simple, in.tr != 0);
     BF3_CASE(2, 2, 2) BF3_CASE(3, 3, 3) BF3_CASE(4, 4, 4) BF3_CASE(5, 5, 5) BF3_CASE(6, 6, 6)
     BF3_CASE(2, 3, 3) BF3_CASE(3, 2, 3) BF3_CASE(2, 2, 3)
     BF3_CASE(3, 4, 4) BF3_CASE(4, 3, 4) BF3_CASE(3, 3, 4)

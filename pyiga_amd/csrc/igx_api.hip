@@ -362,6 +362,7 @@ int igx_grid_jacobian(igx_ctx *ctx, const igx_patch_desc *d, int ncomp, const do
 void igx_patch_destroy(igx_patch *pt)
 {
     if (!pt) return;
+    if (pt->twin) { igx_patch_destroy(pt->twin); pt->twin = nullptr; }
     (void)hipSetDevice(pt->ctx->device);
     (void)hipStreamSynchronize(pt->ctx->stream);
     for (int k = 0; k < 3; ++k) { free_axis(pt->ax[k]); free_geo_axis(pt->gax[k]); }
@@ -511,6 +512,35 @@ igx_patch *igx_patch_create(igx_ctx *ctx, const igx_patch_desc *d)
     }
     if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("igx_patch_create: stream sync failed: %s", hipGetErrorString(hipGetLastError())); rc = IGX_ERR_HIP; }
     if (rc) { igx_patch_destroy(pt); return nullptr; }
+    // Repeated knots on the last axis only, geometry given as a spline: the twin patch (mid and last axis exchanged) through which
+    // the mass and the stiffness matrix are assembled (igx_internal.h, igx_patch::twin).  The twin is an ordinary patch -- same
+    // parameter domain, same map, |det| of the Jacobian unchanged -- only its values land in THIS patch's CSR layout.  A twin that
+    // cannot be created or whose fast chain does not serve the patch is dropped: the stage kernels take such a patch as before.
+    if (dim == 3 && !pt->boxed && pt->sumfact_ok && pt->ax[1].simple && !pt->ax[2].simple && d->ctrl &&
+        (d->geo_kind == IGX_GEO_BSPLINE || d->geo_kind == IGX_GEO_NURBS)) {
+        igx_patch_desc e = *d;
+        const int perm[3] = {0, 2, 1};
+        for (int k = 0; k < 3; ++k) {
+            e.p[k] = d->p[perm[k]]; e.kv[k] = d->kv[perm[k]]; e.kv_len[k] = d->kv_len[perm[k]];
+            e.geo_p[k] = d->geo_p[perm[k]]; e.geo_kv[k] = d->geo_kv[perm[k]]; e.geo_kv_len[k] = d->geo_kv_len[perm[k]];
+        }
+        e.nqp = pt->nqp;
+        const size_t n0 = (size_t)pt->gax[0].N, n1 = (size_t)pt->gax[1].N, n2 = (size_t)pt->gax[2].N, nc = (size_t)pt->ncomp;
+        std::vector<double> ctrl(n0 * n1 * n2 * nc);
+        for (size_t a = 0; a < n0; ++a)
+            for (size_t b = 0; b < n1; ++b)
+                for (size_t c = 0; c < n2; ++c)
+                    for (size_t k = 0; k < nc; ++k) ctrl[((a * n2 + c) * n1 + b) * nc + k] = d->ctrl[((a * n1 + b) * n2 + c) * nc + k];
+        e.ctrl = ctrl.data();
+        const std::string keep = g_err;
+        igx_patch *tw = igx_patch_create(ctx, &e);
+        if (tw) {
+            tw->is_twin = true;
+            const int kinds = sumfact_twin_kinds(tw);
+            if (kinds) { pt->twin = tw; pt->twin_kinds = kinds; }
+            else igx_patch_destroy(tw);
+        } else set_error("%s", keep.c_str());          // (the failure of an optional twin is not the caller's error)
+    }
     return pt;
 }
 

@@ -163,6 +163,13 @@ struct igx_patch {
     } ftab;
     double *ftab_arr = nullptr;                               // [narr][npts_loc] sampled non-constant entries (lazily)
     bool ftab_ready = false;
+    // Repeated knots on the LAST axis only (round 6): k_bf3 contracts an axis of single knots and sweeps one that may have repeated
+    // ones, so such a patch is assembled through its TWIN -- the same patch with mid and last axis exchanged (knot vectors, control
+    // net), created with it -- whose k_bf3 stores straight into the CSR layout of this patch (fused3.hip, TR).  twin_kinds: bit per
+    // IGX_* kind the twin's fast chain serves; is_twin: this patch is one (its values belong to its owner's layout).
+    igx_patch *twin = nullptr;
+    int twin_kinds = 0;
+    bool is_twin = false;
     double *d_coeff = nullptr;                // IGX_CONVDIFF: scalar coefficient on the resident Gauss slab
     int coef_affine = 0;                      // ... set by igx_patch_set_coeff_affine: k_geoA evaluates it from the geometry map
     bool coeff_sampled = false;               // d_coeff holds the values of the current coefficient (an affine one is sampled only when a kernel that reads the array runs: ensure_coeff)
@@ -284,6 +291,7 @@ inline bool igx_kind_symmetric(int kind) { return kind != IGX_CONVDIFF && kind !
 // fused sweep + final stage and mirror pass (fused.hip)
 struct BFInputs {
     int pad_stiff3 = 0;                       // treat the slot set as the full first-order set (absent slots read the zero row): general forms
+    int tr = 0;                               // the patch is the axis-exchanged twin of the caller's (igx_patch::twin): k_bf3 stores to the caller's CSR layout
     const Axis *mid, *last;                   // swept axis, last (contiguous) axis
     int slot_n[4][4];                         // [last-axis type y][mid-axis type t1]: number of input arrays (<= 2)
     const double *slot_ptr[4][4][2];          // their device pointers: array[slice][g_mid - gmid_lo][g_last]
@@ -312,6 +320,7 @@ int launch_mirror(hipStream_t st, const igx_patch *pt, const MirrorInputs &in, d
 bool fused3_supported(const BFInputs &in);
 bool fused3_offsets_fit(int dim, int p0, int p1, int p2, long long S_mid, long long S_last, long long N_last);
 bool fused3_degrees(int P1, int P2, int Q, bool sym3d, bool mid_simple);
+bool fused3_tr_fits(int p0, int p1, int p2, long long S_mid, long long S_last);
 int launch_bf3(hipStream_t st, const igx_patch *pt, const BFInputs &in, double *d_data);
 // fused geometry + stage A (geoa.hip)
 bool geoA_supported(const igx_patch *pt, int kind, int nslots);
@@ -329,6 +338,7 @@ int launch_geoA(hipStream_t st, igx_patch *pt, int kind, int nslots, const int *
                 const GeoAForm *form = nullptr);
 bool geoA_form_supported(const igx_patch *pt);
 bool sumfact_needs_fields(const igx_patch *pt, int kind);
+int sumfact_twin_kinds(const igx_patch *tw);                    // IGX_* kinds (bit mask) the fast chain of an axis-exchanged twin serves
 bool sumfact_single_launch(const igx_patch *pt, int kind);     // the 2D single-launch kernel will run (no stage events inside)
 // device time of the mirror pass of this patch on `buf` (access pattern only: the values are whatever the buffer holds);
 // < 0 when the patch has no such pass

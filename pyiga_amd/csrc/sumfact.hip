@@ -822,8 +822,27 @@ static bool single2d_wanted(const igx_patch *pt, int kind)
 
 bool form_on_fast_chain(const igx_patch *pt);
 bool sumfact_single_launch(const igx_patch *pt, int kind) { return single2d_wanted(pt, kind); }
+// Repeated knots on the last axis only: the patch is assembled through its axis-exchanged twin (igx_internal.h, igx_patch::twin),
+// whose fast chain serves the kinds of twin_kinds (sumfact_twin_kinds, asked once when the twin is created).
+static bool twin_route(const igx_patch *pt, int kind)
+{
+    return pt->twin && !pt->is_twin && kind >= 0 && kind < 31 && ((pt->twin_kinds >> kind) & 1);
+}
+int sumfact_twin_kinds(const igx_patch *tw)
+{
+    if (tw->dim != 3 || !tw->sumfact_ok || tw->knobs.path == 2 || tw->knobs.final_sel || tw->knobs.bf == 2) return 0;
+    if (getenv("IGX_NO_TWIN")) return 0;                 // (experiments: the stage kernels for such patches, as before round 6)
+    const Axis &AM = tw->ax[1], &AL = tw->ax[2];
+    if (!fused3_axes(tw, true) || AM.P > 5 || !fused3_tr_fits(tw->ax[0].p, AM.p, AL.p, AM.S, AL.S)) return 0;
+    int kinds = 0;
+    if (geoA_wanted(tw, IGX_MASS, 1)) kinds |= 1 << IGX_MASS;
+    if (geoA_wanted(tw, IGX_STIFFNESS, 8)) kinds |= 1 << IGX_STIFFNESS;
+    return kinds;
+}
+
 bool sumfact_needs_fields(const igx_patch *pt, int kind)
 {
+    if (twin_route(pt, kind)) return false;
     if (single2d_wanted(pt, kind)) return false;
     if (kind == IGX_FORM && pt->dim == 3 && form_on_fast_chain(pt)) return false;
     if (pt->dim == 2) return !(igx_kind_symmetric(kind) && pt->knobs.path != 1 && geoA_wanted(pt, kind, kind == IGX_MASS ? 1 : 4));
@@ -886,6 +905,8 @@ static int run_fused(igx_patch *pt, BFInputs &in, bool sym, double *d_data, bool
         in.mid_lo = pt->r0_lo; in.mid_hi = sym ? std::min(pt->r0_hi + A0.p, A0.N) : pt->r0_hi; in.span_hi = pt->s0_hi;
     }
     // k_bf3 (fused3.hip): symmetric forms get their upper triangle from the same registers as the lower one -- no mirror pass
+    in.tr = pt->is_twin ? 1 : 0;
+    if (pt->is_twin && !use3) { set_error("internal: the axis-exchanged twin of a patch left k_bf3"); return IGX_ERR_UNSUPPORTED; }
     if (use3) {
         if (dim == 2 && sym) in.mid_hi = pt->r0_hi;      // (no mirror sources above the slab)
         if (int rc = launch_bf3(st, pt, in, d_data)) return rc;
@@ -1084,6 +1105,15 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
     hipStream_t st = pt->ctx->stream;
     const int dim = pt->dim;
     const PatchDev &pd = pt->dev;
+    if (twin_route(pt, kind)) {                           // repeated knots on the last axis: the twin's chain, values to THIS layout
+        igx_patch *tw = pt->twin;
+        memset(&tw->timing, 0, sizeof(tw->timing));
+        tw->last_path = 0;
+        const int rc = sumfact_assemble(tw, kind, d_data);
+        pt->last_path |= tw->last_path | IGX_PATH_TWIN;
+        pt->timing.n_launches += tw->timing.n_launches;
+        return rc;
+    }
     if (kind == IGX_FORM && dim == 3) {                   // a coefficient table on the fast chain: no field arrays
         FormPlan fp = form_table_plan(pt);
         if (fp.ok) return assemble_form_table(pt, fp, d_data);
@@ -1275,6 +1305,7 @@ int sumfact_assemble(igx_patch *pt, int kind, double *d_data)
             return run_fused(pt, in, sym, d_data, can3);
         }
     }
+    if (pt->is_twin) { set_error("internal: the axis-exchanged twin of a patch left the fused chain"); return IGX_ERR_UNSUPPORTED; }
 
     if (int rc = ensure_line_descriptors(pt)) return rc;
     // ---- final-stage input

@@ -1194,6 +1194,66 @@ def test_both_triangles_from_the_fused_stage(iga, monkeypatch):
     monkeypatch.delenv('IGX_BF', raising=False)
 
 
+def test_repeated_knots_on_the_last_axis_through_the_twin(iga, monkeypatch):
+    """Round 6: k_bf3 contracts an axis of single knots, so a patch whose LAST axis has repeated knots (and
+    whose mid axis has not) is assembled through its twin -- mid and last axis exchanged, knot vectors and control net -- whose
+    k_bf3 stores into the CSR layout of the caller's patch (fused3.hip, TR; igx_patch::twin).  Mass and stiffness, degrees 1-4 on
+    the two axes (any lower degree on axis 0), knots of multiplicity 2 .. p, several tiles of the twin's last axis, NURBS and
+    B-spline geometry, row slabs: against the entry-wise kernels (the reference's loop nest, pyiga/assemblers.pyx:1455-1540) and the
+    stage kernels (IGX_NO_TWIN: the path such patches took before), exactly symmetric, every value written, slabs bit for bit."""
+    mk = iga.bspline.make_knots
+    KV = iga.bspline.KnotVector
+    monkeypatch.setenv('IGX_DEBUG_POISON', '1')
+
+    def kv_mults(p, mults):
+        n = len(mults) + 1
+        inner = np.repeat(np.arange(1, n) / n, mults)
+        return KV(np.concatenate([np.zeros(p + 1), inner, np.ones(p + 1)]), p)
+    cases = [((mk(3, 0., 1., 3), mk(3, 0., 1., 4), mk(3, 0., 1., 5, mult=2)), 'cylinder'),
+             ((mk(2, 0., 1., 4), mk(2, 0., 1., 45), mk(2, 0., 1., 6, mult=2)), 'twisted_box'),          # 47 rows: two tiles of the twin's last axis
+             ((mk(4, 0., 1., 3), mk(4, 0., 1., 38), kv_mults(4, [1, 2, 4, 1, 3])), 'cylinder'),          # mixed multiplicities, C^0 knot
+             ((mk(1, 0., 1., 5), mk(1, 0., 1., 6), mk(1, 0., 1., 4)), 'twisted_box'),                    # (degree 1: nothing to repeat -> no twin)
+             ((mk(2, 0., 1., 3), mk(4, 0., 1., 5), kv_mults(4, [2, 2, 1])), 'twisted_box'),              # lower degree on axis 0
+             ((mk(5, 0., 1., 3), mk(5, 0., 1., 4), mk(5, 0., 1., 3, mult=3)), 'cylinder'),               # degree 5: compiled for single knots only -> stages
+             ((mk(3, 0., 1., 6, mult=2), mk(3, 0., 1., 7), kv_mults(3, [3, 1, 2, 2])), 'cylinder')]      # repeated knots on axis 0 as well
+    for kvs, gname in cases:
+        geo = _geo(iga, gname)
+        twin = kvs[1].p == kvs[2].p and 2 <= kvs[2].p <= 4 and kvs[0].p <= kvs[1].p
+        for kind in ('stiffness', 'mass'):
+            patch = iga.assemblers.DevicePatch(kvs, geo)
+            A = patch.csr(kind, algo='sumfact')
+            path = patch.last_path()
+            E = patch.csr(kind, algo='entrywise')
+            patch.close()
+            assert ('twin' in path) == twin, (kind, path, [kv.p for kv in kvs])
+            if twin:
+                assert path == {'geoA', 'fused', 'both', 'bf3', 'twin'}, path
+            assert not np.isnan(A.data).any()
+            assert abs(A - A.T).max() == 0.0
+            assert np.array_equal(A.indptr, E.indptr) and np.array_equal(A.indices, E.indices)
+            assert rel_maxdiff(A, E) <= RTOL, (kind, [kv.numdofs for kv in kvs], rel_maxdiff(A, E))
+            if not twin:
+                continue
+            monkeypatch.setenv('IGX_NO_TWIN', '1')
+            patch = iga.assemblers.DevicePatch(kvs, geo)
+            S = patch.csr(kind, algo='sumfact')
+            assert 'twin' not in patch.last_path() and 'bf3' not in patch.last_path()
+            patch.close()
+            monkeypatch.delenv('IGX_NO_TWIN')
+            assert rel_maxdiff(A, S) <= 1e-13
+            # row slabs of axis 0: the rows of the whole patch, bit for bit
+            N0 = kvs[0].numdofs
+            cuts = [0, 1, N0 // 2, N0]
+            parts = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                patch = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
+                parts.append(patch.csr(kind, algo='sumfact'))
+                assert 'twin' in patch.last_path()
+                patch.close()
+            V = scipy.sparse.vstack(parts).tocsr()
+            assert np.array_equal(V.indptr, A.indptr) and np.array_equal(V.data, A.data), (kind, 'slabs')
+
+
 def test_ablation_variables_have_no_effect(iga, monkeypatch):
     """The switches of the timing experiments (work left out: wrong matrices by construction) exist only in -DIGX_ABLATE
     builds; in the shipped library the variables change nothing, and the chain of a patch is fixed when it is created."""
