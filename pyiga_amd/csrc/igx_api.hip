@@ -556,6 +556,37 @@ int igx_patch_get_info(const igx_patch *pt, igx_patch_info *info)
     return IGX_OK;
 }
 
+// The coefficient of the convection-diffusion form on the twin of a patch (igx_internal.h, igx_patch::twin): an affine one as
+// its four numbers, a sampled one as the parent's array with the two last grid axes exchanged.
+__global__ void k_swap_last_axes(const double *__restrict__ src, double *__restrict__ dst, const int L1, const int L2, const long long n)
+{
+    const long long per = (long long)L1 * L2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long g0 = i / per, r = i - g0 * per;
+        const int g2 = (int)(r / L1), g1 = (int)(r - (long long)g2 * L1);        // dst is [g0][g2][g1]: consecutive threads write consecutive doubles
+        dst[i] = src[g0 * per + (long long)g1 * L2 + g2];
+    }
+}
+static int twin_coeff(igx_patch *pt)
+{
+    igx_patch *tw = pt->twin;
+    if (!tw || !((pt->twin_kinds >> IGX_CONVDIFF) & 1)) return IGX_OK;
+    tw->fields_kind = -1;
+    tw->coef_affine = pt->coef_affine;
+    tw->coeff_sampled = false;
+    for (int k = 0; k < 4; ++k) tw->coef_c[k] = pt->coef_c[k];
+    if (pt->coef_affine || !pt->d_coeff || !pt->coeff_sampled) return IGX_OK;
+    const long long n = pt->dev.npts_loc;
+    if (!tw->d_coeff) IGX_HIP(hipMalloc((void **)&tw->d_coeff, std::max<size_t>(1, (size_t)n) * sizeof(double)));
+    if (n > 0) {
+        k_swap_last_axes<<<dim3((unsigned)std::min<long long>((n + 255) / 256, 65536)), dim3(256), 0, pt->ctx->stream>>>(pt->d_coeff, tw->d_coeff, pt->dev.L1, pt->dev.L2, n);
+        IGX_HIP(hipGetLastError());
+        IGX_HIP(hipStreamSynchronize(pt->ctx->stream));
+    }
+    tw->coeff_sampled = true;
+    return IGX_OK;
+}
+
 int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
 {
     if (!pt || !coeff) { set_error("igx_patch_set_coeff: null argument"); return IGX_ERR_ARG; }
@@ -568,7 +599,7 @@ int igx_patch_set_coeff(igx_patch *pt, const double *coeff)
     pt->fields_kind = -1;
     pt->coef_affine = 0;
     pt->coeff_sampled = true;
-    return IGX_OK;
+    return twin_coeff(pt);
 }
 
 int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
@@ -582,7 +613,7 @@ int igx_patch_set_coeff_affine(igx_patch *pt, const double c[4])
     pt->coef_affine = 1;
     pt->coeff_sampled = false;
     for (int k = 0; k < 4; ++k) pt->coef_c[k] = c[k];
-    return IGX_OK;
+    return twin_coeff(pt);
 }
 
 int igx_patch_set_coeff_expr(igx_patch *pt, const char *expr, int *cache_hit)
@@ -599,7 +630,7 @@ int igx_patch_set_coeff_expr(igx_patch *pt, const char *expr, int *cache_hit)
     pt->fields_kind = -1;
     pt->coef_affine = 0;
     pt->coeff_sampled = true;
-    return IGX_OK;
+    return twin_coeff(pt);
 }
 
 // a function given as a C expression, evaluated at the resident Gauss points into a device array (input of igx_load_vector_d)

@@ -837,6 +837,8 @@ int sumfact_twin_kinds(const igx_patch *tw)
     int kinds = 0;
     if (geoA_wanted(tw, IGX_MASS, 1)) kinds |= 1 << IGX_MASS;
     if (geoA_wanted(tw, IGX_STIFFNESS, 8)) kinds |= 1 << IGX_STIFFNESS;
+    // the convection-diffusion form: its coefficient follows the patch's (igx_api.hip, twin_coeff)
+    if (fused3_axes(tw, false) && geoA_wanted(tw, IGX_CONVDIFF, 8)) kinds |= 1 << IGX_CONVDIFF;
     return kinds;
 }
 

@@ -1252,6 +1252,27 @@ def test_repeated_knots_on_the_last_axis_through_the_twin(iga, monkeypatch):
                 patch.close()
             V = scipy.sparse.vstack(parts).tocsr()
             assert np.array_equal(V.indptr, A.indptr) and np.array_equal(V.data, A.data), (kind, 'slabs')
+        if not twin:
+            continue
+        # the convection-diffusion form (non-symmetric; pyiga/assemble.py:837-897): its coefficient follows the patch to the twin --
+        # an affine one as its numbers, a sampled one with the two last grid axes exchanged
+        for coeff in (iga.assemblers.AffineCoefficient(1.5, 0.2, -0.1, 0.3), lambda x, y, z: 1.5 + 0.2 * x * x - 0.1 * y + 0.3 * z):
+            asm = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff)
+            A = asm.assemble_csr(algo='sumfact')
+            path = asm.patch.last_path()
+            E = asm.assemble_csr(algo='entrywise')
+            asm.patch.close()
+            assert path == {'geoA', 'fused', 'bf3', 'twin'}, path
+            assert not np.isnan(A.data).any()
+            assert rel_maxdiff(A, E) <= RTOL, ('convdiff', [kv.numdofs for kv in kvs], rel_maxdiff(A, E))
+            N0 = kvs[0].numdofs
+            parts = []
+            for lo, hi in ((0, N0 // 2), (N0 // 2, N0)):
+                sl = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff, row0=(lo, hi))
+                parts.append(sl.assemble_csr(algo='sumfact'))
+                sl.patch.close()
+            V = scipy.sparse.vstack(parts).tocsr()
+            assert np.array_equal(V.indptr, A.indptr) and np.array_equal(V.data, A.data), 'convdiff slabs'
 
 
 def test_ablation_variables_have_no_effect(iga, monkeypatch):
@@ -2490,7 +2511,8 @@ def test_fused_stage_with_unequal_degrees_and_repeated_knots(iga, monkeypatch):
              ((mk(3, 0., 1., 4), rep(3, 7, 2), mk(3, 0., 1., 9)), 'cylinder', True),                 # double knots on the swept axis
              ((mk(4, 0., 1., 3), rep(4, 6, 3, at=(1, 3)), mk(4, 0., 1., 40)), 'cylinder', True),     # triple knots, four tiles
              ((rep(2, 5, 2), rep(2, 6, 2, at=(0, 4)), mk(2, 0., 1., 8)), 'twisted_box', True),       # repeated knots on axes 0 and 1
-             ((mk(3, 0., 1., 4), mk(3, 0., 1., 5), rep(3, 6, 2)), 'cylinder', False),                # repeated knots on the LAST axis: stage kernels
+             ((mk(3, 0., 1., 4), mk(3, 0., 1., 5), rep(3, 6, 2)), 'cylinder', True),                 # repeated knots on the LAST axis only: through the twin (round 6)
+             ((mk(3, 0., 1., 4), rep(3, 5, 2, at=(1,)), rep(3, 6, 2)), 'cylinder', False),           # ... on the mid AND the last axis: stage kernels
              ((mk(4, 0., 1., 3), mk(2, 0., 1., 5), mk(4, 0., 1., 6)), 'cylinder', True),             # two degrees below nqp on the swept axis (round 6): (3, 5, 5)
              ((mk(4, 0., 1., 3), mk(4, 0., 1., 5), mk(2, 0., 1., 14)), 'cylinder', True),            # ... on the last axis: (5, 3, 5)
              ((mk(3, 0., 1., 4), mk(1, 0., 1., 6), mk(2, 0., 1., 9)), 'twisted_box', True)]          # (2, 3, 4)
@@ -2503,6 +2525,7 @@ def test_fused_stage_with_unequal_degrees_and_repeated_knots(iga, monkeypatch):
             patch.close()
             tag = (kind, [kv.p for kv in kvs], [kv.numdofs for kv in kvs], sorted(path))
             assert ('bf3' in path and 'both' in path) == fused3, tag
+            assert ('twin' in path) == (fused3 and kvs[2].numdofs > kvs[2].numspans + kvs[2].p), tag
             assert not np.isnan(A.data).any(), tag
             assert abs(A - A.T).max() == 0.0, tag
             assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU box (round 6): 3D patches with repeated knots on the LAST axis only -- assembled through the
 axis-exchanged twin (igx_patch::twin; k_bf3 stores to the caller's CSR layout, fused3.hip TR) -- against the entry-wise kernels:
-mass and stiffness, degrees 2..4 on the mid / last axis, any lower-or-equal degree on axis 0 (with or without repeated knots
+mass, stiffness and the convection-diffusion form, degrees 2..4 on the mid / last axis, any lower-or-equal degree on axis 0 (with or without repeated knots
 there), 2..60 spans on the mid axis (several tiles of the twin's last axis), random multiplicities 1..p on the last axis, five
 geometries, row slabs bit for bit, exact symmetry, NaN poison.  usage: python3 tools/fuzz_twin.py [ncases] [seed]"""
 import os
@@ -35,27 +35,39 @@ def main():
         kv2 = iga.bspline.KnotVector(np.concatenate([np.zeros(p + 1), inner, np.ones(p + 1)]), p)
         kvs = (random_kv(rng, p0, n0), iga.bspline.make_knots(p, 0.0, 1.0, n1), kv2)
         geo = geos[int(rng.integers(0, len(geos)))]()
-        kind = 'stiffness' if rng.random() < 0.6 else 'mass'
-        patch = iga.assemblers.DevicePatch(kvs, geo)
-        A = patch.csr(kind, algo='sumfact')
+        kind = ['stiffness', 'mass', 'convdiff'][int(rng.choice(3, p=[0.45, 0.25, 0.3]))]
+        if kind == 'convdiff':
+            c = [float(x) for x in (1.0 + rng.random(), *(0.3 * rng.standard_normal(3)))]
+            coeff = iga.assemblers.AffineCoefficient(*c) if rng.random() < 0.5 else (lambda x, y, z, c=c: c[0] + c[1] * x * x + c[2] * y + c[3] * z)
+
+            def make(**kw):
+                asm = iga.assemblers.ConvDiffAssembler3D(kvs, geo, coeff, **kw)
+                return asm.patch, (lambda algo: asm.assemble_csr(algo=algo))
+        else:
+            def make(**kw):
+                pt = iga.assemblers.DevicePatch(kvs, geo, **kw)
+                return pt, (lambda algo: pt.csr(kind, algo=algo))
+        patch, run = make()
+        A = run('sumfact')
         path = sorted(patch.last_path())
-        E = patch.csr(kind, algo='entrywise')
+        E = run('entrywise')
         patch.close()
         r = rel(A, E)
-        sym = abs(A - A.T).max()
+        sym = abs(A - A.T).max() if kind != 'convdiff' else 0.0
         nan = bool(np.isnan(A.data).any())
         N0 = kvs[0].numdofs
         cut = sorted(set([0, N0] + [int(x) for x in rng.integers(1, max(2, N0), size=2)]))
         parts = []
         for lo, hi in zip(cut[:-1], cut[1:]):
-            sl = iga.assemblers.DevicePatch(kvs, geo, row0=(lo, hi))
-            parts.append(sl.csr(kind, algo='sumfact'))
+            sl, run = make(row0=(lo, hi))
+            parts.append(run('sumfact'))
             sl.close()
         S = scipy.sparse.vstack(parts).tocsr()
         slab_ok = np.array_equal(S.indptr, A.indptr) and np.array_equal(S.data, A.data)
         ntwin += 'twin' in path
         worst = max(worst, r)
-        status = 'ok' if (r <= 1e-12 and sym == 0.0 and slab_ok and not nan and 'twin' in path) else 'FAIL'
+        want = not (kind == 'convdiff' and p0 < 2)          # (k_geoA has the convection-diffusion form from degree 2 on axis 0)
+        status = 'ok' if (r <= 1e-12 and sym == 0.0 and slab_ok and not nan and ('twin' in path) == want) else 'FAIL'
         print('%3d  p=%s N=%s mult(last)=%s %-9s path=%-26s rel %.1e sym %.0e slabs %s  %s'
               % (case, [kv.p for kv in kvs], [kv.numdofs for kv in kvs], list(mults), kind, '+'.join(path) or 'stage', r, sym, slab_ok, status), flush=True)
         if status != 'ok':
