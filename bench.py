@@ -41,7 +41,8 @@ CONFIGS = {
     # there) -- the stage kernels with 64-bit addresses; and C4 at degree 4 x 3 x 4 (unequal degrees on the mid / last axis)
     'c4k': (3, 4, 128, 'stiffness', 'cylinder'),
     'c4m': (3, 4, 128, 'stiffness', 'cylinder'),
-    # round 6: C4 with double interior knots on the LAST axis, C4 at degree 4 x 2 x 4 (a degree gap of two), the symmetric form at C5's size
+    # round 6: C4 with double interior knots on the LAST axis (through the axis-exchanged twin patch), C4 at degree 4 x 2 x 4 (a degree gap
+    # of two), the symmetric form at C5's size
     'c4l': (3, 4, 128, 'stiffness', 'cylinder'),
     'c4g': (3, 4, 128, 'stiffness', 'cylinder'),
     'c5s': (3, 5, 96, 'stiffness', 'cylinder'),
@@ -589,7 +590,7 @@ def main():
                                   'double interior knots on the mid axis' if args.config == 'c4k' else 'double interior knots on the last axis' if args.config == 'c4l' else 'uniform open knots'),
                    'config': args.config, **({'emulated_slab': args.emulate} if emu is not None else {}), 'elements': nel_total, 'nnz': nnz_total, 'dofs': int(np.prod([k.numdofs for k in kvs])),
                    'algo': {1: 'entrywise', 2: 'sumfact'}.get(algo_used, str(algo_used)),
-                   'path': ' + '.join(parts),
+                   'path': ' + '.join(parts) + (' (on the twin patch: mid and last axis exchanged, values stored to this layout)' if 'twin' in path else ''),
                    'parallelism': 'row slabs of axis-0 dof planes, %d rank(s), no data-path collective' % world},
         'step_ms': {'median': chain_ms, 'min': float(np.min(steps_ms)), 'max': float(np.max(steps_ms))},
         'slab_ms': [round(x, 3) for x in slab_ms],
