@@ -1094,7 +1094,7 @@ static int launch_bf3_c(hipStream_t st, const BFArgs &A, int ncu, int symk, bool
     if (tr) {
         // values to the layout of the caller's patch, whose mid and last axis the host exchanged (BF3Store, TR): equal degrees,
         // repeated knots on the swept axis (that is why they were exchanged), the three 3D forms
-        if constexpr (P1 == P2 && P1 == Q && P1 <= 5) {
+        if constexpr (P1 == P2 && P1 == Q) {
             if constexpr (MASK == BF_MASK_MASS)
                 if (symk == 3 && mult) return launch_bf3_k<P1, P2, Q, NY, MASK, 1, BF3Cfg<P1, MASK>::NLG, BF3Cfg<P1, MASK>::NCW, BF3Cfg<P1, MASK>::NH, 3, true, true>(st, A, ncu);
             if constexpr (MASK == BF_MASK_STIFF3) {

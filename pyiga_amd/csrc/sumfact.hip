@@ -833,7 +833,7 @@ int sumfact_twin_kinds(const igx_patch *tw)
     if (tw->dim != 3 || !tw->sumfact_ok || tw->knobs.path == 2 || tw->knobs.final_sel || tw->knobs.bf == 2) return 0;
     if (getenv("IGX_NO_TWIN")) return 0;                 // (experiments: the stage kernels for such patches, as before round 6)
     const Axis &AM = tw->ax[1], &AL = tw->ax[2];
-    if (!fused3_axes(tw, true) || AM.P > 5 || !fused3_tr_fits(tw->ax[0].p, AM.p, AL.p, AM.S, AL.S)) return 0;
+    if (!fused3_axes(tw, true) || !fused3_tr_fits(tw->ax[0].p, AM.p, AL.p, AM.S, AL.S)) return 0;
     int kinds = 0;
     if (geoA_wanted(tw, IGX_MASS, 1)) kinds |= 1 << IGX_MASS;
     if (geoA_wanted(tw, IGX_STIFFNESS, 8)) kinds |= 1 << IGX_STIFFNESS;

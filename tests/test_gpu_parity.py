@@ -1197,7 +1197,7 @@ def test_both_triangles_from_the_fused_stage(iga, monkeypatch):
 def test_repeated_knots_on_the_last_axis_through_the_twin(iga, monkeypatch):
     """Round 6: k_bf3 contracts an axis of single knots, so a patch whose LAST axis has repeated knots (and
     whose mid axis has not) is assembled through its twin -- mid and last axis exchanged, knot vectors and control net -- whose
-    k_bf3 stores into the CSR layout of the caller's patch (fused3.hip, TR; igx_patch::twin).  Mass and stiffness, degrees 1-4 on
+    k_bf3 stores into the CSR layout of the caller's patch (fused3.hip, TR; igx_patch::twin).  Mass and stiffness, degrees 2-5 on
     the two axes (any lower degree on axis 0), knots of multiplicity 2 .. p, several tiles of the twin's last axis, NURBS and
     B-spline geometry, row slabs: against the entry-wise kernels (the reference's loop nest, pyiga/assemblers.pyx:1455-1540) and the
     stage kernels (IGX_NO_TWIN: the path such patches took before), exactly symmetric, every value written, slabs bit for bit."""
@@ -1214,11 +1214,12 @@ def test_repeated_knots_on_the_last_axis_through_the_twin(iga, monkeypatch):
              ((mk(4, 0., 1., 3), mk(4, 0., 1., 38), kv_mults(4, [1, 2, 4, 1, 3])), 'cylinder'),          # mixed multiplicities, C^0 knot
              ((mk(1, 0., 1., 5), mk(1, 0., 1., 6), mk(1, 0., 1., 4)), 'twisted_box'),                    # (degree 1: nothing to repeat -> no twin)
              ((mk(2, 0., 1., 3), mk(4, 0., 1., 5), kv_mults(4, [2, 2, 1])), 'twisted_box'),              # lower degree on axis 0
-             ((mk(5, 0., 1., 3), mk(5, 0., 1., 4), mk(5, 0., 1., 3, mult=3)), 'cylinder'),               # degree 5: compiled for single knots only -> stages
+             ((mk(5, 0., 1., 3), mk(5, 0., 1., 4), mk(5, 0., 1., 3, mult=3)), 'cylinder'),               # degree 5
+             ((mk(3, 0., 1., 4), mk(3, 0., 1., 5), mk(4, 0., 1., 4, mult=2)), 'cylinder'),               # unequal degrees on the two axes: stage kernels
              ((mk(3, 0., 1., 6, mult=2), mk(3, 0., 1., 7), kv_mults(3, [3, 1, 2, 2])), 'cylinder')]      # repeated knots on axis 0 as well
     for kvs, gname in cases:
         geo = _geo(iga, gname)
-        twin = kvs[1].p == kvs[2].p and 2 <= kvs[2].p <= 4 and kvs[0].p <= kvs[1].p
+        twin = kvs[1].p == kvs[2].p and 2 <= kvs[2].p <= 5 and kvs[0].p <= kvs[1].p
         for kind in ('stiffness', 'mass'):
             patch = iga.assemblers.DevicePatch(kvs, geo)
             A = patch.csr(kind, algo='sumfact')

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU box (round 6): 3D patches with repeated knots on the LAST axis only -- assembled through the
 axis-exchanged twin (igx_patch::twin; k_bf3 stores to the caller's CSR layout, fused3.hip TR) -- against the entry-wise kernels:
-mass, stiffness and the convection-diffusion form, degrees 2..4 on the mid / last axis, any lower-or-equal degree on axis 0 (with or without repeated knots
+mass, stiffness and the convection-diffusion form, degrees 2..pmax (5) on the mid / last axis, any lower-or-equal degree on axis 0 (with or without repeated knots
 there), 2..60 spans on the mid axis (several tiles of the twin's last axis), random multiplicities 1..p on the last axis, five
-geometries, row slabs bit for bit, exact symmetry, NaN poison.  usage: python3 tools/fuzz_twin.py [ncases] [seed]"""
+geometries, row slabs bit for bit, exact symmetry, NaN poison.  usage: python3 tools/fuzz_twin.py [ncases] [seed] [pmax]"""
 import os
 import sys
 
@@ -19,13 +19,14 @@ from fuzz_paths import random_kv, rel
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    pmax = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     g = iga.geometry
     geos = [lambda: g.tensor_product(g.line_segment(0.0, 1.0), g.quarter_annulus()), g.twisted_box, lambda: g.unit_cube(3, 2),
             lambda: g.tensor_product(g.line_segment(0.0, 2.0, intervals=3), g.bspline_quarter_annulus()),
             lambda: g.tensor_product(g.quarter_annulus(), g.line_segment(0.0, 1.0))]
     worst, ntwin = 0.0, 0
     for case in range(ncases):
-        p = int(rng.integers(2, 5))
+        p = int(rng.integers(2, pmax + 1))
         p0 = int(rng.integers(1, p + 1))
         n0, n1, n2 = int(rng.integers(2, 9)), int(rng.integers(2, 61 if rng.random() < 0.4 else 12)), int(rng.integers(2, 12))
         mults = rng.integers(1, p + 1, size=n2 - 1)
