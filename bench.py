@@ -566,6 +566,8 @@ def main():
         stage_ms = {k: v for k, v in stage_ms.items() if k == 'stage1_ms'}
     if 'bf3' in path or 'both' in path:
         stage_ms.pop('final_ms', None)          # k_bf3 writes both triangles (or the form has one): no kernel behind it
+    if dim == 2 and not fused and 'single' not in path:
+        stage_ms.pop('stage1_ms', None)         # 2D stage chain: axis-0 sweep -> final stage, nothing between the two events
     parts = {names[k]: round(v, 4) for k, v in stage_ms.items() if k in names and v > 0}
     dominant = max(parts, key=parts.get) if parts else None
     flops = algorithmic_flops(dim, p, kvs, mkind) if algo_used == 2 else None
