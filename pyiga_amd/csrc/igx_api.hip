@@ -720,6 +720,7 @@ int igx_patch_set_pform(igx_patch *pt, int n, const int *masks, const double *co
     pt->dev.form_n = n;
     pt->dev.form_par = 1;
     pt->ftab.valid = false;
+    if (pt->twin) pt->twin->ftab.valid = false;
     pt->fields_kind = -1;
     return IGX_OK;
 }
@@ -768,6 +769,7 @@ static int basis_orders_ok(const igx_patch *pt, int kind, const char *who)
 int igx_patch_set_form(igx_patch *pt, const double *const coef[16])
 {
     if (pt) pt->ftab.valid = false;                      // (sampled coefficients: the stage kernels over the field arrays)
+    if (pt && pt->twin) pt->twin->ftab.valid = false;
     return set_form_impl(pt, coef, false, "igx_patch_set_form");
 }
 
@@ -843,6 +845,9 @@ int igx_patch_set_form_expr(igx_patch *pt, const char *const expr[16], int *cach
             if (expr[4 * r + s] && (r >= nj || s >= nj)) { set_error("igx_patch_set_form_expr: coefficient (%d,%d) does not exist in %dD", r, s, pt->dim); return IGX_ERR_ARG; }
     IGX_HIP(hipSetDevice(pt->ctx->device));
     capture_form_table(pt, expr);
+    // (the table is one of PHYSICAL coefficients in physical coordinates: the twin of a patch with repeated knots on its last axis
+    // -- igx_patch::twin -- takes it as it is and samples its functions on its own Gauss grid when its chain first runs)
+    if (pt->twin) capture_form_table(pt->twin, expr);
     if (form_fields_applicable(pt)) {
         int form_ab[16];
         const int nt = form_terms(pt->dim, expr, form_ab);
@@ -887,6 +892,7 @@ int igx_rtc_compile_form_fields(int dim, int ncomp, const char *const expr[16], 
 int igx_patch_set_form_d(igx_patch *pt, const double *const d_coef[16])
 {
     if (pt) pt->ftab.valid = false;                      // (sampled coefficients: the stage kernels over the field arrays)
+    if (pt && pt->twin) pt->twin->ftab.valid = false;
     return set_form_impl(pt, d_coef, true, "igx_patch_set_form_d");
 }
 

@@ -826,7 +826,10 @@ bool sumfact_single_launch(const igx_patch *pt, int kind) { return single2d_want
 // whose fast chain serves the kinds of twin_kinds (sumfact_twin_kinds, asked once when the twin is created).
 static bool twin_route(const igx_patch *pt, int kind)
 {
-    return pt->twin && !pt->is_twin && kind >= 0 && kind < 31 && ((pt->twin_kinds >> kind) & 1);
+    if (!pt->twin || pt->is_twin) return false;
+    // a form given as a table of expressions (igx_patch_set_form_expr hands it to the twin as well): where the twin's fast chain takes it
+    if (kind == IGX_FORM) return pt->twin->ftab.valid && pt->ftab.valid && !pt->dev.form_par && form_on_fast_chain(pt->twin);
+    return kind >= 0 && kind < 31 && ((pt->twin_kinds >> kind) & 1);
 }
 int sumfact_twin_kinds(const igx_patch *tw)
 {

@@ -701,9 +701,14 @@ def test_form_tables_on_the_fast_chain(iga, monkeypatch):
              ((mk(4, 0., 1., 3), mk(4, 0., 1., 4), mk(4, 0., 1., 40)), 'cylinder'),
              ((mk(5, 0., 1., 3), mk(5, 0., 1., 3), mk(5, 0., 1., 4)), 'twisted_box'),
              ((mk(3, 0., 1., 4, mult=2), mk(3, 0., 1., 6, mult=2), mk(3, 0., 1., 7)), 'bannulus_x_line'),
-             ((mk(4, 0., 1., 3), mk(3, 0., 1., 6), mk(4, 0., 1., 5)), 'twisted_box')]                  # mid axis one degree below nqp: symmetric tables only
+             ((mk(4, 0., 1., 3), mk(3, 0., 1., 6), mk(4, 0., 1., 5)), 'twisted_box'),                  # mid axis one degree below nqp: symmetric tables only
+             # repeated knots on the LAST axis: the table goes to the twin patch as it is (physical coefficients), whose chain stores
+             # into this patch's layout (test_repeated_knots_on_the_last_axis_through_the_twin)
+             ((mk(3, 0., 1., 4), mk(3, 0., 1., 6), mk(3, 0., 1., 5, mult=2)), 'cylinder'),
+             ((mk(2, 0., 1., 3), mk(4, 0., 1., 38), mk(4, 0., 1., 4, mult=3)), 'bannulus_x_line')]
     for kvs, gname in cases:
         geo = geos[gname]
+        lastmult = kvs[2].numdofs > kvs[2].numspans + kvs[2].p
         for form, inputs, sym in forms:
             asm = G(kvs, geo, form, inputs=inputs)
             assert asm.compiled
@@ -715,6 +720,7 @@ def test_form_tables_on_the_fast_chain(iga, monkeypatch):
             if sym or equal_degrees:
                 assert 'geoA' in path and 'bf3' in path, tag
                 assert ('both' in path) == sym, tag
+                assert ('twin' in path) == lastmult, tag
             assert not np.isnan(A.data).any(), tag
             assert rel_maxdiff(A, E) <= RTOL, (tag, rel_maxdiff(A, E))
             if sym:

@@ -59,6 +59,8 @@ def main():
             ps[1 + int(rng.integers(0, 2))] = max(2, max(ps) - 1) if max(ps) > 2 else ps[1]
         ns = [int(rng.integers(2, 9)) for _ in range(3)]
         kvs = (random_kv(rng, ps[0], ns[0]), random_kv(rng, ps[1], ns[1]), iga.bspline.make_knots(ps[2], 0.0, 1.0, ns[2]))
+        if ps[1] == ps[2] and rng.random() < 0.3:        # repeated knots on the LAST axis only: through the twin patch
+            kvs = (kvs[0], iga.bspline.make_knots(ps[1], 0.0, 1.0, ns[1]), iga.bspline.make_knots(ps[2], 0.0, 1.0, max(2, ns[2]), mult=int(rng.integers(2, ps[2] + 1))))
         geo = geos[int(rng.integers(0, 4))]()
         cls = iga.assemblers.GeneralFormAssembler3D
         asm = cls(kvs, geo, form, inputs=inputs)
@@ -76,6 +78,14 @@ def main():
         sym_ok = (abs(A - A.T).max() == 0.0) if (fast and 'both' in path) else True
         worst = max(worst, r)
         status = 'ok' if (r <= 1e-12 and slab_ok and sym_ok) else 'FAIL'
+        if kvs[2].numdofs > kvs[2].numspans + kvs[2].p and 'twin' not in path:
+            # repeated knots on the last axis and not through the twin: then the form must be one the fast chain does not take with
+            # the same knots on the MID axis either (a non-symmetric diffusion tensor, degrees)
+            sw = cls((kvs[0], kvs[2], kvs[1]), geo, form, inputs=inputs)
+            sw.assemble_csr(algo='sumfact')
+            if 'bf3' in sw.patch.last_path() and 'geoA' in sw.patch.last_path():
+                status = 'FAIL (no twin)'
+            sw.patch.close()
         print('%3d  p=%s N=%s %-9s rel %.1e slabs %s sym %s  %s  %s' % (case, ps, [kv.numdofs for kv in kvs], '+'.join(sorted(path)) or 'stages', r, slab_ok, sym_ok, status, form[:90]), flush=True)
         if status != 'ok':
             sys.exit(1)
