@@ -1019,6 +1019,27 @@ def test_full_size_c4_every_entry(iga):
     asm.patch.close()
 
 
+def test_full_size_c4_with_repeated_knots_on_the_last_axis_every_entry(iga):
+    """C4's patch with double interior knots on the LAST axis (bench.py --config c4l: 128 x 128 x 64 spans, 1.41 G entries) at
+    full size: the twin route (k_geoA + k_bf3 on the patch with mid and last axis exchanged, values stored into this patch's CSR
+    layout: fused3.hip TR -- 32-bit offsets, 24-bit row constants) against the entry-wise kernels, EVERY entry; exactly the
+    path and size the bench line of that config measures."""
+    kv = iga.bspline.make_knots(4, 0., 1., 128)
+    kvl = iga.bspline.make_knots(4, 0., 1., 64, mult=2)
+    patch = iga.assemblers.DevicePatch((kv, kv, kvl), _geo(iga, 'cylinder'))
+    data = patch.assemble('stiffness', algo='sumfact', to_host=True)
+    assert patch.last_path() == {'geoA', 'fused', 'both', 'bf3', 'twin'} and data.size == 1409243392
+    ref = patch.assemble('stiffness', algo='entrywise', to_host=True)
+    assert patch.timing()['algo_used'] == 1 and ref.size == data.size
+    patch.close()
+    scale = float(np.abs(ref[::997]).max())
+    worst = 0.0
+    step = 1 << 26
+    for a in range(0, data.size, step):
+        worst = max(worst, float(np.abs(data[a:a + step] - ref[a:a + step]).max()))
+    assert worst <= RTOL * scale, worst / scale
+
+
 def test_fast_variants_match_fixtures(iga, capsys):
     """test/test_assemble.py:187-217 (test_fast_{mass,stiffness}_geo_{2,3}d): the low-rank (ACA) assemblers against the
     bundled fixtures with the reference's tolerance 1e-9; the approximation really is low-rank (few crosses, fewer entries
