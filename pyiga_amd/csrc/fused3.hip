@@ -47,6 +47,9 @@
 #ifndef BF3_MASS_STW
 #define BF3_MASS_STW 1        // ... with the store duty on its sweeper waves (dense slots) at low degree; 0: always on the contractors
 #endif
+#ifndef BF3_MASS_STW_QMAX
+#define BF3_MASS_STW_QMAX 3   // ... "low degree": up to this many Gauss points per span
+#endif
 
 namespace igx {
 
@@ -907,7 +910,7 @@ __global__ void __launch_bounds__((bf_nroles(MASK) * NLG + NCW) * 64) k_bf3(cons
     // store duty: on the sweepers of the roles 1.. where the form has them (staged, dense), else on the contractors (at once)
     // (mass: on the sweepers at degree <= 2 -- 0.157 against 0.178 ms at BASELINE config 3 --, on the contractors above: the fifteen
     // staged slots of a sweeper at degree 4 cost 154 registers and 6.5-7.1 against 6.3 ms at C4's size)
-    constexpr bool STW = NR >= 2 || (SYM == 3 && BF3_MASS_STW && Q <= 3);
+    constexpr bool STW = NR >= 2 || (SYM == 3 && BF3_MASS_STW && Q <= BF3_MASS_STW_QMAX);
     constexpr int NQ = (Gm::RMAX * W1 * W2 + 63) / 64;
     using Split = BF3DenseSplit<NR < 2 ? 2 : NR, NLG, NQ>;
     using StoreA = BF3StoreDense<Gm, NH, SYM, Split::KA < 1 ? 1 : Split::KA, 0, Split::QB, Split::NA < 1 ? 1 : Split::NA, TR>;   // middle roles
@@ -1066,7 +1069,16 @@ constexpr int BF_MASK_MASS = 0x0001, BF_MASK_STIFF3 = 0x135F, BF_MASK_STIFF2 = 0
 #define BF3_FIXED_PASS 1      // the contractor waves keep their passes from step to step (no rotation)
 #endif
 template <int PM, int MASK> struct BF3Cfg { static constexpr int NLG = 2, NCW = 4, NH = 1; };
-template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? 3 : 2, NCW = PM == 5 ? 8 : 4, NH = 1; };
+// Shape of the degree-4 mass kernel (C4's size).  With the per-axis symmetry (SYM = 3) every block is contracted like a diagonal
+// one: 5 lines x 2 pieces = 4 passes per step, so FOUR contractor waves all have a pass (of the eight of round 5 -- chosen when an
+// off-diagonal block still had 9 lines -- four only shared the store duty), and a block of 3 + 4 waves leaves room for a second
+// one on the CU: k_bf3 5.79 -> 4.95 ms at C4's size (6.33 -> 5.56 on a slower box; profiles/r06_g_c4mass_shapes.txt).  Two lane
+// groups (smaller tiles) or the store duty on the sweepers are worse there (5.8 / 7.1 ms).
+#ifndef BF3_MASS_P5_NCW
+#define BF3_MASS_P5_NLG 3
+#define BF3_MASS_P5_NCW 4
+#endif
+template <int PM> struct BF3Cfg<PM, BF_MASK_MASS> { static constexpr int NLG = PM == 5 ? BF3_MASS_P5_NLG : 2, NCW = PM == 5 ? BF3_MASS_P5_NCW : 4, NH = 1; };
 // Degree 5 (PM = 6) of the NON-SYMMETRIC form (SYM = 0, BASELINE config 5): sixteen waves per CU -- three lane groups, 27-row
 // tiles, half-units only, half a span of K1 prefetch to fit 128 registers -- against twelve waves of 150 registers: 13.25 against
 // 14.1-14.4 ms at C5 (profiles/r06_a_c5_geoa_variants.txt).  The SYMMETRIC form at the same size keeps the twelve-wave shape:
